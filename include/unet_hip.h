@@ -1,0 +1,109 @@
+/* libunet_hip.so -- C ABI of the MI355X (gfx950) U-Net train / inference hot path.
+ *
+ * Drop-in boundary for the ONE hot path of usnistgov/semantic-segmentation-unet: the body of class `UNet`
+ * (reference UNet/model.py:19-256).  The reference has no FFI of its own for this path (its arithmetic is implicit in
+ * TensorFlow/Keras layer calls); each entry point below cites the reference call site whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless it says "host"; nothing is allocated, freed or retained;
+ *   - activations are fp32 NHWC; `ld*` = channel stride in elements between consecutive pixels, so a tensor may be a
+ *     channel slice of a wider buffer (the zero-copy concat of UNet/model.py:55-58); P = N*H*W pixels;
+ *   - weights keep the Keras layouts: Conv2D kernel HWIO [kh][kw][Cin][Cout]; Conv2DTranspose kernel [kh][kw][Cout][Cin];
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued asynchronously;
+ *   - return value: 0 ok, UNET_EINVAL (-1) bad argument, UNET_ENOSPC (-2) workspace too small, >0 a hipError_t;
+ *   - no global mutable state: callable concurrently from different streams/threads;
+ *   - `*_workspace()` return the scratch bytes the matching call needs for the same shape arguments.
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_OK 0
+#define UNET_EINVAL (-1)
+#define UNET_ENOSPC (-2)
+
+int unet_hip_abi_version(void);
+
+/* ---- Conv2D(3x3, 'same', relu) of UNet._conv_layer, UNet/model.py:28-35 (18 instances, :88-134) ------------------ */
+/* fp32 matrix-core implicit GEMM; needs Cin % 32 == 0 and Cout % 64 == 0 (unet_conv3x3_mfma_supported). */
+int unet_conv3x3_mfma_supported(int Cin, int Cout);
+int unet_conv3x3_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                          int N, int H, int W, int Cin, int Cout, int relu, void* stream);
+/* derived backward of the same layer (tf.GradientTape, UNet/model.py:219): data gradient and weight gradient */
+int unet_conv3x3_dgrad_mfma(const float* dz, int lddz, const float* w, float* dx, int lddx,
+                            int N, int H, int W, int Cin, int Cout, void* stream);
+size_t unet_conv3x3_wgrad_mfma_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_conv3x3_wgrad_mfma(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                            int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
+int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                            int N, int H, int W, int Cin, int Cout, int relu, void* stream);
+size_t unet_conv3x3_wgrad_direct_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                              int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Conv2D(1x1, relu) class map, UNet/model.py:136 (w is [Cin][Cout]) ------------------------------------------- */
+int unet_conv1x1_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                     long P, int Cin, int Cout, int relu, void* stream);
+int unet_conv1x1_dgrad(const float* dz, int lddz, const float* w, float* dx, int lddx, long P, int Cin, int Cout, void* stream);
+size_t unet_conv1x1_wgrad_workspace(long P, int Cin, int Cout);
+int unet_conv1x1_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                       long P, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Conv2DTranspose(2x2, stride 2) of UNet._deconv_layer, UNet/model.py:39-46 (:116,121,126,131) ---------------- */
+/* N,H,W = INPUT dims of the layer; output is [N,2H,2W,Cout].  Needs Cin % 64 == 0 and Cout % 64 == 0. */
+int unet_convT2x2_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                      int N, int H, int W, int Cin, int Cout, void* stream);
+int unet_convT2x2_dgrad(const float* dz, int lddz, const float* w, float* dx, int lddx,
+                        int N, int H, int W, int Cin, int Cout, void* stream);
+size_t unet_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_convT2x2_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                        int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- BatchNormalization(axis=1), UNet/model.py:36,47 ------------------------------------------------------------- */
+size_t unet_bn_workspace(long P, int C);
+/* training=True: batch mean / biased variance of r -> mean, invstd = 1/sqrt(var+eps), scale = gamma*invstd,
+ * shift = beta - mean*scale; moving_mean/var (nullable pair) updated with `momentum`. */
+int unet_bn_train_stats(const float* r, int ldr, long P, int C, const float* gamma, const float* beta,
+                        float eps, float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
+                        float* mean, float* invstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
+/* training=False (UNet/model.py:239, UNet/inference.py:105,164): coefficients from the moving statistics */
+int unet_bn_eval_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                        float eps, int C, float* scale, float* shift, void* stream);
+int unet_bn_apply(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy, long P, int C, void* stream);
+/* backward of [ReLU ->] BN: dz = relu'(r) * d r, plus dgamma, dbeta and dbias = column sums of dz */
+int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
+                const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,
+                float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- MaxPool2D(2), UNet/model.py:50-53; Dropout(0.5), UNet/model.py:60-63 ---------------------------------------- */
+int unet_maxpool2x2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int unet_maxpool2x2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx,
+                        int N, int H, int W, int C, int accumulate, void* stream);
+/* mask (nullable, dense [P][C] bytes) overrides the counter-based RNG keyed by (seed, element index) */
+int unet_dropout(const float* x, int ldx, float* out, int ldo, long P, int C, const uint8_t* mask,
+                 uint32_t seed, float rate, void* stream);
+
+/* ---- Softmax(axis=-1) + CategoricalCrossentropy + loss reduction + accuracy, UNet/model.py:142,77,211-215,226 ----- */
+size_t unet_softmax_ce_workspace(long P);
+int unet_softmax_ce(const float* logits, int ldz, const int* labels_onehot, float* prob, float* dlogits, int lddz,
+                    long P, int K, float label_smoothing, float loss_scale, float grad_scale,
+                    float* loss_out, float* correct_out, void* ws, size_t ws_bytes, void* stream);
+/* np.argmax(softmax, axis=-1), UNet/inference.py:107,166 (first maximum wins) */
+int unet_argmax(const float* p, int ldp, int* out, long P, int K, void* stream);
+
+/* ---- tf.keras.optimizers.Adam.apply_gradients, UNet/model.py:79,223; alpha = lr*sqrt(1-b2^t)/(1-b1^t) from host -- */
+int unet_adam_keras(float* theta, const float* grad, float* m, float* v, long n, float alpha, float beta1,
+                    float beta2, float eps, void* stream);
+
+/* ---- reference input contract is NCHW (UNet/model.py:73; UNet/imagereader.py:298) -------------------------------- */
+int unet_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

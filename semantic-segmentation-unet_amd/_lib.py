@@ -1,0 +1,73 @@
+"""ctypes binding of the C-ABI library (include/unet_hip.h).  Prototypes are parsed from the header itself so the
+Python side can never drift from the declared ABI.  There is NO fallback: if the HIP library is missing the product
+path raises (build it with `python __graft_entry__.py` or `semantic-segmentation-unet_amd/_build.py`)."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "unet_hip.h")
+LIB_PATH = os.path.join(HERE, "csrc", "libunet_hip.so")
+
+_DECL = re.compile(r"\b(int|size_t)\s+(unet_\w+)\s*\(([^)]*)\)\s*;", re.S)
+
+
+def _ctype(decl):
+    d = decl.strip()
+    if d == "void" or not d:
+        return None
+    if "*" in d:
+        return ctypes.c_void_p
+    base = d.rsplit(" ", 1)[0].replace("const", "").strip() if " " in d else d
+    return {"int": ctypes.c_int, "long": ctypes.c_long, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
+            "uint32_t": ctypes.c_uint32}[base]
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function the header declares."""
+    text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    out = {}
+    for ret, name, args in _DECL.findall(text):
+        at = [t for t in (_ctype(a) for a in args.split(",")) if t is not None]
+        out[name] = (ctypes.c_int if ret == "int" else ctypes.c_size_t, at)
+    return out
+
+
+class UnetHipError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise UnetHipError("HIP extension %s is missing; run build() -- there is no CPU fallback" % LIB_PATH)
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (res, args) in self.protos.items():
+            fn = getattr(self.cdll, name)          # AttributeError = header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+            if res is ctypes.c_int and name not in ("unet_hip_abi_version", "unet_conv3x3_mfma_supported"):
+                setattr(self, name, self._checked(name, fn))
+            else:
+                setattr(self, name, fn)
+
+    @staticmethod
+    def _checked(name, fn):
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise UnetHipError("%s failed with status %d (%s)" % (
+                    name, rc, {-1: "bad argument", -2: "workspace too small"}.get(rc, "hipError_t")))
+        call.__name__ = name
+        return call
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib

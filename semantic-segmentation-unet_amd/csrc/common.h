@@ -1,0 +1,30 @@
+// Shared helpers for the gfx950 U-Net kernels.  All tensors are fp32, activations NHWC with an explicit
+// channel stride `ld` (elements between consecutive pixels) so producers can write into / consumers can read
+// from channel slices of a wider buffer (the zero-copy concat of UNet/model.py:55-58).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define UNET_OK 0
+#define UNET_EINVAL (-1)      // bad argument (shape / alignment / null pointer)
+#define UNET_ENOSPC (-2)      // workspace too small
+
+#define UNET_CHECK_ARG(cond) do { if (!(cond)) return UNET_EINVAL; } while (0)
+#define UNET_LAUNCH_STATUS() ((int)hipGetLastError())
+
+static inline bool unet_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int unet_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// counter-based RNG for dropout: one 32-bit hash per element, keep = top bit.  The same (seed, index)
+// regenerates the mask in backward, so no mask tensor is stored.
+__device__ __forceinline__ uint32_t unet_hash32(uint32_t seed, uint64_t idx) {
+    uint64_t z = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(seed + 1u);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}

@@ -1,0 +1,277 @@
+// Implicit-GEMM convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   out[pixel][n] = sum_{tap} sum_{k} in[pixel (+) tap][k] * Wt[tap][k][n]      (+ bias, ReLU)
+//
+// One kernel template serves the four dense "activation-producing" contractions of the U-Net
+// (reference layer recipes: UNet/model.py:28-48):
+//   MODE 0  3x3 'same' conv forward (9 taps over an LDS halo tile) and, with flipped taps and the
+//           [tap][n][k] weight view, its data gradient (dgrad);
+//   MODE 1  one tap, output scattered with stride 2: the 2x2/stride-2 transposed conv forward
+//           (blockIdx.z = tap (a,b), out pixel (2i+a, 2j+b));
+//   MODE 2  four taps gathered with stride 2 as a K-extension: the transposed conv's data gradient.
+//
+// Tiling (wave64, MFMA 32x32x2 f32): workgroup = 4 waves; a wave owns 64 pixels x 64 channels
+// (2x2 MFMA tiles, 64 accumulator VGPRs); the MFMA M dimension is 32 consecutive pixels of one image row.
+// K is consumed in chunks of CK=32 channels staged through LDS:
+//   A tile  [pixels][CK+4]  (pixel stride 36 floats: a lane's 4 consecutive k are one ds_read_b128,
+//            16-lane groups land on 16 distinct 16-B slots -> conflict-free),
+//   B tile  [CK][BN] (weights stored [k][n]: four ds_read_b32 per fragment) or [BN][CK+4] (stored [n][k]).
+// The k order inside a chunk is permuted (lane half h takes k = 8*kk + 4*h + s); A and B use the same
+// permutation so the sum is unchanged.  Weights for iteration i+1 are prefetched into registers while
+// iteration i's MFMAs run (global -> VGPR -> LDS, write after the barrier).
+#include "common.h"
+
+namespace {
+
+constexpr int CK = 32;
+constexpr int SA = CK + 4;
+constexpr int TW = 32;
+
+struct IgemmArgs {
+    const float* x; const float* w; const float* bias; float* out;
+    int ldx, ldo;
+    int N, H, W;            // tile-grid image dims (conv output dims; convT fwd: input dims; convT dgrad: dx dims)
+    int Hi, Wi;             // dims of the image `x` is read from
+    int Ho, Wo;             // dims of the image `out` is written to
+    int Kdim, Ndim;         // GEMM K per tap, GEMM N
+    int in_scale;           // MODE 1/2: input pixel = grid pixel * in_scale + tap offset
+    int out_scale;          // output pixel = grid pixel * out_scale + (tap offset when tap_by_z)
+    int relu, flip, tap_by_z;
+    int tiles_y, tiles_x, tiles_n;
+};
+
+template <int MODE, int WM, int WN, bool B_NK>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
+    constexpr int TH = 2 * WM;
+    constexpr int BN = 64 * WN;
+    constexpr int NT = MODE == 0 ? 9 : (MODE == 1 ? 1 : 4);
+    constexpr int A_ROWS = MODE == 0 ? TH + 2 : TH;
+    constexpr int A_COLS = MODE == 0 ? TW + 2 : TW;
+    constexpr int A_FLOATS = A_ROWS * A_COLS * SA;
+    constexpr int B_FLOATS = B_NK ? BN * SA : CK * BN;
+    constexpr int B_F4 = CK * BN / 4 / 256;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
+    float* sA = smem;
+    float* sB = smem + A_FLOATS;
+
+    int b = blockIdx.x;
+    const int tn = b % p.tiles_n; b /= p.tiles_n;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int img = b / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = tn * BN;
+    const int ztap = p.tap_by_z ? (int)blockIdx.z : 0;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int n_chunks = p.Kdim / CK;
+    const int n_it = n_chunks * NT;
+    f32x4 rb[B_F4];
+
+    auto gload_B = [&](int chunk, int tap) {
+        int tapw = tap;
+        if (MODE == 0 && p.flip) tapw = 8 - tap;
+        if (p.tap_by_z) tapw = ztap;
+        const int c0 = chunk * CK;
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int idx = tid + i * 256;
+            if (!B_NK) {
+                const int k = idx / (BN / 4), q = idx % (BN / 4);
+                rb[i] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(tapw * p.Kdim + c0 + k) * p.Ndim + n0 + 4 * q));
+            } else {
+                const int nn = idx >> 3, q = idx & 7;
+                rb[i] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(tapw * p.Ndim + n0 + nn) * p.Kdim + c0 + 4 * q));
+            }
+        }
+    };
+    auto store_B = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int idx = tid + i * 256;
+            if (!B_NK) {
+                const int k = idx / (BN / 4), q = idx % (BN / 4);
+                *reinterpret_cast<f32x4*>(sB + k * BN + 4 * q) = rb[i];
+            } else {
+                const int nn = idx >> 3, q = idx & 7;
+                *reinterpret_cast<f32x4*>(sB + nn * SA + 4 * q) = rb[i];
+            }
+        }
+    };
+    auto stage_A = [&](int chunk, int tap) {
+        const int c0 = chunk * CK;
+        constexpr int TOTAL = A_ROWS * A_COLS * (CK / 4);
+        for (int idx = tid; idx < TOTAL; idx += 256) {
+            const int pix = idx >> 3, q = idx & 7;
+            const int iy = pix / A_COLS, ix = pix - iy * A_COLS;
+            int gy, gx;
+            bool ok;
+            if (MODE == 0) {
+                gy = oy0 + iy - 1; gx = ox0 + ix - 1;
+                ok = (gy >= 0) && (gy < p.Hi) && (gx >= 0) && (gx < p.Wi);
+            } else {
+                const int oy = oy0 + iy, ox = ox0 + ix;
+                ok = (oy < p.H) && (ox < p.W);
+                gy = oy * p.in_scale + (MODE == 2 ? (tap >> 1) : 0);
+                gx = ox * p.in_scale + (MODE == 2 ? (tap & 1) : 0);
+            }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(img * p.Hi + gy) * p.Wi + gx) * p.ldx + c0 + 4 * q);
+            *reinterpret_cast<f32x4*>(sA + pix * SA + 4 * q) = v;
+        }
+    };
+
+    // per-lane fragment bases (floats)
+    int a_base[2], b_base[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) a_base[t] = ((2 * wm + t) * A_COLS + li) * SA + 4 * lh;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        b_base[u] = B_NK ? (wn * 64 + u * 32 + li) * SA + 4 * lh : (4 * lh) * BN + wn * 64 + u * 32 + li;
+
+    gload_B(0, 0);
+    int chunk = 0, tap = 0;
+    for (int it = 0; it < n_it; ++it) {
+        __syncthreads();
+        if (MODE != 0 || tap == 0) stage_A(chunk, tap);
+        store_B();
+        __syncthreads();
+        int nchunk = chunk, ntap = tap + 1;
+        if (ntap == NT) { ntap = 0; nchunk = chunk + 1; }
+        if (it + 1 < n_it) gload_B(nchunk, ntap);
+
+        const int tap_off = MODE == 0 ? ((tap / 3) * A_COLS + (tap % 3)) * SA : 0;
+#pragma unroll
+        for (int kk = 0; kk < CK / 8; ++kk) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const f32x4*>(sA + a_base[t] + tap_off + kk * 8);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (B_NK) {
+                    bf[u] = *reinterpret_cast<const f32x4*>(sB + b_base[u] + kk * 8);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bf[u][s] = sB[b_base[u] + (kk * 8 + s) * BN];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][s], bf[u][s], acc[t][u], 0, 0, 0);
+        }
+        chunk = nchunk; tap = ntap;
+    }
+
+    // epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel along x)
+    const int ooy = p.tap_by_z ? (ztap >> 1) : 0, oox = p.tap_by_z ? (ztap & 1) : 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int oy = oy0 + 2 * wm + t;
+        if (oy >= p.H) continue;
+        const int py = oy * p.out_scale + ooy;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = n0 + wn * 64 + u * 32 + li;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ox < p.W) {
+                    float v = acc[t][u][r] + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    const int px = ox * p.out_scale + oox;
+                    p.out[((size_t)(img * p.Ho + py) * p.Wo + px) * p.ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, bool B_NK>
+int launch_igemm(IgemmArgs a, int zdim, hipStream_t st) {
+    // 128-wide channel tile when N allows it, else 64 wide x 8 rows.
+    const bool wide = (a.Ndim % 128) == 0;
+    const int TH = wide ? 4 : 8, BN = wide ? 128 : 64;
+    a.tiles_y = unet_cdiv(a.H, TH);
+    a.tiles_x = unet_cdiv(a.W, TW);
+    a.tiles_n = a.Ndim / BN;
+    const long blocks = (long)a.N * a.tiles_y * a.tiles_x * a.tiles_n;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
+    dim3 grid((unsigned)blocks, 1, (unsigned)zdim);
+    if (wide) igemm_kernel<MODE, 2, 2, B_NK><<<grid, 256, 0, st>>>(a);
+    else      igemm_kernel<MODE, 4, 1, B_NK><<<grid, 256, 0, st>>>(a);
+    return UNET_LAUNCH_STATUS();
+}
+
+bool igemm_shape_ok(int Kdim, int Ndim) { return Kdim > 0 && Ndim > 0 && (Kdim % CK) == 0 && (Ndim % 64) == 0; }
+
+}  // namespace
+
+// ---- C ABI (declared in include/unet_hip.h) -----------------------------------------------------------------
+extern "C" int unet_conv3x3_mfma_supported(int Cin, int Cout) { return igemm_shape_ok(Cin, Cout) ? 1 : 0; }
+
+extern "C" int unet_conv3x3_fwd_mfma(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                     int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    UNET_CHECK_ARG(x && w && out && N > 0 && H > 0 && W > 0);
+    UNET_CHECK_ARG(igemm_shape_ok(Cin, Cout) && ldx >= Cin && ldo >= Cout && (ldx % 4) == 0);
+    UNET_CHECK_ARG(unet_aligned16(x) && unet_aligned16(w));
+    IgemmArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo;
+    a.N = N; a.H = H; a.W = W; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W;
+    a.Kdim = Cin; a.Ndim = Cout; a.in_scale = 1; a.out_scale = 1; a.relu = relu; a.flip = 0; a.tap_by_z = 0;
+    return launch_igemm<0, false>(a, 1, (hipStream_t)stream);
+}
+
+// dx[N,H,W,Cin] = sum_{a,b,co} dz[n, y-(a-1), x-(b-1), co] * w[a,b,ci,co]   (w is the forward HWIO kernel)
+extern "C" int unet_conv3x3_dgrad_mfma(const float* dz, int lddz, const float* w, float* dx, int lddx,
+                                       int N, int H, int W, int Cin, int Cout, void* stream) {
+    UNET_CHECK_ARG(dz && w && dx && N > 0 && H > 0 && W > 0);
+    UNET_CHECK_ARG(igemm_shape_ok(Cout, Cin) && lddz >= Cout && lddx >= Cin && (lddz % 4) == 0);
+    UNET_CHECK_ARG(unet_aligned16(dz) && unet_aligned16(w));
+    IgemmArgs a{};
+    a.x = dz; a.w = w; a.bias = nullptr; a.out = dx; a.ldx = lddz; a.ldo = lddx;
+    a.N = N; a.H = H; a.W = W; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W;
+    a.Kdim = Cout; a.Ndim = Cin; a.in_scale = 1; a.out_scale = 1; a.relu = 0; a.flip = 1; a.tap_by_z = 0;
+    return launch_igemm<0, true>(a, 1, (hipStream_t)stream);
+}
+
+// out[n, 2i+a, 2j+b, co] = bias[co] + sum_ci x[n,i,j,ci] * w[a,b,co,ci]      (Keras Conv2DTranspose kernel layout)
+extern "C" int unet_convT2x2_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                 int N, int H, int W, int Cin, int Cout, void* stream) {
+    UNET_CHECK_ARG(x && w && out && N > 0 && H > 0 && W > 0);
+    UNET_CHECK_ARG(igemm_shape_ok(Cin, Cout) && ldx >= Cin && ldo >= Cout && (ldx % 4) == 0);
+    UNET_CHECK_ARG(unet_aligned16(x) && unet_aligned16(w));
+    IgemmArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo;
+    a.N = N; a.H = H; a.W = W; a.Hi = H; a.Wi = W; a.Ho = 2 * H; a.Wo = 2 * W;
+    a.Kdim = Cin; a.Ndim = Cout; a.in_scale = 1; a.out_scale = 2; a.relu = 0; a.flip = 0; a.tap_by_z = 1;
+    return launch_igemm<1, true>(a, 4, (hipStream_t)stream);
+}
+
+// dx[n,i,j,ci] = sum_{a,b,co} dz[n,2i+a,2j+b,co] * w[a,b,co,ci]
+extern "C" int unet_convT2x2_dgrad(const float* dz, int lddz, const float* w, float* dx, int lddx,
+                                   int N, int H, int W, int Cin, int Cout, void* stream) {
+    UNET_CHECK_ARG(dz && w && dx && N > 0 && H > 0 && W > 0);
+    UNET_CHECK_ARG(igemm_shape_ok(Cout, Cin) && lddz >= Cout && lddx >= Cin && (lddz % 4) == 0);
+    UNET_CHECK_ARG(unet_aligned16(dz) && unet_aligned16(w));
+    IgemmArgs a{};
+    a.x = dz; a.w = w; a.bias = nullptr; a.out = dx; a.ldx = lddz; a.ldo = lddx;
+    a.N = N; a.H = H; a.W = W; a.Hi = 2 * H; a.Wi = 2 * W; a.Ho = H; a.Wo = W;
+    a.Kdim = Cout; a.Ndim = Cin; a.in_scale = 2; a.out_scale = 1; a.relu = 0; a.flip = 0; a.tap_by_z = 0;
+    return launch_igemm<2, false>(a, 1, (hipStream_t)stream);
+}

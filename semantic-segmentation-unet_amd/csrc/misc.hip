@@ -1,0 +1,263 @@
+// Remaining HBM-bound ops of the train / inference step:
+//   2x2 max-pool fwd/bwd (UNet/model.py:50-53), dropout (UNet/model.py:60-63), softmax + categorical cross-entropy
+//   + accuracy + d(loss)/d(logits) (UNet/model.py:142,77,211-215,226), argmax (UNet/inference.py:107,166),
+//   Keras-Adam over the flat parameter buffer (UNet/model.py:79,223), NCHW -> NHWC input permute.
+#include "common.h"
+
+namespace {
+
+template <int VEC> __device__ __forceinline__ void vload(float (&v)[VEC], const float* p) {
+    if constexpr (VEC == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    else v[0] = *p;
+}
+template <int VEC> __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
+    else *p = v[0];
+}
+
+// ---- max-pool 2x2 stride 2; ties -> first max in row-major window order (a*2+b) --------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+        uint8_t* __restrict__ idx, int N, int H, int W, int C) {
+    const int H2 = H / 2, W2 = W / 2, nq = C / VEC;
+    const long total = (long)N * H2 * W2 * nq, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        long t = i; const int cq = (int)(t % nq); t /= nq;
+        const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const int n = (int)(t / H2);
+        const long opix = ((long)n * H2 + oy) * W2 + ox;
+        float best[VEC]; uint8_t bi[VEC];
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            float v[VEC];
+            vload<VEC>(v, x + ((size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1)) * ldx + cq * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (pos == 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)pos; }
+            }
+        }
+        vstore<VEC>(y + (size_t)opix * ldy + cq * VEC, best);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) idx[(size_t)opix * C + cq * VEC + e] = bi[e];
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx,
+        float* __restrict__ dx, int lddx, int N, int H, int W, int C, int accumulate) {
+    const int H2 = H / 2, W2 = W / 2, nq = C / VEC;
+    const long total = (long)N * H2 * W2 * nq, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        long t = i; const int cq = (int)(t % nq); t /= nq;
+        const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const int n = (int)(t / H2);
+        const long opix = ((long)n * H2 + oy) * W2 + ox;
+        float g[VEC]; vload<VEC>(g, dy + (size_t)opix * lddy + cq * VEC);
+        uint8_t bi[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) bi[e] = idx[(size_t)opix * C + cq * VEC + e];
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            float* dst = dx + ((size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1)) * lddx + cq * VEC;
+            float v[VEC];
+            if (accumulate) vload<VEC>(v, dst);
+            else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) if (bi[e] == pos) v[e] += g[e];
+            vstore<VEC>(dst, v);
+        }
+    }
+}
+
+// ---- dropout: out = x * keep / (1 - rate); keep from an explicit mask (tests) or the counter hash --------------
+template <int VEC>
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo,
+        long P, int C, const uint8_t* __restrict__ mask, uint32_t seed, float rate, float scale) {
+    const int nq = C / VEC;
+    const long total = P * nq, stride = (long)gridDim.x * 256;
+    const uint32_t thr = (uint32_t)((double)rate * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)rate * 4294967296.0);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const long pix = i / nq; const int c0 = (int)(i - pix * nq) * VEC;
+        float v[VEC]; vload<VEC>(v, x + (size_t)pix * ldx + c0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const uint64_t el = (uint64_t)pix * C + c0 + e;
+            const bool keep = mask ? (mask[el] != 0) : (unet_hash32(seed, el) >= thr);
+            v[e] = keep ? v[e] * scale : 0.f;
+        }
+        vstore<VEC>(out + (size_t)pix * ldo + c0, v);
+    }
+}
+
+// ---- softmax + CE (from logits) + accuracy + dlogits ------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ z, int ldz, const int* __restrict__ labels,
+        float* __restrict__ prob, float* __restrict__ dz, int lddz, long P, int K, float label_smoothing, float grad_scale,
+        double* __restrict__ part_loss, unsigned long long* __restrict__ part_correct) {
+    __shared__ double sL[256];
+    __shared__ unsigned int sC[256];
+    double lsum = 0.0; unsigned int csum = 0;
+    const long stride = (long)gridDim.x * 256;
+    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < P; pix += stride) {
+        const float* zp = z + (size_t)pix * ldz;
+        float m = zp[0]; int am = 0;
+        for (int k = 1; k < K; ++k) { const float v = zp[k]; if (v > m) { m = v; am = k; } }
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(zp[k] - m);
+        const float lse = logf(se), inv = 1.f / se;
+        float ysum = 0.f, ell = 0.f; int al = 0; int lbest = 0;
+        if (labels) {
+            lbest = labels[(size_t)pix * K];
+            for (int k = 0; k < K; ++k) {
+                const int li = labels[(size_t)pix * K + k];
+                if (li > lbest) { lbest = li; al = k; }
+                float y = (float)li;
+                if (label_smoothing > 0.f) y = y * (1.f - label_smoothing) + label_smoothing / (float)K;
+                ysum += y; ell -= y * ((zp[k] - m) - lse);
+            }
+        }
+        for (int k = 0; k < K; ++k) {
+            const float pk = expf(zp[k] - m) * inv;
+            if (prob) prob[(size_t)pix * K + k] = pk;
+            if (dz) {
+                float y = (float)labels[(size_t)pix * K + k];
+                if (label_smoothing > 0.f) y = y * (1.f - label_smoothing) + label_smoothing / (float)K;
+                dz[(size_t)pix * lddz + k] = (pk * ysum - y) * grad_scale;
+            }
+        }
+        lsum += (double)ell; csum += (labels && al == am) ? 1u : 0u;
+    }
+    sL[threadIdx.x] = lsum; sC[threadIdx.x] = csum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { sL[threadIdx.x] += sL[threadIdx.x + s]; sC[threadIdx.x] += sC[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part_loss[blockIdx.x] = sL[0]; part_correct[blockIdx.x] = sC[0]; }
+}
+
+__global__ void softmax_ce_finalize_kernel(const double* part_loss, const unsigned long long* part_correct, int nblk,
+                                           float loss_scale, float* loss_out, float* correct_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0; unsigned long long c = 0;
+        for (int k = 0; k < nblk; ++k) { s += part_loss[k]; c += part_correct[k]; }
+        if (loss_out) loss_out[0] = (float)(s * (double)loss_scale);
+        if (correct_out) correct_out[0] = (float)c;
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ p, int ldp, int* __restrict__ out, long P, int K) {
+    const long stride = (long)gridDim.x * 256;
+    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < P; pix += stride) {
+        const float* zp = p + (size_t)pix * ldp;
+        float m = zp[0]; int am = 0;
+        for (int k = 1; k < K; ++k) { const float v = zp[k]; if (v > m) { m = v; am = k; } }
+        out[pix] = am;
+    }
+}
+
+// ---- Keras Adam: m += (g-m)(1-b1); v += (g*g-v)(1-b2); theta -= alpha*m/(sqrt(v)+eps), alpha from the host ----
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m,
+        float* __restrict__ v, long n4, float alpha, float one_minus_b1, float one_minus_b2, float eps) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        f32x4 t = reinterpret_cast<f32x4*>(theta)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mm[e] = mm[e] + (gg[e] - mm[e]) * one_minus_b1;
+            vv[e] = vv[e] + (gg[e] * gg[e] - vv[e]) * one_minus_b2;
+            t[e] = t[e] - alpha * mm[e] / (sqrtf(vv[e]) + eps);
+        }
+        reinterpret_cast<f32x4*>(theta)[i] = t;
+        reinterpret_cast<f32x4*>(m)[i] = mm; reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, long HW) {
+    const long total = (long)N * C * HW, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        long t = i; const int c = (int)(t % C); t /= C; const long hw = t % HW; const long n = t / HW;
+        y[i] = x[((size_t)n * C + c) * HW + hw];
+    }
+}
+
+int grid_for(long total, int cap) { long b = (total + 255) / 256; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b; }
+
+}  // namespace
+
+extern "C" int unet_maxpool2x2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    UNET_CHECK_ARG(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && ldx >= C && ldy >= C);
+    const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && unet_aligned16(x) && unet_aligned16(y);
+    const long total = (long)N * (H / 2) * (W / 2) * (v4 ? C / 4 : C);
+    if (v4) maxpool_fwd_kernel<4><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, idx, N, H, W, C);
+    else    maxpool_fwd_kernel<1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, idx, N, H, W, C);
+    return UNET_LAUNCH_STATUS();
+}
+
+// H, W are the dims of dx (the pool input); dy is [N, H/2, W/2, C].
+extern "C" int unet_maxpool2x2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx,
+                                   int N, int H, int W, int C, int accumulate, void* stream) {
+    UNET_CHECK_ARG(dy && dx && idx && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && lddx >= C && lddy >= C);
+    const bool v4 = C % 4 == 0 && lddx % 4 == 0 && lddy % 4 == 0 && unet_aligned16(dx) && unet_aligned16(dy);
+    const long total = (long)N * (H / 2) * (W / 2) * (v4 ? C / 4 : C);
+    if (v4) maxpool_bwd_kernel<4><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(dy, lddy, idx, dx, lddx, N, H, W, C, accumulate);
+    else    maxpool_bwd_kernel<1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(dy, lddy, idx, dx, lddx, N, H, W, C, accumulate);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_dropout(const float* x, int ldx, float* out, int ldo, long P, int C, const uint8_t* mask,
+                            uint32_t seed, float rate, void* stream) {
+    UNET_CHECK_ARG(x && out && P > 0 && C > 0 && ldx >= C && ldo >= C && rate >= 0.f && rate < 1.f);
+    const float scale = 1.f / (1.f - rate);
+    const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(out);
+    const long total = P * (v4 ? C / 4 : C);
+    if (v4) dropout_kernel<4><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, out, ldo, P, C, mask, seed, rate, scale);
+    else    dropout_kernel<1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, out, ldo, P, C, mask, seed, rate, scale);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" size_t unet_softmax_ce_workspace(long P) { return (size_t)grid_for(P, 1024) * 16; }
+
+// prob, dlogits, labels, loss_out, correct_out may each be null (inference: prob only).
+extern "C" int unet_softmax_ce(const float* logits, int ldz, const int* labels_onehot, float* prob, float* dlogits, int lddz,
+        long P, int K, float label_smoothing, float loss_scale, float grad_scale, float* loss_out, float* correct_out,
+        void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(logits && ws && P > 0 && K > 0 && ldz >= K && (!dlogits || (labels_onehot && lddz >= K)));
+    UNET_CHECK_ARG((!loss_out && !correct_out) || labels_onehot);
+    const int nblk = grid_for(P, 1024);
+    if (ws_bytes < unet_softmax_ce_workspace(P)) return UNET_ENOSPC;
+    double* pl = (double*)ws;
+    unsigned long long* pc = (unsigned long long*)((char*)ws + (size_t)nblk * 8);
+    softmax_ce_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(logits, ldz, labels_onehot, prob, dlogits, lddz, P, K,
+                                                             label_smoothing, grad_scale, pl, pc);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    if (loss_out || correct_out) {
+        softmax_ce_finalize_kernel<<<1, 64, 0, (hipStream_t)stream>>>(pl, pc, nblk, loss_scale, loss_out, correct_out);
+        rc = UNET_LAUNCH_STATUS();
+    }
+    return rc;
+}
+
+extern "C" int unet_argmax(const float* p, int ldp, int* out, long P, int K, void* stream) {
+    UNET_CHECK_ARG(p && out && P > 0 && K > 0 && ldp >= K);
+    argmax_kernel<<<grid_for(P, 4096), 256, 0, (hipStream_t)stream>>>(p, ldp, out, P, K);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_adam_keras(float* theta, const float* grad, float* m, float* v, long n, float alpha, float beta1,
+                               float beta2, float eps, void* stream) {
+    UNET_CHECK_ARG(theta && grad && m && v && n > 0 && n % 4 == 0);
+    UNET_CHECK_ARG(unet_aligned16(theta) && unet_aligned16(grad) && unet_aligned16(m) && unet_aligned16(v));
+    adam_kernel<<<grid_for(n / 4, 4096), 256, 0, (hipStream_t)stream>>>(theta, grad, m, v, n / 4, alpha, 1.f - beta1, 1.f - beta2, eps);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+    UNET_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0);
+    nchw_to_nhwc_kernel<<<grid_for((long)N * C * H * W, 8192), 256, 0, (hipStream_t)stream>>>(x, y, N, C, (long)H * W);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_hip_abi_version(void) { return 1; }

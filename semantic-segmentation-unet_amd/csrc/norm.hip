@@ -1,0 +1,269 @@
+// BatchNormalization(axis=channels) as used by every layer of the reference (UNet/model.py:36,47): it follows the
+// ReLU, so statistics are over the post-activation tensor r.  Training mode: biased batch variance, eps inside the
+// sqrt, moving stats updated with momentum (unbiased variance fed to moving_variance, Keras fused path).
+//
+// All kernels are HBM-bound streams over NHWC tensors with channel stride `ld`.  Thread layout: `tpp` consecutive
+// lanes cover one pixel's channels (VEC=4: one float4 quad per lane; VEC=1: one channel per lane for the narrow
+// class-map tensors), 256/tpp pixels in flight per block.  Per-channel sums are accumulated in fp64 per lane,
+// combined through LDS, written as per-block partials and summed in a fixed order (bit-stable run to run).
+#include "common.h"
+
+namespace {
+
+template <int VEC> __device__ __forceinline__ void vload(float (&v)[VEC], const float* p) {
+    if constexpr (VEC == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    else v[0] = *p;
+}
+template <int VEC> __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
+    else *p = v[0];
+}
+
+struct Lay { int tpp, npl, q, pl, c0; bool active; };
+
+template <int VEC> __device__ __forceinline__ Lay make_lay(int C, int tpp) {
+    Lay l; l.tpp = tpp; l.npl = 256 / tpp; l.q = threadIdx.x % tpp; l.pl = threadIdx.x / tpp;
+    l.c0 = l.q * VEC; l.active = l.c0 < C; return l;
+}
+
+// block-level combine of NV per-lane fp64 vectors (each VEC wide) over the pixel lanes; result to part[v][blk][C]
+template <int VEC, int NV>
+__device__ __forceinline__ void block_combine(double (&acc)[NV][VEC], const Lay& l, int C, double* part, int nblk, double* sR) {
+    // sR: [npl][NV][tpp*VEC]
+    const int cw = l.tpp * VEC;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sR[((size_t)l.pl * NV + v) * cw + l.c0 + e] = acc[v][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV * cw; i += 256) {
+        const int v = i / cw, c = i % cw;
+        if (c < C) {
+            double s = 0.0;
+            for (int k = 0; k < l.npl; ++k) s += sR[((size_t)k * NV + v) * cw + c];
+            part[((size_t)v * nblk + blockIdx.x) * C + c] = s;
+        }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ r, int ldr, long P, int C, int tpp,
+                                                       long ppb, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double sRd[];
+    const Lay l = make_lay<VEC>(C, tpp);
+    const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P) p1 = P;
+    double acc[2][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { acc[0][e] = 0.0; acc[1][e] = 0.0; }
+    if (l.active)
+        for (long pix = p0 + l.pl; pix < p1; pix += l.npl) {
+            float v[VEC]; vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { acc[0][e] += (double)v[e]; acc[1][e] += (double)v[e] * (double)v[e]; }
+        }
+    block_combine<VEC, 2>(acc, l, C, part, gridDim.x, sRd);
+}
+
+__global__ void bn_train_finalize_kernel(const double* __restrict__ part, int nblk, long P, int C,
+        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, int unbiased,
+        float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nblk; ++k) { s += part[(size_t)k * C + c]; ss += part[((size_t)nblk + k) * C + c]; }
+    const double m = s / (double)P;
+    double var = ss / (double)P - m * m;
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    mean[c] = (float)m; invstd[c] = (float)inv;
+    const double a = (double)gamma[c] * inv;
+    scale[c] = (float)a; shift[c] = (float)((double)beta[c] - m * a);
+    if (moving_mean) {
+        const double uv = (unbiased && P > 1) ? var * ((double)P / (double)(P - 1)) : var;
+        moving_mean[c] = (float)((double)moving_mean[c] * momentum + m * (1.0 - (double)momentum));
+        moving_var[c] = (float)((double)moving_var[c] * momentum + uv * (1.0 - (double)momentum));
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float eps,
+                                      int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double inv = 1.0 / sqrt((double)mv[c] + (double)eps);
+    const double a = (double)gamma[c] * inv;
+    scale[c] = (float)a; shift[c] = (float)((double)beta[c] - (double)mm[c] * a);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
+        const float* __restrict__ shift, float* __restrict__ y, int ldy, long P, int C) {
+    const int nq = C / VEC;
+    const long total = P * nq, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const long pix = i / nq; const int c0 = (int)(i - pix * nq) * VEC;
+        float v[VEC], a[VEC], b[VEC];
+        vload<VEC>(v, r + (size_t)pix * ldr + c0); vload<VEC>(a, scale + c0); vload<VEC>(b, shift + c0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = fmaf(a[e], v[e], b[e]);
+        vstore<VEC>(y + (size_t)pix * ldy + c0, v);
+    }
+}
+
+// backward pass 1: per-channel sum(dy) and sum(dy * xhat)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
+        int ldr, const float* __restrict__ mean, const float* __restrict__ invstd, long P, int C, int tpp, long ppb,
+        double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double sRd[];
+    const Lay l = make_lay<VEC>(C, tpp);
+    const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P) p1 = P;
+    double acc[2][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { acc[0][e] = 0.0; acc[1][e] = 0.0; }
+    if (l.active) {
+        float mu[VEC], is[VEC]; vload<VEC>(mu, mean + l.c0); vload<VEC>(is, invstd + l.c0);
+        for (long pix = p0 + l.pl; pix < p1; pix += l.npl) {
+            float g[VEC], v[VEC];
+            vload<VEC>(g, dy + (size_t)pix * lddy + l.c0); vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (v[e] - mu[e]) * is[e];
+                acc[0][e] += (double)g[e]; acc[1][e] += (double)g[e] * (double)xh;
+            }
+        }
+    }
+    block_combine<VEC, 2>(acc, l, C, part, gridDim.x, sRd);
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) { s1 += part[(size_t)k * C + c]; s2 += part[((size_t)nblk + k) * C + c]; }
+    dbeta[c] = (float)s1; dgamma[c] = (float)s2;
+}
+
+// backward pass 2: dz = relu'(r) * gamma*invstd * (dy - mean(dy) - xhat * mean(dy*xhat)); also per-channel sum(dz)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
+        int ldr, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+        const float* __restrict__ dgamma, const float* __restrict__ dbeta, long P, int C, int tpp, long ppb, int relu,
+        float* __restrict__ dz, int lddz, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double sRd[];
+    const Lay l = make_lay<VEC>(C, tpp);
+    const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P) p1 = P;
+    double acc[1][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = 0.0;
+    if (l.active) {
+        float mu[VEC], is[VEC], ga[VEC], dg[VEC], db[VEC];
+        vload<VEC>(mu, mean + l.c0); vload<VEC>(is, invstd + l.c0); vload<VEC>(ga, gamma + l.c0);
+        vload<VEC>(dg, dgamma + l.c0); vload<VEC>(db, dbeta + l.c0);
+        float a[VEC], c1[VEC], c2[VEC];
+        const float invP = 1.0f / (float)P;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { a[e] = ga[e] * is[e]; c1[e] = db[e] * invP; c2[e] = dg[e] * invP; }
+        for (long pix = p0 + l.pl; pix < p1; pix += l.npl) {
+            float g[VEC], v[VEC], o[VEC];
+            vload<VEC>(g, dy + (size_t)pix * lddy + l.c0); vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (v[e] - mu[e]) * is[e];
+                float d = a[e] * (g[e] - c1[e] - xh * c2[e]);
+                if (relu && !(v[e] > 0.f)) d = 0.f;
+                o[e] = d; acc[0][e] += (double)d;
+            }
+            vstore<VEC>(dz + (size_t)pix * lddz + l.c0, o);
+        }
+    }
+    block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
+}
+
+__global__ void colsum_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * C + c];
+    out[c] = (float)s;
+}
+
+struct Plan { int vec, tpp, nblk; long ppb; size_t smem2, smem1; };
+
+bool make_plan(long P, int C, int ld_a, int ld_b, int ld_c, bool aligned, Plan* pl) {
+    int vec = 0, tpp = 0;
+    if (C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && ld_c % 4 == 0 && aligned) { vec = 4; tpp = C / 4; }
+    else if (C <= 256) { vec = 1; tpp = 1; while (tpp < C) tpp <<= 1; }
+    else return false;
+    long nblk = (P + 511) / 512; if (nblk > 1024) nblk = 1024; if (nblk < 1) nblk = 1;
+    pl->vec = vec; pl->tpp = tpp; pl->nblk = (int)nblk; pl->ppb = (P + nblk - 1) / nblk;
+    pl->smem2 = (size_t)256 * vec * 2 * sizeof(double); pl->smem1 = (size_t)256 * vec * sizeof(double);
+    return true;
+}
+
+int nblk_for(long P) { long n = (P + 511) / 512; if (n > 1024) n = 1024; if (n < 1) n = 1; return (int)n; }
+
+}  // namespace
+
+extern "C" size_t unet_bn_workspace(long P, int C) { return (size_t)3 * nblk_for(P) * C * sizeof(double); }
+
+extern "C" int unet_bn_train_stats(const float* r, int ldr, long P, int C, const float* gamma, const float* beta,
+        float eps, float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
+        float* mean, float* invstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(r && gamma && beta && mean && invstd && scale && shift && ws && P > 0 && C > 0 && ldr >= C);
+    UNET_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
+    Plan pl;
+    UNET_CHECK_ARG(make_plan(P, C, ldr, 4, 4, unet_aligned16(r), &pl));
+    if (ws_bytes < unet_bn_workspace(P, C)) return UNET_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)ws;
+    if (pl.vec == 4) bn_stats_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(r, ldr, P, C, pl.tpp, pl.ppb, part);
+    else             bn_stats_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(r, ldr, P, C, pl.tpp, pl.ppb, part);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    bn_train_finalize_kernel<<<unet_cdiv(C, 128), 128, 0, st>>>(part, pl.nblk, P, C, gamma, beta, eps, momentum,
+        unbiased_moving_var, moving_mean, moving_var, mean, invstd, scale, shift);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_bn_eval_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                                   float eps, int C, float* scale, float* shift, void* stream) {
+    UNET_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && C > 0);
+    bn_eval_coeffs_kernel<<<unet_cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(gamma, beta, moving_mean, moving_var, eps, C, scale, shift);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_bn_apply(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy,
+                             long P, int C, void* stream) {
+    UNET_CHECK_ARG(r && scale && shift && y && P > 0 && C > 0 && ldr >= C && ldy >= C);
+    const bool v4 = C % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0 && unet_aligned16(r) && unet_aligned16(y) &&
+                    unet_aligned16(scale) && unet_aligned16(shift);
+    const long total = v4 ? P * (C / 4) : P * C;
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    if (v4) bn_apply_kernel<4><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C);
+    else    bn_apply_kernel<1><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
+        const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta, float* dbias,
+        void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(dy && r && gamma && mean && invstd && dz && dgamma && dbeta && dbias && ws && P > 0 && C > 0);
+    UNET_CHECK_ARG(lddy >= C && ldr >= C && lddz >= C);
+    Plan pl;
+    const bool al = unet_aligned16(dy) && unet_aligned16(r) && unet_aligned16(dz) && unet_aligned16(gamma) && unet_aligned16(mean) &&
+                    unet_aligned16(invstd) && unet_aligned16(dgamma) && unet_aligned16(dbeta);
+    UNET_CHECK_ARG(make_plan(P, C, lddy, ldr, lddz, al, &pl));
+    if (ws_bytes < unet_bn_workspace(P, C)) return UNET_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)ws;
+    if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part);
+    else             bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    bn_bwd_finalize_kernel<<<unet_cdiv(C, 128), 128, 0, st>>>(part, pl.nblk, C, dgamma, dbeta);
+    rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    double* part2 = part + (size_t)2 * pl.nblk * C;
+    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
+    else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
+    rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    colsum_finalize_kernel<<<unet_cdiv(C, 128), 128, 0, st>>>(part2, pl.nblk, C, dbias);
+    return UNET_LAUNCH_STATUS();
+}

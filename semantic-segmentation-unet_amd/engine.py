@@ -1,0 +1,377 @@
+"""Static forward / backward / Adam schedule of the U-Net hot path on one MI355X.
+
+Replaces the part of TensorFlow the reference's `UNet` class uses (UNet/model.py:85-146 graph, :204-228 train step,
+:237-250 test step): every op is a call into the C-ABI library (include/unet_hip.h) on raw device pointers.  PyTorch is
+only the allocator (tensors own the HBM), the stream provider and -- in parallel.py -- the RCCL binding; there is no
+autograd graph: the backward schedule below is written out by hand.
+
+HBM layout
+  * activations: fp32 NHWC; each layer keeps r (post-ReLU, pre-BN; BN backward + ReLU mask need it) and y (BN output =
+    the next conv's input, needed by its weight gradient);
+  * the four skip concatenations are zero-copy: `cat_l` is one [N,H,W,2C] buffer; the encoder's BN-apply writes
+    channels [0,C), the decoder's transposed-conv BN-apply writes [C,2C); consumers read with channel stride 2C.
+    Gradients mirror this (`dcat_l`): the decoder dgrad fills all 2C channels, max-pool backward accumulates into [0,C);
+  * parameters, gradients and both Adam moments are four flat fp32 buffers in backward-completion order
+    (logits first, conv_1a last) so data-parallel gradient buckets are contiguous ranges that become ready in order.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from ._lib import lib
+
+BASE = 64                      # UNet._BASELINE_FEATURE_DEPTH  (reference UNet/model.py:20)
+SIZE_FACTOR = 16               # UNet.SIZE_FACTOR              (reference UNet/model.py:25)
+
+# Keras defaults the reference relies on (SURVEY.md 8(a) "(K)"): one place to flip them.
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.99
+BN_MOVING_VAR_UNBIASED = 1
+DROPOUT_RATE = 0.5
+ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-7
+
+
+def layer_table(number_channels, number_classes):
+    """(name, kind, Cin, Cout) in Keras layer-creation order (reference UNet/model.py:85-136)."""
+    C, K, B = number_channels, number_classes, BASE
+    return [
+        ("conv_1a", "conv3", C, B), ("conv_1b", "conv3", B, B),
+        ("conv_2a", "conv3", B, 2 * B), ("conv_2b", "conv3", 2 * B, 2 * B),
+        ("conv_3a", "conv3", 2 * B, 4 * B), ("conv_3b", "conv3", 4 * B, 4 * B),
+        ("conv_4a", "conv3", 4 * B, 8 * B), ("conv_4b", "conv3", 8 * B, 8 * B),
+        ("bott_a", "conv3", 8 * B, 16 * B), ("bott_b", "conv3", 16 * B, 16 * B),
+        ("up_4", "deconv", 16 * B, 8 * B), ("dec_4a", "conv3", 16 * B, 8 * B), ("dec_4b", "conv3", 8 * B, 8 * B),
+        ("up_3", "deconv", 8 * B, 4 * B), ("dec_3a", "conv3", 8 * B, 4 * B), ("dec_3b", "conv3", 4 * B, 4 * B),
+        ("up_2", "deconv", 4 * B, 2 * B), ("dec_2a", "conv3", 4 * B, 2 * B), ("dec_2b", "conv3", 2 * B, 2 * B),
+        ("up_1", "deconv", 2 * B, B), ("dec_1a", "conv3", 2 * B, B), ("dec_1b", "conv3", B, B),
+        ("logits", "conv1", B, K),
+    ]
+
+
+def kernel_shape(kind, cin, cout):
+    return {"conv3": (3, 3, cin, cout), "conv1": (1, 1, cin, cout), "deconv": (2, 2, cout, cin)}[kind]
+
+
+BACKWARD_ORDER = ["logits", "dec_1b", "dec_1a", "up_1", "dec_2b", "dec_2a", "up_2", "dec_3b", "dec_3a", "up_3",
+                  "dec_4b", "dec_4a", "up_4", "bott_b", "bott_a", "conv_4b", "conv_4a", "conv_3b", "conv_3a",
+                  "conv_2b", "conv_2a", "conv_1b", "conv_1a"]
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ld(t):
+    """channel stride (elements between consecutive pixels) of an NHWC view; checks the view is a plain channel slice."""
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    assert t.stride(3) == 1 and t.stride(1) == w * ld and t.stride(0) == h * w * ld, "not an NHWC channel slice"
+    return ld
+
+
+class Engine:
+    def __init__(self, number_classes, number_channels, device="cuda", seed=0):
+        self.K, self.C = number_classes, number_channels
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("the U-Net hot path runs on an MI355X only (device must be cuda); no CPU fallback exists")
+        self.L = lib()
+        self.layers = layer_table(number_channels, number_classes)
+        self.kind = {n: k for n, k, _, _ in self.layers}
+        self.cin = {n: ci for n, _, ci, _ in self.layers}
+        self.cout = {n: co for n, _, _, co in self.layers}
+        # ---- flat parameter / gradient / moment buffers, backward-completion order, every tensor padded to 4 floats
+        self.slices = {}
+        off = 0
+        self.layer_range = {}
+        for name in BACKWARD_ORDER:
+            start = off
+            for suffix, shape in (("kernel", kernel_shape(self.kind[name], self.cin[name], self.cout[name])),
+                                  ("bias", (self.cout[name],)), ("gamma", (self.cout[name],)), ("beta", (self.cout[name],))):
+                n = int(np.prod(shape))
+                self.slices[name + "/" + suffix] = (off, n, shape)
+                off += (n + 3) // 4 * 4
+            self.layer_range[name] = (start, off)
+        self.n_flat = off
+        self.theta = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.grad = torch.zeros_like(self.theta)
+        self.adam_m = torch.zeros_like(self.theta)
+        self.adam_v = torch.zeros_like(self.theta)
+        self.p = {k: self.theta[o:o + n].view(shape) for k, (o, n, shape) in self.slices.items()}
+        self.g = {k: self.grad[o:o + n].view(shape) for k, (o, n, shape) in self.slices.items()}
+        self.moving = {}
+        self.stat = {}
+        for name, _, _, co in self.layers:
+            self.moving[name + "/moving_mean"] = torch.zeros(co, dtype=torch.float32, device=self.dev)
+            self.moving[name + "/moving_var"] = torch.ones(co, dtype=torch.float32, device=self.dev)
+            cp = (co + 3) // 4 * 4
+            self.stat[name] = torch.zeros(4, cp, dtype=torch.float32, device=self.dev)   # mean, invstd, scale, shift
+        self.iterations = 0
+        self.bufs = {}
+        self._ws = None
+        self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.dev)             # [loss, correct]
+        self.dropout_seed = seed
+        self.init_parameters(seed)
+        self.on_layer_grads_ready = None        # hook(name) for data-parallel bucketing (parallel.py)
+
+    # ------------------------------------------------------------------------------------------------ parameters
+    def trainable_names(self):
+        return [n + "/" + s for n, _, _, _ in self.layers for s in ("kernel", "bias", "gamma", "beta")]
+
+    def init_parameters(self, seed=0):
+        """Keras defaults: glorot-uniform kernels, zero bias, gamma 1, beta 0, moving mean 0 / var 1."""
+        rng = np.random.default_rng(seed)
+        vals = {}
+        for name, kind, cin, cout in self.layers:
+            shp = kernel_shape(kind, cin, cout)
+            rf = shp[0] * shp[1]
+            limit = math.sqrt(6.0 / (rf * shp[2] + rf * shp[3]))
+            vals[name + "/kernel"] = rng.uniform(-limit, limit, size=shp).astype(np.float32)
+            vals[name + "/bias"] = np.zeros(cout, np.float32)
+            vals[name + "/gamma"] = np.ones(cout, np.float32)
+            vals[name + "/beta"] = np.zeros(cout, np.float32)
+            vals[name + "/moving_mean"] = np.zeros(cout, np.float32)
+            vals[name + "/moving_var"] = np.ones(cout, np.float32)
+        self.load_parameters(vals)
+
+    def load_parameters(self, values):
+        """values: {keras-style name: array in the Keras layout}.  Resets nothing else."""
+        for k, v in values.items():
+            t = torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float32)))
+            if k in self.p:
+                self.p[k].copy_(t.view(self.p[k].shape))
+            elif k in self.moving:
+                self.moving[k].copy_(t)
+            else:
+                raise KeyError(k)
+
+    def export_parameters(self):
+        out = {k: v.detach().cpu().numpy().copy() for k, v in self.p.items()}
+        out.update({k: v.detach().cpu().numpy().copy() for k, v in self.moving.items()})
+        return out
+
+    def export_gradients(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.g.items()}
+
+    # ------------------------------------------------------------------------------------------------ buffers
+    def _buf(self, name, shape, dtype=torch.float32):
+        t = self.bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.dev)
+            self.bufs[name] = t
+        return t
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.dev)
+        return self._ws
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def _block_fwd(self, name, x, y_out, training):
+        """x: NHWC view (input of the layer), y_out: NHWC view the BN output is written to."""
+        L, st = self.L, self._stream()
+        kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
+        n, h, w, _ = x.shape
+        w_, b_ = self.p[name + "/kernel"], self.p[name + "/bias"]
+        if kind == "deconv":
+            r = self._buf("r_" + name, (n, 2 * h, 2 * w, cout))
+            L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, st)
+        elif kind == "conv1":
+            r = self._buf("r_" + name, (n, h, w, cout))
+            L.unet_conv1x1_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
+        else:
+            r = self._buf("r_" + name, (n, h, w, cout))
+            if L.unet_conv3x3_mfma_supported(cin, cout):
+                L.unet_conv3x3_fwd_mfma(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+            else:
+                L.unet_conv3x3_fwd_direct(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+        P = r.shape[0] * r.shape[1] * r.shape[2]
+        s = self.stat[name]
+        gm, bt = self.p[name + "/gamma"], self.p[name + "/beta"]
+        mm, mv = self.moving[name + "/moving_mean"], self.moving[name + "/moving_var"]
+        if training:
+            nb = L.unet_bn_workspace(P, cout)
+            ws = self._workspace(nb)
+            L.unet_bn_train_stats(_p(r), cout, P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM, BN_MOVING_VAR_UNBIASED,
+                                  _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(ws), nb, st)
+        else:
+            L.unet_bn_eval_coeffs(_p(gm), _p(bt), _p(mm), _p(mv), BN_EPS, cout, _p(s[2]), _p(s[3]), st)
+        L.unet_bn_apply(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), P, cout, st)
+        self.saved[name] = (x, r)
+        return y_out
+
+    def _dropout(self, t, key, masks, backward=False):
+        n, h, w, c = t.shape
+        m = None
+        if masks is not None:
+            m = masks[key]
+        seed = (self.dropout_seed * 1000003 + self.iterations * 2 + (0 if key == "drop_4" else 1)) & 0xFFFFFFFF
+        self.L.unet_dropout(_p(t), _ld(t), _p(t), _ld(t), n * h * w, c, _p(m), seed, DROPOUT_RATE, self._stream())
+
+    def _prep_masks(self, dropout_masks):
+        """NCHW 0/1 arrays (the oracle's convention) -> dense NHWC uint8 device tensors."""
+        if dropout_masks is None:
+            return None
+        out = {}
+        for k, v in dropout_masks.items():
+            a = np.ascontiguousarray(np.asarray(v).transpose(0, 2, 3, 1)).astype(np.uint8)
+            out[k] = torch.as_tensor(a).to(self.dev)
+        return out
+
+    def forward(self, images, training=False, dropout_masks=None, labels=None, global_batch_size=None,
+                label_smoothing=0.0, want_grad=False):
+        """images: fp32 [N,C,H,W] (reference input contract, UNet/imagereader.py:298-300).  Returns softmax [N,H,W,K]
+        (a device tensor owned by the engine; valid until the next call).  With labels (int32 one-hot [N,H,W,K]) the
+        loss and the count of correctly classified pixels land in self.loss_buf."""
+        L, st = self.L, self._stream()
+        x = images
+        assert x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.C, "images must be fp32 [N,C,H,W]"
+        x = x.to(self.dev).contiguous()
+        n, c, h, w = x.shape
+        if h % SIZE_FACTOR or w % SIZE_FACTOR:
+            raise IOError("Input Image tile size must be a multiple of %d" % SIZE_FACTOR)   # cf. UNet/inference.py:39-40
+        if c == 1:
+            x0 = x.view(n, h, w, 1)
+        else:
+            x0 = self._buf("x_nhwc", (n, h, w, c))
+            L.unet_nchw_to_nhwc(_p(x), _p(x0), n, c, h, w, st)
+        self.saved = {}
+        self.masks = self._prep_masks(dropout_masks) if training else None
+        B = BASE
+        f = self._block_fwd
+        cur = x0
+        self.idx = {}
+        self.cat = {}
+        for lvl, ch in ((1, B), (2, 2 * B), (3, 4 * B), (4, 8 * B)):
+            hh, ww = cur.shape[1], cur.shape[2]
+            ya = f("conv_%da" % lvl, cur, self._buf("y_conv_%da" % lvl, (n, hh, ww, ch)), training)
+            cat = self._buf("cat_%d" % lvl, (n, hh, ww, 2 * ch))
+            self.cat[lvl] = cat
+            skip = f("conv_%db" % lvl, ya, cat[..., :ch], training)
+            if lvl == 4 and training:
+                self._dropout(skip, "drop_4", self.masks)
+            pooled = self._buf("pool_%d" % lvl, (n, hh // 2, ww // 2, ch))
+            idx = self._buf("idx_%d" % lvl, (n, hh // 2, ww // 2, ch), torch.uint8)
+            L.unet_maxpool2x2_fwd(_p(skip), _ld(skip), _p(pooled), ch, _p(idx), n, hh, ww, ch, st)
+            self.idx[lvl] = idx
+            cur = pooled
+        hh, ww = cur.shape[1], cur.shape[2]
+        ya = f("bott_a", cur, self._buf("y_bott_a", (n, hh, ww, 16 * B)), training)
+        cur = f("bott_b", ya, self._buf("y_bott_b", (n, hh, ww, 16 * B)), training)
+        if training:
+            self._dropout(cur, "drop_b", self.masks)
+        for lvl, ch in ((4, 8 * B), (3, 4 * B), (2, 2 * B), (1, B)):
+            cat = self.cat[lvl]
+            f("up_%d" % lvl, cur, cat[..., ch:], training)
+            hh, ww = cat.shape[1], cat.shape[2]
+            ya = f("dec_%da" % lvl, cat, self._buf("y_dec_%da" % lvl, (n, hh, ww, ch)), training)
+            cur = f("dec_%db" % lvl, ya, self._buf("y_dec_%db" % lvl, (n, hh, ww, ch)), training)
+        yl = f("logits", cur, self._buf("y_logits", (n, h, w, self.K)), training)
+        prob = self._buf("softmax", (n, h, w, self.K))
+        P = n * h * w
+        nb = L.unet_softmax_ce_workspace(P)
+        ws = self._workspace(nb)
+        if labels is None:
+            L.unet_softmax_ce(_p(yl), self.K, None, _p(prob), None, 0, P, self.K, 0.0, 0.0, 0.0, None, None, _p(ws), nb, st)
+        else:
+            lab = labels.to(self.dev).contiguous()
+            assert lab.dtype == torch.int32 and tuple(lab.shape) == (n, h, w, self.K), "labels must be int32 one-hot [N,H,W,K]"
+            G = global_batch_size if global_batch_size else n
+            scale = 1.0 / (float(G) * h * w)                       # sum_n / G then mean over H,W  (UNet/model.py:213-215)
+            dl = self._buf("dy_logits", (n, h, w, self.K)) if want_grad else None
+            L.unet_softmax_ce(_p(yl), self.K, _p(lab), _p(prob), _p(dl), self.K, P, self.K, float(label_smoothing), scale,
+                              scale, _p(self.loss_buf[0:1]), _p(self.loss_buf[1:2]), _p(ws), nb, st)
+            self._labels_keepalive = lab
+        return prob
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def _block_bwd(self, name, dy, need_dx=True):
+        """dy: NHWC view = gradient w.r.t. the layer's BN output.  Returns gradient w.r.t. the layer input (or None)."""
+        L, st = self.L, self._stream()
+        kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
+        x, r = self.saved[name]
+        n, ho, wo, _ = r.shape
+        P = n * ho * wo
+        s = self.stat[name]
+        dz = self._buf("dz_" + name, tuple(r.shape))
+        nb = L.unet_bn_workspace(P, cout)
+        ws = self._workspace(nb)
+        L.unet_bn_bwd(_p(dy), _ld(dy), _p(r), cout, _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
+                      0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
+                      _p(self.g[name + "/bias"]), _p(ws), nb, st)
+        w_, dw = self.p[name + "/kernel"], self.g[name + "/kernel"]
+        hi, wi = x.shape[1], x.shape[2]
+        dx = None
+        if kind == "deconv":
+            nb = L.unet_convT2x2_wgrad_workspace(n, hi, wi, cin, cout)
+            ws = self._workspace(nb)
+            L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(ws), nb, st)
+            if need_dx:
+                dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
+                L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
+        elif kind == "conv1":
+            nb = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
+            ws = self._workspace(nb)
+            L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(ws), nb, st)
+            if need_dx:
+                dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
+                L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
+        else:
+            if L.unet_conv3x3_mfma_supported(cin, cout) and cin % 64 == 0:
+                nb = L.unet_conv3x3_wgrad_mfma_workspace(n, ho, wo, cin, cout)
+                ws = self._workspace(nb)
+                L.unet_conv3x3_wgrad_mfma(_p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(ws), nb, st)
+            else:
+                nb = L.unet_conv3x3_wgrad_direct_workspace(n, ho, wo, cin, cout)
+                ws = self._workspace(nb)
+                L.unet_conv3x3_wgrad_direct(_p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(ws), nb, st)
+            if need_dx:
+                dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
+                L.unet_conv3x3_dgrad_mfma(_p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
+        if self.on_layer_grads_ready is not None:
+            self.on_layer_grads_ready(name)
+        return dx
+
+    def backward(self):
+        """Gradients of the loss computed by the last forward(training=True, labels=..., want_grad=True) -> self.grad."""
+        L, st = self.L, self._stream()
+        b = self._block_bwd
+        B = BASE
+        d = b("logits", self.bufs["dy_logits"])
+        for lvl, ch in ((1, B), (2, 2 * B), (3, 4 * B), (4, 8 * B)):
+            d = b("dec_%db" % lvl, d)
+            dcat = b("dec_%da" % lvl, d)                       # [N,H,W,2ch]: [0,ch) skip grad, [ch,2ch) upsampled grad
+            self.bufs["dcat_%d" % lvl] = dcat
+            d = b("up_%d" % lvl, dcat[..., ch:])
+        self._dropout(d, "drop_b", self.masks)
+        d = b("bott_b", d)
+        d = b("bott_a", d)
+        for lvl, ch in ((4, 8 * B), (3, 4 * B), (2, 2 * B), (1, B)):
+            dcat = self.bufs["dcat_%d" % lvl]
+            ds = dcat[..., :ch]
+            n, hh, ww, _ = ds.shape
+            L.unet_maxpool2x2_bwd(_p(d), _ld(d), _p(self.idx[lvl]), _p(ds), _ld(ds), n, hh, ww, ch, 1, st)
+            if lvl == 4:
+                self._dropout(ds, "drop_4", self.masks)
+            d = b("conv_%db" % lvl, ds)
+            d = b("conv_%da" % lvl, d, need_dx=(lvl != 1))
+
+    def adam_step(self, learning_rate):
+        """Keras Adam on the flat buffers (reference UNet/model.py:79,223)."""
+        self.iterations += 1
+        t = self.iterations
+        alpha = learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
+        self.L.unet_adam_keras(_p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v), self.n_flat, alpha,
+                               ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self._stream())
+
+    def argmax(self, prob):
+        n, h, w, k = prob.shape
+        out = self._buf("argmax", (n, h, w), torch.int32)
+        self.L.unet_argmax(_p(prob), k, _p(out), n * h * w, k, self._stream())
+        return out

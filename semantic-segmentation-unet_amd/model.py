@@ -1,0 +1,184 @@
+"""Drop-in for the reference's `UNet/model.py`: same class name, constructor signature, constants and method names
+(reference UNet/model.py:19-256), with the TensorFlow graph replaced by the HIP engine (engine.py).
+
+    UNet(number_classes, global_batch_size, number_channels, learning_rate=3e-4, label_smoothing=0)
+
+Callers written against the reference keep working:
+  * `train.py` uses get_keras_model()/get_optimizer()/set_learning_rate()/dist_train_step()/dist_test_step()
+    (reference UNet/train.py:94-161);
+  * `inference.py` uses load_checkpoint(), estimate_radius() and `model(batch_data)` returning softmax [N,H,W,K] that
+    np.squeeze/np.argmax accept (reference UNet/inference.py:54,105-107,164-166,191-192).
+"""
+import numpy as np
+import torch
+
+from . import engine as _engine
+from .engine import Engine
+
+
+class Mean:
+    """Look-alike of tf.keras.metrics.Mean (reference UNet/train.py:105,107): update_state / result / reset_states."""
+
+    def __init__(self, name="mean"):
+        self.name = name
+        self.total, self.count = 0.0, 0.0
+
+    def update_state(self, value, sample_weight=None):
+        self.total += float(value)
+        self.count += 1.0
+
+    def result(self):
+        return np.float32(self.total / self.count) if self.count else np.float32(0.0)
+
+    def reset_states(self):
+        self.total, self.count = 0.0, 0.0
+
+
+class CategoricalAccuracy(Mean):
+    """Look-alike of tf.keras.metrics.CategoricalAccuracy (reference UNet/train.py:106,108): mean over pixels of
+    argmax(labels) == argmax(softmax).  The engine counts matches on the device; update_state(correct, total) adds them."""
+
+    def update_state(self, correct, total):
+        self.total += float(correct)
+        self.count += float(total)
+
+
+class _Optimizer:
+    """The part of tf.keras.optimizers.Adam the reference touches: `.learning_rate` (UNet/model.py:154-158)."""
+
+    def __init__(self, learning_rate):
+        self.learning_rate = learning_rate
+
+
+class _Loss:
+    """What dist_train_step returns: something with .numpy() (reference UNet/train.py:141,159,161)."""
+
+    def __init__(self, tensor):
+        self._t = tensor
+
+    def numpy(self):
+        return np.float32(self._t.item())
+
+    def __float__(self):
+        return float(self._t.item())
+
+
+class _KerasLikeModel:
+    """`unet.get_keras_model()`: callable as m(x, training=False) with x fp32 [N,C,H,W] (numpy or torch), returning the
+    softmax [N,H,W,K] (reference UNet/inference.py:105,164; UNet/model.py:177,209,239)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def __call__(self, x, training=False, dropout_masks=None):
+        o = self._o
+        xt = torch.as_tensor(np.asarray(x, dtype=np.float32)) if not torch.is_tensor(x) else x.float()
+        prob = o.engine.forward(xt, training=bool(training), dropout_masks=dropout_masks)
+        return prob.clone()          # engine buffers are reused by the next call
+
+    @property
+    def trainable_weights(self):
+        return [self._o.engine.p[k] for k in self._o.engine.trainable_names()]
+
+
+class UNet:
+    _BASELINE_FEATURE_DEPTH = 64
+    _KERNEL_SIZE = 3
+    _DECONV_KERNEL_SIZE = 2
+    _POOLING_STRIDE = 2
+
+    SIZE_FACTOR = 16
+    RADIUS = 96
+
+    def __init__(self, number_classes, global_batch_size, number_channels, learning_rate=3e-4, label_smoothing=0,
+                 device="cuda", seed=0):
+        self.number_channels = number_channels
+        self.learning_rate = learning_rate
+        self.number_classes = number_classes
+        self.global_batch_size = global_batch_size
+        self.label_smoothing = label_smoothing
+        self.engine = Engine(number_classes, number_channels, device=device, seed=seed)
+        self.model = _KerasLikeModel(self)
+        self.optimizer = _Optimizer(learning_rate)
+        self.parallel = None         # set by parallel.DataParallel
+
+    # -- reference UNet/model.py:81-83 (tf.train.Checkpoint -> this build's own format, see checkpoint.py)
+    def load_checkpoint(self, checkpoint_filepath):
+        from .checkpoint import load_checkpoint
+        load_checkpoint(self, checkpoint_filepath)
+
+    def save_checkpoint(self, checkpoint_filepath):
+        from .checkpoint import save_checkpoint
+        save_checkpoint(self, checkpoint_filepath)
+
+    def get_keras_model(self):
+        return self.model
+
+    def get_optimizer(self):
+        return self.optimizer
+
+    def set_learning_rate(self, learning_rate):
+        self.optimizer.learning_rate = learning_rate
+
+    def get_learning_rate(self):
+        return self.optimizer.learning_rate
+
+    def estimate_radius(self):
+        """Reference UNet/model.py:165-202 probes the effective receptive field with an input gradient; that needs the
+        first layer's data gradient, which the training path never computes.  Until that kernel exists this returns the
+        reference's own fallback value (its `len(idx) < 2` branch), the theoretical radius."""
+        return UNet.RADIUS
+
+    # -- reference UNet/model.py:204-228
+    def train_step(self, inputs, dropout_masks=None):
+        (images, labels, loss_metric, accuracy_metric) = inputs
+        e = self.engine
+        images = torch.as_tensor(np.asarray(images, dtype=np.float32)) if not torch.is_tensor(images) else images
+        labels = torch.as_tensor(np.asarray(labels, dtype=np.int32)) if not torch.is_tensor(labels) else labels
+        e.forward(images, training=True, dropout_masks=dropout_masks, labels=labels,
+                  global_batch_size=self.global_batch_size, label_smoothing=self.label_smoothing, want_grad=True)
+        if self.parallel is not None:
+            self.parallel.begin_step()
+        e.backward()
+        if self.parallel is not None:
+            self.parallel.finish_step()
+        e.adam_step(float(self.optimizer.learning_rate))
+        return self._update_metrics(images, loss_metric, accuracy_metric)
+
+    # -- reference UNet/model.py:237-250
+    def test_step(self, inputs):
+        (images, labels, loss_metric, accuracy_metric) = inputs
+        e = self.engine
+        images = torch.as_tensor(np.asarray(images, dtype=np.float32)) if not torch.is_tensor(images) else images
+        labels = torch.as_tensor(np.asarray(labels, dtype=np.int32)) if not torch.is_tensor(labels) else labels
+        e.forward(images, training=False, labels=labels, global_batch_size=self.global_batch_size,
+                  label_smoothing=self.label_smoothing)
+        return self._update_metrics(images, loss_metric, accuracy_metric)
+
+    def _update_metrics(self, images, loss_metric, accuracy_metric):
+        e = self.engine
+        loss = e.loss_buf[0:1].clone()
+        if loss_metric is not None or accuracy_metric is not None:       # forces the per-step host sync the reference has
+            lb = e.loss_buf.tolist()
+            n, _, h, w = images.shape
+            if loss_metric is not None:
+                loss_metric.update_state(lb[0])
+            if accuracy_metric is not None:
+                accuracy_metric.update_state(lb[1], n * h * w)
+        return _Loss(loss)
+
+    # -- reference UNet/model.py:230-235,252-256: one replica per process here; the cross-replica SUM of the per-replica
+    #    losses is an RCCL all-reduce in parallel.DataParallel (reference: dist_strategy.reduce(SUM, ...)).
+    def dist_train_step(self, dist_strategy, inputs):
+        loss = self.train_step(inputs)
+        return self._reduce_loss(dist_strategy, loss)
+
+    def dist_test_step(self, dist_strategy, inputs):
+        loss = self.test_step(inputs)
+        return self._reduce_loss(dist_strategy, loss)
+
+    def _reduce_loss(self, dist_strategy, loss):
+        strat = dist_strategy if dist_strategy is not None else self.parallel
+        if strat is not None and getattr(strat, "world_size", 1) > 1:
+            return _Loss(strat.reduce_sum(loss._t))
+        return loss

@@ -1,0 +1,313 @@
+"""GPU parity tests, per kernel family: each C-ABI entry point of include/unet_hip.h against the numpy oracle
+(oracle/unet_numpy.py, fp64) on the same seeded inputs.  Tolerances are fp32 reassociation bounds, stated per test as
+max|hip - oracle| <= tol * max|oracle|."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_numpy as on
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ST():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_nhwc(a):       # oracle NCHW -> device NHWC fp32
+    return torch.as_tensor(np.ascontiguousarray(a.transpose(0, 2, 3, 1)).astype(np.float32)).to(DEV)
+
+
+def from_nhwc(t):     # device NHWC -> NCHW float64
+    return t.detach().cpu().numpy().transpose(0, 3, 1, 2).astype(np.float64)
+
+
+def dev(a, dtype=np.float32):
+    return torch.as_tensor(np.ascontiguousarray(a).astype(dtype)).to(DEV)
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def ws_bytes(n):
+    return torch.empty(int(n) + 256, dtype=torch.uint8, device=DEV)
+
+
+CONV_SHAPES = [  # N, H, W, Cin, Cout
+    (2, 8, 32, 64, 64),        # exact tiles, 64-wide N tile (8-row config)
+    (1, 12, 40, 32, 128),      # ragged rows and columns, 128-wide N tile
+    (2, 16, 16, 128, 256),     # W < tile width (deep layers of small inputs)
+    (1, 5, 33, 64, 192),       # odd sizes, N = 192 -> 64-wide config
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_fwd_dgrad_wgrad_mfma(hip, shape):
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.standard_normal((n, ci, h, w))
+    wt = rng.standard_normal((3, 3, ci, co)) / np.sqrt(9 * ci)
+    b = rng.standard_normal(co)
+    dz = rng.standard_normal((n, co, h, w))
+    z_ref = np.maximum(on.conv_same_fwd(x, wt, b), 0)
+    dx_ref, dw_ref, _ = on.conv_same_bwd(x, wt, dz)
+    # input read from a channel slice of a wider buffer (ld > C), as the concat consumers do
+    xbuf = torch.zeros(n, h, w, ci + 8, device=DEV); xbuf[..., 4:4 + ci] = to_nhwc(x)
+    xv = xbuf[..., 4:4 + ci]
+    wd, bd, dzd = dev(wt), dev(b), to_nhwc(dz)
+    out = torch.full((n, h, w, co), 7.0, device=DEV)
+    hip.unet_conv3x3_fwd_mfma(P(xv), ci + 8, P(wd), P(bd), P(out), co, n, h, w, ci, co, 1, ST())
+    assert relerr(from_nhwc(out), z_ref) < 2e-5
+    if ci % 64 == 0:          # dgrad's GEMM N is Cin: needs a multiple of 64 (true for every U-Net layer that needs dgrad)
+        dx = torch.full((n, h, w, ci), 7.0, device=DEV)
+        hip.unet_conv3x3_dgrad_mfma(P(dzd), co, P(wd), P(dx), ci, n, h, w, ci, co, ST())
+        assert relerr(from_nhwc(dx), dx_ref) < 2e-5
+    if ci % 64 == 0:
+        nb = hip.unet_conv3x3_wgrad_mfma_workspace(n, h, w, ci, co)
+        ws = ws_bytes(nb)
+        dw = torch.full((3, 3, ci, co), 7.0, device=DEV)
+        hip.unet_conv3x3_wgrad_mfma(P(xv), ci + 8, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+        assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 2e-5
+
+
+def test_conv3x3_mfma_linearity_at_full_size(hip):
+    # size-independent property at a BASELINE config-2 layer shape (B=8, 512x512, 64->64): conv(x1 + 2*x2) ==
+    # conv(x1) + 2*conv(x2) (bias 0, no ReLU), and a delta kernel reproduces the shifted input exactly.
+    n, h, w, c = 8, 512, 512, 64
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    x1 = torch.randn(n, h, w, c, device=DEV, generator=g); x2 = torch.randn(n, h, w, c, device=DEV, generator=g)
+    wt = torch.randn(3, 3, c, c, device=DEV, generator=g) / 24.0
+    o = [torch.empty(n, h, w, c, device=DEV) for _ in range(3)]
+    for xin, out in ((x1, o[0]), (x2, o[1]), (x1 + 2 * x2, o[2])):
+        hip.unet_conv3x3_fwd_mfma(P(xin), c, P(wt), None, P(out), c, n, h, w, c, c, 0, ST())
+    err = (o[2] - (o[0] + 2 * o[1])).abs().max().item() / o[2].abs().max().item()
+    assert err < 1e-5
+    wd = torch.zeros(3, 3, c, c, device=DEV); wd[0, 2] = torch.eye(c, device=DEV)     # tap (a=0,b=2): reads (y-1, x+1)
+    hip.unet_conv3x3_fwd_mfma(P(x1), c, P(wd), None, P(o[0]), c, n, h, w, c, c, 0, ST())
+    assert torch.equal(o[0][:, 1:, :-1], x1[:, :-1, 1:])
+    assert o[0][:, 0].abs().max().item() == 0 and o[0][:, :, -1].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 32, 128, 64), (1, 6, 20, 64, 128), (2, 2, 2, 1024, 512)])
+def test_convT2x2_fwd_dgrad_wgrad(hip, shape):
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, ci, h, w))
+    wt = rng.standard_normal((2, 2, co, ci)) / np.sqrt(ci)
+    b = rng.standard_normal(co)
+    dz = rng.standard_normal((n, co, 2 * h, 2 * w))
+    z_ref = on.deconv2x2_fwd(x, wt, b)
+    dx_ref, dw_ref, _ = on.deconv2x2_bwd(x, wt, dz)
+    xd, wd, bd, dzd = to_nhwc(x), dev(wt), dev(b), to_nhwc(dz)
+    # output written into the upper half of a concat buffer
+    cat = torch.zeros(n, 2 * h, 2 * w, 2 * co, device=DEV)
+    outv = cat[..., co:]
+    hip.unet_convT2x2_fwd(P(xd), ci, P(wd), P(bd), P(outv), 2 * co, n, h, w, ci, co, ST())
+    assert relerr(from_nhwc(outv), z_ref) < 2e-5
+    assert cat[..., :co].abs().max().item() == 0
+    dx = torch.empty(n, h, w, ci, device=DEV)
+    hip.unet_convT2x2_dgrad(P(dzd), co, P(wd), P(dx), ci, n, h, w, ci, co, ST())
+    assert relerr(from_nhwc(dx), dx_ref) < 2e-5
+    nb = hip.unet_convT2x2_wgrad_workspace(n, h, w, ci, co)
+    ws = ws_bytes(nb)
+    dw = torch.empty(2, 2, co, ci, device=DEV)
+    hip.unet_convT2x2_wgrad(P(xd), ci, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+    assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 2e-5
+
+
+@pytest.mark.parametrize("cin", [1, 3])
+def test_first_layer_direct_conv(hip, cin):
+    n, h, w, co = 2, 18, 21, 64
+    rng = np.random.default_rng(cin)
+    x = rng.standard_normal((n, cin, h, w)); wt = rng.standard_normal((3, 3, cin, co)); b = rng.standard_normal(co)
+    dz = rng.standard_normal((n, co, h, w))
+    z_ref = np.maximum(on.conv_same_fwd(x, wt, b), 0)
+    _, dw_ref, _ = on.conv_same_bwd(x, wt, dz)
+    xn = dev(x)                               # NCHW as the reader delivers it
+    if cin == 1:
+        xd = xn.view(n, h, w, 1)
+    else:
+        xd = torch.empty(n, h, w, cin, device=DEV)
+        hip.unet_nchw_to_nhwc(P(xn), P(xd), n, cin, h, w, ST())
+        assert torch.equal(xd, xn.permute(0, 2, 3, 1))
+    wd, bd, dzd = dev(wt), dev(b), to_nhwc(dz)
+    out = torch.empty(n, h, w, co, device=DEV)
+    hip.unet_conv3x3_fwd_direct(P(xd), cin, P(wd), P(bd), P(out), co, n, h, w, cin, co, 1, ST())
+    assert relerr(from_nhwc(out), z_ref) < 1e-5
+    nb = hip.unet_conv3x3_wgrad_direct_workspace(n, h, w, cin, co)
+    ws = ws_bytes(nb)
+    dw = torch.empty(3, 3, cin, co, device=DEV)
+    hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dzd), co, P(dw), n, h, w, cin, co, P(ws), nb, ST())
+    assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 1e-5
+
+
+@pytest.mark.parametrize("k", [2, 6, 11])
+def test_conv1x1_class_map(hip, k):
+    n, h, w, ci = 2, 9, 13, 64
+    rng = np.random.default_rng(k)
+    x = rng.standard_normal((n, ci, h, w)); wt = rng.standard_normal((1, 1, ci, k)); b = rng.standard_normal(k)
+    dz = rng.standard_normal((n, k, h, w))
+    z_ref = np.maximum(on.conv_same_fwd(x, wt, b), 0)
+    dx_ref, dw_ref, _ = on.conv_same_bwd(x, wt, dz)
+    xd, wd, bd, dzd = to_nhwc(x), dev(wt), dev(b), to_nhwc(dz)
+    pix = n * h * w
+    out = torch.empty(n, h, w, k, device=DEV)
+    hip.unet_conv1x1_fwd(P(xd), ci, P(wd), P(bd), P(out), k, pix, ci, k, 1, ST())
+    assert relerr(from_nhwc(out), z_ref) < 1e-5
+    dx = torch.empty(n, h, w, ci, device=DEV)
+    hip.unet_conv1x1_dgrad(P(dzd), k, P(wd), P(dx), ci, pix, ci, k, ST())
+    assert relerr(from_nhwc(dx), dx_ref) < 1e-5
+    nb = hip.unet_conv1x1_wgrad_workspace(pix, ci, k)
+    ws = ws_bytes(nb)
+    dw = torch.empty(1, 1, ci, k, device=DEV)
+    hip.unet_conv1x1_wgrad(P(xd), ci, P(dzd), k, P(dw), pix, ci, k, P(ws), nb, ST())
+    assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 1e-5
+
+
+@pytest.mark.parametrize("c,relu", [(64, 1), (256, 0), (2, 1), (6, 1), (4, 1)])
+def test_batchnorm_train_eval_backward(hip, c, relu):
+    n, h, w = 3, 10, 14
+    rng = np.random.default_rng(c)
+    r = rng.standard_normal((n, c, h, w)) + 0.3
+    if relu:
+        r = np.maximum(r, 0)
+    gamma = rng.uniform(0.5, 1.5, c); beta = rng.standard_normal(c)
+    mm0 = rng.standard_normal(c); mv0 = rng.uniform(0.5, 2, c)
+    dy = rng.standard_normal((n, c, h, w))
+    y_ref, cache = on.bn_train_fwd(r, gamma, beta, 1e-3)
+    dr_ref, dg_ref, db_ref = on.bn_train_bwd(dy, gamma, cache)
+    dz_ref = dr_ref * (r > 0) if relu else dr_ref
+    pix = n * h * w
+    rd = to_nhwc(r)
+    cp = (c + 3) // 4 * 4
+    stat = torch.zeros(4, cp, device=DEV)
+    par = torch.zeros(2, cp, device=DEV); par[0, :c] = dev(gamma); par[1, :c] = dev(beta)
+    mov = torch.zeros(2, cp, device=DEV); mov[0, :c] = dev(mm0); mov[1, :c] = dev(mv0)
+    nb = hip.unet_bn_workspace(pix, c)
+    ws = ws_bytes(nb)
+    hip.unet_bn_train_stats(P(rd), c, pix, c, P(par[0]), P(par[1]), 1e-3, 0.99, 1, P(mov[0]), P(mov[1]),
+                            P(stat[0]), P(stat[1]), P(stat[2]), P(stat[3]), P(ws), nb, ST())
+    mu, var = cache[2], cache[3]
+    assert np.abs(stat[0, :c].cpu().numpy() - mu).max() < 1e-6
+    assert relerr(stat[1, :c].cpu().numpy(), 1 / np.sqrt(var + 1e-3)) < 2e-6
+    assert relerr(mov[0, :c].cpu().numpy(), 0.99 * mm0 + 0.01 * mu) < 2e-6
+    assert relerr(mov[1, :c].cpu().numpy(), 0.99 * mv0 + 0.01 * var * pix / (pix - 1)) < 2e-6
+    # apply into a channel slice of a wider buffer
+    ybuf = torch.zeros(n, h, w, c + 4, device=DEV)
+    yv = ybuf[..., 4:]
+    hip.unet_bn_apply(P(rd), c, P(stat[2]), P(stat[3]), P(yv), c + 4, pix, c, ST())
+    assert relerr(from_nhwc(yv), y_ref) < 5e-6
+    # eval-mode coefficients
+    hip.unet_bn_eval_coeffs(P(par[0]), P(par[1]), P(mov[0]), P(mov[1]), 1e-3, c, P(stat[2]), P(stat[3]), ST())
+    mmn, mvn = mov[0, :c].cpu().numpy().astype(np.float64), mov[1, :c].cpu().numpy().astype(np.float64)
+    hip.unet_bn_apply(P(rd), c, P(stat[2]), P(stat[3]), P(yv), c + 4, pix, c, ST())
+    assert relerr(from_nhwc(yv), on.bn_eval_fwd(r, gamma, beta, mmn, mvn, 1e-3)) < 5e-6
+    # backward
+    dyd = to_nhwc(dy)
+    dz = torch.empty(n, h, w, c, device=DEV)
+    gr = torch.zeros(3, cp, device=DEV)
+    hip.unet_bn_bwd(P(dyd), c, P(rd), c, P(par[0]), P(stat[0]), P(stat[1]), pix, c, relu, P(dz), c, P(gr[0]), P(gr[1]),
+                    P(gr[2]), P(ws), nb, ST())
+    assert relerr(gr[0, :c].cpu().numpy(), dg_ref) < 1e-5
+    assert relerr(gr[1, :c].cpu().numpy(), db_ref) < 1e-5
+    assert relerr(from_nhwc(dz), dz_ref) < 1e-5
+    assert np.abs(gr[2, :c].cpu().numpy() - dz_ref.sum(axis=(0, 2, 3))).max() < 1e-4 * np.abs(dz_ref).sum(axis=(0, 2, 3)).max()
+
+
+def test_maxpool_fwd_bwd_with_ties(hip):
+    n, h, w, c = 2, 8, 12, 64
+    rng = np.random.default_rng(0)
+    x = np.round(rng.standard_normal((n, c, h, w)) * 1.5)           # many exact ties
+    x[0, :, 0:2, 0:2] = 0.25                                       # an all-equal window
+    dy = rng.standard_normal((n, c, h // 2, w // 2))
+    y_ref, idx_ref = on.maxpool2x2_fwd(x)
+    dx_ref = on.maxpool2x2_bwd(dy, idx_ref)
+    base = rng.standard_normal((n, c, h, w))
+    cat = torch.zeros(n, h, w, 2 * c, device=DEV); cat[..., :c] = to_nhwc(x)
+    xv = cat[..., :c]
+    y = torch.empty(n, h // 2, w // 2, c, device=DEV)
+    idx = torch.empty(n, h // 2, w // 2, c, dtype=torch.uint8, device=DEV)
+    hip.unet_maxpool2x2_fwd(P(xv), 2 * c, P(y), c, P(idx), n, h, w, c, ST())
+    assert np.array_equal(from_nhwc(y), y_ref)
+    assert np.array_equal(idx.cpu().numpy().transpose(0, 3, 1, 2), idx_ref)
+    dcat = torch.zeros(n, h, w, 2 * c, device=DEV); dcat[..., :c] = to_nhwc(base)
+    dv = dcat[..., :c]
+    hip.unet_maxpool2x2_bwd(P(to_nhwc(dy)), c, P(idx), P(dv), 2 * c, n, h, w, c, 1, ST())
+    assert relerr(from_nhwc(dv), dx_ref + base) < 1e-6
+    assert dcat[..., c:].abs().max().item() == 0
+
+
+def test_dropout_mask_and_rng(hip):
+    pix, c = 4096, 512
+    x = torch.randn(pix, c, device=DEV)
+    mask = (torch.rand(pix, c, device=DEV) < 0.5).to(torch.uint8)
+    out = torch.empty_like(x)
+    hip.unet_dropout(P(x), c, P(out), c, pix, c, P(mask), 0, 0.5, ST())
+    assert torch.equal(out, x * mask.float() * 2.0)
+    o1, o2, o3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    hip.unet_dropout(P(x), c, P(o1), c, pix, c, None, 123, 0.5, ST())
+    hip.unet_dropout(P(x), c, P(o2), c, pix, c, None, 123, 0.5, ST())
+    hip.unet_dropout(P(x), c, P(o3), c, pix, c, None, 124, 0.5, ST())
+    assert torch.equal(o1, o2)                                    # same (seed, index) -> same mask (backward regenerates it)
+    keep = (o1 != 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.005
+    assert (o1 != o3).float().mean().item() > 0.3
+    kept = o1 != 0
+    assert torch.equal(o1[kept], (x * 2.0)[kept])
+
+
+@pytest.mark.parametrize("k,ls", [(2, 0.0), (4, 0.0), (6, 0.1)])
+def test_softmax_ce_accuracy_argmax(hip, k, ls):
+    n, h, w = 2, 16, 24
+    rng = np.random.default_rng(k)
+    z = rng.standard_normal((n, h, w, k)) * 3
+    cls = rng.integers(0, k, (n, h, w))
+    lab = (cls[..., None] == np.arange(k)).astype(np.int32)
+    G = 4
+    loss_ref, p_ref, y = on.ce_loss_fwd(z, lab, G, ls, on.Contract())
+    dl_ref = on.ce_loss_bwd(p_ref, y, G)
+    zd, labd = dev(z), dev(lab, np.int32)
+    pix = n * h * w
+    prob = torch.empty(n, h, w, k, device=DEV); dl = torch.empty(n, h, w, k, device=DEV)
+    res = torch.zeros(2, device=DEV)
+    nb = hip.unet_softmax_ce_workspace(pix)
+    ws = ws_bytes(nb)
+    s = 1.0 / (G * h * w)
+    hip.unet_softmax_ce(P(zd), k, P(labd), P(prob), P(dl), k, pix, k, ls, s, s, P(res[0:1]), P(res[1:2]), P(ws), nb, ST())
+    assert relerr(prob.cpu().numpy(), p_ref) < 2e-6
+    assert relerr(dl.cpu().numpy(), dl_ref) < 5e-6
+    assert abs(res[0].item() - loss_ref) < 2e-6 * abs(loss_ref)
+    assert res[1].item() == float((np.argmax(p_ref, -1) == cls).sum())
+    am = torch.empty(n, h, w, dtype=torch.int32, device=DEV)
+    hip.unet_argmax(P(prob), k, P(am), pix, k, ST())
+    assert np.array_equal(am.cpu().numpy(), np.argmax(prob.cpu().numpy(), -1))
+    # exact tie -> first index (np.argmax semantics, reference UNet/inference.py:107)
+    tie = torch.zeros(1, 1, 4, k, device=DEV)
+    hip.unet_argmax(P(tie), k, P(am), 4, k, ST())
+    assert am.view(-1)[:4].abs().max().item() == 0
+
+
+def test_keras_adam_flat(hip):
+    n = 4 * 1000
+    rng = np.random.default_rng(0)
+    th = rng.standard_normal(n); g = rng.standard_normal(n) * 10.0 ** rng.uniform(-7, 0, n)
+    m = np.zeros(n); v = np.zeros(n)
+    thd, gd, md, vd = dev(th), dev(g), dev(m), dev(v)
+    c = on.Contract()
+    ref_th, ref_m, ref_v = th.astype(np.float32).astype(np.float64), m, v
+    g32 = g.astype(np.float32).astype(np.float64)
+    for t in (1, 2, 3):
+        alpha = 3e-4 * np.sqrt(1 - c.adam_beta2 ** t) / (1 - c.adam_beta1 ** t)
+        hip.unet_adam_keras(P(thd), P(gd), P(md), P(vd), n, alpha, 0.9, 0.999, 1e-7, ST())
+        ref_th, ref_m, ref_v = on.adam_keras_step(ref_th, g32, ref_m, ref_v, t, 3e-4, c)
+    assert np.abs(thd.cpu().numpy() - ref_th).max() < 2e-6
+    assert relerr(vd.cpu().numpy(), ref_v) < 1e-5

@@ -1,0 +1,130 @@
+"""GPU end-to-end parity: the HIP engine behind the reference's `UNet` class surface against the oracle on the same
+seeded inputs and weights -- eval forward + argmax mask, training forward/loss/gradients, Adam steps and BN moving
+statistics, test_step.  fp32-vs-fp64 tolerances are stated per assertion."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import unet_numpy as on
+from oracle import unet_torch as ot
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def make_case(seed, n, c, k, hw):
+    rng = np.random.default_rng(seed)
+    img, lab = on.synthetic_batch(n, c, k, hw, hw, seed=seed)
+    prm = on.init_params(c, k, seed=seed)
+    for key in prm:
+        if key.endswith(("bias", "beta")):
+            prm[key] = rng.normal(0, 0.1, prm[key].shape).astype(np.float32)
+        if key.endswith("gamma"):
+            prm[key] = rng.uniform(0.5, 1.5, prm[key].shape).astype(np.float32)
+        if key.endswith("moving_mean"):
+            prm[key] = rng.normal(0.3, 0.1, prm[key].shape).astype(np.float32)
+        if key.endswith("moving_var"):
+            prm[key] = rng.uniform(0.5, 1.5, prm[key].shape).astype(np.float32)
+    masks = {"drop_4": rng.integers(0, 2, (n, 512, hw // 8, hw // 8)), "drop_b": rng.integers(0, 2, (n, 1024, hw // 16, hw // 16))}
+    return img, lab, prm, masks
+
+
+def argmax_agreement(p_hip, p_ref, margin=1e-4):
+    """argmax must be identical on every pixel whose top-2 margin in the oracle exceeds `margin`."""
+    a, b = np.argmax(p_hip, -1), np.argmax(p_ref, -1)
+    srt = np.sort(p_ref, -1)
+    gap = srt[..., -1] - srt[..., -2]
+    decided = gap > margin
+    return (a == b)[decided].all(), int((~decided).sum()), int((a != b).sum())
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, 2, 32), (2, 3, 4, 32)])
+def test_unet_matches_numpy_oracle(cfg):
+    n, c, k, hw = cfg
+    img, lab, prm, masks = make_case(17, n, c, k, hw)
+    model = pkg("model")
+    G = 2 * n                                   # pretend this replica holds half of the global batch
+    net = model.UNet(k, G, c, learning_rate=3e-4)
+    net.engine.load_parameters(prm)
+    ref = on.OracleUNet(k, G, c, learning_rate=3e-4, params=prm, dtype=np.float64)
+
+    # --- inference path: eval-mode forward + argmax mask (reference UNet/inference.py:159-166)
+    sm = net.get_keras_model()(img).cpu().numpy()
+    sm_ref, _ = ref.forward(img, training=False)
+    assert sm.shape == (n, hw, hw, k)
+    assert np.abs(sm - sm_ref).max() < 2e-5
+    ok, undecided, differ = argmax_agreement(sm, sm_ref)
+    assert ok and differ == 0, (undecided, differ)
+    mask = net.engine.argmax(net.engine.forward(torch.as_tensor(img))).cpu().numpy()
+    assert np.array_equal(mask, np.argmax(sm, -1))
+
+    # --- training forward, loss and every gradient (reference UNet/model.py:208-219)
+    e = net.engine
+    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab),
+              global_batch_size=G, want_grad=True)
+    e.backward()
+    loss_ref, _, g_ref, _, _ = ref.loss_and_grads(img, lab, masks)
+    assert abs(e.loss_buf[0].item() - loss_ref) < 1e-5 * abs(loss_ref)
+    g = e.export_gradients()
+    worst = max((relerr(g[key].astype(np.float64), g_ref[key]), key) for key in g_ref)
+    assert worst[0] < 2e-3, worst
+
+    # --- two full train steps through the class API, then test_step (reference UNet/model.py:204-250)
+    lm, am = model.Mean(), model.CategoricalAccuracy()
+    for _ in range(2):
+        l_hip = net.train_step((img, lab, lm, am), dropout_masks=masks).numpy()
+        l_ref, _, _ = ref.train_step(img, lab, masks)
+        assert abs(l_hip - l_ref) < 5e-5 * abs(l_ref)
+    prm_hip = e.export_parameters()
+    # Adam's first steps move every weight by ~lr regardless of |g| (sign-like), so compare the *update*
+    for key in ref.trainable:
+        upd_ref = ref.params[key] - prm[key]
+        upd_hip = prm_hip[key].astype(np.float64) - prm[key]
+        assert np.abs(upd_hip - upd_ref).max() < 0.05 * 6e-4 + 1e-7, key
+    for name, _, _, _ in ref.layers:
+        for s in ("/moving_mean", "/moving_var"):
+            assert relerr(prm_hip[name + s].astype(np.float64), ref.params[name + s]) < 2e-4, name + s
+    lt = net.test_step((img, lab, lm, am)).numpy()
+    lt_ref, _ = ref.test_step(img, lab)
+    assert abs(lt - lt_ref) < 2e-3 * abs(lt_ref)
+    assert 0.0 <= float(am.result()) <= 1.0
+
+
+def test_unet_matches_torch_restatement_at_128():
+    # larger tile (bottleneck 8x8, every MFMA tiling exercised); second-opinion oracle (torch-CPU fp64 + autograd)
+    n, c, k, hw = 2, 1, 2, 128
+    img, lab, prm, masks = make_case(23, n, c, k, hw)
+    model = pkg("model")
+    net = model.UNet(k, n, c)
+    net.engine.load_parameters(prm)
+    ref = ot.TorchUNet(k, n, c, params=prm, dtype=torch.float64)
+    sm = net.get_keras_model()(img).cpu().numpy()
+    with torch.no_grad():
+        sm_ref = ref.forward(img, False)[0].numpy()
+    assert np.abs(sm - sm_ref).max() < 5e-5
+    ok, undecided, differ = argmax_agreement(sm, sm_ref)
+    assert ok, (undecided, differ)
+    e = net.engine
+    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n,
+              want_grad=True)
+    e.backward()
+    loss_ref, _, g_ref, _ = ref.loss_and_grads(img, lab, masks)
+    assert abs(e.loss_buf[0].item() - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    g = e.export_gradients()
+    worst = max((relerr(g[key].astype(np.float64), g_ref[key].numpy()), key) for key in g_ref)
+    assert worst[0] < 5e-3, worst
+
+
+def test_rng_dropout_train_step_runs_and_learns():
+    # device-RNG dropout (no injected masks): loss must fall on a fixed batch within a few steps
+    n, c, k, hw = 2, 1, 2, 64
+    img, lab = on.synthetic_batch(n, c, k, hw, hw, seed=5)
+    model = pkg("model")
+    net = model.UNet(k, n, c, learning_rate=1e-3)
+    losses = [float(net.train_step((img, lab, None, None)).numpy()) for _ in range(12)]
+    assert all(np.isfinite(losses))
+    assert min(losses[-3:]) < losses[0]
