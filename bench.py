@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: U-Net training images/sec on synthetic 512x512x1 tiles, 2 classes, batch 8 per GPU, fp32
+(BASELINE.json configs[1]; configs[2] when launched on 8 GPUs).  One "step" = one full optimizer step of the hot path:
+forward + per-pixel softmax-CE + backward + (gradient all-reduce) + Keras-Adam, dropout active, inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (the fp32-MFMA 3x3 implicit-GEMM conv that
+serves forward and dgrad): algorithmic FLOPs of its launches / their HIP-event durations measured live in the timed
+steps, against the dense fp32 matrix peak.  `cpu_baseline` times the oracle's torch-CPU restatement of the same train
+step on the host cores over a bounded sample (rank 0, N=1 only) -- a reported baseline, not the target.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "semantic-segmentation-unet_amd"
+
+PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, chip table (dense, spec)
+TRAIN_GFLOP_PER_IMG = {(512, 1, 2): 1154.00}
+
+
+def synthetic(batch, channels, classes, hw, seed, device):
+    import torch
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    img = torch.randn(batch, channels, hw, hw, generator=g)
+    cls = torch.randint(0, classes, (batch, hw // 8, hw // 8), generator=g)
+    cls = cls.repeat_interleave(8, 1).repeat_interleave(8, 2)
+    lab = torch.nn.functional.one_hot(cls, classes).to(torch.int32)
+    return img.to(device), lab.to(device)
+
+
+def cpu_baseline(hw, channels, classes, batch=2, steps=2):
+    import numpy as np
+    import torch
+    from oracle import unet_numpy as on
+    from oracle import unet_torch as ot
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    img, lab = on.synthetic_batch(batch, channels, classes, hw, hw, seed=1234)
+    rng = np.random.default_rng(0)
+    masks = {"drop_4": rng.integers(0, 2, (batch, 512, hw // 8, hw // 8)),
+             "drop_b": rng.integers(0, 2, (batch, 1024, hw // 16, hw // 16))}
+    net = ot.TorchUNet(classes, batch, channels, dtype=torch.float32)
+    net.train_step(img[:1], lab[:1], {k: v[:1] for k, v in masks.items()})        # warm-up (threads, allocator)
+    t0 = time.time()
+    for _ in range(steps):
+        net.train_step(img, lab, masks)
+    dt = time.time() - t0
+    return {"value": round(batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d train steps of batch %d (%dx%dx%d, %d classes), torch-CPU fp32 restatement, %.1f s"
+                      % (steps, batch, hw, hw, channels, classes, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    model = importlib.import_module(PKG + ".model")
+    G = args.batch * world
+    net = model.UNet(args.classes, G, args.channels, learning_rate=3e-4, device=dev, seed=0)
+    if world > 1:
+        par = importlib.import_module(PKG + ".parallel")
+        net.parallel = par.DataParallel(net.engine)
+    img, lab = synthetic(args.batch, args.channels, args.classes, args.size, 1234 + rank, dev)
+    inputs = (img, lab, None, None)          # no metric objects -> no per-step host sync inside the timed loop
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        net.train_step(inputs)
+    if not args.no_kernel_events:
+        net.engine.profile = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.train_step(inputs)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(net.engine.loss_buf[0].item())
+
+    roofline = None
+    extra = {}
+    if net.engine.profile:
+        for key, evs in net.engine.profile.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            extra[key] = {"launches_per_step": len(evs) // args.steps, "ms_per_step": round(ms / args.steps, 3),
+                          "avg_launch_ms": round(ms / len(evs), 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
+        k = extra.get("conv3x3_igemm")
+        if k:
+            roofline = {"bound": "mfma", "kernel": "igemm_kernel (3x3 conv forward + dgrad, v_mfma_f32_32x32x2_f32)",
+                        "achieved": k["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(k["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}
+    if rank == 0:
+        ips = G * args.steps / dt
+        out = {
+            "metric": "training images/sec", "value": round(ips, 3), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "U-Net train step (fwd + softmax-CE + bwd + Keras-Adam%s), synthetic %dx%dx%d tiles, "
+                                   "%d classes, batch %d per GPU, random-init weights, dropout on"
+                                   % (" + RCCL gradient all-reduce" if world > 1 else "", args.size, args.size,
+                                      args.channels, args.classes, args.batch),
+                       "global_batch": G, "parallelism": "dp%d" % world},
+            "roofline": roofline, "kernels": extra, "final_loss": round(final_loss, 6),
+        }
+        gf = TRAIN_GFLOP_PER_IMG.get((args.size, args.channels, args.classes))
+        if gf:
+            out["step_tflops_per_gpu"] = round(ips / world * gf / 1e3, 2)
+            out["step_frac_of_fp32_mfma_peak"] = round(ips / world * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size, args.channels, args.classes)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

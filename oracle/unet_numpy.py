@@ -221,8 +221,12 @@ def adam_keras_step(theta, g, m, v, t, lr, contract):
     """Keras OptimizerV2 Adam (non-amsgrad), epsilon OUTSIDE the bias correction. UNet/model.py:79,223."""
     b1, b2, eps = contract.adam_beta1, contract.adam_beta2, contract.adam_eps
     alpha = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
-    m = m + (g - m) * (1.0 - b1)
-    v = v + (g * g - v) * (1.0 - b2)
+    # the reference runs in fp32: TF's ApplyAdam forms (1 - beta) as float32(1) - float32(beta), which is
+    # 0.100000024 / 0.00099998713, not 0.1 / 0.001 (a 1.3e-5 relative difference in v) (K)
+    omb1 = float(np.float32(1.0) - np.float32(b1))
+    omb2 = float(np.float32(1.0) - np.float32(b2))
+    m = m + (g - m) * omb1
+    v = v + (g * g - v) * omb2
     theta = theta - alpha * m / (np.sqrt(v) + eps)
     return theta, m, v
 

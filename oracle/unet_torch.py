@@ -100,8 +100,8 @@ class TorchUNet:
         with torch.no_grad():
             for k in self.trainable:
                 m, v = self.adam_m[k], self.adam_v[k]
-                m.add_((g[k] - m) * (1.0 - c.adam_beta1))
-                v.add_((g[k] * g[k] - v) * (1.0 - c.adam_beta2))
+                m.add_((g[k] - m) * float(np.float32(1.0) - np.float32(c.adam_beta1)))
+                v.add_((g[k] * g[k] - v) * float(np.float32(1.0) - np.float32(c.adam_beta2)))
                 self.params[k].sub_(alpha * m / (v.sqrt() + c.adam_eps))
             for name, (mu, var, n) in st.items():
                 vv = var * (n / (n - 1.0)) if c.bn_moving_var_unbiased else var

@@ -115,6 +115,17 @@ class Engine:
         self.dropout_seed = seed
         self.init_parameters(seed)
         self.on_layer_grads_ready = None        # hook(name) for data-parallel bucketing (parallel.py)
+        self.profile = None                     # bench.py: {"conv3x3_igemm": [(ev0, ev1, flops)], ...} when enabled
+
+    def _timed(self, key, flops, fn, *args):
+        """Call fn(*args); when profiling is on, bracket it with HIP events on the launch stream."""
+        if self.profile is None:
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(*args)
+        e1.record()
+        self.profile.setdefault(key, []).append((e0, e1, flops))
 
     # ------------------------------------------------------------------------------------------------ parameters
     def trainable_names(self):
@@ -188,7 +199,8 @@ class Engine:
         else:
             r = self._buf("r_" + name, (n, h, w, cout))
             if L.unet_conv3x3_mfma_supported(cin, cout):
-                L.unet_conv3x3_fwd_mfma(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+                self._timed("conv3x3_igemm", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
+                            _p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
             else:
                 L.unet_conv3x3_fwd_direct(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
         P = r.shape[0] * r.shape[1] * r.shape[2]
@@ -326,14 +338,16 @@ class Engine:
             if L.unet_conv3x3_mfma_supported(cin, cout) and cin % 64 == 0:
                 nb = L.unet_conv3x3_wgrad_mfma_workspace(n, ho, wo, cin, cout)
                 ws = self._workspace(nb)
-                L.unet_conv3x3_wgrad_mfma(_p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(ws), nb, st)
+                self._timed("conv3x3_wgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_mfma,
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(ws), nb, st)
             else:
                 nb = L.unet_conv3x3_wgrad_direct_workspace(n, ho, wo, cin, cout)
                 ws = self._workspace(nb)
                 L.unet_conv3x3_wgrad_direct(_p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(ws), nb, st)
             if need_dx:
                 dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
-                L.unet_conv3x3_dgrad_mfma(_p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
+                self._timed("conv3x3_igemm", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_mfma,
+                            _p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
         if self.on_layer_grads_ready is not None:
             self.on_layer_grads_ready(name)
         return dx

@@ -1,0 +1,76 @@
+"""Single-node data parallelism, one process per GPU, replacing tf.distribute.MirroredStrategy (reference
+UNet/train.py:57-58; UNet/model.py:230-235,252-256).
+
+Collective call sites of the reference and what replaces them:
+  X1  optimizer.apply_gradients all-reduces gradients with SUM (the loss is already divided by the GLOBAL batch,
+      UNet/model.py:213)            -> bucketed all_reduce(SUM) over contiguous ranges of the flat gradient buffer,
+      launched from the backward schedule as soon as a bucket's last layer has its gradients (engine hook), so RCCL
+      runs on its own stream underneath the remaining backward conv kernels; Adam waits for the last bucket;
+  X2  strategy.reduce(SUM, per-replica loss)  -> one 4-byte all_reduce (reduce_sum);
+  X4  BN moving statistics are per replica; they are averaged only when a checkpoint is written (average_moving_stats);
+  X5  variables mirrored from replica 0 at creation -> broadcast from rank 0 (broadcast_state).
+BatchNorm batch statistics stay per replica, as in the reference (plain BatchNormalization, UNet/model.py:36,47).
+
+The class touches the engine only through: grad, theta, adam_m, adam_v, moving, layer_range, on_layer_grads_ready --
+so the bucket logic is testable on CPU with the gloo backend and a stub engine.
+"""
+import torch
+import torch.distributed as dist
+
+from .engine import BACKWARD_ORDER
+
+
+class DataParallel:
+    def __init__(self, engine, bucket_bytes=25 * 1024 * 1024, process_group=None, broadcast=True):
+        assert dist.is_initialized(), "torch.distributed must be initialised (backend nccl == RCCL on ROCm)"
+        self.engine = engine
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        # contiguous buckets in gradient-readiness order (logits ... conv_1a)
+        self.buckets = []            # (start, end, last_layer_name)
+        start = None
+        for name in BACKWARD_ORDER:
+            a, b = engine.layer_range[name]
+            if start is None:
+                start = a
+            if (b - start) * 4 >= bucket_bytes or name == BACKWARD_ORDER[-1]:
+                self.buckets.append((start, b, name))
+                start = None
+        self._trigger = {last: i for i, (_, _, last) in enumerate(self.buckets)}
+        self._pending = []
+        engine.on_layer_grads_ready = self._on_layer
+        if broadcast and self.world_size > 1:
+            self.broadcast_state()
+
+    def broadcast_state(self):
+        e = self.engine
+        for t in [e.theta, e.adam_m, e.adam_v] + list(e.moving.values()):
+            dist.broadcast(t, src=0, group=self.group)
+
+    def begin_step(self):
+        self._pending = []
+
+    def _on_layer(self, name):
+        i = self._trigger.get(name)
+        if i is None or self.world_size == 1:
+            return
+        a, b, _ = self.buckets[i]
+        self._pending.append(dist.all_reduce(self.engine.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish_step(self):
+        for w in self._pending:
+            w.wait()                 # makes the compute stream wait for the collective; no host sync on nccl
+        self._pending = []
+
+    def reduce_sum(self, t):
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def average_moving_stats(self):
+        """sync-on-read MEAN of BN moving statistics at checkpoint time."""
+        if self.world_size > 1:
+            for t in self.engine.moving.values():
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                t.div_(self.world_size)

@@ -67,7 +67,7 @@ def test_keras_adam_first_step_closed_form():
     g = np.array([1e-5, -2e-3, 0.5])
     th, m, v = on.adam_keras_step(np.zeros(3), g, np.zeros(3), np.zeros(3), 1, 3e-4, c)
     expect = -3e-4 * np.sign(g) / (1 + c.adam_eps / (np.sqrt(1 - c.adam_beta2) * np.abs(g)))
-    assert np.allclose(th, expect, rtol=1e-12)
+    assert np.allclose(th, expect, rtol=2e-5)       # (1-beta) is formed in float32 like TF's kernel: 1.3e-5 off the ideal
     torch_style = -3e-4 * np.sign(g) / (1 + 1e-7 / np.abs(g))
     assert abs(th[0] - torch_style[0]) > 1e-8               # differs measurably from torch.optim.Adam for tiny |g|
 
