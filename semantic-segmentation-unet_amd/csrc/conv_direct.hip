@@ -89,13 +89,16 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const float* 
     }
 }
 
-__global__ void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nparts) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double s = 0.0;
-        for (int k = 0; k < nparts; ++k) s += (double)part[(size_t)k * n + i];
-        out[i] = (float)s;
-    }
+// one wave per output element: lanes stride over the per-block partials, fixed shuffle tree (deterministic)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nparts) {
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int k = lane; k < nparts; k += 64) s += (double)part[(size_t)k * n + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[i] = (float)s;
 }
 
 // ---- 1x1 conv, small Cout (class map) -------------------------------------------------------------------------
@@ -246,7 +249,7 @@ extern "C" int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float*
     conv3x3_direct_wgrad_kernel<<<dim3(blocks, Cin), 256, smem, (hipStream_t)stream>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cin, Cout, ppb);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     const long n = 9L * Cin * Cout;
-    sum_partials_kernel<<<unet_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const float*)ws, dw, n, blocks);
+    sum_partials_kernel<<<unet_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>((const float*)ws, dw, n, blocks);
     return UNET_LAUNCH_STATUS();
 }
 
@@ -284,6 +287,6 @@ extern "C" int unet_conv1x1_wgrad(const float* xin, int ldx, const float* dz, in
     conv1x1_narrow_wgrad_kernel<<<blocks, 256, smem, (hipStream_t)stream>>>(xin, ldx, dz, lddz, (float*)ws, P, Cin, Cout, ppb);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     const long n = (long)Cin * Cout;
-    sum_partials_kernel<<<unet_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const float*)ws, dw, n, blocks);
+    sum_partials_kernel<<<unet_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>((const float*)ws, dw, n, blocks);
     return UNET_LAUNCH_STATUS();
 }

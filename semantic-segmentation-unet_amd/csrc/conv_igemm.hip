@@ -109,26 +109,38 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
             }
         }
     };
-    auto stage_A = [&](int chunk, int tap) {
+    // A tile: global -> registers (gload_A) -> LDS (store_A), so the next tile's loads fly under the current MFMAs.
+    constexpr int A_TOTAL = A_ROWS * A_COLS * (CK / 4);
+    constexpr int A_F4 = (A_TOTAL + 255) / 256;
+    f32x4 ra[A_F4];
+    auto gload_A = [&](int chunk, int tap) {
         const int c0 = chunk * CK;
-        constexpr int TOTAL = A_ROWS * A_COLS * (CK / 4);
-        for (int idx = tid; idx < TOTAL; idx += 256) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = tid + i * 256;
             const int pix = idx >> 3, q = idx & 7;
             const int iy = pix / A_COLS, ix = pix - iy * A_COLS;
             int gy, gx;
-            bool ok;
+            bool ok = idx < A_TOTAL;
             if (MODE == 0) {
                 gy = oy0 + iy - 1; gx = ox0 + ix - 1;
-                ok = (gy >= 0) && (gy < p.Hi) && (gx >= 0) && (gx < p.Wi);
+                ok = ok && (gy >= 0) && (gy < p.Hi) && (gx >= 0) && (gx < p.Wi);
             } else {
                 const int oy = oy0 + iy, ox = ox0 + ix;
-                ok = (oy < p.H) && (ox < p.W);
+                ok = ok && (oy < p.H) && (ox < p.W);
                 gy = oy * p.in_scale + (MODE == 2 ? (tap >> 1) : 0);
                 gx = ox * p.in_scale + (MODE == 2 ? (tap & 1) : 0);
             }
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(img * p.Hi + gy) * p.Wi + gx) * p.ldx + c0 + 4 * q);
-            *reinterpret_cast<f32x4*>(sA + pix * SA + 4 * q) = v;
+            ra[i] = v;
+        }
+    };
+    auto store_A = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < A_TOTAL) *reinterpret_cast<f32x4*>(sA + (idx >> 3) * SA + 4 * (idx & 7)) = ra[i];
         }
     };
 
@@ -140,16 +152,32 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     for (int u = 0; u < 2; ++u)
         b_base[u] = B_NK ? (wn * 64 + u * 32 + li) * SA + 4 * lh : (4 * lh) * BN + wn * 64 + u * 32 + li;
 
+    // bias is fetched (and waited for) before the main loop, see the epilogue note
+    float bias_v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        bias_v[u] = p.bias ? p.bias[n0 + wn * 64 + u * 32 + li] : 0.f;
+        asm volatile("" :: "v"(bias_v[u]));
+    }
+
+    constexpr bool PREFETCH_A = (MODE != 0) || (WM == 4);
+    gload_A(0, 0);
     gload_B(0, 0);
     int chunk = 0, tap = 0;
     for (int it = 0; it < n_it; ++it) {
         __syncthreads();
-        if (MODE != 0 || tap == 0) stage_A(chunk, tap);
+        if (MODE != 0 || tap == 0) {
+            if (!PREFETCH_A && it > 0) gload_A(chunk, tap);
+            store_A();
+        }
         store_B();
         __syncthreads();
         int nchunk = chunk, ntap = tap + 1;
         if (ntap == NT) { ntap = 0; nchunk = chunk + 1; }
-        if (it + 1 < n_it) gload_B(nchunk, ntap);
+        if (it + 1 < n_it) {
+            gload_B(nchunk, ntap);
+            if (PREFETCH_A && (MODE != 0 || ntap == 0)) gload_A(nchunk, ntap);     // MODE 0: issued during the chunk's last tap
+        }
 
         const int tap_off = MODE == 0 ? ((tap / 3) * A_COLS + (tap % 3)) * SA : 0;
 #pragma unroll
@@ -177,8 +205,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
         chunk = nchunk; tap = ntap;
     }
 
-    // epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel along x)
+    // epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel along x).
+    // One 64-bit base per (row, channel tile); per-element offsets are 32-bit.  No load may be pending here:
+    // stores count in vmcnt, so a late `s_waitcnt vmcnt(0)` for the bias would serialise all 64 stores.
     const int ooy = p.tap_by_z ? (ztap >> 1) : 0, oox = p.tap_by_z ? (ztap & 1) : 0;
+    const bool full_x = (ox0 + TW <= p.W);
+    const int xstep = p.out_scale * p.ldo;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int oy = oy0 + 2 * wm + t;
@@ -186,17 +218,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
         const int py = oy * p.out_scale + ooy;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int n = n0 + wn * 64 + u * 32 + li;
-            const float bv = p.bias ? p.bias[n] : 0.f;
+            float* base = p.out + ((size_t)(img * p.Ho + py) * p.Wo + (ox0 * p.out_scale + oox)) * p.ldo + n0 + wn * 64 + u * 32 + li;
+            const float bv = bias_v[u];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (ox < p.W) {
-                    float v = acc[t][u][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    const int px = ox * p.out_scale + oox;
-                    p.out[((size_t)(img * p.Ho + py) * p.Wo + px) * p.ldo + n] = v;
-                }
+                const int dx = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[t][u][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (full_x || ox0 + dx < p.W) base[dx * xstep] = v;
             }
         }
     }

@@ -8,11 +8,15 @@
 //           B = layer input (n = ci) at (i, j)  ->  dW in the Keras layout [a][b][co][ci].
 //
 // The contraction runs over pixels (GEMM K = N*H*W, up to 2M), so the grid is
-// (m tiles of 64) x (n tiles of 64) x S pixel-range splits.  A workgroup (4 waves) keeps ALL taps of its
-// 64x64 block in registers (wave = one 32x32 quadrant x NT taps: 144 accumulator VGPRs for 3x3), stages a
-// spatial tile of A (with halo) and B in LDS once and feeds every tap from it: 9x the MFMA work per staged byte.
-// Both operands are channel-contiguous in LDS, so a fragment read is 32 consecutive floats per half-wave
-// (conflict-free ds_read_b32); the two halves of a wave take adjacent pixels as MFMA k = 0/1.
+// (m tiles of 64) x (n tiles of 64) x S pixel-range splits with S chosen so that the launch is ONE persistent
+// workgroup per CU (4 waves, one per SIMD, up to 512 VGPRs each).  A workgroup keeps ALL taps of its 64x64 block in
+// registers (wave = one 32x32 quadrant x NT taps: 144 accumulator VGPRs for 3x3) and walks its pixel tiles:
+//   * a tile = A rows with halo + B rows, channel-contiguous [pixel][64] in LDS (51 KB for 3x3), double-buffered;
+//   * tiles are filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 4 pixels per instruction, no VGPR
+//     staging); the DMA for tile i+1 is issued before tile i's MFMAs and retired (vmcnt(0) + one barrier) after
+//     them, so HBM/L2 latency hides under ~18k cycles of matrix work; out-of-image pixels read a zero page;
+//   * every tap is fed from the same LDS tile: 9x the MFMA work per staged byte; a fragment read is 32 consecutive
+//     floats per half-wave (conflict-free ds_read_b32); the two halves of a wave take adjacent pixels as k = 0/1.
 // Each split writes its partial block to the workspace; a second pass sums the S partials in a fixed order
 // (deterministic, no float atomics).
 #include "common.h"
@@ -21,6 +25,8 @@ namespace {
 
 constexpr int TW = 32;
 constexpr int CT = 64;   // channel tile (both m and n)
+
+__device__ __attribute__((aligned(256))) float g_zero_page[CT];   // zero-initialised; source for padded pixels
 
 struct WgradArgs {
     const float* a; const float* b; float* ws;
@@ -32,16 +38,26 @@ struct WgradArgs {
     int mt, nt;
 };
 
+typedef __attribute__((address_space(3))) void lds_void;
+
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs p) {
     constexpr int NT = MODE == 0 ? 9 : 4;
     constexpr int TH = MODE == 0 ? 2 : 1;
     constexpr int A_ROWS = MODE == 0 ? TH + 2 : 2 * TH;
     constexpr int A_COLS = MODE == 0 ? TW + 2 : 2 * TW;
-    constexpr int A_PIX = A_ROWS * A_COLS, B_PIX = TH * TW;
-    __shared__ __attribute__((aligned(16))) float smem[(A_PIX + B_PIX) * CT];
-    float* sA = smem;
-    float* sB = smem + A_PIX * CT;
+    constexpr int A_PIX = A_ROWS * A_COLS;
+    // DMA piece = 4 pixels x 256 B (one wave instruction).  Piece k of wave w is 4k + w; A and B regions are padded to
+    // multiples of 16 pixels so that piece index k is an A piece for k < KA and a B piece otherwise, for every wave.
+    constexpr int A_PIX_PAD = (A_PIX + 15) & ~15;
+    constexpr int B_PIX = TH * TW;
+    constexpr int B_PIX_PAD = (B_PIX + 15) & ~15;
+    constexpr int KA = A_PIX_PAD / 16, KB = B_PIX_PAD / 16, KP = KA + KB;   // pieces per wave
+    constexpr int TILE_PIX = A_PIX_PAD + B_PIX_PAD;
+    constexpr int TILE_FLOATS = TILE_PIX * CT;
+    constexpr int STEPS = TH * (TW / 2);
+    static_assert(KP <= STEPS, "one DMA issue per MFMA step at most");
+    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE_FLOATS];
 
     int bid = blockIdx.x;
     const int tmn = bid % (p.mt * p.nt);
@@ -49,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
     const int tm = tmn / p.nt, tn = tmn % p.nt;
     const int m0 = tm * CT, n0 = tn * CT;
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mi = wv & 1, ni = wv >> 1;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -60,53 +77,90 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int a_lane = 32 * mi + li, b_lane = 32 * ni + li;
+    const int dq = lane & 15, dp = lane >> 4;         // DMA lane -> (channel quad, pixel within the piece)
+    const float* zsrc = g_zero_page + 4 * dq;
+    const float* abase = p.a + m0 + 4 * dq;
+    const float* bbase = p.b + n0 + 4 * dq;
 
-    for (int tile = split; tile < p.n_tiles; tile += p.splits) {
+    // tile-invariant part of each piece's lane address: (row, col) inside the A / B region
+    int prow[KP], pcol[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (k < KA) { const int pix = (4 * k + wv) * 4 + dp; prow[k] = pix / A_COLS; pcol[k] = pix - prow[k] * A_COLS; if (pix >= A_PIX) prow[k] = 1 << 20; }
+        else        { const int pix = (4 * (k - KA) + wv) * 4 + dp; prow[k] = pix / TW; pcol[k] = pix - prow[k] * TW; if (pix >= B_PIX) prow[k] = 1 << 20; }
+    }
+
+    int t_img = 0, t_oy0 = 0, t_ox0 = 0;
+    auto set_tile = [&](int tile) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y;
-        const int img = t / p.tiles_y;
-        const int oy0 = ty * TH, ox0 = tx * TW;
-
-        __syncthreads();
-        for (int idx = tid; idx < A_PIX * (CT / 4); idx += 256) {
-            const int pix = idx >> 4, q = idx & 15;
-            const int iy = pix / A_COLS, ix = pix - iy * A_COLS;
+        t_img = t / p.tiles_y; t_oy0 = ty * TH; t_ox0 = tx * TW;
+    };
+    // branch-free: out-of-image (or padding) lanes read the zero page
+    auto issue_piece = [&](int k, float* dst) {
+        const float* src;
+        if (k < KA) {
             int gy, gx;
-            if (MODE == 0) { gy = oy0 + iy - 1; gx = ox0 + ix - 1; }
-            else           { gy = 2 * oy0 + iy; gx = 2 * ox0 + ix; }
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < p.Ha && gx >= 0 && gx < p.Wa)
-                v = *reinterpret_cast<const f32x4*>(p.a + ((size_t)(img * p.Ha + gy) * p.Wa + gx) * p.lda + m0 + 4 * q);
-            *reinterpret_cast<f32x4*>(sA + pix * CT + 4 * q) = v;
+            if (MODE == 0) { gy = t_oy0 + prow[k] - 1; gx = t_ox0 + pcol[k] - 1; }
+            else           { gy = 2 * t_oy0 + prow[k]; gx = 2 * t_ox0 + pcol[k]; }
+            const bool ok = (unsigned)gy < (unsigned)p.Ha && (unsigned)gx < (unsigned)p.Wa;
+            const float* g = abase + ((size_t)(t_img * p.Ha + gy) * p.Wa + gx) * p.lda;
+            src = ok ? g : zsrc;
+            __builtin_amdgcn_global_load_lds(src, (lds_void*)(dst + (4 * k + wv) * 4 * CT), 16, 0, 0);
+        } else {
+            const int gy = t_oy0 + prow[k], gx = t_ox0 + pcol[k];
+            const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const float* g = bbase + ((size_t)(t_img * p.H + gy) * p.W + gx) * p.ldb;
+            src = ok ? g : zsrc;
+            __builtin_amdgcn_global_load_lds(src, (lds_void*)(dst + A_PIX_PAD * CT + (4 * (k - KA) + wv) * 4 * CT), 16, 0, 0);
         }
-        for (int idx = tid; idx < B_PIX * (CT / 4); idx += 256) {
-            const int pix = idx >> 4, q = idx & 15;
-            const int iy = pix / TW, ix = pix - iy * TW;
-            const int gy = oy0 + iy, gx = ox0 + ix;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy < p.H && gx < p.W)
-                v = *reinterpret_cast<const f32x4*>(p.b + ((size_t)(img * p.H + gy) * p.W + gx) * p.ldb + n0 + 4 * q);
-            *reinterpret_cast<f32x4*>(sB + pix * CT + 4 * q) = v;
-        }
-        __syncthreads();
+    };
 
+    int tile = split;
+    if (tile < p.n_tiles) {
+        set_tile(tile);
 #pragma unroll
-        for (int py = 0; py < TH; ++py) {
+        for (int k = 0; k < KP; ++k) issue_piece(k, smem);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (; tile < p.n_tiles; tile += p.splits) {
+        const float* sA = smem + cur * TILE_FLOATS;
+        const float* sB = sA + A_PIX_PAD * CT;
+        float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
+        const bool more = tile + p.splits < p.n_tiles;       // wave-uniform
+        if (more) set_tile(tile + p.splits);
+
+        // fragments of step st+1 are read while step st's MFMAs issue; the next tile's DMA pieces are issued
+        // one per step so their address arithmetic hides under matrix-pipe time
+        float ac[NT], an[NT], bc, bn;
+        auto load_frag = [&](int st, float (&av)[NT], float& bv) {
+            const int py = st / (TW / 2), px = 2 * (st % (TW / 2)) + lh;
+            bv = sB[(py * TW + px) * CT + b_lane];
 #pragma unroll
-            for (int sx = 0; sx < TW / 2; ++sx) {
-                const int px = 2 * sx + lh;
-                const float bv = sB[(py * TW + px) * CT + b_lane];
-#pragma unroll
-                for (int tap = 0; tap < NT; ++tap) {
-                    int apix;
-                    if (MODE == 0) apix = (py + tap / 3) * A_COLS + px + (tap % 3);
-                    else           apix = (2 * py + (tap >> 1)) * A_COLS + 2 * px + (tap & 1);
-                    const float av = sA[apix * CT + a_lane];
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
-                }
+            for (int tap = 0; tap < NT; ++tap) {
+                int apix;
+                if (MODE == 0) apix = (py + tap / 3) * A_COLS + px + (tap % 3);
+                else           apix = (2 * py + (tap >> 1)) * A_COLS + 2 * px + (tap & 1);
+                av[tap] = sA[apix * CT + a_lane];
             }
+        };
+        load_frag(0, ac, bc);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            if (st + 1 < STEPS) load_frag(st + 1, an, bn);
+            if (st < KP && more) issue_piece(st, nxt);
+#pragma unroll
+            for (int tap = 0; tap < NT; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[tap], bc, acc[tap], 0, 0, 0);
+#pragma unroll
+            for (int tap = 0; tap < NT; ++tap) ac[tap] = an[tap];
+            bc = bn;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next tile landed (this wave's pieces)
+        __syncthreads();                                       // ... everyone's pieces; everyone done with `cur`
+        cur ^= 1;
     }
 
     // partial block -> workspace [split][tap][Cm][Cn]
@@ -130,7 +184,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 }
 
 int choose_splits(int mt_nt, int n_tiles) {
-    int s = 1024 / mt_nt;
+    int s = 256 / mt_nt;           // one persistent workgroup per CU (256 CUs)
     if (s < 1) s = 1;
     if (s > n_tiles) s = n_tiles;
     return s;

@@ -55,22 +55,43 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     double acc[2][VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { acc[0][e] = 0.0; acc[1][e] = 0.0; }
-    if (l.active)
-        for (long pix = p0 + l.pl; pix < p1; pix += l.npl) {
+    if (l.active) {
+        long pix = p0 + l.pl;
+        const long st = l.npl;
+        for (; pix + 3 * st < p1; pix += 4 * st) {          // 4 independent loads in flight per lane
+            float v[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vload<VEC>(v[u], r + (size_t)(pix + u * st) * ldr + l.c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { acc[0][e] += (double)v[u][e]; acc[1][e] += (double)v[u][e] * (double)v[u][e]; }
+        }
+        for (; pix < p1; pix += st) {
             float v[VEC]; vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { acc[0][e] += (double)v[e]; acc[1][e] += (double)v[e] * (double)v[e]; }
         }
+    }
     block_combine<VEC, 2>(acc, l, C, part, gridDim.x, sRd);
 }
 
-__global__ void bn_train_finalize_kernel(const double* __restrict__ part, int nblk, long P, int C,
+// The finalize kernels run one 64-lane wave per channel: lanes stride over the per-block partials, then a fixed
+// xor-shuffle tree combines them (same order every run -> bit-stable).  blockDim = 64, gridDim = C.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void bn_train_finalize_kernel(const double* __restrict__ part, int nblk, long P, int C,
         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, int unbiased,
         float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < nblk; ++k) { s += part[(size_t)k * C + c]; ss += part[((size_t)nblk + k) * C + c]; }
+    for (int k = threadIdx.x; k < nblk; k += 64) { s += part[(size_t)k * C + c]; ss += part[((size_t)nblk + k) * C + c]; }
+    s = wave_sum(s); ss = wave_sum(ss);
+    if (threadIdx.x != 0) return;
     const double m = s / (double)P;
     double var = ss / (double)P - m * m;
     if (var < 0.0) var = 0.0;
@@ -122,7 +143,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     for (int e = 0; e < VEC; ++e) { acc[0][e] = 0.0; acc[1][e] = 0.0; }
     if (l.active) {
         float mu[VEC], is[VEC]; vload<VEC>(mu, mean + l.c0); vload<VEC>(is, invstd + l.c0);
-        for (long pix = p0 + l.pl; pix < p1; pix += l.npl) {
+        long pix = p0 + l.pl;
+        const long st = l.npl;
+        for (; pix + 3 * st < p1; pix += 4 * st) {
+            float g[4][VEC], v[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vload<VEC>(g[u], dy + (size_t)(pix + u * st) * lddy + l.c0); vload<VEC>(v[u], r + (size_t)(pix + u * st) * ldr + l.c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float xh = (v[u][e] - mu[e]) * is[e];
+                    acc[0][e] += (double)g[u][e]; acc[1][e] += (double)g[u][e] * (double)xh;
+                }
+        }
+        for (; pix < p1; pix += st) {
             float g[VEC], v[VEC];
             vload<VEC>(g, dy + (size_t)pix * lddy + l.c0); vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
 #pragma unroll
@@ -135,12 +172,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     block_combine<VEC, 2>(acc, l, C, part, gridDim.x, sRd);
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) { s1 += part[(size_t)k * C + c]; s2 += part[((size_t)nblk + k) * C + c]; }
-    dbeta[c] = (float)s1; dgamma[c] = (float)s2;
+    for (int k = threadIdx.x; k < nblk; k += 64) { s1 += part[(size_t)k * C + c]; s2 += part[((size_t)nblk + k) * C + c]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (threadIdx.x == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
 }
 
 // backward pass 2: dz = relu'(r) * gamma*invstd * (dy - mean(dy) - xhat * mean(dy*xhat)); also per-channel sum(dz)
@@ -163,7 +200,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float invP = 1.0f / (float)P;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { a[e] = ga[e] * is[e]; c1[e] = db[e] * invP; c2[e] = dg[e] * invP; }
-        for (long pix = p0 + l.pl; pix < p1; pix += l.npl) {
+        long pix = p0 + l.pl;
+        const long st = l.npl;
+        for (; pix + 3 * st < p1; pix += 4 * st) {
+            float g[4][VEC], v[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vload<VEC>(g[u], dy + (size_t)(pix + u * st) * lddy + l.c0); vload<VEC>(v[u], r + (size_t)(pix + u * st) * ldr + l.c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float xh = (v[u][e] - mu[e]) * is[e];
+                    float d = a[e] * (g[u][e] - c1[e] - xh * c2[e]);
+                    if (relu && !(v[u][e] > 0.f)) d = 0.f;
+                    o[e] = d; acc[0][e] += (double)d;
+                }
+                vstore<VEC>(dz + (size_t)(pix + u * st) * lddz + l.c0, o);
+            }
+        }
+        for (; pix < p1; pix += st) {
             float g[VEC], v[VEC], o[VEC];
             vload<VEC>(g, dy + (size_t)pix * lddy + l.c0); vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
 #pragma unroll
@@ -179,12 +237,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
 }
 
-__global__ void colsum_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(64) void colsum_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* out) {
+    const int c = blockIdx.x;
     double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * C + c];
-    out[c] = (float)s;
+    for (int k = threadIdx.x; k < nblk; k += 64) s += part[(size_t)k * C + c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 struct Plan { int vec, tpp, nblk; long ppb; size_t smem2, smem1; };
@@ -194,13 +252,13 @@ bool make_plan(long P, int C, int ld_a, int ld_b, int ld_c, bool aligned, Plan* 
     if (C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && ld_c % 4 == 0 && aligned) { vec = 4; tpp = C / 4; }
     else if (C <= 256) { vec = 1; tpp = 1; while (tpp < C) tpp <<= 1; }
     else return false;
-    long nblk = (P + 511) / 512; if (nblk > 1024) nblk = 1024; if (nblk < 1) nblk = 1;
+    long nblk = (P + 511) / 512; if (nblk > 2048) nblk = 2048; if (nblk < 1) nblk = 1;
     pl->vec = vec; pl->tpp = tpp; pl->nblk = (int)nblk; pl->ppb = (P + nblk - 1) / nblk;
     pl->smem2 = (size_t)256 * vec * 2 * sizeof(double); pl->smem1 = (size_t)256 * vec * sizeof(double);
     return true;
 }
 
-int nblk_for(long P) { long n = (P + 511) / 512; if (n > 1024) n = 1024; if (n < 1) n = 1; return (int)n; }
+int nblk_for(long P) { long n = (P + 511) / 512; if (n > 2048) n = 2048; if (n < 1) n = 1; return (int)n; }
 
 }  // namespace
 
@@ -219,7 +277,7 @@ extern "C" int unet_bn_train_stats(const float* r, int ldr, long P, int C, const
     if (pl.vec == 4) bn_stats_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(r, ldr, P, C, pl.tpp, pl.ppb, part);
     else             bn_stats_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(r, ldr, P, C, pl.tpp, pl.ppb, part);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    bn_train_finalize_kernel<<<unet_cdiv(C, 128), 128, 0, st>>>(part, pl.nblk, P, C, gamma, beta, eps, momentum,
+    bn_train_finalize_kernel<<<C, 64, 0, st>>>(part, pl.nblk, P, C, gamma, beta, eps, momentum,
         unbiased_moving_var, moving_mean, moving_var, mean, invstd, scale, shift);
     return UNET_LAUNCH_STATUS();
 }
@@ -258,12 +316,12 @@ extern "C" int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, c
     if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part);
     else             bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    bn_bwd_finalize_kernel<<<unet_cdiv(C, 128), 128, 0, st>>>(part, pl.nblk, C, dgamma, dbeta);
+    bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(part, pl.nblk, C, dgamma, dbeta);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     double* part2 = part + (size_t)2 * pl.nblk * C;
     if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
     else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    colsum_finalize_kernel<<<unet_cdiv(C, 128), 128, 0, st>>>(part2, pl.nblk, C, dbias);
+    colsum_finalize_kernel<<<C, 64, 0, st>>>(part2, pl.nblk, C, dbias);
     return UNET_LAUNCH_STATUS();
 }
