@@ -37,12 +37,32 @@ def synthetic(batch, channels, classes, hw, seed, device):
     return img.to(device), lab.to(device)
 
 
+def usable_cores():
+    """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (os.cpu_count() reports the
+    host's cores, and oversubscribing torch's thread pool on a 16-core share makes the baseline meaninglessly slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("UNET_CPU_BASELINE_THREADS", "32"))))
+
+
 def cpu_baseline(hw, channels, classes, batch=2, steps=2):
     import numpy as np
     import torch
     from oracle import unet_numpy as on
     from oracle import unet_torch as ot
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     img, lab = on.synthetic_batch(batch, channels, classes, hw, hw, seed=1234)
     rng = np.random.default_rng(0)
@@ -59,8 +79,27 @@ def cpu_baseline(hw, channels, classes, batch=2, steps=2):
                       % (steps, batch, hw, hw, channels, classes, dt)}
 
 
+def cpu_baseline_bounded(args, budget_s=240):
+    """Run the CPU leg in a child process (never touches the GPU) with a hard time budget, so a slow or oversubscribed
+    host cannot hold back the benchmark's JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(args.size),
+           "--channels", str(args.channels), "--classes", str(args.classes)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
+                "sample": "cpu baseline child failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
+                "sample": "cpu baseline exceeded its %d s budget on this host" % budget_s}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -71,6 +110,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.size, args.channels, args.classes)), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -147,7 +189,7 @@ def main():
             out["step_tflops_per_gpu"] = round(ips / world * gf / 1e3, 2)
             out["step_frac_of_fp32_mfma_peak"] = round(ips / world * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.size, args.channels, args.classes)
+            out["cpu_baseline"] = cpu_baseline_bounded(args)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""`inference` -- caller of the eval-mode forward + argmax (reference UNet/inference.py), on the HIP engine.
+
+Flags are the reference's (UNet/inference.py:234-241).  Behaviour kept: image -> float32 -> z-score over the whole image
+(:201-206); reflect-pad bottom/right to a multiple of 16 (:30-47,143-157); images larger than 1024 px go through the
+tiled path: zones of responsibility of 1024 - 2*radius with a halo of `radius` clamped at the borders, eval forward per
+tile, halo stripped, pasted (:54-129); mask = argmax over classes, first maximum wins (:107,166), cast to
+uint8/uint16/int32 by its maximum (:215-220).  The argmax runs on the device (`unet_argmax`).  I/O: .npy always;
+.tif/.png when Pillow is importable (the reference uses scikit-image, absent here).
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from . import model as unet_model_module
+from .readers import zscore_normalize
+
+TILE_SIZE = 1024
+SIZE_FACTOR = unet_model_module.UNet.SIZE_FACTOR
+
+
+def _pad_to_factor(img):
+    if img.ndim not in (2, 3):
+        raise IOError("Invalid number of dimensions for input image. Expecting HW or HWC dimension ordering.")
+    if img.ndim == 2:
+        img = img[:, :, None]
+    pad_y = (-img.shape[0]) % SIZE_FACTOR
+    pad_x = (-img.shape[1]) % SIZE_FACTOR
+    if pad_x or pad_y:
+        img = np.pad(img, ((0, pad_y), (0, pad_x), (0, 0)), mode="reflect")
+    return img, pad_y, pad_x
+
+
+def _predict(unet, tile_hwc):
+    """HWC fp32 tile -> int32 [H,W] class map via the eval-mode forward and the device argmax."""
+    x = torch.as_tensor(np.ascontiguousarray(tile_hwc.transpose(2, 0, 1))[None].astype(np.float32))
+    e = unet.engine
+    return e.argmax(e.forward(x, training=False))[0].cpu().numpy()
+
+
+def _inference(img, unet):
+    img, pad_y, pad_x = _pad_to_factor(img)
+    mask = _predict(unet, img)
+    return mask[:mask.shape[0] - pad_y, :mask.shape[1] - pad_x]
+
+
+def _inference_tiling(img, unet, tile_size):
+    img, pad_y, pad_x = _pad_to_factor(img)
+    height, width = img.shape[:2]
+    mask = np.zeros((height, width), dtype=np.int32)
+    radius = unet.estimate_radius()
+    assert tile_size % SIZE_FACTOR == 0 and radius % SIZE_FACTOR == 0
+    zone = tile_size - 2 * radius
+    assert zone >= radius
+    for y0 in range(0, height, zone):
+        for x0 in range(0, width, zone):
+            y1, x1 = min(y0 + zone, height), min(x0 + zone, width)
+            # halo of `radius` on every side that exists; the reference drops the far halo entirely when the padded
+            # window would cross the image edge (UNet/inference.py:86-96), which is reproduced here
+            ty0 = y0 - radius if y0 - radius >= 0 else 0
+            tx0 = x0 - radius if x0 - radius >= 0 else 0
+            ty1 = y0 + zone + radius if y0 + zone + radius <= height else height
+            tx1 = x0 + zone + radius if x0 + zone + radius <= width else width
+            pred = _predict(unet, img[ty0:ty1, tx0:tx1])
+            oy, ox = y0 - ty0, x0 - tx0
+            mask[y0:y1, x0:x1] = pred[oy:oy + (y1 - y0), ox:ox + (x1 - x0)]
+    return mask[:height - pad_y, :width - pad_x]
+
+
+def _read(path):
+    if path.endswith(".npy"):
+        return np.load(path)
+    from PIL import Image
+    return np.array(Image.open(path))
+
+
+def _write(path, mask):
+    if path.endswith(".npy"):
+        np.save(path, mask)
+        return
+    from PIL import Image
+    Image.fromarray(mask).save(path)
+
+
+def inference(checkpoint_filepath, image_folder, output_folder, number_classes, number_channels, image_format):
+    os.makedirs(output_folder, exist_ok=True)
+    names = sorted(f for f in os.listdir(image_folder) if f.endswith("." + image_format))
+    unet = unet_model_module.UNet(number_classes, 1, number_channels, 1e-4)
+    unet.load_checkpoint(checkpoint_filepath)
+    for i, name in enumerate(names):
+        print("{}/{}".format(i, len(names)))
+        img = _read(os.path.join(image_folder, name)).astype(np.float32)
+        hwc = img[:, :, None] if img.ndim == 2 else img
+        img = zscore_normalize(hwc.transpose(2, 0, 1)).transpose(1, 2, 0)
+        if img.shape[0] > TILE_SIZE or img.shape[1] > TILE_SIZE:
+            seg = _inference_tiling(img, unet, TILE_SIZE)
+        else:
+            seg = _inference(img, unet)
+        mx = int(seg.max())
+        seg = seg.astype(np.uint8 if mx < 255 else (np.uint16 if mx < 65536 else np.int32))
+        _write(os.path.join(output_folder, name), seg)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="inference", description="Script to detect stars with the selected unet model")
+    ap.add_argument("--checkpoint_filepath", dest="checkpoint_filepath", type=str, required=True)
+    ap.add_argument("--image_folder", dest="image_folder", type=str, required=True)
+    ap.add_argument("--output_folder", dest="output_folder", type=str, required=True)
+    ap.add_argument("--number_classes", dest="number_classes", type=int, required=True)
+    ap.add_argument("--number_channels", dest="number_channels", type=int, required=True)
+    ap.add_argument("--image_format", dest="image_format", type=str, default="tif")
+    a = ap.parse_args(argv)
+    inference(a.checkpoint_filepath, a.image_folder, a.output_folder, a.number_classes, a.number_channels, a.image_format)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+"""Batch sources for the train / test loops.  The reference feeds the hot path from its LMDB `ImageReader`
+(UNet/imagereader.py:77-355), which this build keeps out of scope; what the hot path needs from a reader is
+only its OUTPUT CONTRACT (UNet/imagereader.py:298-312,353-355): images fp32 [C,H,W] z-scored per channel, labels int32
+one-hot [H,W,K].  Two small sources implement that contract here so the CLIs run without lmdb:
+
+  SyntheticReader  seeded N(0,1) tiles + piecewise-constant 8x8-block labels (the benchmark workload);
+  TileFolderReader a folder of `<name>.npy` image tiles ([H,W] or [H,W,C], any dtype) with `<name>_mask.npy` class maps.
+
+Both expose the reader surface train.py uses: startup(), shutdown(), get_image_count(), get_image_size() -> (H, W, C),
+batches(batch_size) -> iterator of (images [B,C,H,W] fp32, labels [B,H,W,K] int32) that never ends (like the reference's
+generator, UNet/imagereader.py:338-343).  Batches are pinned host tensors so the H2D copy is asynchronous.
+"""
+import os
+
+import numpy as np
+import torch
+
+
+def zscore_normalize(chw):
+    """Per-channel z-score; only mean-subtract when std <= 1 (reference UNet/imagereader.py:33-49)."""
+    out = np.asarray(chw, dtype=np.float32).copy()
+    for c in range(out.shape[0]):
+        std, mean = float(np.std(out[c])), float(np.mean(out[c]))
+        out[c] = (out[c] - mean) if std <= 1.0 else (out[c] - mean) / std
+    return out
+
+
+def one_hot(mask_hw, number_classes):
+    m = np.asarray(mask_hw).astype(np.int64)
+    if m.max(initial=0) >= number_classes or m.min(initial=0) < 0:
+        raise IndexError("Number of classes specified differs from number of observed classes in data")
+    return (m[..., None] == np.arange(number_classes)).astype(np.int32)
+
+
+def _pin(t):
+    return t.pin_memory() if torch.cuda.is_available() else t
+
+
+class _Base:
+    def startup(self):
+        pass
+
+    def shutdown(self):
+        pass
+
+
+class SyntheticReader(_Base):
+    def __init__(self, count, height, width, channels, number_classes, seed=0):
+        self.count, self.h, self.w, self.c, self.k, self.seed = count, height, width, channels, number_classes, seed
+
+    def get_image_count(self):
+        return self.count
+
+    def get_image_size(self):
+        return (self.h, self.w, self.c)
+
+    def batches(self, batch_size):
+        g = torch.Generator().manual_seed(self.seed)
+        while True:
+            img = torch.randn(batch_size, self.c, self.h, self.w, generator=g)
+            cls = torch.randint(0, self.k, (batch_size, (self.h + 7) // 8, (self.w + 7) // 8), generator=g)
+            cls = cls.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :self.h, :self.w]
+            yield _pin(img), _pin(torch.nn.functional.one_hot(cls, self.k).to(torch.int32))
+
+
+class TileFolderReader(_Base):
+    def __init__(self, folder, number_classes, shuffle=False, seed=0):
+        self.folder, self.k, self.shuffle, self.seed = folder, number_classes, shuffle, seed
+        self.names = sorted(f[:-4] for f in os.listdir(folder) if f.endswith(".npy") and not f.endswith("_mask.npy"))
+        if not self.names:
+            raise IOError("no <name>.npy tiles in " + folder)
+        first = np.load(os.path.join(folder, self.names[0] + ".npy"))
+        self.h, self.w = first.shape[:2]
+        self.c = 1 if first.ndim == 2 else first.shape[2]
+        if self.h % 16 or self.w % 16:
+            raise IOError("Input Image tile size must be a multiple of 16")     # cf. UNet/imagereader.py:136-139
+
+    def get_image_count(self):
+        return len(self.names)
+
+    def get_image_size(self):
+        return (self.h, self.w, self.c)
+
+    def _load(self, name):
+        im = np.load(os.path.join(self.folder, name + ".npy"))
+        im = im[..., None] if im.ndim == 2 else im
+        mk = np.load(os.path.join(self.folder, name + "_mask.npy"))
+        return zscore_normalize(im.transpose(2, 0, 1)), one_hot(mk, self.k)
+
+    def batches(self, batch_size):
+        rng = np.random.default_rng(self.seed)
+        pos = 0
+        order = np.arange(len(self.names))
+        while True:
+            imgs, labs = [], []
+            for _ in range(batch_size):
+                if pos == 0 and self.shuffle:
+                    rng.shuffle(order)
+                i, l = self._load(self.names[order[pos]])
+                imgs.append(i); labs.append(l)
+                pos = (pos + 1) % len(order)
+            yield _pin(torch.as_tensor(np.stack(imgs))), _pin(torch.as_tensor(np.stack(labs)))
