@@ -77,5 +77,6 @@ def test_hip_path_reproduces_golden():
               global_batch_size=2, want_grad=True)
     e.backward()
     assert abs(e.loss_buf[0].item() - float(G["loss_train"])) < 1e-5 * float(G["loss_train"])
-    assert np.abs(e.bufs["softmax"].cpu().numpy() - G["softmax_train"]).max() < 2e-5
+    # training-mode forward: batch statistics over as few as 8 samples (2x2 bottleneck, N=2) amplify fp32 rounding
+    assert np.abs(e.bufs["softmax"].cpu().numpy() - G["softmax_train"]).max() < 1e-4
     _check_grads(e.export_gradients(), 5e-2)        # fp32 ReLU-mask flips bound this (see test_gpu_unet.grad_errors)
