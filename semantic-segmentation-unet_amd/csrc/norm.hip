@@ -245,6 +245,7 @@ __global__ __launch_bounds__(64) void colsum_finalize_kernel(const double* __res
     if (threadIdx.x == 0) out[c] = (float)s;
 }
 
+constexpr long MAX_BLOCKS = 2048;
 struct Plan { int vec, tpp, nblk; long ppb; size_t smem2, smem1; };
 
 bool make_plan(long P, int C, int ld_a, int ld_b, int ld_c, bool aligned, Plan* pl) {
@@ -252,13 +253,15 @@ bool make_plan(long P, int C, int ld_a, int ld_b, int ld_c, bool aligned, Plan* 
     if (C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && ld_c % 4 == 0 && aligned) { vec = 4; tpp = C / 4; }
     else if (C <= 256) { vec = 1; tpp = 1; while (tpp < C) tpp <<= 1; }
     else return false;
-    long nblk = (P + 511) / 512; if (nblk > 2048) nblk = 2048; if (nblk < 1) nblk = 1;
+    // a block covers 256/tpp pixels per pass; give every lane ~8 passes, up to 2048 blocks (8 per CU)
+    const long npl = 256 / tpp;
+    long nblk = (P + npl * 8 - 1) / (npl * 8); if (nblk > MAX_BLOCKS) nblk = MAX_BLOCKS; if (nblk < 1) nblk = 1;
     pl->vec = vec; pl->tpp = tpp; pl->nblk = (int)nblk; pl->ppb = (P + nblk - 1) / nblk;
     pl->smem2 = (size_t)256 * vec * 2 * sizeof(double); pl->smem1 = (size_t)256 * vec * sizeof(double);
     return true;
 }
 
-int nblk_for(long P) { long n = (P + 511) / 512; if (n > 2048) n = 2048; if (n < 1) n = 1; return (int)n; }
+int nblk_for(long P) { (void)P; return (int)MAX_BLOCKS; }        // workspace is sized for the largest grid
 
 }  // namespace
 
