@@ -7,9 +7,9 @@ forward + per-pixel softmax-CE + backward + (gradient all-reduce) + Keras-Adam, 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (the fp32-MFMA 3x3 implicit-GEMM conv that
-serves forward and dgrad): algorithmic FLOPs of its launches / their HIP-event durations measured live in the timed
-steps, against the dense fp32 matrix peak.  `cpu_baseline` times the oracle's torch-CPU restatement of the same train
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA 3x3 implicit-GEMM conv): algorithmic
+FLOPs of its forward launches / their HIP-event durations measured live in the timed steps, against the dense fp32
+matrix peak (backward launches overlap on two streams and are listed under `kernels`).  `cpu_baseline` times the oracle's torch-CPU restatement of the same train
 step on the host cores over a bounded sample (rank 0, N=1 only) -- a reported baseline, not the target.
 """
 import argparse
@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream (A/B switch)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.size, args.channels, args.classes)), flush=True)
@@ -131,6 +132,7 @@ def main():
     model = importlib.import_module(PKG + ".model")
     G = args.batch * world
     net = model.UNet(args.classes, G, args.channels, learning_rate=3e-4, device=dev, seed=0)
+    net.engine.overlap_wgrad = not args.no_overlap
     if world > 1:
         par = importlib.import_module(PKG + ".parallel")
         net.parallel = par.DataParallel(net.engine)
@@ -166,11 +168,16 @@ def main():
             fl = sum(f for _, _, f in evs)
             extra[key] = {"launches_per_step": len(evs) // args.steps, "ms_per_step": round(ms / args.steps, 3),
                           "avg_launch_ms": round(ms / len(evs), 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
-        k = extra.get("conv3x3_igemm")
+        # Dominant kernel = igemm_kernel (3x3 implicit GEMM).  Its FORWARD launches (template instantiation
+        # igemm_kernel<0,*,*,false>) run alone on the GPU, so their event durations are the kernel's own; the dgrad
+        # launches (<0,*,*,true>) and wgrad_kernel run concurrently on two streams in backward, so their per-launch
+        # durations in `kernels` include time shared with the other stream.
+        k = extra.get("conv3x3_fwd")
         if k:
-            roofline = {"bound": "mfma", "kernel": "igemm_kernel (3x3 conv forward + dgrad, v_mfma_f32_32x32x2_f32)",
+            roofline = {"bound": "mfma", "kernel": "igemm_kernel<0,*,*,false> (3x3 conv forward, v_mfma_f32_32x32x2_f32)",
                         "achieved": k["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(k["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}
+                        "frac": round(k["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": k["launches_per_step"], "avg_launch_ms": k["avg_launch_ms"]}
     if rank == 0:
         ips = G * args.steps / dt
         out = {

@@ -115,7 +115,13 @@ class Engine:
         self.dropout_seed = seed
         self.init_parameters(seed)
         self.on_layer_grads_ready = None        # hook(name) for data-parallel bucketing (parallel.py)
-        self.profile = None                     # bench.py: {"conv3x3_igemm": [(ev0, ev1, flops)], ...} when enabled
+        self.profile = None                     # bench.py: {"conv3x3_fwd": [(ev0, ev1, flops)], ...} when enabled
+        # Backward runs two HIP streams: the critical chain dgrad(L) -> bn_bwd(L-1) -> dgrad(L-1) ... on the caller's
+        # stream, every weight gradient on `side` (it is needed only by the all-reduce / Adam).  The persistent wgrad
+        # workgroups (106 KB LDS) co-reside with igemm workgroups and with the HBM-bound BN streams.
+        self.overlap_wgrad = True
+        self.side = torch.cuda.Stream(device=self.dev)
+        self._ws_side = None
 
     def _timed(self, key, flops, fn, *args):
         """Call fn(*args); when profiling is on, bracket it with HIP events on the launch stream."""
@@ -174,10 +180,15 @@ class Engine:
             self.bufs[name] = t
         return t
 
-    def _workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.dev)
-        return self._ws
+    def _workspace(self, nbytes, side=False):
+        cur = self._ws_side if side else self._ws
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.dev)
+            if side:
+                self._ws_side = cur
+            else:
+                self._ws = cur
+        return cur
 
     @staticmethod
     def _stream():
@@ -199,7 +210,7 @@ class Engine:
         else:
             r = self._buf("r_" + name, (n, h, w, cout))
             if L.unet_conv3x3_mfma_supported(cin, cout):
-                self._timed("conv3x3_igemm", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
+                self._timed("conv3x3_fwd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
                             _p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
             else:
                 L.unet_conv3x3_fwd_direct(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
@@ -320,36 +331,41 @@ class Engine:
         w_, dw = self.p[name + "/kernel"], self.g[name + "/kernel"]
         hi, wi = x.shape[1], x.shape[2]
         dx = None
-        if kind == "deconv":
-            nb = L.unet_convT2x2_wgrad_workspace(n, hi, wi, cin, cout)
-            ws = self._workspace(nb)
-            L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(ws), nb, st)
-            if need_dx:
-                dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
-                L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
-        elif kind == "conv1":
-            nb = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
-            ws = self._workspace(nb)
-            L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(ws), nb, st)
-            if need_dx:
-                dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
-                L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
-        else:
-            if L.unet_conv3x3_mfma_supported(cin, cout) and cin % 64 == 0:
-                nb = L.unet_conv3x3_wgrad_mfma_workspace(n, ho, wo, cin, cout)
-                ws = self._workspace(nb)
+
+        def wgrad():
+            sd = self.overlap_wgrad
+            st2 = self._stream()
+            if kind == "deconv":
+                nb2 = L.unet_convT2x2_wgrad_workspace(n, hi, wi, cin, cout)
+                L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+            elif kind == "conv1":
+                nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
+                L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+            elif L.unet_conv3x3_mfma_supported(cin, cout) and cin % 64 == 0:
+                nb2 = L.unet_conv3x3_wgrad_mfma_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_mfma,
-                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(ws), nb, st)
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             else:
-                nb = L.unet_conv3x3_wgrad_direct_workspace(n, ho, wo, cin, cout)
-                ws = self._workspace(nb)
-                L.unet_conv3x3_wgrad_direct(_p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(ws), nb, st)
-            if need_dx:
-                dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
-                self._timed("conv3x3_igemm", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_mfma,
+                nb2 = L.unet_conv3x3_wgrad_direct_workspace(n, ho, wo, cin, cout)
+                L.unet_conv3x3_wgrad_direct(_p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+            if self.on_layer_grads_ready is not None:
+                self.on_layer_grads_ready(name)          # under the stream the gradients were produced on
+
+        if self.overlap_wgrad:
+            self.side.wait_stream(torch.cuda.current_stream())       # dz (and this layer's bias/gamma/beta grads) ready
+            with torch.cuda.stream(self.side):
+                wgrad()
+        if need_dx:
+            dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
+            if kind == "deconv":
+                L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
+            elif kind == "conv1":
+                L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
+            else:
+                self._timed("conv3x3_dgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_mfma,
                             _p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
-        if self.on_layer_grads_ready is not None:
-            self.on_layer_grads_ready(name)
+        if not self.overlap_wgrad:
+            wgrad()
         return dx
 
     def backward(self):
@@ -375,6 +391,8 @@ class Engine:
                 self._dropout(ds, "drop_4", self.masks)
             d = b("conv_%db" % lvl, ds)
             d = b("conv_%da" % lvl, d, need_dx=(lvl != 1))
+        if self.overlap_wgrad:
+            torch.cuda.current_stream().wait_stream(self.side)        # every weight gradient done before Adam
 
     def adam_step(self, learning_rate):
         """Keras Adam on the flat buffers (reference UNet/model.py:79,223)."""
