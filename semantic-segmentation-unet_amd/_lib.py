@@ -7,7 +7,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "unet_hip.h")
-LIB_PATH = os.path.join(HERE, "csrc", "libunet_hip.so")
+LIB_PATH = os.environ.get("UNET_HIP_LIB") or os.path.join(HERE, "csrc", "libunet_hip.so")     # override: diagnostics only
 
 _DECL = re.compile(r"\b(int|size_t)\s+(unet_\w+)\s*\(([^)]*)\)\s*;", re.S)
 

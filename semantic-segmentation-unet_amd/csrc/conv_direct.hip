@@ -18,37 +18,61 @@ __global__ __launch_bounds__(256) void conv3x3_direct_fwd_kernel(const float* __
     const int tpp = Cout >> 2, ppb = 256 / tpp;
     const int q = threadIdx.x % tpp, pl = threadIdx.x / tpp;
     const long P = (long)N * H * W;
-    const long pix = (long)blockIdx.x * ppb + pl;
-    const bool live = pix < P;
-    int n = 0, y = 0, xx = 0;
-    if (live) { long t = pix; xx = (int)(t % W); t /= W; y = (int)(t % H); n = (int)(t / H); }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < Cin; c0 += CI_CHUNK) {
-        const int cc = min(CI_CHUNK, Cin - c0);
+    const long groups = (P + ppb - 1) / ppb;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    if (Cin <= CI_CHUNK) {
+        // common case (first layer): weights staged once per block, blocks stride over pixel groups
+        for (int i = threadIdx.x; i < 9 * Cin * Cout; i += 256) sW[i] = w[i];       // [9][Cin][Cout] is already the layout
         __syncthreads();
-        for (int i = threadIdx.x; i < 9 * cc * Cout; i += 256) {
-            const int co = i % Cout, r = i / Cout, ci = r % cc, tap = r / cc;
-            sW[i] = w[((size_t)tap * Cin + c0 + ci) * Cout + co];
-        }
-        __syncthreads();
-        if (live) {
+        for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+            const long pix = grp * ppb + pl;
+            if (pix >= P) continue;
+            long t = pix; const int xx = (int)(t % W); t /= W; const int y = (int)(t % H); const int n = (int)(t / H);
+            f32x4 acc = bv;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int gy = y + tap / 3 - 1, gx = xx + tap % 3 - 1;
                 if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
-                const float* xp = x + ((size_t)(n * H + gy) * W + gx) * ldx + c0;
-                for (int ci = 0; ci < cc; ++ci) {
-                    const float xv = xp[ci];
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(sW + (tap * cc + ci) * Cout + 4 * q);
-                    acc += xv * wv;
+                const float* xp = x + ((size_t)(n * H + gy) * W + gx) * ldx;
+                for (int ci = 0; ci < Cin; ++ci)
+                    acc += xp[ci] * *reinterpret_cast<const f32x4*>(sW + (tap * Cin + ci) * Cout + 4 * q);
+            }
+            if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+            *reinterpret_cast<f32x4*>(out + (size_t)pix * ldo + 4 * q) = acc;
+        }
+        return;
+    }
+    // general Cin: chunks of CI_CHUNK input channels through LDS, one pixel group per block pass
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long pix = grp * ppb + pl;
+        const bool live = pix < P;
+        int n = 0, y = 0, xx = 0;
+        if (live) { long t = pix; xx = (int)(t % W); t /= W; y = (int)(t % H); n = (int)(t / H); }
+        f32x4 acc = bv;
+        for (int c0 = 0; c0 < Cin; c0 += CI_CHUNK) {
+            const int cc = min(CI_CHUNK, Cin - c0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < 9 * cc * Cout; i += 256) {
+                const int co = i % Cout, r = i / Cout, ci = r % cc, tap = r / cc;
+                sW[i] = w[((size_t)tap * Cin + c0 + ci) * Cout + co];
+            }
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int gy = y + tap / 3 - 1, gx = xx + tap % 3 - 1;
+                    if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
+                    const float* xp = x + ((size_t)(n * H + gy) * W + gx) * ldx + c0;
+                    for (int ci = 0; ci < cc; ++ci)
+                        acc += xp[ci] * *reinterpret_cast<const f32x4*>(sW + (tap * cc + ci) * Cout + 4 * q);
                 }
             }
         }
-    }
-    if (live) {
-        if (bias) acc += *reinterpret_cast<const f32x4*>(bias + 4 * q);
-        if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
-        *reinterpret_cast<f32x4*>(out + (size_t)pix * ldo + 4 * q) = acc;
+        if (live) {
+            if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+            *reinterpret_cast<f32x4*>(out + (size_t)pix * ldo + 4 * q) = acc;
+        }
     }
 }
 
@@ -110,39 +134,52 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_fwd_kernel(const float* __
     for (int i = threadIdx.x; i < Cin * K; i += 256) sW[i] = w[i];
     __syncthreads();
     const int sub = threadIdx.x & 15;
-    const long pstride = (long)gridDim.x * 16;
     const int nq = Cin >> 2;
-    // the 16 lanes of a pixel share `pix`, so a shuffle group is always entirely active or entirely exited
-    for (long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < P; pix += pstride) {
-        const bool live = true;
-        for (int k0 = 0; k0 < K; k0 += 8) {
-            float acc[8];
+    constexpr int PU = 4;                                             // pixels per 16-lane group per pass
+    const long pstride = (long)gridDim.x * 16 * PU;
+    // the 16 lanes of a group share `base`, so a shuffle group is always entirely active or entirely exited
+    for (long base = ((long)blockIdx.x * 16 + (threadIdx.x >> 4)) * PU; base < P; base += pstride) {
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            float acc[PU][4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-            if (live) {
-                for (int cq = sub; cq < nq; cq += 16) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)pix * ldx + 4 * cq);
+            for (int u = 0; u < PU; ++u)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                for (int j = 0; j < 4; ++j) acc[u][j] = 0.f;
+            for (int cq = sub; cq < nq; cq += 16) {
+                f32x4 xv[PU];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (k0 + j < K) acc[j] += xv[e] * sW[(4 * cq + e) * K + k0 + j];
+                for (int u = 0; u < PU; ++u) {
+                    const long pix = base + u < P ? base + u : P - 1;
+                    xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)pix * ldx + 4 * cq);
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = acc[j];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                acc[j] = v;
-            }
-            if (live) {
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (sub == j && k0 + j < K) {
-                        float v = acc[j] + (bias ? bias[k0 + j] : 0.f);
-                        if (relu) v = fmaxf(v, 0.f);
-                        out[(size_t)pix * ldo + k0 + j] = v;
+                    for (int j = 0; j < 4; ++j) {
+                        const float wv = (k0 + j < K) ? sW[(4 * cq + e) * K + k0 + j] : 0.f;
+#pragma unroll
+                        for (int u = 0; u < PU; ++u) acc[u][j] += xv[u][e] * wv;
                     }
+            }
+#pragma unroll
+            for (int u = 0; u < PU; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[u][j];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    acc[u][j] = v;
+                }
+            // lane sub = 4*u + j writes pixel u, class k0 + j
+            const int u = sub >> 2, j = sub & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int uu = 0; uu < PU; ++uu)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) if (uu == u && jj == j) v = acc[uu][jj];
+            if (base + u < P && k0 + j < K) {
+                v += bias ? bias[k0 + j] : 0.f;
+                if (relu) v = fmaxf(v, 0.f);
+                out[(size_t)(base + u) * ldo + k0 + j] = v;
             }
         }
     }
@@ -225,7 +262,8 @@ extern "C" int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, 
     const int ppb = 256 / tpp;
     const size_t smem = (size_t)9 * CI_CHUNK * Cout * sizeof(float);
     UNET_CHECK_ARG(smem <= 64 * 1024);
-    conv3x3_direct_fwd_kernel<<<unet_cdiv(P, ppb), 256, smem, (hipStream_t)stream>>>(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, relu);
+    long blocks = (P + ppb - 1) / ppb; if (blocks > 4096) blocks = 4096;
+    conv3x3_direct_fwd_kernel<<<(int)blocks, 256, smem, (hipStream_t)stream>>>(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, relu);
     return UNET_LAUNCH_STATUS();
 }
 
@@ -257,7 +295,7 @@ extern "C" int unet_conv1x1_fwd(const float* x, int ldx, const float* w, const f
                                 long P, int Cin, int Cout, int relu, void* stream) {
     UNET_CHECK_ARG(x && w && out && P > 0 && Cin > 0 && Cout > 0 && Cin % 4 == 0 && ldx % 4 == 0 && ldx >= Cin && ldo >= Cout);
     UNET_CHECK_ARG(unet_aligned16(x) && (size_t)Cin * Cout * 4 <= 64 * 1024);
-    long blocks = (P + 15) / 16; if (blocks > 4096) blocks = 4096;
+    long blocks = (P + 63) / 64; if (blocks > 4096) blocks = 4096;
     conv1x1_narrow_fwd_kernel<<<(int)blocks, 256, (size_t)Cin * Cout * 4, (hipStream_t)stream>>>(x, ldx, w, bias, out, ldo, P, Cin, Cout, relu);
     return UNET_LAUNCH_STATUS();
 }

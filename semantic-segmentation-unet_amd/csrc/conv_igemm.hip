@@ -26,6 +26,9 @@ namespace {
 constexpr int CK = 32;
 constexpr int SA = CK + 4;
 constexpr int TW = 32;
+#ifndef UNET_ABLATE
+#define UNET_ABLATE 0
+#endif
 
 struct IgemmArgs {
     const float* x; const float* w; const float* bias; float* out;
@@ -165,6 +168,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     gload_B(0, 0);
     int chunk = 0, tap = 0;
     for (int it = 0; it < n_it; ++it) {
+#if UNET_ABLATE >= 1        /* diagnostic builds only (scripts/ablate_igemm.sh): results are wrong by construction */
+        if (it == 0) { store_A(); store_B(); __syncthreads(); }
+#if UNET_ABLATE < 2
+        __syncthreads(); __syncthreads();
+#endif
+#else
         __syncthreads();
         if (MODE != 0 || tap == 0) {
             if (!PREFETCH_A && it > 0) gload_A(chunk, tap);
@@ -172,17 +181,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
         }
         store_B();
         __syncthreads();
+#endif
         int nchunk = chunk, ntap = tap + 1;
         if (ntap == NT) { ntap = 0; nchunk = chunk + 1; }
+#if UNET_ABLATE < 1
         if (it + 1 < n_it) {
             gload_B(nchunk, ntap);
             if (PREFETCH_A && (MODE != 0 || ntap == 0)) gload_A(nchunk, ntap);     // MODE 0: issued during the chunk's last tap
         }
+#endif
 
         const int tap_off = MODE == 0 ? ((tap / 3) * A_COLS + (tap % 3)) * SA : 0;
 #pragma unroll
         for (int kk = 0; kk < CK / 8; ++kk) {
             f32x4 af[2], bf[2];
+#if UNET_ABLATE >= 3
+            af[0] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(it + kk); af[1] = af[0] + 1.f; bf[0] = af[0] - 1.f; bf[1] = af[1] * 0.5f;
+            asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0]), "+v"(bf[1]));
+#else
 #pragma unroll
             for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const f32x4*>(sA + a_base[t] + tap_off + kk * 8);
 #pragma unroll
@@ -194,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
                     for (int s = 0; s < 4; ++s) bf[u][s] = sB[b_base[u] + (kk * 8 + s) * BN];
                 }
             }
+#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll

@@ -136,11 +136,13 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     if (threadIdx.x == 0) { part_loss[blockIdx.x] = sL[0]; part_correct[blockIdx.x] = sC[0]; }
 }
 
-__global__ void softmax_ce_finalize_kernel(const double* part_loss, const unsigned long long* part_correct, int nblk,
+__global__ __launch_bounds__(64) void softmax_ce_finalize_kernel(const double* part_loss, const unsigned long long* part_correct, int nblk,
                                            float loss_scale, float* loss_out, float* correct_out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0; unsigned long long c = 0;
-        for (int k = 0; k < nblk; ++k) { s += part_loss[k]; c += part_correct[k]; }
+    double s = 0.0; unsigned long long c = 0;
+    for (int k = threadIdx.x; k < nblk; k += 64) { s += part_loss[k]; c += part_correct[k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); c += __shfl_xor(c, o); }
+    if (threadIdx.x == 0) {
         if (loss_out) loss_out[0] = (float)(s * (double)loss_scale);
         if (correct_out) correct_out[0] = (float)c;
     }

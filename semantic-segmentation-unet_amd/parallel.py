@@ -21,7 +21,7 @@ from .engine import BACKWARD_ORDER
 
 
 class DataParallel:
-    def __init__(self, engine, bucket_bytes=25 * 1024 * 1024, process_group=None, broadcast=True):
+    def __init__(self, engine, bucket_bytes=25 * 1024 * 1024, process_group=None, broadcast=True, force=False):
         assert dist.is_initialized(), "torch.distributed must be initialised (backend nccl == RCCL on ROCm)"
         self.engine = engine
         self.group = process_group
@@ -39,8 +39,9 @@ class DataParallel:
                 start = None
         self._trigger = {last: i for i, (_, _, last) in enumerate(self.buckets)}
         self._pending = []
+        self.force = force            # tests: issue the collectives even with a single rank
         engine.on_layer_grads_ready = self._on_layer
-        if broadcast and self.world_size > 1:
+        if broadcast and (self.world_size > 1 or force):
             self.broadcast_state()
 
     def broadcast_state(self):
@@ -53,7 +54,7 @@ class DataParallel:
 
     def _on_layer(self, name):
         i = self._trigger.get(name)
-        if i is None or self.world_size == 1:
+        if i is None or (self.world_size == 1 and not self.force):
             return
         a, b, _ = self.buckets[i]
         self._pending.append(dist.all_reduce(self.engine.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
