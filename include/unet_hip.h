@@ -96,6 +96,15 @@ int unet_softmax_ce(const float* logits, int ldz, const int* labels_onehot, floa
 /* np.argmax(softmax, axis=-1), UNet/inference.py:107,166 (first maximum wins) */
 int unet_argmax(const float* p, int ldp, int* out, long P, int K, void* stream);
 
+/* ---- eval-mode backward to the input image: the ERF probe of UNet.estimate_radius, UNet/model.py:165-202 ----------- */
+/* dlogits_k = p_k (g_k - sum_j g_j p_j); BN with moving statistics is affine: dz = dy*scale (times the ReLU mask);
+ * data gradient of the first 3x3 layer (Cin = number_channels), which the training path never needs. */
+int unet_softmax_bwd(const float* prob, const float* dprob, float* dlogits, int lddz, long P, int K, void* stream);
+int unet_bn_eval_bwd(const float* dy, int lddy, const float* r, int ldr, const float* scale, float* dz, int lddz,
+                     long P, int C, int relu, void* stream);
+int unet_conv3x3_dgrad_direct(const float* dz, int lddz, const float* w, float* dx, int lddx,
+                              int N, int H, int W, int Cin, int Cout, void* stream);
+
 /* ---- tf.keras.optimizers.Adam.apply_gradients, UNet/model.py:79,223; alpha = lr*sqrt(1-b2^t)/(1-b1^t) from host -- */
 int unet_adam_keras(float* theta, const float* grad, float* m, float* v, long n, float alpha, float beta1,
                     float beta2, float eps, void* stream);

@@ -119,5 +119,30 @@ class TorchUNet:
             softmax, _, _ = self.forward(images, False)
         return np.argmax(softmax.numpy(), axis=-1).astype(np.int32)
 
+    def input_gradient_eval(self, images, dprob):
+        """d sum(dprob * softmax) / d image with the graph in eval mode (autograd)."""
+        x = torch.as_tensor(np.asarray(images)).to(self.dtype).requires_grad_(True)
+        softmax, _, _ = self.forward(x, False)
+        (softmax * torch.as_tensor(np.asarray(dprob)).to(self.dtype)).sum().backward()
+        return x.grad.detach().numpy()
+
+    def estimate_radius(self, img):
+        """UNet.estimate_radius (reference UNet/model.py:165-202) on a given probe image [1,C,N,N]."""
+        x = torch.as_tensor(np.asarray(img)).to(self.dtype).requires_grad_(True)
+        mid = int(x.shape[2] / 2)
+        softmax, _, _ = self.forward(x, False)
+        msk = softmax.detach().clone()
+        msk[0, mid, mid, :] = 1.0 - msk[0, mid, mid, :]
+        loss = (msk - softmax).abs().mean(-1)                      # MeanAbsoluteError(reduction=NONE): [1,H,W]
+        loss.sum().backward()                                      # tape.gradient of a non-scalar sums it
+        g = np.abs(x.grad[0].numpy())
+        g = np.average(g, axis=0) if g.shape[0] > 1 else g[0]
+        vec = np.maximum(np.max(g, axis=0), np.max(g, axis=1))
+        idx = np.nonzero(vec > 1e-8)[0]
+        if len(idx) < 2:
+            return on.RADIUS
+        erf = int((np.max(idx) - np.min(idx)) / 2)
+        return int(on.SIZE_FACTOR * np.ceil(float(erf) / on.SIZE_FACTOR))
+
     def numpy_params(self):
         return {k: v.detach().numpy().copy() for k, v in self.params.items()}

@@ -185,6 +185,53 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+// ---- eval-mode backward pieces (input-gradient probe of UNet.estimate_radius, reference UNet/model.py:165-202) ----
+// softmax backward: dz_k = p_k * (g_k - sum_j g_j p_j)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ dz, int lddz, long P, int K) {
+    const long stride = (long)gridDim.x * 256;
+    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < P; pix += stride) {
+        float dot = 0.f;
+        for (int k = 0; k < K; ++k) dot += g[(size_t)pix * K + k] * p[(size_t)pix * K + k];
+        for (int k = 0; k < K; ++k) dz[(size_t)pix * lddz + k] = p[(size_t)pix * K + k] * (g[(size_t)pix * K + k] - dot);
+    }
+}
+
+// BatchNorm with fixed (moving) statistics is an affine map: dz = dy * scale, times the ReLU mask of the layer below
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_eval_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r, int ldr,
+        const float* __restrict__ scale, float* __restrict__ dz, int lddz, long P, int C, int relu) {
+    const int nq = C / VEC;
+    const long total = P * nq, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const long pix = i / nq; const int c0 = (int)(i - pix * nq) * VEC;
+        float g[VEC], v[VEC], a[VEC];
+        vload<VEC>(g, dy + (size_t)pix * lddy + c0); vload<VEC>(v, r + (size_t)pix * ldr + c0); vload<VEC>(a, scale + c0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] = (relu && !(v[e] > 0.f)) ? 0.f : g[e] * a[e];
+        vstore<VEC>(dz + (size_t)pix * lddz + c0, g);
+    }
+}
+
+// data gradient of the first 3x3 layer (tiny Cin): dx[p][ci] = sum_{tap,co} dz[p - shift(tap)][co] * w[tap][ci][co]
+__global__ __launch_bounds__(256) void conv3x3_direct_dgrad_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ w,
+        float* __restrict__ dx, int lddx, int N, int H, int W, int Cin, int Cout) {
+    const long total = (long)N * H * W * Cin, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        long t = i; const int ci = (int)(t % Cin); t /= Cin;
+        const int xx = (int)(t % W); t /= W; const int y = (int)(t % H); const int n = (int)(t / H);
+        float acc = 0.f;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int gy = y - (tap / 3 - 1), gx = xx - (tap % 3 - 1);
+            if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
+            const float* gp = dz + ((size_t)(n * H + gy) * W + gx) * lddz;
+            const float* wp = w + ((size_t)tap * Cin + ci) * Cout;
+            for (int co = 0; co < Cout; ++co) acc += gp[co] * wp[co];
+        }
+        dx[((size_t)(n * H + y) * W + xx) * lddx + ci] = acc;
+    }
+}
+
 int grid_for(long total, int cap) { long b = (total + 255) / 256; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b; }
 
 }  // namespace
@@ -259,6 +306,30 @@ extern "C" int unet_adam_keras(float* theta, const float* grad, float* m, float*
 extern "C" int unet_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream) {
     UNET_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0);
     nchw_to_nhwc_kernel<<<grid_for((long)N * C * H * W, 8192), 256, 0, (hipStream_t)stream>>>(x, y, N, C, (long)H * W);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_softmax_bwd(const float* prob, const float* dprob, float* dlogits, int lddz, long P, int K, void* stream) {
+    UNET_CHECK_ARG(prob && dprob && dlogits && P > 0 && K > 0 && lddz >= K);
+    softmax_bwd_kernel<<<grid_for(P, 4096), 256, 0, (hipStream_t)stream>>>(prob, dprob, dlogits, lddz, P, K);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_bn_eval_bwd(const float* dy, int lddy, const float* r, int ldr, const float* scale, float* dz, int lddz,
+                                long P, int C, int relu, void* stream) {
+    UNET_CHECK_ARG(dy && r && scale && dz && P > 0 && C > 0 && lddy >= C && ldr >= C && lddz >= C);
+    const bool v4 = C % 4 == 0 && lddy % 4 == 0 && ldr % 4 == 0 && lddz % 4 == 0 && unet_aligned16(dy) && unet_aligned16(r) &&
+                    unet_aligned16(dz) && unet_aligned16(scale);
+    const long total = P * (v4 ? C / 4 : C);
+    if (v4) bn_eval_bwd_kernel<4><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(dy, lddy, r, ldr, scale, dz, lddz, P, C, relu);
+    else    bn_eval_bwd_kernel<1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(dy, lddy, r, ldr, scale, dz, lddz, P, C, relu);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_conv3x3_dgrad_direct(const float* dz, int lddz, const float* w, float* dx, int lddx,
+                                         int N, int H, int W, int Cin, int Cout, void* stream) {
+    UNET_CHECK_ARG(dz && w && dx && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && lddz >= Cout && lddx >= Cin);
+    conv3x3_direct_dgrad_kernel<<<grid_for((long)N * H * W * Cin, 8192), 256, 0, (hipStream_t)stream>>>(dz, lddz, w, dx, lddx, N, H, W, Cin, Cout);
     return UNET_LAUNCH_STATUS();
 }
 

@@ -314,8 +314,9 @@ class Engine:
         return prob
 
     # ------------------------------------------------------------------------------------------------ backward
-    def _block_bwd(self, name, dy, need_dx=True):
-        """dy: NHWC view = gradient w.r.t. the layer's BN output.  Returns gradient w.r.t. the layer input (or None)."""
+    def _block_bwd(self, name, dy, need_dx=True, eval_mode=False):
+        """dy: NHWC view = gradient w.r.t. the layer's BN output.  Returns gradient w.r.t. the layer input (or None).
+        eval_mode: BN used its moving statistics (an affine map) and no parameter gradients are wanted."""
         L, st = self.L, self._stream()
         kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
         x, r = self.saved[name]
@@ -323,11 +324,14 @@ class Engine:
         P = n * ho * wo
         s = self.stat[name]
         dz = self._buf("dz_" + name, tuple(r.shape))
-        nb = L.unet_bn_workspace(P, cout)
-        ws = self._workspace(nb)
-        L.unet_bn_bwd(_p(dy), _ld(dy), _p(r), cout, _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
-                      0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
-                      _p(self.g[name + "/bias"]), _p(ws), nb, st)
+        if eval_mode:
+            L.unet_bn_eval_bwd(_p(dy), _ld(dy), _p(r), cout, _p(s[2]), _p(dz), cout, P, cout, 0 if kind == "deconv" else 1, st)
+        else:
+            nb = L.unet_bn_workspace(P, cout)
+            ws = self._workspace(nb)
+            L.unet_bn_bwd(_p(dy), _ld(dy), _p(r), cout, _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
+                          0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
+                          _p(self.g[name + "/bias"]), _p(ws), nb, st)
         w_, dw = self.p[name + "/kernel"], self.g[name + "/kernel"]
         hi, wi = x.shape[1], x.shape[2]
         dx = None
@@ -351,7 +355,7 @@ class Engine:
             if self.on_layer_grads_ready is not None:
                 self.on_layer_grads_ready(name)          # under the stream the gradients were produced on
 
-        if self.overlap_wgrad:
+        if self.overlap_wgrad and not eval_mode:
             self.side.wait_stream(torch.cuda.current_stream())       # dz (and this layer's bias/gamma/beta grads) ready
             with torch.cuda.stream(self.side):
                 wgrad()
@@ -361,17 +365,32 @@ class Engine:
                 L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
                 L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
-            else:
+            elif L.unet_conv3x3_mfma_supported(cout, cin):
                 self._timed("conv3x3_dgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_mfma,
                             _p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
-        if not self.overlap_wgrad:
+            else:                                   # first layer (Cin = number_channels): only the ERF probe needs it
+                L.unet_conv3x3_dgrad_direct(_p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
+        if not self.overlap_wgrad and not eval_mode:
             wgrad()
         return dx
 
-    def backward(self):
-        """Gradients of the loss computed by the last forward(training=True, labels=..., want_grad=True) -> self.grad."""
+    def input_gradient_eval(self, dprob):
+        """After forward(training=False): gradient of sum(dprob * softmax) w.r.t. the input image, fp32 [N,C,H,W].
+        (tf.GradientTape().gradient(loss, img) with the model in eval mode, reference UNet/model.py:176-184.)"""
+        prob = self.bufs["softmax"]
+        n, h, w, k = prob.shape
+        g = dprob.to(self.dev).contiguous()
+        assert g.dtype == torch.float32 and tuple(g.shape) == (n, h, w, k)
+        dl = self._buf("dy_logits", (n, h, w, k))
+        self.L.unet_softmax_bwd(_p(prob), _p(g), _p(dl), k, n * h * w, k, self._stream())
+        dimg = self.backward(eval_mode=True)
+        return dimg.permute(0, 3, 1, 2).contiguous()
+
+    def backward(self, eval_mode=False):
+        """Gradients of the loss computed by the last forward(training=True, labels=..., want_grad=True) -> self.grad.
+        eval_mode=True instead propagates `dy_logits` through the eval-mode graph down to the input image."""
         L, st = self.L, self._stream()
-        b = self._block_bwd
+        b = lambda name, dy, need_dx=True: self._block_bwd(name, dy, need_dx=need_dx, eval_mode=eval_mode)
         B = BASE
         d = b("logits", self.bufs["dy_logits"])
         for lvl, ch in ((1, B), (2, 2 * B), (3, 4 * B), (4, 8 * B)):
@@ -379,7 +398,8 @@ class Engine:
             dcat = b("dec_%da" % lvl, d)                       # [N,H,W,2ch]: [0,ch) skip grad, [ch,2ch) upsampled grad
             self.bufs["dcat_%d" % lvl] = dcat
             d = b("up_%d" % lvl, dcat[..., ch:])
-        self._dropout(d, "drop_b", self.masks)
+        if not eval_mode:
+            self._dropout(d, "drop_b", self.masks)
         d = b("bott_b", d)
         d = b("bott_a", d)
         for lvl, ch in ((4, 8 * B), (3, 4 * B), (2, 2 * B), (1, B)):
@@ -387,12 +407,13 @@ class Engine:
             ds = dcat[..., :ch]
             n, hh, ww, _ = ds.shape
             L.unet_maxpool2x2_bwd(_p(d), _ld(d), _p(self.idx[lvl]), _p(ds), _ld(ds), n, hh, ww, ch, 1, st)
-            if lvl == 4:
+            if lvl == 4 and not eval_mode:
                 self._dropout(ds, "drop_4", self.masks)
             d = b("conv_%db" % lvl, ds)
-            d = b("conv_%da" % lvl, d, need_dx=(lvl != 1))
-        if self.overlap_wgrad:
+            d = b("conv_%da" % lvl, d, need_dx=(lvl != 1 or eval_mode))
+        if self.overlap_wgrad and not eval_mode:
             torch.cuda.current_stream().wait_stream(self.side)        # every weight gradient done before Adam
+        return d
 
     def adam_step(self, learning_rate):
         """Keras Adam on the flat buffers (reference UNet/model.py:79,223)."""

@@ -123,11 +123,50 @@ class UNet:
     def get_learning_rate(self):
         return self.optimizer.learning_rate
 
-    def estimate_radius(self):
-        """Reference UNet/model.py:165-202 probes the effective receptive field with an input gradient; that needs the
-        first layer's data gradient, which the training path never computes.  Until that kernel exists this returns the
-        reference's own fallback value (its `len(idx) < 2` branch), the theoretical radius."""
-        return UNet.RADIUS
+    @staticmethod
+    def _round_radius(x):
+        return int(UNet.SIZE_FACTOR * np.ceil(float(x) / UNet.SIZE_FACTOR))
+
+    def input_gradient(self, img, dprob):
+        """d sum(dprob * softmax(img)) / d img with the model in eval mode; img [N,C,H,W], dprob [N,H,W,K]."""
+        x = torch.as_tensor(np.asarray(img, dtype=np.float32)) if not torch.is_tensor(img) else img.float()
+        self.engine.forward(x, training=False)
+        g = torch.as_tensor(np.asarray(dprob, dtype=np.float32)) if not torch.is_tensor(dprob) else dprob.float()
+        return self.engine.input_gradient_eval(g)
+
+    def estimate_radius(self, img=None):
+        """Effective-receptive-field probe (reference UNet/model.py:165-202): eval-mode forward of a random-normal
+        [1,C,192,192] image, mean-absolute-error loss against a copy of the softmax whose centre pixel is flipped
+        (1 - p), gradient of that loss w.r.t. the image, extent of |grad| > 1e-8, rounded up to a multiple of 16;
+        falls back to the theoretical radius when fewer than 2 rows/columns respond.  (The reference repeats the
+        identical forward 10 times and keeps the last tape; one pass is the same result.)"""
+        N = 2 * UNet.RADIUS
+        if img is None:
+            img = np.random.normal(size=(1, self.number_channels, N, N))
+        img = np.asarray(img, dtype=np.float32)
+        mid = int(img.shape[2] / 2)
+        x = torch.as_tensor(img)
+        prob = self.engine.forward(x, training=False)
+        k = prob.shape[-1]
+        # loss[h,w] = mean_k |msk - p| is non-zero only at the centre pixel, where msk = 1 - p:
+        # d/dp_k of mean_k |1 - 2 p_k| = -2 sign(1 - 2 p_k) / K
+        g = torch.zeros_like(prob)
+        pm = prob[0, mid, mid, :]
+        g[0, mid, mid, :] = -2.0 * torch.sign(1.0 - 2.0 * pm) / k
+        grad_img = np.abs(self.engine.input_gradient_eval(g)[0].cpu().numpy())      # [C,H,W]
+        grad_img = np.average(grad_img, axis=0) if self.number_channels > 1 else grad_img[0]
+        print('Theoretical RF: {}'.format(UNet.RADIUS))
+        eps = 1e-8
+        vec = np.maximum(np.max(grad_img, axis=0), np.max(grad_img, axis=1))
+        idx = np.nonzero(vec > eps)[0]
+        if len(idx) < 2:
+            radius = UNet.RADIUS
+            print('ERF based radius detection failed, defaulting to theoretical radius: {}'.format(radius))
+        else:
+            erf = int((np.max(idx) - np.min(idx)) / 2)
+            radius = UNet._round_radius(erf)
+            print('computed radius : "{}"'.format(radius))
+        return radius
 
     # -- reference UNet/model.py:204-228
     def train_step(self, inputs, dropout_masks=None):

@@ -156,3 +156,24 @@ def test_rng_dropout_train_step_runs_and_learns():
     losses = [float(net.train_step((img, lab, None, None)).numpy()) for _ in range(12)]
     assert all(np.isfinite(losses))
     assert min(losses[-3:]) < losses[0]
+
+
+def test_input_gradient_and_estimate_radius_match_oracle():
+    # eval-mode backward to the image (reference UNet/model.py:165-202) incl. the first-layer data gradient
+    n, c, k, hw = 1, 3, 4, 64
+    img, lab, prm, _ = make_case(31, n, c, k, hw)
+    model = pkg("model")
+    net = model.UNet(k, 1, c)
+    net.engine.load_parameters(prm)
+    ref = ot.TorchUNet(k, 1, c, params=prm, dtype=torch.float64)
+    rng = np.random.default_rng(1)
+    dprob = rng.standard_normal((n, hw, hw, k)).astype(np.float32)
+    g = net.input_gradient(img, dprob).cpu().numpy()
+    g_ref = ref.input_gradient_eval(img, dprob)
+    assert g.shape == g_ref.shape == (n, c, hw, hw)
+    assert np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref) < 5e-2          # ReLU-mask flips, see grad_errors()
+    # the radius estimate on the reference's 192x192 probe: same value from both, a multiple of 16
+    probe = np.random.default_rng(7).normal(size=(1, c, 192, 192)).astype(np.float32)
+    r_hip = net.estimate_radius(probe)
+    r_ref = ref.estimate_radius(probe)
+    assert r_hip % 16 == 0 and r_hip == r_ref, (r_hip, r_ref)
