@@ -178,6 +178,14 @@ def main():
                         "achieved": k["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(k["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                         "launches_per_step": k["launches_per_step"], "avg_launch_ms": k["avg_launch_ms"]}
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction,
+            # WRITE_SIZE) of this same workload, committed under profiles/; only valid for the default workload.
+            tf = os.path.join(ROOT, "profiles", "r01_igemm_fwd_pmc_traffic.json")
+            if os.path.exists(tf) and (args.size, args.channels, args.classes, args.batch) == (512, 1, 2, 8):
+                t = json.load(open(tf))
+                roofline["traffic"] = round(t["hbm_bytes_per_launch"])
+                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r01_igemm_fwd_pmc_traffic.json)"
+                roofline["algorithmic_bytes_per_launch"] = round(t["algorithmic_bytes_per_launch"])
     if rank == 0:
         ips = G * args.steps / dt
         out = {
