@@ -39,6 +39,15 @@ int unet_conv3x3_dgrad_mfma(const float* dz, int lddz, const float* w, float* dx
 size_t unet_conv3x3_wgrad_mfma_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_conv3x3_wgrad_mfma(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                             int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* Winograd F(2x2,3x3) route for the same layer when channels are wide (exact fp32, 2.25x fewer matrix multiplies):
+ * U = weight transform (16*Cin*Cout floats; mode 0 forward, mode 1 data gradient), refreshed whenever w changes. */
+int unet_winograd_supported(int N, int H, int W, int Cin, int Cout);
+int unet_winograd_weight_transform(const float* w, float* U, int Cin, int Cout, int mode, void* stream);
+size_t unet_conv3x3_winograd_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_conv3x3_fwd_winograd(const float* x, int ldx, const float* U, const float* bias, float* out, int ldo,
+                              int N, int H, int W, int Cin, int Cout, int relu, void* ws, size_t ws_bytes, void* stream);
+int unet_conv3x3_dgrad_winograd(const float* dz, int lddz, const float* Ud, float* dx, int lddx,
+                                int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
 int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                             int N, int H, int W, int Cin, int Cout, int relu, void* stream);

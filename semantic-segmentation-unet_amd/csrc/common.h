@@ -28,3 +28,6 @@ __device__ __forceinline__ uint32_t unet_hash32(uint32_t seed, uint64_t idx) {
     z = z ^ (z >> 31);
     return (uint32_t)(z >> 32);
 }
+
+// conv_igemm.hip: `planes` independent fp32-MFMA GEMMs out[z][t][n] = sum_k x[z][t][k] * w[z][k][n] (T % 32 == 0)
+int unet_igemm_batched_planes(const float* x, const float* w, float* out, long T, int K, int N, int planes, hipStream_t st);

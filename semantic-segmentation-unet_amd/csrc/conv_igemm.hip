@@ -40,6 +40,7 @@ struct IgemmArgs {
     int in_scale;           // MODE 1/2: input pixel = grid pixel * in_scale + tap offset
     int out_scale;          // output pixel = grid pixel * out_scale + (tap offset when tap_by_z)
     int relu, flip, tap_by_z;
+    long zs_x, zs_out;      // MODE 3: element strides between the blockIdx.z planes of x / out
     int tiles_y, tiles_x, tiles_n;
 };
 
@@ -47,7 +48,7 @@ template <int MODE, int WM, int WN, bool B_NK>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     constexpr int TH = 2 * WM;
     constexpr int BN = 64 * WN;
-    constexpr int NT = MODE == 0 ? 9 : (MODE == 1 ? 1 : 4);
+    constexpr int NT = MODE == 0 ? 9 : (MODE == 2 ? 4 : 1);
     constexpr int A_ROWS = MODE == 0 ? TH + 2 : TH;
     constexpr int A_COLS = MODE == 0 ? TW + 2 : TW;
     constexpr int A_FLOATS = A_ROWS * A_COLS * SA;
@@ -65,6 +66,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     const int img = b / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW, n0 = tn * BN;
     const int ztap = p.tap_by_z ? (int)blockIdx.z : 0;
+    const float* xin = MODE == 3 ? p.x + (size_t)blockIdx.z * p.zs_x : p.x;
+    float* xout = MODE == 3 ? p.out + (size_t)blockIdx.z * p.zs_out : p.out;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
                 gx = ox * p.in_scale + (MODE == 2 ? (tap & 1) : 0);
             }
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(img * p.Hi + gy) * p.Wi + gx) * p.ldx + c0 + 4 * q);
+            if (ok) v = *reinterpret_cast<const f32x4*>(xin + ((size_t)(img * p.Hi + gy) * p.Wi + gx) * p.ldx + c0 + 4 * q);
             ra[i] = v;
         }
     };
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     // epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel along x).
     // One 64-bit base per (row, channel tile); per-element offsets are 32-bit.  No load may be pending here:
     // stores count in vmcnt, so a late `s_waitcnt vmcnt(0)` for the bias would serialise all 64 stores.
-    const int ooy = p.tap_by_z ? (ztap >> 1) : 0, oox = p.tap_by_z ? (ztap & 1) : 0;
+    const int ooy = (p.tap_by_z && MODE != 3) ? (ztap >> 1) : 0, oox = (p.tap_by_z && MODE != 3) ? (ztap & 1) : 0;
     const bool full_x = (ox0 + TW <= p.W);
     const int xstep = p.out_scale * p.ldo;
 #pragma unroll
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
         const int py = oy * p.out_scale + ooy;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            float* base = p.out + ((size_t)(img * p.Ho + py) * p.Wo + (ox0 * p.out_scale + oox)) * p.ldo + n0 + wn * 64 + u * 32 + li;
+            float* base = xout + ((size_t)(img * p.Ho + py) * p.Wo + (ox0 * p.out_scale + oox)) * p.ldo + n0 + wn * 64 + u * 32 + li;
             const float bv = bias_v[u];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -263,6 +266,22 @@ int launch_igemm(IgemmArgs a, int zdim, hipStream_t st) {
     else      igemm_kernel<MODE, 4, 1, B_NK><<<grid, 256, 0, st>>>(a);
     return UNET_LAUNCH_STATUS();
 }
+
+}  // namespace
+
+// Batched pointwise GEMM over `planes` independent [T x K] x [K x N] products (the 16 Winograd points):
+// out[z][t][n] = sum_k x[z][t][k] * w[z][k][n]; T must be a multiple of 32.  Used by winograd.hip.
+int unet_igemm_batched_planes(const float* x, const float* w, float* out, long T, int K, int N, int planes, hipStream_t st) {
+    if (!x || !w || !out || T <= 0 || T % 32 || K % CK || N % 64 || planes <= 0) return UNET_EINVAL;
+    IgemmArgs a{};
+    a.x = x; a.w = w; a.bias = nullptr; a.out = out; a.ldx = K; a.ldo = N;
+    a.N = 1; a.H = (int)(T / 32); a.W = 32; a.Hi = a.H; a.Wi = 32; a.Ho = a.H; a.Wo = 32;
+    a.Kdim = K; a.Ndim = N; a.in_scale = 1; a.out_scale = 1; a.relu = 0; a.flip = 0; a.tap_by_z = 1;
+    a.zs_x = T * K; a.zs_out = T * N;
+    return launch_igemm<3, false>(a, planes, st);
+}
+
+namespace {
 
 bool igemm_shape_ok(int Kdim, int Ndim) { return Kdim > 0 && Ndim > 0 && (Kdim % CK) == 0 && (Ndim % 64) == 0; }
 

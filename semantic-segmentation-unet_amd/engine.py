@@ -120,6 +120,12 @@ class Engine:
         # stream, every weight gradient on `side` (it is needed only by the all-reduce / Adam).  The persistent wgrad
         # workgroups (106 KB LDS) co-reside with igemm workgroups and with the HBM-bound BN streams.
         self.overlap_wgrad = True
+        # Winograd F(2x2,3x3) route for the wide 3x3 layers (forward + dgrad): transformed kernels cached per layer and
+        # refreshed after every parameter update.  Threshold from measurement (scripts/bench_conv.py): wins from 256
+        # channels on both sides, break-even at 128, loses below (the unfused transforms move ~14x the activation bytes).
+        self.winograd_min_channels = 256
+        self.wino_U = {}
+        self._wino_dirty = True
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -153,8 +159,30 @@ class Engine:
             vals[name + "/moving_var"] = np.ones(cout, np.float32)
         self.load_parameters(vals)
 
+    def _use_winograd(self, name, n, h, w):
+        cin, cout = self.cin[name], self.cout[name]
+        return (self.kind[name] == "conv3" and min(cin, cout) >= self.winograd_min_channels
+                and self.L.unet_winograd_supported(n, h, w, cin, cout) == 1)
+
+    def _winograd_kernels(self, name):
+        """(U forward, U dgrad) for a layer; all cached transforms are recomputed lazily after a parameter change."""
+        if self._wino_dirty:
+            self.wino_U.clear()
+            self._wino_dirty = False
+        u = self.wino_U.get(name)
+        if u is None:
+            cin, cout = self.cin[name], self.cout[name]
+            u = (torch.empty(16, cin, cout, dtype=torch.float32, device=self.dev),
+                 torch.empty(16, cout, cin, dtype=torch.float32, device=self.dev))
+            st = self._stream()
+            self.L.unet_winograd_weight_transform(_p(self.p[name + "/kernel"]), _p(u[0]), cin, cout, 0, st)
+            self.L.unet_winograd_weight_transform(_p(self.p[name + "/kernel"]), _p(u[1]), cin, cout, 1, st)
+            self.wino_U[name] = u
+        return u
+
     def load_parameters(self, values):
         """values: {keras-style name: array in the Keras layout}.  Resets nothing else."""
+        self._wino_dirty = True
         for k, v in values.items():
             t = torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float32)))
             if k in self.p:
@@ -209,7 +237,12 @@ class Engine:
             L.unet_conv1x1_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
         else:
             r = self._buf("r_" + name, (n, h, w, cout))
-            if L.unet_conv3x3_mfma_supported(cin, cout):
+            if self._use_winograd(name, n, h, w):
+                nbw = L.unet_conv3x3_winograd_workspace(n, h, w, cin, cout)
+                self._timed("conv3x3_fwd_winograd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd,
+                            _p(x), _ld(x), _p(self._winograd_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1,
+                            _p(self._workspace(nbw)), nbw, st)
+            elif L.unet_conv3x3_mfma_supported(cin, cout):
                 self._timed("conv3x3_fwd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
                             _p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
             else:
@@ -365,6 +398,11 @@ class Engine:
                 L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
                 L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
+            elif self._use_winograd(name, n, ho, wo):
+                nbw = L.unet_conv3x3_winograd_workspace(n, ho, wo, cin, cout)
+                self._timed("conv3x3_dgrad_winograd", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd,
+                            _p(dz), cout, _p(self._winograd_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
+                            _p(self._workspace(nbw)), nbw, st)
             elif L.unet_conv3x3_mfma_supported(cout, cin):
                 self._timed("conv3x3_dgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_mfma,
                             _p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
@@ -418,6 +456,7 @@ class Engine:
     def adam_step(self, learning_rate):
         """Keras Adam on the flat buffers (reference UNet/model.py:79,223)."""
         self.iterations += 1
+        self._wino_dirty = True
         t = self.iterations
         alpha = learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
         self.L.unet_adam_keras(_p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v), self.n_flat, alpha,

@@ -311,3 +311,33 @@ def test_keras_adam_flat(hip):
         ref_th, ref_m, ref_v = on.adam_keras_step(ref_th, g32, ref_m, ref_v, t, 3e-4, c)
     assert np.abs(thd.cpu().numpy() - ref_th).max() < 2e-6
     assert relerr(vd.cpu().numpy(), ref_v) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 64, 64), (1, 16, 32, 128, 256), (2, 4, 64, 256, 128)])
+def test_conv3x3_winograd_fwd_dgrad(hip, shape):
+    # Winograd F(2x2,3x3): exact-arithmetic-equivalent to the direct conv; fp32 tolerance slightly wider (transforms)
+    n, h, w, ci, co = shape
+    assert hip.unet_winograd_supported(n, h, w, ci, co) == 1
+    rng = np.random.default_rng(ci + co)
+    x = rng.standard_normal((n, ci, h, w))
+    wt = rng.standard_normal((3, 3, ci, co)) / np.sqrt(9 * ci)
+    b = rng.standard_normal(co)
+    dz = rng.standard_normal((n, co, h, w))
+    z_ref = np.maximum(on.conv_same_fwd(x, wt, b), 0)
+    dx_ref, _, _ = on.conv_same_bwd(x, wt, dz)
+    xbuf = torch.zeros(n, h, w, ci + 8, device=DEV); xbuf[..., 4:4 + ci] = to_nhwc(x)
+    xv = xbuf[..., 4:4 + ci]
+    wd, bd, dzd = dev(wt), dev(b), to_nhwc(dz)
+    U = torch.empty(16, ci, co, device=DEV); Ud = torch.empty(16, co, ci, device=DEV)
+    hip.unet_winograd_weight_transform(P(wd), P(U), ci, co, 0, ST())
+    hip.unet_winograd_weight_transform(P(wd), P(Ud), ci, co, 1, ST())
+    nb = hip.unet_conv3x3_winograd_workspace(n, h, w, ci, co)
+    ws = ws_bytes(nb)
+    cat = torch.zeros(n, h, w, 2 * co, device=DEV)
+    outv = cat[..., co:]
+    hip.unet_conv3x3_fwd_winograd(P(xv), ci + 8, P(U), P(bd), P(outv), 2 * co, n, h, w, ci, co, 1, P(ws), nb, ST())
+    assert relerr(from_nhwc(outv), z_ref) < 3e-5
+    assert cat[..., :co].abs().max().item() == 0
+    dx = torch.full((n, h, w, ci), 7.0, device=DEV)
+    hip.unet_conv3x3_dgrad_winograd(P(dzd), co, P(Ud), P(dx), ci, n, h, w, ci, co, P(ws), nb, ST())
+    assert relerr(from_nhwc(dx), dx_ref) < 3e-5

@@ -108,7 +108,7 @@ def test_unet_matches_numpy_oracle(cfg):
         upd_hip = prm_hip[key].astype(np.float64) - prm[key]
         diff = np.abs(upd_hip - upd_ref)
         assert diff.mean() < 0.15 * lr, (key, diff.mean())      # a wrong lr / sign / bias correction would give >= 1*lr
-        assert (diff > 0.5 * lr).mean() < 0.08, key
+        assert (diff > 0.5 * lr).mean() < 0.15, key
         assert diff.max() <= 4.2 * lr, key
     for name, _, _, _ in ref.layers:
         for s in ("/moving_mean", "/moving_var"):
