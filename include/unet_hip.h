@@ -48,6 +48,10 @@ int unet_conv3x3_fwd_winograd(const float* x, int ldx, const float* U, const flo
                               int N, int H, int W, int Cin, int Cout, int relu, void* ws, size_t ws_bytes, void* stream);
 int unet_conv3x3_dgrad_winograd(const float* dz, int lddz, const float* Ud, float* dx, int lddx,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int unet_winograd_wgrad_supported(int N, int H, int W, int Cin, int Cout);
+size_t unet_conv3x3_wgrad_winograd_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
 int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                             int N, int H, int W, int Cin, int Cout, int relu, void* stream);

@@ -30,14 +30,20 @@ for name, h, ci, co in shapes:
     if wok:
         L.unet_winograd_weight_transform(P(w), P(U), ci, co, 0, ST()); L.unet_winograd_weight_transform(P(w), P(Ud), ci, co, 1, ST())
         nbw = L.unet_conv3x3_winograd_workspace(B, h, h, ci, co); wsw = torch.empty(nbw + 256, dtype=torch.uint8, device="cuda")
-    fns = {"wfwd": lambda: L.unet_conv3x3_fwd_winograd(P(x), ci, P(U), P(b), P(out), co, B, h, h, ci, co, 1, P(wsw), nbw, ST()),
+    wwok = L.unet_winograd_wgrad_supported(B, h, h, ci, co)
+    if wwok:
+        nbg = L.unet_conv3x3_wgrad_winograd_workspace(B, h, h, ci, co); wsg = torch.empty(nbg + 256, dtype=torch.uint8, device="cuda")
+    fns = {"wwgrad": lambda: L.unet_conv3x3_wgrad_winograd(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(wsg), nbg, ST()),
+           "wfwd": lambda: L.unet_conv3x3_fwd_winograd(P(x), ci, P(U), P(b), P(out), co, B, h, h, ci, co, 1, P(wsw), nbw, ST()),
            "wdgrad": lambda: L.unet_conv3x3_dgrad_winograd(P(dz), co, P(Ud), P(dx), ci, B, h, h, ci, co, P(wsw), nbw, ST()),
            "fwd": lambda: L.unet_conv3x3_fwd_mfma(P(x), ci, P(w), P(b), P(out), co, B, h, h, ci, co, 1, ST()),
            "dgrad": lambda: L.unet_conv3x3_dgrad_mfma(P(dz), co, P(w), P(dx), ci, B, h, h, ci, co, ST()),
            "wgrad": lambda: L.unet_conv3x3_wgrad_mfma(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(ws), nb, ST())}
     line = "%-7s h%4d %4d->%4d " % (name, h, ci, co)
     for k in which:
-        if k.startswith("w") and k != "wgrad" and not wok:
+        if k in ("wfwd", "wdgrad") and not wok:
+            continue
+        if k == "wwgrad" and not wwok:
             continue
         ms = timeit(fns[k]); tot[k][0] += ms; tot[k][1] += fl
         line += " %s %7.3f ms %6.1f TF |" % (k, ms, fl / ms / 1e9)

@@ -16,6 +16,7 @@ HBM layout
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -120,10 +121,12 @@ class Engine:
         # stream, every weight gradient on `side` (it is needed only by the all-reduce / Adam).  The persistent wgrad
         # workgroups (106 KB LDS) co-reside with igemm workgroups and with the HBM-bound BN streams.
         self.overlap_wgrad = True
-        # Winograd F(2x2,3x3) route for the wide 3x3 layers (forward + dgrad): transformed kernels cached per layer and
-        # refreshed after every parameter update.  Threshold from measurement (scripts/bench_conv.py): wins from 256
-        # channels on both sides, break-even at 128, loses below (the unfused transforms move ~14x the activation bytes).
-        self.winograd_min_channels = 256
+        # Winograd F(2x2,3x3) route for the wide 3x3 layers: transformed kernels (forward, dgrad) cached per layer and
+        # refreshed after every parameter update.  Thresholds from same-box A/B runs of bench.py: forward/dgrad win from
+        # 256 channels on both sides (break-even at 128: the unfused transforms move ~14x the activation bytes); the
+        # weight gradient already wins at 128 (121.8 -> 123.1 images/s).
+        self.winograd_min_channels = int(os.environ.get("UNET_WINOGRAD_MIN_C", "256"))
+        self.winograd_wgrad_min_channels = int(os.environ.get("UNET_WINOGRAD_WGRAD_MIN_C", "128"))
         self.wino_U = {}
         self._wino_dirty = True
         self.side = torch.cuda.Stream(device=self.dev)
@@ -378,6 +381,11 @@ class Engine:
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
                 L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+            elif (min(cin, cout) >= self.winograd_wgrad_min_channels
+                  and L.unet_winograd_wgrad_supported(n, ho, wo, cin, cout) == 1):
+                nb2 = L.unet_conv3x3_wgrad_winograd_workspace(n, ho, wo, cin, cout)
+                self._timed("conv3x3_wgrad_winograd", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_winograd,
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif L.unet_conv3x3_mfma_supported(cin, cout) and cin % 64 == 0:
                 nb2 = L.unet_conv3x3_wgrad_mfma_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_mfma,

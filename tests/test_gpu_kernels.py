@@ -341,3 +341,21 @@ def test_conv3x3_winograd_fwd_dgrad(hip, shape):
     dx = torch.full((n, h, w, ci), 7.0, device=DEV)
     hip.unet_conv3x3_dgrad_winograd(P(dzd), co, P(Ud), P(dx), ci, n, h, w, ci, co, P(ws), nb, ST())
     assert relerr(from_nhwc(dx), dx_ref) < 3e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 128, 128), (1, 16, 32, 256, 128), (4, 8, 8, 128, 384)])
+def test_conv3x3_winograd_wgrad(hip, shape):
+    n, h, w, ci, co = shape
+    assert hip.unet_winograd_wgrad_supported(n, h, w, ci, co) == 1
+    rng = np.random.default_rng(ci * 3 + co)
+    x = rng.standard_normal((n, ci, h, w)); dz = rng.standard_normal((n, co, h, w))
+    wt = np.zeros((3, 3, ci, co))
+    _, dw_ref, _ = on.conv_same_bwd(x, wt, dz)
+    xbuf = torch.zeros(n, h, w, ci + 4, device=DEV); xbuf[..., 4:] = to_nhwc(x)
+    xv = xbuf[..., 4:]
+    dzd = to_nhwc(dz)
+    nb = hip.unet_conv3x3_wgrad_winograd_workspace(n, h, w, ci, co)
+    ws = ws_bytes(nb)
+    dw = torch.full((3, 3, ci, co), 7.0, device=DEV)
+    hip.unet_conv3x3_wgrad_winograd(P(xv), ci + 4, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+    assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 3e-5

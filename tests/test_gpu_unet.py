@@ -93,27 +93,31 @@ def test_unet_matches_numpy_oracle(cfg):
     # --- two full train steps through the class API, then test_step (reference UNet/model.py:204-250)
     lm, am = model.Mean(), model.CategoricalAccuracy()
     e.load_parameters(prm)          # the gradient check above ran a training-mode forward: restore the BN moving stats
+    lr = 3e-4
     for step in range(2):
         l_hip = net.train_step((img, lab, lm, am), dropout_masks=masks).numpy()
         l_ref, _, _ = ref.train_step(img, lab, masks)
         # step 0 sees identical weights (fp32 forward tolerance); step 1 sees weights after one sign-like Adam update,
         # where elements whose gradient is within fp32 noise of zero have legitimately moved the other way
         assert abs(l_hip - l_ref) < (1e-5 if step == 0 else 2e-3) * abs(l_ref)
-    prm_hip = e.export_parameters()
-    # Adam's first steps move every weight by ~lr regardless of |g| (sign-like), so compare the *update*
-    # (and statistically: an element whose gradient is within fp32 noise of 0 may legitimately step the other way)
-    lr = 3e-4
-    for key in ref.trainable:
-        upd_ref = ref.params[key] - prm[key]
-        upd_hip = prm_hip[key].astype(np.float64) - prm[key]
-        diff = np.abs(upd_hip - upd_ref)
-        assert diff.mean() < 0.15 * lr, (key, diff.mean())      # a wrong lr / sign / bias correction would give >= 1*lr
-        assert (diff > 0.5 * lr).mean() < 0.15, key
-        assert diff.max() <= 4.2 * lr, key
-    for name, _, _, _ in ref.layers:
-        for s in ("/moving_mean", "/moving_var"):
-            # the step-2 batch statistics see weights after one sign-like Adam update (deep layers: 8..32 samples)
-            assert relerr(prm_hip[name + s].astype(np.float64), ref.params[name + s]) < 1e-3, name + s
+        if step == 0:
+            prm_hip = e.export_parameters()
+            # BN moving statistics after ONE step depend only on the (deterministic) forward pass: tight
+            for name, _, _, _ in ref.layers:
+                for sfx in ("/moving_mean", "/moving_var"):
+                    assert relerr(prm_hip[name + sfx].astype(np.float64), ref.params[name + sfx]) < 2e-5, name + sfx
+            # Adam's first step moves every weight by ~lr regardless of |g| (sign-like), so compare the *update*,
+            # statistically: an element whose gradient is within fp32 noise of 0 may legitimately step the other way
+            tot, big, cnt, worst_max = 0.0, 0, 0, 0.0
+            for key in ref.trainable:
+                diff = np.abs((prm_hip[key].astype(np.float64) - prm[key]) - (ref.params[key] - prm[key]))
+                tot += diff.sum(); big += int((diff > 0.5 * lr).sum()); cnt += diff.size
+                worst_max = max(worst_max, diff.max())
+                assert diff.mean() < 0.5 * lr, (key, diff.mean())       # per tensor: loose (small tensors are noisy)
+            # over all 31 M parameters: a wrong lr / sign / bias correction would give a mean >= 1*lr
+            assert tot / cnt < 0.15 * lr, tot / cnt / lr
+            assert big / cnt < 0.10, big / cnt
+            assert worst_max <= 2.1 * lr
     lt = net.test_step((img, lab, lm, am)).numpy()
     lt_ref, _ = ref.test_step(img, lab)
     assert abs(lt - lt_ref) < 2e-3 * abs(lt_ref)
