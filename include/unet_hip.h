@@ -44,13 +44,16 @@ int unet_conv3x3_wgrad_mfma(const float* xin, int ldx, const float* dz, int lddz
 int unet_winograd_supported(int N, int H, int W, int Cin, int Cout);
 int unet_winograd_weight_transform(const float* w, float* U, int Cin, int Cout, int mode, void* stream);
 size_t unet_conv3x3_winograd_workspace(int N, int H, int W, int Cin, int Cout);
+/* V_keep (nullable, 16*T*Cin floats, T = N*H/2*W/2): where to leave the transformed input for the weight gradient */
 int unet_conv3x3_fwd_winograd(const float* x, int ldx, const float* U, const float* bias, float* out, int ldo,
-                              int N, int H, int W, int Cin, int Cout, int relu, void* ws, size_t ws_bytes, void* stream);
+                              int N, int H, int W, int Cin, int Cout, int relu, float* V_keep,
+                              void* ws, size_t ws_bytes, void* stream);
 int unet_conv3x3_dgrad_winograd(const float* dz, int lddz, const float* Ud, float* dx, int lddx,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int unet_winograd_wgrad_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_conv3x3_wgrad_winograd_workspace(int N, int H, int W, int Cin, int Cout);
-int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+/* V_saved (nullable): the V_keep of the forward call on the same xin; when given, xin is not read */
+int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* V_saved, const float* dz, int lddz, float* dw,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
 int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,

@@ -317,13 +317,15 @@ extern "C" size_t unet_conv3x3_winograd_workspace(int N, int H, int W, int Cin, 
 
 // forward: out = relu?(conv3x3_same(x, w) + bias) with U = unet_winograd_weight_transform(w, mode 0)
 extern "C" int unet_conv3x3_fwd_winograd(const float* x, int ldx, const float* U, const float* bias, float* out, int ldo,
-        int N, int H, int W, int Cin, int Cout, int relu, void* ws, size_t ws_bytes, void* stream) {
+        int N, int H, int W, int Cin, int Cout, int relu, float* V_keep, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(x && U && out && ws && N > 0 && wino_ok(N, H, W, Cin, Cout) && ldx >= Cin && ldo >= Cout);
     UNET_CHECK_ARG(ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(out) && unet_aligned16(ws) && unet_aligned16(U));
     UNET_CHECK_ARG(!bias || unet_aligned16(bias));
     if (ws_bytes < unet_conv3x3_winograd_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
     const size_t T = (size_t)N * (H / 2) * (W / 2);
-    float* V = (float*)ws; float* M = V + 16 * T * Cin;
+    UNET_CHECK_ARG(!V_keep || unet_aligned16(V_keep));
+    float* V = V_keep ? V_keep : (float*)ws;          // V_keep (16*T*Cin floats): keep B^T d B for the weight gradient
+    float* M = (float*)ws + 16 * T * Cin;
     return run_wino(x, ldx, U, bias, out, ldo, N, H, W, Cin, Cout, relu, V, M, (hipStream_t)stream);
 }
 
@@ -339,17 +341,21 @@ extern "C" size_t unet_conv3x3_wgrad_winograd_workspace(int N, int H, int W, int
 
 // dw[a][b][ci][co] = sum_{n,y,x} xin[n, y+a-1, x+b-1, ci] * dz[n,y,x,co], through the Winograd domain:
 // dU[xi] = V[xi]^T dM[xi] (V = B^T d B of xin, dM = A dY A^T of dz), dw = G^T dU G
-extern "C" int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+extern "C" int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* V_saved, const float* dz, int lddz, float* dw,
         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
-    UNET_CHECK_ARG(xin && dz && dw && ws && N > 0 && unet_winograd_wgrad_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG((xin || V_saved) && dz && dw && ws && N > 0 && unet_winograd_wgrad_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0);
-    UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
+    UNET_CHECK_ARG((V_saved ? unet_aligned16(V_saved) : unet_aligned16(xin)) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
     if (ws_bytes < unet_conv3x3_wgrad_winograd_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     const long T = (long)N * (H / 2) * (W / 2);
-    float* V = (float*)ws; float* dM = V + 16 * (size_t)T * Cin; float* part = dM + 16 * (size_t)T * Cout;
-    wino_input_kernel<<<grid_for(T * (Cin / 4), 16384), 256, 0, st>>>(xin, ldx, V, N, H, W, Cin);
-    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    float* Vw = (float*)ws; float* dM = Vw + 16 * (size_t)T * Cin; float* part = dM + 16 * (size_t)T * Cout;
+    const float* V = V_saved ? V_saved : Vw;           // V_saved: B^T d B kept by the forward pass (same xin)
+    int rc = UNET_OK;
+    if (!V_saved) {
+        wino_input_kernel<<<grid_for(T * (Cin / 4), 16384), 256, 0, st>>>(xin, ldx, Vw, N, H, W, Cin);
+        rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    }
     wino_dz_kernel<<<grid_for(T * (Cout / 4), 16384), 256, 0, st>>>(dz, lddz, dM, N, H, W, Cout);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     GemmTnArgs g{};

@@ -242,9 +242,14 @@ class Engine:
             r = self._buf("r_" + name, (n, h, w, cout))
             if self._use_winograd(name, n, h, w):
                 nbw = L.unet_conv3x3_winograd_workspace(n, h, w, cin, cout)
+                vk = None
+                if training and min(cin, cout) >= self.winograd_wgrad_min_channels and \
+                        L.unet_winograd_wgrad_supported(n, h, w, cin, cout) == 1:
+                    vk = self._buf("V_" + name, (16, n * (h // 2) * (w // 2), cin))     # kept for the weight gradient
+                self.saved_V[name] = vk
                 self._timed("conv3x3_fwd_winograd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd,
                             _p(x), _ld(x), _p(self._winograd_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1,
-                            _p(self._workspace(nbw)), nbw, st)
+                            _p(vk), _p(self._workspace(nbw)), nbw, st)
             elif L.unet_conv3x3_mfma_supported(cin, cout):
                 self._timed("conv3x3_fwd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
                             _p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
@@ -301,6 +306,7 @@ class Engine:
             x0 = self._buf("x_nhwc", (n, h, w, c))
             L.unet_nchw_to_nhwc(_p(x), _p(x0), n, c, h, w, st)
         self.saved = {}
+        self.saved_V = {}
         self.masks = self._prep_masks(dropout_masks) if training else None
         B = BASE
         f = self._block_fwd
@@ -385,7 +391,8 @@ class Engine:
                   and L.unet_winograd_wgrad_supported(n, ho, wo, cin, cout) == 1):
                 nb2 = L.unet_conv3x3_wgrad_winograd_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad_winograd", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_winograd,
-                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                            _p(x), _ld(x), _p(self.saved_V.get(name)), _p(dz), cout, _p(dw), n, ho, wo, cin, cout,
+                            _p(self._workspace(nb2, sd)), nb2, st2)
             elif L.unet_conv3x3_mfma_supported(cin, cout) and cin % 64 == 0:
                 nb2 = L.unet_conv3x3_wgrad_mfma_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_mfma,

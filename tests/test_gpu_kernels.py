@@ -335,7 +335,7 @@ def test_conv3x3_winograd_fwd_dgrad(hip, shape):
     ws = ws_bytes(nb)
     cat = torch.zeros(n, h, w, 2 * co, device=DEV)
     outv = cat[..., co:]
-    hip.unet_conv3x3_fwd_winograd(P(xv), ci + 8, P(U), P(bd), P(outv), 2 * co, n, h, w, ci, co, 1, P(ws), nb, ST())
+    hip.unet_conv3x3_fwd_winograd(P(xv), ci + 8, P(U), P(bd), P(outv), 2 * co, n, h, w, ci, co, 1, None, P(ws), nb, ST())
     assert relerr(from_nhwc(outv), z_ref) < 3e-5
     assert cat[..., :co].abs().max().item() == 0
     dx = torch.full((n, h, w, ci), 7.0, device=DEV)
@@ -357,5 +357,5 @@ def test_conv3x3_winograd_wgrad(hip, shape):
     nb = hip.unet_conv3x3_wgrad_winograd_workspace(n, h, w, ci, co)
     ws = ws_bytes(nb)
     dw = torch.full((3, 3, ci, co), 7.0, device=DEV)
-    hip.unet_conv3x3_wgrad_winograd(P(xv), ci + 4, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+    hip.unet_conv3x3_wgrad_winograd(P(xv), ci + 4, None, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 3e-5
