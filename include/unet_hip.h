@@ -50,6 +50,13 @@ int unet_conv3x3_fwd_winograd(const float* x, int ldx, const float* U, const flo
                               void* ws, size_t ws_bytes, void* stream);
 int unet_conv3x3_dgrad_winograd(const float* dz, int lddz, const float* Ud, float* dx, int lddx,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* fully fused Winograd for the narrow layers (raw patch -> LDS, transform in-kernel, 16-point MFMA, output transform in the
+ * epilogue); Uc from unet_winograd_weight_transform mode 2 (forward) / 3 (data gradient); H, W even, reduce channels % 8,
+ * output channels % 64 */
+int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
+                                    int N, int H, int W, int Cin, int Cout, int relu, void* stream);
+int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
+                                      int N, int H, int W, int Cin, int Cout, void* stream);
 int unet_winograd_wgrad_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_conv3x3_wgrad_winograd_workspace(int N, int H, int W, int Cin, int Cout);
 /* V_saved (nullable): the V_keep of the forward call on the same xin; when given, xin is not read */

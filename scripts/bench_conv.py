@@ -33,7 +33,11 @@ for name, h, ci, co in shapes:
     wwok = L.unet_winograd_wgrad_supported(B, h, h, ci, co)
     if wwok:
         nbg = L.unet_conv3x3_wgrad_winograd_workspace(B, h, h, ci, co); wsg = torch.empty(nbg + 256, dtype=torch.uint8, device="cuda")
-    fns = {"wwgrad": lambda: L.unet_conv3x3_wgrad_winograd(P(x), ci, None, P(dz), co, P(dw), B, h, h, ci, co, P(wsg), nbg, ST()),
+    Uc = torch.empty(16 * ci * co, device="cuda"); Ucd = torch.empty(16 * ci * co, device="cuda")
+    L.unet_winograd_weight_transform(P(w), P(Uc), ci, co, 2, ST()); L.unet_winograd_weight_transform(P(w), P(Ucd), ci, co, 3, ST())
+    fns = {"ffwd": lambda: L.unet_conv3x3_fwd_winograd_fused(P(x), ci, P(Uc), P(b), P(out), co, B, h, h, ci, co, 1, ST()),
+           "fdgrad": lambda: L.unet_conv3x3_dgrad_winograd_fused(P(dz), co, P(Ucd), P(dx), ci, B, h, h, ci, co, ST()),
+           "wwgrad": lambda: L.unet_conv3x3_wgrad_winograd(P(x), ci, None, P(dz), co, P(dw), B, h, h, ci, co, P(wsg), nbg, ST()),
            "wfwd": lambda: L.unet_conv3x3_fwd_winograd(P(x), ci, P(U), P(b), P(out), co, B, h, h, ci, co, 1, None, P(wsw), nbw, ST()),
            "wdgrad": lambda: L.unet_conv3x3_dgrad_winograd(P(dz), co, P(Ud), P(dx), ci, B, h, h, ci, co, P(wsw), nbw, ST()),
            "fwd": lambda: L.unet_conv3x3_fwd_mfma(P(x), ci, P(w), P(b), P(out), co, B, h, h, ci, co, 1, ST()),

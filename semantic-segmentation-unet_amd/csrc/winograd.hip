@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-                const int aa = mode ? 2 - a : a, bb = mode ? 2 - b : b;
+                const int aa = (mode & 1) ? 2 - a : a, bb = (mode & 1) ? 2 - b : b;
                 g[a][b] = w[((size_t)(aa * 3 + bb) * Ci + ci) * Co + co];
             }
         float s[4][3];
@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
             s[3][b] = g[2][b];
         }
         const size_t plane = (size_t)Ci * Co;
-        const size_t off = mode ? (size_t)co * Ci + ci : (size_t)ci * Co + co;
+        size_t off;
+        if (mode == 0)      off = (size_t)ci * Co + co;                                     // [k=ci][n=co]
+        else if (mode == 1) off = (size_t)co * Ci + ci;                                     // [k=co][n=ci]
+        else if (mode == 2) off = ((size_t)(ci >> 3) * Co + co) * 8 + (ci & 7);             // [k/8][n=co][k%8]  (fused kernel)
+        else                off = ((size_t)(co >> 3) * Ci + ci) * 8 + (co & 7);             // [k/8][n=ci][k%8]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             U[(size_t)(4 * r + 0) * plane + off] = s[r][0];
@@ -280,6 +284,167 @@ int wgrad_splits(long T, int Ci, int Co) {
     return (int)s;
 }
 
+// ---- fully fused Winograd F(2x2,3x3) for the narrow (64/128-channel) layers ---------------------------------------------
+// One workgroup = 8x8 Winograd tiles (16x16 output pixels) x 64 output channels; wave (mi, ni) owns [32 tiles x 32 channels]
+// for ALL 16 Winograd points (16 x f32x16 = 256 AGPRs, one wave per SIMD).  K is streamed in chunks of 8 input channels:
+//   D  raw input patch 18x18 px x 8 ch   <- LDS-DMA from x (zero page outside the image)            2 buffers x 11 KB
+//   V  [xi][tile][8] = B^T d B           <- waves 0,1 transform D(c+1) while all waves run chunk c   2 buffers x 32 KB
+//   U  [xi][n][8] transformed weights    <- LDS-DMA from Uc[xi][K/8][N][8] (L2-resident)             2 buffers x 32 KB
+// A lane's 4 consecutive k (lane half picks the quad) are one ds_read_b128 for both operands; the quad slot is XOR-ed with
+// bit 3 of the row (on the DMA source side for U, on the transform's write side for V) so the 16-lane read groups hit 16
+// distinct 16-B slots.  The output transform A^T m A is lane-local in the epilogue.  HBM sees the input once (x1.27 halo)
+// and the output once; the 4x-expanded V / M planes of the unfused route never exist.
+struct WinoFusedArgs {
+    const float* x; const float* Uc; const float* bias; float* out;
+    int ldx, ldo, N, H, W, K, Nout, relu;
+    int tbx, tby, nt;            // tile-block grid
+};
+typedef __attribute__((address_space(3))) void lds_void_f;
+__device__ __attribute__((aligned(256))) float g_zero_page_f[8];
+
+__global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
+    constexpr int DPIX = 18 * 18, DPIECES = 11, DFL = DPIECES * 256;       // D image padded to whole 1-KB pieces
+    constexpr int IMG = 16 * 64 * 8;
+    __shared__ __attribute__((aligned(1024))) float smem[2 * DFL + 4 * IMG];
+    float* sD = smem; float* sV = smem + 2 * DFL; float* sU = sV + 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = wv & 1, ni = wv >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    int b = blockIdx.x;
+    const int tn = b % p.nt; b /= p.nt;
+    const int bx = b % p.tbx; b /= p.tbx;
+    const int by = b % p.tby; const int img = b / p.tby;
+    const int n0 = tn * 64;
+    const int gy0 = 16 * by - 1, gx0 = 16 * bx - 1;           // image coords of patch pixel (0,0)
+    const int nchunks = p.K / 8;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    const int drow = lane >> 1, dh = lane & 1;
+    // D piece id (0..10): pixels 32*id + lane/2 of the 18x18 patch
+    auto issue_D = [&](int id, int chunk, float* dst) {
+        const int pix = 32 * id + drow;
+        const int py = pix / 18, px = pix - py * 18;
+        const int gy = gy0 + py, gx = gx0 + px;
+        const bool ok = pix < DPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const float* src = ok ? p.x + ((size_t)(img * p.H + gy) * p.W + gx) * p.ldx + chunk * 8 + 4 * dh : g_zero_page_f + 4 * dh;
+        __builtin_amdgcn_global_load_lds(src, (lds_void_f*)(dst + id * 256), 16, 0, 0);
+    };
+    // U piece id (0..31): xi = id>>1, rows 32*(id&1) + lane/2; quad slot swizzled by bit 3 of the row
+    auto issue_U = [&](int id, int chunk, float* dst) {
+        const int xi = id >> 1, row = 32 * (id & 1) + drow;
+        const int hs = dh ^ ((row >> 3) & 1);
+        const float* src = p.Uc + (((size_t)xi * nchunks + chunk) * p.Nout + n0 + row) * 8 + 4 * hs;
+        __builtin_amdgcn_global_load_lds(src, (lds_void_f*)(dst + id * 256), 16, 0, 0);
+    };
+    // DMA duty: waves 2,3 issue everything (waves 0,1 run the transform)
+    auto issue_all = [&](int chunkU, bool doU, int chunkD, bool doD, int bufU, int bufD) {
+        if (wv >= 2) {
+            const int w2 = wv - 2;
+            if (doU) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) issue_U(2 * k + w2, chunkU, sU + bufU * IMG);
+            }
+            if (doD) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { const int id = 2 * k + w2; if (id < DPIECES) issue_D(id, chunkD, sD + bufD * DFL); }
+            }
+        }
+    };
+
+    // transform of one chunk: thread (tile lt = lane, quad q = wv) for wv in {0,1}: V[xi][lt][slot] = (B^T d B)[xi]
+    const int ty_l = lane >> 3, tx_l = lane & 7;
+    const int d_base = ((2 * ty_l) * 18 + 2 * tx_l) * 8 + 4 * (wv & 1);
+    const int v_base = lane * 8 + 4 * ((wv & 1) ^ ((lane >> 3) & 1));
+    f32x4 dd[4][4], tt[4][4];
+    auto transform_step = [&](int step, const float* D, float* V) {
+        if (wv >= 2) return;
+        if (step < 4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dd[step][c] = *reinterpret_cast<const f32x4*>(D + d_base + (step * 18 + c) * 8);
+        } else if (step < 8) {
+            const int c = step - 4;
+            tt[0][c] = dd[0][c] - dd[2][c]; tt[1][c] = dd[1][c] + dd[2][c];
+            tt[2][c] = dd[2][c] - dd[1][c]; tt[3][c] = dd[1][c] - dd[3][c];
+        } else {
+            const int r = (step - 8) >> 1;
+            if (((step - 8) & 1) == 0) {
+                *reinterpret_cast<f32x4*>(V + (4 * r + 0) * 512 + v_base) = tt[r][0] - tt[r][2];
+                *reinterpret_cast<f32x4*>(V + (4 * r + 1) * 512 + v_base) = tt[r][1] + tt[r][2];
+            } else {
+                *reinterpret_cast<f32x4*>(V + (4 * r + 2) * 512 + v_base) = tt[r][2] - tt[r][1];
+                *reinterpret_cast<f32x4*>(V + (4 * r + 3) * 512 + v_base) = tt[r][1] - tt[r][3];
+            }
+        }
+    };
+
+    // prologue: D(0), U(0), D(1) in flight; V(0) from D(0)
+    issue_all(0, true, 0, true, 0, 0);
+    if (nchunks > 1) issue_all(0, false, 1, true, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < 16; ++st) transform_step(st, sD, sV);
+    __syncthreads();
+
+    const int arow = 32 * mi + li, brow = 32 * ni + li;
+    const int a_off = arow * 8 + 4 * (lh ^ ((arow >> 3) & 1));
+    const int b_off = brow * 8 + 4 * (lh ^ ((brow >> 3) & 1));
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const float* cV = sV + cur * IMG; const float* cU = sU + cur * IMG;
+        // next chunk's weights and the chunk-after-next's raw patch (its buffer was consumed by the previous transform)
+        issue_all(chunk + 1, chunk + 1 < nchunks, chunk + 2, chunk + 2 < nchunks, cur ^ 1, cur);
+        const bool tr = chunk + 1 < nchunks;
+        const float* nD = sD + (cur ^ 1) * DFL; float* nV = sV + (cur ^ 1) * IMG;
+        f32x4 af = *reinterpret_cast<const f32x4*>(cV + a_off), bf = *reinterpret_cast<const f32x4*>(cU + b_off);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            f32x4 an = af, bn = bf;
+            if (xi + 1 < 16) {
+                an = *reinterpret_cast<const f32x4*>(cV + a_off + (xi + 1) * 512);
+                bn = *reinterpret_cast<const f32x4*>(cU + b_off + (xi + 1) * 512);
+            }
+            if (tr) transform_step(xi, nD, nV);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sidx], bf[sidx], acc[xi], 0, 0, 0);
+            af = an; bf = bn;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue: lane-local output transform, + bias, ReLU
+    const int Th = p.H >> 1, Tw = p.W >> 1;
+    const int co = n0 + 32 * ni + li;
+    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lt = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int ty = 8 * by + (lt >> 3), tx = 8 * bx + (lt & 7);
+        if (ty >= Th || tx >= Tw) continue;
+        float rr[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            rr[0][c] = acc[0 + c][r] + acc[4 + c][r] + acc[8 + c][r];
+            rr[1][c] = acc[4 + c][r] - acc[8 + c][r] - acc[12 + c][r];
+        }
+        float* o = p.out + ((size_t)(img * p.H + 2 * ty) * p.W + 2 * tx) * p.ldo + co;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float y0 = rr[i][0] + rr[i][1] + rr[i][2] + bv, y1 = rr[i][1] - rr[i][2] - rr[i][3] + bv;
+            if (p.relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+            o[(size_t)i * p.W * p.ldo] = y0;
+            o[(size_t)i * p.W * p.ldo + p.ldo] = y1;
+        }
+    }
+}
+
 int grid_for(long total, int cap) { long b = (total + 255) / 256; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b; }
 
 bool wino_ok(int N, int H, int W, int Ci, int Co) {
@@ -297,7 +462,33 @@ int run_wino(const float* x, int ldx, const float* U, const float* bias, float* 
     return UNET_LAUNCH_STATUS();
 }
 
+int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo, int N, int H, int W,
+                   int K, int Nout, int relu, hipStream_t st) {
+    WinoFusedArgs a{};
+    a.x = x; a.Uc = Uc; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo; a.N = N; a.H = H; a.W = W; a.K = K; a.Nout = Nout; a.relu = relu;
+    a.tby = (H / 2 + 7) / 8; a.tbx = (W / 2 + 7) / 8; a.nt = Nout / 64;
+    const long blocks = (long)N * a.tby * a.tbx * a.nt;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
+    wino_fused_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(a);
+    return UNET_LAUNCH_STATUS();
+}
+
 }  // namespace
+
+// Fully fused Winograd (narrow layers): Uc = unet_winograd_weight_transform(w, mode 2 forward / mode 3 data gradient).
+extern "C" int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
+        int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    UNET_CHECK_ARG(x && Uc && out && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 8 == 0 && Cout % 64 == 0);
+    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(Uc));
+    return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
+}
+
+extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
+        int N, int H, int W, int Cin, int Cout, void* stream) {
+    UNET_CHECK_ARG(dz && Ucd && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
+    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd));
+    return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream);
+}
 
 extern "C" int unet_winograd_supported(int N, int H, int W, int Cin, int Cout) {
     return (wino_ok(N, H, W, Cin, Cout) && Cin % 64 == 0) ? 1 : 0;
@@ -305,7 +496,7 @@ extern "C" int unet_winograd_supported(int N, int H, int W, int Cin, int Cout) {
 
 // U must hold 16*Cin*Cout floats.  mode 0: forward kernel transform; mode 1: data-gradient kernel transform.
 extern "C" int unet_winograd_weight_transform(const float* w, float* U, int Cin, int Cout, int mode, void* stream) {
-    UNET_CHECK_ARG(w && U && Cin > 0 && Cout > 0 && (mode == 0 || mode == 1));
+    UNET_CHECK_ARG(w && U && Cin > 0 && Cout > 0 && mode >= 0 && mode <= 3 && (mode < 2 || (Cin % 8 == 0 && Cout % 8 == 0)));
     wino_weight_kernel<<<grid_for((long)Cin * Cout, 4096), 256, 0, (hipStream_t)stream>>>(w, U, Cin, Cout, mode);
     return UNET_LAUNCH_STATUS();
 }

@@ -125,6 +125,9 @@ class Engine:
         # refreshed after every parameter update.  Thresholds from same-box A/B runs of bench.py: forward/dgrad win from
         # 256 channels on both sides (break-even at 128: the unfused transforms move ~14x the activation bytes); the
         # weight gradient already wins at 128 (121.8 -> 123.1 images/s).
+        # route for forward / dgrad: "fused" = fully fused Winograd kernel wherever it applies (default, fastest on every
+        # layer shape measured); "unfused" = planes + batched GEMM for >= winograd_min_channels, direct below; "direct"
+        self.conv_route = os.environ.get("UNET_CONV_ROUTE", "fused")
         self.winograd_min_channels = int(os.environ.get("UNET_WINOGRAD_MIN_C", "256"))
         self.winograd_wgrad_min_channels = int(os.environ.get("UNET_WINOGRAD_WGRAD_MIN_C", "128"))
         self.wino_U = {}
@@ -164,8 +167,31 @@ class Engine:
 
     def _use_winograd(self, name, n, h, w):
         cin, cout = self.cin[name], self.cout[name]
-        return (self.kind[name] == "conv3" and min(cin, cout) >= self.winograd_min_channels
+        return (self.conv_route == "unfused" and self.kind[name] == "conv3" and min(cin, cout) >= self.winograd_min_channels
                 and self.L.unet_winograd_supported(n, h, w, cin, cout) == 1)
+
+    def _use_fused(self, name, h, w, dgrad=False):
+        """fully fused Winograd kernel: H, W even, reduce channels % 8 == 0, output channels % 64 == 0"""
+        cin, cout = self.cin[name], self.cout[name]
+        k, nn = (cout, cin) if dgrad else (cin, cout)
+        return (self.conv_route == "fused" and self.kind[name] == "conv3" and h % 2 == 0 and w % 2 == 0
+                and k % 8 == 0 and nn % 64 == 0)
+
+    def _fused_kernels(self, name):
+        """(Uc forward, Uc dgrad) in the chunked layout of the fused kernel, cached until the next parameter change."""
+        if self._wino_dirty:
+            self.wino_U.clear()
+            self._wino_dirty = False
+        u = self.wino_U.get("f/" + name)
+        if u is None:
+            cin, cout = self.cin[name], self.cout[name]
+            u = (torch.empty(16 * cin * cout, dtype=torch.float32, device=self.dev),
+                 torch.empty(16 * cin * cout, dtype=torch.float32, device=self.dev))
+            st = self._stream()
+            self.L.unet_winograd_weight_transform(_p(self.p[name + "/kernel"]), _p(u[0]), cin, cout, 2, st)
+            self.L.unet_winograd_weight_transform(_p(self.p[name + "/kernel"]), _p(u[1]), cin, cout, 3, st)
+            self.wino_U["f/" + name] = u
+        return u
 
     def _winograd_kernels(self, name):
         """(U forward, U dgrad) for a layer; all cached transforms are recomputed lazily after a parameter change."""
@@ -240,7 +266,11 @@ class Engine:
             L.unet_conv1x1_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
         else:
             r = self._buf("r_" + name, (n, h, w, cout))
-            if self._use_winograd(name, n, h, w):
+            if self._use_fused(name, h, w):
+                self.saved_V[name] = None
+                self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused,
+                            _p(x), _ld(x), _p(self._fused_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+            elif self._use_winograd(name, n, h, w):
                 nbw = L.unet_conv3x3_winograd_workspace(n, h, w, cin, cout)
                 vk = None
                 if training and min(cin, cout) >= self.winograd_wgrad_min_channels and \
@@ -413,6 +443,9 @@ class Engine:
                 L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
                 L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
+            elif self._use_fused(name, ho, wo, dgrad=True):
+                self._timed("conv3x3_dgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd_fused,
+                            _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout, st)
             elif self._use_winograd(name, n, ho, wo):
                 nbw = L.unet_conv3x3_winograd_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_dgrad_winograd", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd,

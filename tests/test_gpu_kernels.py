@@ -359,3 +359,33 @@ def test_conv3x3_winograd_wgrad(hip, shape):
     dw = torch.full((3, 3, ci, co), 7.0, device=DEV)
     hip.unet_conv3x3_wgrad_winograd(P(xv), ci + 4, None, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 3e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (2, 32, 48, 64, 128), (1, 6, 10, 72, 64),
+                                   (1, 20, 36, 256, 128)])
+def test_conv3x3_winograd_fully_fused_fwd_dgrad(hip, shape):
+    # raw patch -> LDS, in-kernel transform, 16-point MFMA, output transform in the epilogue; ragged tile grids included
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(ci + 7 * co + h)
+    x = rng.standard_normal((n, ci, h, w))
+    wt = rng.standard_normal((3, 3, ci, co)) / np.sqrt(9 * ci)
+    b = rng.standard_normal(co)
+    z_ref = np.maximum(on.conv_same_fwd(x, wt, b), 0)
+    xbuf = torch.zeros(n, h, w, ci + 8, device=DEV); xbuf[..., 4:4 + ci] = to_nhwc(x)
+    xv = xbuf[..., 4:4 + ci]
+    wd, bd = dev(wt), dev(b)
+    Uc = torch.empty(16 * ci * co, device=DEV)
+    hip.unet_winograd_weight_transform(P(wd), P(Uc), ci, co, 2, ST())
+    cat = torch.zeros(n, h, w, 2 * co, device=DEV)
+    outv = cat[..., co:]
+    hip.unet_conv3x3_fwd_winograd_fused(P(xv), ci + 8, P(Uc), P(bd), P(outv), 2 * co, n, h, w, ci, co, 1, ST())
+    assert relerr(from_nhwc(outv), z_ref) < 3e-5
+    assert cat[..., :co].abs().max().item() == 0
+    if ci % 64 == 0:
+        dz = rng.standard_normal((n, co, h, w))
+        dx_ref, _, _ = on.conv_same_bwd(x, wt, dz)
+        Ucd = torch.empty(16 * ci * co, device=DEV)
+        hip.unet_winograd_weight_transform(P(wd), P(Ucd), ci, co, 3, ST())
+        dx = torch.full((n, h, w, ci), 7.0, device=DEV)
+        hip.unet_conv3x3_dgrad_winograd_fused(P(to_nhwc(dz)), co, P(Ucd), P(dx), ci, n, h, w, ci, co, ST())
+        assert relerr(from_nhwc(dx), dx_ref) < 3e-5
