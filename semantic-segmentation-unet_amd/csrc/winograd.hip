@@ -10,6 +10,9 @@
 //
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
 #include "common.h"
+#ifndef UNET_ABLATE
+#define UNET_ABLATE 0
+#endif
 
 namespace {
 
@@ -357,10 +360,13 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
         }
     };
 
-    // transform of one chunk: thread (tile lt = lane, quad q = wv) for wv in {0,1}: V[xi][lt][slot] = (B^T d B)[xi]
-    const int ty_l = lane >> 3, tx_l = lane & 7;
-    const int d_base = ((2 * ty_l) * 18 + 2 * tx_l) * 8 + 4 * (wv & 1);
-    const int v_base = lane * 8 + 4 * ((wv & 1) ^ ((lane >> 3) & 1));
+    // transform of one chunk by waves 0,1: lane -> (tile lt = 32*wv + lane/2, channel quad q = lane&1), so a 16-lane
+    // ds_read_b128 group touches 8 distinct 16-B slots of the raw patch (2-way; tile-per-lane would be 4-way) and the V
+    // writes of a tile's two quads are adjacent.  V[xi][lt][slot] = (B^T d B)[xi], slot = q ^ bit3(lt).
+    const int t_lt = 32 * (wv & 1) + (lane >> 1), t_q = lane & 1;
+    const int ty_l = t_lt >> 3, tx_l = t_lt & 7;
+    const int d_base = ((2 * ty_l) * 18 + 2 * tx_l) * 8 + 4 * t_q;
+    const int v_base = t_lt * 8 + 4 * (t_q ^ ((t_lt >> 3) & 1));
     f32x4 dd[4][4], tt[4][4];
     auto transform_step = [&](int step, const float* D, float* V) {
         if (wv >= 2) return;
@@ -399,8 +405,17 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
         const int cur = chunk & 1;
         const float* cV = sV + cur * IMG; const float* cU = sU + cur * IMG;
         // next chunk's weights and the chunk-after-next's raw patch (its buffer was consumed by the previous transform)
+#if UNET_ABLATE == 1        /* diagnostics only: no weight DMA in the loop */
+        issue_all(chunk + 1, false, chunk + 2, chunk + 2 < nchunks, cur ^ 1, cur);
+#elif UNET_ABLATE == 3      /* no DMA at all in the loop */
+#else
         issue_all(chunk + 1, chunk + 1 < nchunks, chunk + 2, chunk + 2 < nchunks, cur ^ 1, cur);
+#endif
+#if UNET_ABLATE >= 2        /* no in-loop transform */
+        const bool tr = false;
+#else
         const bool tr = chunk + 1 < nchunks;
+#endif
         const float* nD = sD + (cur ^ 1) * DFL; float* nV = sV + (cur ^ 1) * IMG;
         f32x4 af = *reinterpret_cast<const f32x4*>(cV + a_off), bf = *reinterpret_cast<const f32x4*>(cU + b_off);
 #pragma unroll
