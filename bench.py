@@ -168,24 +168,36 @@ def main():
             fl = sum(f for _, _, f in evs)
             extra[key] = {"launches_per_step": len(evs) // args.steps, "ms_per_step": round(ms / args.steps, 3),
                           "avg_launch_ms": round(ms / len(evs), 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
-        # Dominant kernel = igemm_kernel (3x3 implicit GEMM).  Its FORWARD launches (template instantiation
-        # igemm_kernel<0,*,*,false>) run alone on the GPU, so their event durations are the kernel's own; the dgrad
-        # launches (<0,*,*,true>) and wgrad_kernel run concurrently on two streams in backward, so their per-launch
-        # durations in `kernels` include time shared with the other stream.
-        k = extra.get("conv3x3_fwd")
-        if k:
+        # Dominant kernel = the 3x3 conv forward kernel of the active route: wino_fused_kernel (fully fused Winograd
+        # F(2x2,3x3), default) or igemm_kernel<0,*,*,false> (UNET_CONV_ROUTE=direct).  Forward launches run alone on the
+        # GPU, so their event durations are the kernel's own; backward launches (dgrad / wgrad on two streams) overlap and
+        # are listed under `kernels` with shared time included.  `achieved` is ALGORITHMIC (direct-convolution) FLOP/s as
+        # SURVEY.md 8(d) defines the work; Winograd executes 2.25x fewer multiplies, so `executed` = achieved / 2.25 is
+        # the rate the matrix cores actually run at and `achieved` may exceed the MFMA peak.
+        kf, kd = extra.get("conv3x3_fwd_winograd_fused"), extra.get("conv3x3_fwd")
+        if kf:
+            roofline = {"bound": "mfma", "kernel": "wino_fused_kernel (3x3 conv forward, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
+                        "achieved": kf["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(kf["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "executed": round(kf["tflops"] / 2.25, 2), "executed_frac": round(kf["tflops"] / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "traffic": None, "launches_per_step": kf["launches_per_step"], "avg_launch_ms": kf["avg_launch_ms"]}
+            tfile = "r01_wino_fused_fwd_pmc_traffic.json"
+        elif kd:
             roofline = {"bound": "mfma", "kernel": "igemm_kernel<0,*,*,false> (3x3 conv forward, v_mfma_f32_32x32x2_f32)",
-                        "achieved": k["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(k["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                        "launches_per_step": k["launches_per_step"], "avg_launch_ms": k["avg_launch_ms"]}
+                        "achieved": kd["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(kd["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": kd["launches_per_step"], "avg_launch_ms": kd["avg_launch_ms"]}
+            tfile = "r01_igemm_fwd_pmc_traffic.json"
+        if roofline:
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction,
             # WRITE_SIZE) of this same workload, committed under profiles/; only valid for the default workload.
-            tf = os.path.join(ROOT, "profiles", "r01_igemm_fwd_pmc_traffic.json")
+            tf = os.path.join(ROOT, "profiles", tfile)
             if os.path.exists(tf) and (args.size, args.channels, args.classes, args.batch) == (512, 1, 2, 8):
                 t = json.load(open(tf))
-                roofline["traffic"] = round(t["hbm_bytes_per_launch"])
-                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r01_igemm_fwd_pmc_traffic.json)"
-                roofline["algorithmic_bytes_per_launch"] = round(t["algorithmic_bytes_per_launch"])
+                if t.get("launches_per_step") == roofline["launches_per_step"]:
+                    roofline["traffic"] = round(t["hbm_bytes_per_launch"])
+                    roofline["traffic_unit"] = "bytes/launch (PMC, profiles/%s)" % tfile
+                    roofline["algorithmic_bytes_per_launch"] = round(t["algorithmic_bytes_per_launch"])
     if rank == 0:
         ips = G * args.steps / dt
         out = {
