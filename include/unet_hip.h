@@ -57,6 +57,12 @@ int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* Uc, co
                                     int N, int H, int W, int Cin, int Cout, int relu, void* stream);
 int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
                                       int N, int H, int W, int Cin, int Cout, void* stream);
+/* fused Winograd weight gradient: raw rows through LDS, per-lane transforms in registers, G^T dU G in the epilogue;
+ * needs H, W even and Cin, Cout multiples of 64 */
+int unet_winograd_wgrad_fused_supported(int N, int H, int W, int Cin, int Cout);
+size_t unet_conv3x3_wgrad_winograd_fused_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                      int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int unet_winograd_wgrad_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_conv3x3_wgrad_winograd_workspace(int N, int H, int W, int Cin, int Cout);
 /* V_saved (nullable): the V_keep of the forward call on the same xin; when given, xin is not read */

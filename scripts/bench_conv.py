@@ -35,7 +35,9 @@ for name, h, ci, co in shapes:
         nbg = L.unet_conv3x3_wgrad_winograd_workspace(B, h, h, ci, co); wsg = torch.empty(nbg + 256, dtype=torch.uint8, device="cuda")
     Uc = torch.empty(16 * ci * co, device="cuda"); Ucd = torch.empty(16 * ci * co, device="cuda")
     L.unet_winograd_weight_transform(P(w), P(Uc), ci, co, 2, ST()); L.unet_winograd_weight_transform(P(w), P(Ucd), ci, co, 3, ST())
-    fns = {"ffwd": lambda: L.unet_conv3x3_fwd_winograd_fused(P(x), ci, P(Uc), P(b), P(out), co, B, h, h, ci, co, 1, ST()),
+    nbq = L.unet_conv3x3_wgrad_winograd_fused_workspace(B, h, h, ci, co); wsq = torch.empty(nbq + 256, dtype=torch.uint8, device="cuda")
+    fns = {"fwgrad": lambda: L.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(wsq), nbq, ST()),
+           "ffwd": lambda: L.unet_conv3x3_fwd_winograd_fused(P(x), ci, P(Uc), P(b), P(out), co, B, h, h, ci, co, 1, ST()),
            "fdgrad": lambda: L.unet_conv3x3_dgrad_winograd_fused(P(dz), co, P(Ucd), P(dx), ci, B, h, h, ci, co, ST()),
            "wwgrad": lambda: L.unet_conv3x3_wgrad_winograd(P(x), ci, None, P(dz), co, P(dw), B, h, h, ci, co, P(wsg), nbg, ST()),
            "wfwd": lambda: L.unet_conv3x3_fwd_winograd(P(x), ci, P(U), P(b), P(out), co, B, h, h, ci, co, 1, None, P(wsw), nbw, ST()),

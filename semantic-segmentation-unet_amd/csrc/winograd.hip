@@ -460,6 +460,159 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
     }
 }
 
+// ---- fully fused Winograd weight gradient ----------------------------------------------------------------------------
+//   dW = G^T [ sum_tiles (B^T d B)[xi][ci] * (A dY A^T)[xi][co] ] G
+// Workgroup = 64 input channels x 64 output channels x all 16 Winograd points (wave = [32 ci x 32 co] x 16 points in 256
+// AGPRs); the MFMA reduce dimension is TILES: a chunk = 8 consecutive tiles of one tile row.  Raw rows only go through
+// LDS -- x: 4 pixel rows x 18 px x 64 ci, dz: 2 rows x 16 px x 64 co, LDS-DMA'd two chunks ahead into a 3-deep ring --
+// and every lane transforms ITS OWN 4 tiles in registers (lane = channel, lane half = tile quad): no transformed LDS
+// images, no transform waves, one barrier per chunk.  Tile s of the chunk feeds 16 independent MFMAs (one per point).
+// Epilogue: G^T dU G is lane-local; split partials go to the workspace [split][9][Ci][Co] and are reduced in fixed order.
+struct WinoWgradArgs {
+    const float* x; const float* dz; float* ws;
+    int ldx, lddz, N, H, W, Ci, Co;
+    int mt, nt, splits, tbx, nchunks;
+};
+typedef __attribute__((address_space(3))) void lds_void_g;
+__device__ __attribute__((aligned(256))) float g_zero_page_g[64];
+
+__global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs p) {
+    constexpr int XP = 4 * 18, ZP = 2 * 16;                 // raw pixels per chunk
+    constexpr int XPIECES = XP / 4, ZPIECES = ZP / 4;       // 1-KB DMA pieces (4 pixels x 64 channels)
+    constexpr int BUF = (XP + ZP) * 64;                     // floats per ring slot (26 KB)
+    __shared__ __attribute__((aligned(1024))) float smem[3 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = wv & 1, ni = wv >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tmn = bid % (p.mt * p.nt);
+    const int split = bid / (p.mt * p.nt);
+    const int m0 = (tmn / p.nt) * 64, n0 = (tmn % p.nt) * 64;
+    const int Th = p.H >> 1;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    const int dq = lane & 15, dp = lane >> 4;
+    auto issue_chunk = [&](int c, float* dst) {
+        if (c >= p.nchunks) return;
+        int t = c;
+        const int txb = t % p.tbx; t /= p.tbx;
+        const int ty = t % Th; const int img = t / Th;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int piece = 4 * k + wv;
+            if (piece < XPIECES) {
+                const int px = 4 * piece + dp, row = px / 18, col = px - row * 18;
+                const int gy = 2 * ty - 1 + row, gx = 16 * txb - 1 + col;
+                const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const float* src = ok ? p.x + ((size_t)(img * p.H + gy) * p.W + gx) * p.ldx + m0 + 4 * dq : g_zero_page_g + 4 * dq;
+                __builtin_amdgcn_global_load_lds(src, (lds_void_g*)(dst + piece * 256), 16, 0, 0);
+            } else if (piece < XPIECES + ZPIECES) {
+                const int px = 4 * (piece - XPIECES) + dp, row = px >> 4, col = px & 15;
+                const int gy = 2 * ty + row, gx = 16 * txb + col;
+                const bool ok = gy < p.H && gx < p.W;
+                const float* src = ok ? p.dz + ((size_t)(img * p.H + gy) * p.W + gx) * p.lddz + n0 + 4 * dq : g_zero_page_g + 4 * dq;
+                __builtin_amdgcn_global_load_lds(src, (lds_void_g*)(dst + piece * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    int c = split;
+    issue_chunk(c, smem);
+    issue_chunk(c + p.splits, smem + BUF);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int xa = (8 * lh) * 64 + 32 * mi + li;                    // + (row*18 + cc)*64
+    const int za = XP * 64 + (8 * lh) * 64 + 32 * ni + li;          // + (row*16 + cc)*64
+    int slot = 0;
+    for (; c < p.nchunks; c += p.splits) {
+        const float* buf = smem + slot * BUF;
+        issue_chunk(c + 2 * p.splits, smem + ((slot + 2) % 3) * BUF);
+        // raw rows of this lane's 4 tiles: x columns 8*lh .. 8*lh+9 (4 rows), dz columns 8*lh .. 8*lh+7 (2 rows)
+        float xr[4][10], zr[2][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 10; ++cc) xr[r][cc] = buf[xa + (r * 18 + cc) * 64];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) zr[r][cc] = buf[za + (r * 16 + cc) * 64];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            // V = B^T d B of the 4x4 patch at columns 2s..2s+3
+            float tt[4][4], V[16], M[16];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const float d0 = xr[0][2 * sidx + cc], d1 = xr[1][2 * sidx + cc], d2 = xr[2][2 * sidx + cc], d3 = xr[3][2 * sidx + cc];
+                tt[0][cc] = d0 - d2; tt[1][cc] = d1 + d2; tt[2][cc] = d2 - d1; tt[3][cc] = d1 - d3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                V[4 * r + 0] = tt[r][0] - tt[r][2]; V[4 * r + 1] = tt[r][1] + tt[r][2];
+                V[4 * r + 2] = tt[r][2] - tt[r][1]; V[4 * r + 3] = tt[r][1] - tt[r][3];
+            }
+            // dM = A dY A^T of the 2x2 gradient tile
+            const float y00 = zr[0][2 * sidx], y01 = zr[0][2 * sidx + 1], y10 = zr[1][2 * sidx], y11 = zr[1][2 * sidx + 1];
+            const float ra[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                M[4 * a + 0] = ra[a][0]; M[4 * a + 1] = ra[a][0] + ra[a][1];
+                M[4 * a + 2] = ra[a][0] - ra[a][1]; M[4 * a + 3] = -ra[a][1];
+            }
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi], M[xi], acc[xi], 0, 0, 0);
+        }
+        // the chunk after this one must have landed (it was issued one iteration ago); the newest batch may stay in flight
+        if (c + 2 * p.splits < p.nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else                              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        slot = (slot + 1) % 3;
+    }
+
+    // epilogue: dw[a][b] = (G^T dU G)[a][b], lane-local per (ci, co)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float sv[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sv[0][j] = acc[0 + j][r] + 0.5f * (acc[4 + j][r] + acc[8 + j][r]);
+            sv[1][j] = 0.5f * (acc[4 + j][r] - acc[8 + j][r]);
+            sv[2][j] = 0.5f * (acc[4 + j][r] + acc[8 + j][r]) + acc[12 + j][r];
+        }
+        float* o = p.ws + (((size_t)split * 9) * p.Ci + m0 + 32 * mi + row) * p.Co + n0 + 32 * ni + li;
+        const size_t tapstride = (size_t)p.Ci * p.Co;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            o[(3 * a + 0) * tapstride] = sv[a][0] + 0.5f * (sv[a][1] + sv[a][2]);
+            o[(3 * a + 1) * tapstride] = 0.5f * (sv[a][1] - sv[a][2]);
+            o[(3 * a + 2) * tapstride] = 0.5f * (sv[a][1] + sv[a][2]) + sv[a][3];
+        }
+    }
+}
+
+__global__ void wino_partial_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 sacc = reinterpret_cast<const f32x4*>(ws)[i];
+        for (int k = 1; k < splits; ++k) sacc += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
+        reinterpret_cast<f32x4*>(dw)[i] = sacc;
+    }
+}
+
+int wgrad_fused_splits(int N, int H, int W, int Ci, int Co) {
+    const int blocks = (Ci / 64) * (Co / 64);
+    const long nchunks = (long)N * (H / 2) * ((W / 2 + 7) / 8);
+    long sp = 256 / blocks; if (sp < 1) sp = 1; if (sp > nchunks) sp = nchunks;
+    return (int)sp;
+}
+
 int grid_for(long total, int cap) { long b = (total + 255) / 256; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b; }
 
 bool wino_ok(int N, int H, int W, int Ci, int Co) {
@@ -503,6 +656,33 @@ extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, cons
     UNET_CHECK_ARG(dz && Ucd && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd));
     return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream);
+}
+
+extern "C" int unet_winograd_wgrad_fused_supported(int N, int H, int W, int Cin, int Cout) {
+    return (N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 64 == 0 && Cout % 64 == 0) ? 1 : 0;
+}
+
+extern "C" size_t unet_conv3x3_wgrad_winograd_fused_workspace(int N, int H, int W, int Cin, int Cout) {
+    return (size_t)wgrad_fused_splits(N, H, W, Cin, Cout) * 9 * Cin * Cout * sizeof(float);
+}
+
+// dw[a][b][ci][co] = sum_{n,y,x} xin[n, y+a-1, x+b-1, ci] * dz[n,y,x,co] via the fused Winograd-domain kernel
+extern "C" int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+        int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(xin && dz && dw && ws && unet_winograd_wgrad_fused_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0);
+    UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
+    if (ws_bytes < unet_conv3x3_wgrad_winograd_fused_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    WinoWgradArgs a{};
+    a.x = xin; a.dz = dz; a.ws = (float*)ws; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Ci = Cin; a.Co = Cout;
+    a.mt = Cin / 64; a.nt = Cout / 64; a.tbx = (W / 2 + 7) / 8; a.nchunks = N * (H / 2) * a.tbx;
+    a.splits = wgrad_fused_splits(N, H, W, Cin, Cout);
+    wino_wgrad_fused_kernel<<<dim3((unsigned)(a.mt * a.nt * a.splits)), 256, 0, st>>>(a);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    const long n4 = 9L * Cin * Cout / 4;
+    wino_partial_reduce_kernel<<<grid_for(n4, 2048), 256, 0, st>>>((const float*)ws, dw, n4, a.splits);
+    return UNET_LAUNCH_STATUS();
 }
 
 extern "C" int unet_winograd_supported(int N, int H, int W, int Cin, int Cout) {

@@ -130,6 +130,10 @@ class Engine:
         self.conv_route = os.environ.get("UNET_CONV_ROUTE", "fused")
         self.winograd_min_channels = int(os.environ.get("UNET_WINOGRAD_MIN_C", "256"))
         self.winograd_wgrad_min_channels = int(os.environ.get("UNET_WINOGRAD_WGRAD_MIN_C", "128"))
+        # weight-gradient route: "fused" = fused Winograd wgrad wherever it applies; "hybrid" = unfused planes + TN GEMM from
+        # `wgrad_unfused_from` channels up, fused below; "unfused" = the previous policy (unfused >= 128, direct below)
+        self.wgrad_route = os.environ.get("UNET_WGRAD_ROUTE", "hybrid")
+        self.wgrad_unfused_from = int(os.environ.get("UNET_WGRAD_UNFUSED_FROM", "512"))
         self.wino_U = {}
         self._wino_dirty = True
         self.side = torch.cuda.Stream(device=self.dev)
@@ -417,6 +421,12 @@ class Engine:
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
                 L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+            elif (self.wgrad_route in ("fused", "hybrid") and L.unet_winograd_wgrad_fused_supported(n, ho, wo, cin, cout) == 1
+                  and not (self.wgrad_route == "hybrid" and min(cin, cout) >= self.wgrad_unfused_from
+                           and L.unet_winograd_wgrad_supported(n, ho, wo, cin, cout) == 1)):
+                nb2 = L.unet_conv3x3_wgrad_winograd_fused_workspace(n, ho, wo, cin, cout)
+                self._timed("conv3x3_wgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_winograd_fused,
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif (min(cin, cout) >= self.winograd_wgrad_min_channels
                   and L.unet_winograd_wgrad_supported(n, ho, wo, cin, cout) == 1):
                 nb2 = L.unet_conv3x3_wgrad_winograd_workspace(n, ho, wo, cin, cout)

@@ -389,3 +389,21 @@ def test_conv3x3_winograd_fully_fused_fwd_dgrad(hip, shape):
         dx = torch.full((n, h, w, ci), 7.0, device=DEV)
         hip.unet_conv3x3_dgrad_winograd_fused(P(to_nhwc(dz)), co, P(Ucd), P(dx), ci, n, h, w, ci, co, ST())
         assert relerr(from_nhwc(dx), dx_ref) < 3e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 64), (3, 8, 24, 64, 192), (1, 6, 10, 64, 64), (2, 32, 48, 128, 128)])
+def test_conv3x3_winograd_fused_wgrad(hip, shape):
+    # raw rows through LDS, per-lane Winograd transforms in registers, G^T dU G in the epilogue; ragged tile rows included
+    n, h, w, ci, co = shape
+    assert hip.unet_winograd_wgrad_fused_supported(n, h, w, ci, co) == 1
+    rng = np.random.default_rng(ci * 5 + co + h)
+    x = rng.standard_normal((n, ci, h, w)); dz = rng.standard_normal((n, co, h, w))
+    _, dw_ref, _ = on.conv_same_bwd(x, np.zeros((3, 3, ci, co)), dz)
+    xbuf = torch.zeros(n, h, w, ci + 4, device=DEV); xbuf[..., 4:] = to_nhwc(x)
+    xv = xbuf[..., 4:]
+    dzd = to_nhwc(dz)
+    nb = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co)
+    ws = ws_bytes(nb)
+    dw = torch.full((3, 3, ci, co), 7.0, device=DEV)
+    hip.unet_conv3x3_wgrad_winograd_fused(P(xv), ci + 4, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+    assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 3e-5
