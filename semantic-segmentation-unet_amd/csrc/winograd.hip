@@ -478,14 +478,22 @@ __device__ __attribute__((aligned(256))) float g_zero_page_g[64];
 
 __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs p) {
     constexpr int XP = 4 * 18, ZP = 2 * 16;                 // raw pixels per chunk
-    constexpr int XPIECES = XP / 4, ZPIECES = ZP / 4;       // 1-KB DMA pieces (4 pixels x 64 channels)
-    constexpr int BUF = (XP + ZP) * 64;                     // floats per ring slot (26 KB)
-    __shared__ __attribute__((aligned(1024))) float smem[3 * BUF];
+    constexpr int XPIECES = XP / 4, ZPIECES = ZP / 4;       // 1-KB DMA pieces (4 pixels x 64 channels): 18 + 8
+    constexpr int KPW = 7;                                  // pieces per wave per chunk (4 x 7 = 28 slots, 2 of them dummies)
+    constexpr int BUF = 4 * KPW * 256;                      // floats per ring slot (28 KB)
+    constexpr int NSLOT = 5, LEAD = NSLOT - 1;              // chunks in flight: HBM latency under load exceeds one chunk time
+    __shared__ __attribute__((aligned(1024))) float smem[NSLOT * BUF];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mi = wv & 1, ni = wv >> 1;
     const int li = lane & 31, lh = lane >> 5;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Renumber so that one XCD holds consecutive
+    // logical ids = the (ci, co) tiles of as few splits as possible: tiles of one split read the same x / dz chunks, so
+    // they should hit one L2 rather than pull the chunk over the fabric once per XCD.
     int bid = blockIdx.x;
+#if UNET_ABLATE != 6
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+#endif
     const int tmn = bid % (p.mt * p.nt);
     const int split = bid / (p.mt * p.nt);
     const int m0 = (tmn / p.nt) * 64, n0 = (tmn % p.nt) * 64;
@@ -497,83 +505,173 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
+    // DMA geometry, chunk-invariant: piece 4k+wv of wave wv; pieces 0..17 are x rows (pixels (-1,-1)..(2,16) relative to
+    // the chunk's first output pixel), 18..25 dz rows, 26..27 dummies that re-read an always-valid x pixel into an unused LDS
+    // piece (so every wave issues exactly KPW DMAs per chunk).  Per lane and piece only a byte offset from a per-chunk
+    // scalar base and a 4-bit border code (top / bottom / left / right pixel of the halo) are kept; the per-chunk part is
+    // scalar arithmetic.  Address generation is ~4 VALU instructions per piece: with one wave per SIMD every VALU
+    // instruction is matrix-pipe time.
     const int dq = lane & 15, dp = lane >> 4;
-    auto issue_chunk = [&](int c, float* dst) {
-        if (c >= p.nchunks) return;
-        int t = c;
-        const int txb = t % p.tbx; t /= p.tbx;
-        const int ty = t % Th; const int img = t / Th;
+    const int wlast = p.W - 16 * (p.tbx - 1);      // image columns covered by the last chunk of a tile row (16 unless W is ragged)
+    unsigned g_off[KPW];                 // byte offset from the chunk base (x: pixel (-1,-1); dz: pixel (0,0))
+    unsigned g_codes = 0;                // 4 bits per piece: pixel lies in the top row / bottom row / left column / beyond the last image column (1, 2, 4, 8)
+                                         // of a chunk at the corresponding image border
+    bool g_isx[KPW];                     // wave-uniform
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int piece = 4 * k + wv;
-            if (piece < XPIECES) {
-                const int px = 4 * piece + dp, row = px / 18, col = px - row * 18;
-                const int gy = 2 * ty - 1 + row, gx = 16 * txb - 1 + col;
-                const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                const float* src = ok ? p.x + ((size_t)(img * p.H + gy) * p.W + gx) * p.ldx + m0 + 4 * dq : g_zero_page_g + 4 * dq;
-                __builtin_amdgcn_global_load_lds(src, (lds_void_g*)(dst + piece * 256), 16, 0, 0);
-            } else if (piece < XPIECES + ZPIECES) {
-                const int px = 4 * (piece - XPIECES) + dp, row = px >> 4, col = px & 15;
-                const int gy = 2 * ty + row, gx = 16 * txb + col;
-                const bool ok = gy < p.H && gx < p.W;
-                const float* src = ok ? p.dz + ((size_t)(img * p.H + gy) * p.W + gx) * p.lddz + n0 + 4 * dq : g_zero_page_g + 4 * dq;
-                __builtin_amdgcn_global_load_lds(src, (lds_void_g*)(dst + piece * 256), 16, 0, 0);
-            }
+    for (int k = 0; k < KPW; ++k) {
+        const int piece = 4 * k + wv;
+        g_isx[k] = piece < XPIECES || piece >= XPIECES + ZPIECES;
+        if (piece < XPIECES) {
+            const int px = 4 * piece + dp, row = px / 18, col = px % 18;          // halo coordinates 0..3 x 0..17
+            g_off[k] = (unsigned)(((row * p.W + col) * p.ldx + 4 * dq) * 4);
+            g_codes |= (unsigned)((row == 0) | ((row == 3) << 1) | ((col == 0) << 2) | ((col > wlast) << 3)) << (4 * k);
+        } else if (piece < XPIECES + ZPIECES) {
+            const int px = 4 * (piece - XPIECES) + dp;
+            g_off[k] = (unsigned)((((px >> 4) * p.W + (px & 15)) * p.lddz + 4 * dq) * 4);
+            g_codes |= (unsigned)(((px & 15) >= wlast) << 3) << (4 * k);
+        } else {
+            g_off[k] = (unsigned)(((p.W + 1) * p.ldx + 4 * dq) * 4);              // halo pixel (1,1): never out of bounds
         }
+    }
+    const float* zpage = g_zero_page_g + 4 * dq;
+    // chunk coordinates of the next batch to issue, advanced by `splits` chunks at a time without divisions
+    int ic = split, i_txb, i_ty, i_img;
+    { int t = ic; i_txb = t % p.tbx; t /= p.tbx; i_ty = t % Th; i_img = t / Th; }
+    const int d_txb = p.splits % p.tbx, d_ty = (p.splits / p.tbx) % Th, d_img = p.splits / (p.tbx * Th);
+    auto issue_next = [&](float* dst) {
+        const bool cv = ic < p.nchunks;                                           // past the end: re-read chunk 0, never used
+        const int txb = cv ? i_txb : 0, ty = cv ? i_ty : 0, img = cv ? i_img : 0;
+#if UNET_ABLATE == 5        /* diagnostics only: every DMA reads the same few KB (always an L2 hit) */
+        const long long pixz = 0;
+#else
+        const long long pixz = (long long)(img * p.H + 2 * ty) * p.W + 16 * txb;
+#endif
+        const char* bx = reinterpret_cast<const char*>(p.x + m0) + (pixz - p.W - 1) * p.ldx * 4;
+        const char* bz = reinterpret_cast<const char*>(p.dz + n0) + pixz * p.lddz * 4;
+        const unsigned scode = (unsigned)((ty == 0) | ((ty == Th - 1) << 1) | ((txb == 0) << 2) | ((txb == p.tbx - 1) << 3));
+        const unsigned hit = g_codes & (scode * 0x01111111u);
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) {
+            const char* src = (g_isx[k] ? bx : bz) + g_off[k];
+            src = (hit & (0xFu << (4 * k))) ? reinterpret_cast<const char*>(zpage) : src;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void_g*)(dst + (4 * k + wv) * 256), 16, 0, 0);
+        }
+        ic += p.splits;
+        i_txb += d_txb; const int c1 = i_txb >= p.tbx; i_txb -= c1 ? p.tbx : 0;
+        i_ty += d_ty + c1; const int c2 = i_ty >= Th; i_ty -= c2 ? Th : 0;
+        i_img += d_img + c2;
     };
 
     int c = split;
-    issue_chunk(c, smem);
-    issue_chunk(c + p.splits, smem + BUF);
+#pragma unroll
+    for (int k = 0; k < LEAD; ++k) issue_next(smem + k * BUF);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int xa = (8 * lh) * 64 + 32 * mi + li;                    // + (row*18 + cc)*64
     const int za = XP * 64 + (8 * lh) * 64 + 32 * ni + li;          // + (row*16 + cc)*64
+    // Raw rows of this lane's 4 tiles: x columns 8*lh .. 8*lh+9 (4 rows), dz columns 8*lh .. 8*lh+7 (2 rows), as column pairs
+    // (one ds_read2st64_b32 each).  The LDS reads are inline asm on purpose: left to itself the compiler sinks each read next
+    // to its first use and waits on it there, which with one wave per SIMD exposes the LDS latency ~16 times per chunk
+    // (WAIT_INST_ANY 0.61, matrix pipe 50 % busy).  Here the whole batch for chunk i+1 is issued behind chunk i's last
+    // transform and lands under its last 16 MFMAs; READ_PAIR ties one MFMA operand to each read so those MFMAs stay behind it,
+    // and the single lgkmcnt(0) at the top of the next iteration carries every pair as an operand so no use can move above it.
+    f32x2 xp[4][5], zp[2][4];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_g*)smem;
+    const unsigned xa_b = lds0 + 4u * xa, za_b = lds0 + 4u * za;
+#define READ_PAIR(dst, base, off, tie, tieacc) \
+    asm volatile("ds_read2st64_b32 %0, %3 offset0:%4 offset1:%5" : "=&v"(dst), "+v"(tie), "+a"(tieacc) : "v"(base), "n"(off), "n"((off) + 1))
+#define ALL_PAIRS \
+    "+v"(xp[0][0]), "+v"(xp[0][1]), "+v"(xp[0][2]), "+v"(xp[0][3]), "+v"(xp[0][4]), "+v"(xp[1][0]), "+v"(xp[1][1]), \
+    "+v"(xp[1][2]), "+v"(xp[1][3]), "+v"(xp[1][4]), "+v"(xp[2][0]), "+v"(xp[2][1]), "+v"(xp[2][2]), "+v"(xp[2][3]), \
+    "+v"(xp[2][4]), "+v"(xp[3][0]), "+v"(xp[3][1]), "+v"(xp[3][2]), "+v"(xp[3][3]), "+v"(xp[3][4]), "+v"(zp[0][0]), \
+    "+v"(zp[0][1]), "+v"(zp[0][2]), "+v"(zp[0][3]), "+v"(zp[1][0]), "+v"(zp[1][1]), "+v"(zp[1][2]), "+v"(zp[1][3])
+    float V[4][16], M[4][16];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { V[i >> 4][i & 15] = 0.f; M[i >> 4][i & 15] = 0.f; }
+    // read number k (0..27) of a batch; `tie` / `tieacc` are an operand of the MFMA that must follow it and the accumulator of
+    // the MFMA that must precede it (fake in/out operands: they only order the read inside the MFMA stream)
+#define READ_K(k, xb, zb, tie, tieacc) do { \
+        if ((k) < 20) READ_PAIR(xp[(k) / 5][(k) % 5], xb, ((k) / 5) * 18 + 2 * ((k) % 5), tie, tieacc); \
+        else READ_PAIR(zp[((k) - 20) / 4][((k) - 20) % 4], zb, (((k) - 20) / 4) * 16 + 2 * (((k) - 20) % 4), tie, tieacc); \
+    } while (0)
+    {
+#pragma unroll
+        for (int k = 0; k < 28; ++k) READ_K(k, xa_b, za_b, V[0][0], acc[0]);
+    }
+    auto xr = [&](int r, int cc) -> float { return (cc & 1) ? xp[r][cc >> 1].y : xp[r][cc >> 1].x; };
+    auto zr = [&](int r, int cc) -> float { return (cc & 1) ? zp[r][cc >> 1].y : zp[r][cc >> 1].x; };
     int slot = 0;
+#if UNET_ABLATE == 7        /* diagnostics only: s_memtime stamps around the phases of one iteration (block 0, wave 0) */
+    long long tl[5] = {0, 0, 0, 0, 0}, ts0, ts1, ts2, ts3, ts4 = 0;
+#define STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
+#else
+#define STAMP(t)
+#endif
+    // One wave per SIMD (the 16 point-accumulators take all 256 AGPRs), and measured on gfx950 (scripts/micro/mfma_issue_cost)
+    // a VALU instruction between two MFMAs of the same wave is not hidden: it costs its own ~4 cycles plus ~10 each time the
+    // stream switches from the matrix pipe to the VALU and back.  Only asynchronous work (LDS reads, DMA) hides under MFMAs.
+    // So per chunk: all four tiles' transforms first, in one VALU block; then the LDS reads for the next chunk and this
+    // wave's share of the DMA for the chunk LEAD ahead are issued; then 64 MFMAs back to back with both in flight.
     for (; c < p.nchunks; c += p.splits) {
-        const float* buf = smem + slot * BUF;
-        issue_chunk(c + 2 * p.splits, smem + ((slot + 2) % 3) * BUF);
-        // raw rows of this lane's 4 tiles: x columns 8*lh .. 8*lh+9 (4 rows), dz columns 8*lh .. 8*lh+7 (2 rows)
-        float xr[4][10], zr[2][8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 10; ++cc) xr[r][cc] = buf[xa + (r * 18 + cc) * 64];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) zr[r][cc] = buf[za + (r * 16 + cc) * 64];
+        STAMP(ts0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : ALL_PAIRS);
+        STAMP(ts1);
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
-            // V = B^T d B of the 4x4 patch at columns 2s..2s+3
-            float tt[4][4], V[16], M[16];
+            float tt[4][4];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const float d0 = xr[0][2 * sidx + cc], d1 = xr[1][2 * sidx + cc], d2 = xr[2][2 * sidx + cc], d3 = xr[3][2 * sidx + cc];
+                const float d0 = xr(0, 2 * sidx + cc), d1 = xr(1, 2 * sidx + cc), d2 = xr(2, 2 * sidx + cc), d3 = xr(3, 2 * sidx + cc);
                 tt[0][cc] = d0 - d2; tt[1][cc] = d1 + d2; tt[2][cc] = d2 - d1; tt[3][cc] = d1 - d3;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                V[4 * r + 0] = tt[r][0] - tt[r][2]; V[4 * r + 1] = tt[r][1] + tt[r][2];
-                V[4 * r + 2] = tt[r][2] - tt[r][1]; V[4 * r + 3] = tt[r][1] - tt[r][3];
+                V[sidx][4 * r + 0] = tt[r][0] - tt[r][2]; V[sidx][4 * r + 1] = tt[r][1] + tt[r][2];
+                V[sidx][4 * r + 2] = tt[r][2] - tt[r][1]; V[sidx][4 * r + 3] = tt[r][1] - tt[r][3];
             }
-            // dM = A dY A^T of the 2x2 gradient tile
-            const float y00 = zr[0][2 * sidx], y01 = zr[0][2 * sidx + 1], y10 = zr[1][2 * sidx], y11 = zr[1][2 * sidx + 1];
+            const float y00 = zr(0, 2 * sidx), y01 = zr(0, 2 * sidx + 1), y10 = zr(1, 2 * sidx), y11 = zr(1, 2 * sidx + 1);
             const float ra[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                M[4 * a + 0] = ra[a][0]; M[4 * a + 1] = ra[a][0] + ra[a][1];
-                M[4 * a + 2] = ra[a][0] - ra[a][1]; M[4 * a + 3] = -ra[a][1];
+                M[sidx][4 * a + 0] = ra[a][0]; M[sidx][4 * a + 1] = ra[a][0] + ra[a][1];
+                M[sidx][4 * a + 2] = ra[a][0] - ra[a][1]; M[sidx][4 * a + 3] = -ra[a][1];
             }
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi], M[xi], acc[xi], 0, 0, 0);
         }
-        // the chunk after this one must have landed (it was issued one iteration ago); the newest batch may stay in flight
-        if (c + 2 * p.splits < p.nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else                              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        slot = (slot + 1) % 3;
+        // The chunk after this one must have landed; the LEAD-1 newest batches (KPW DMAs each) may stay in flight.  A bare
+        // s_barrier, not __syncthreads(): its fence makes the compiler drain vmcnt to 0, i.e. the whole ring.  (No LDS read
+        // is outstanding here: the only ones are read_raw's, retired at the top of this iteration.)
+        __builtin_amdgcn_sched_barrier(0);            // keep the VALU block out of the MFMA block
+        STAMP(ts2);
+        asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
+        static_assert((LEAD - 2) * KPW == 14, "vmcnt immediate");
+        STAMP(ts3);
+#if UNET_ABLATE == 7
+        if (ts4) tl[3] += ts0 - ts4;
+        tl[0] += ts1 - ts0; tl[1] += ts2 - ts1; tl[2] += ts3 - ts2; tl[4] += 1; ts4 = ts3;
+#endif
+        slot = (slot + 1) % NSLOT;
+        issue_next(smem + ((slot + LEAD - 1) % NSLOT) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        // 64 MFMAs; behind each of the first 28 one LDS read of the next chunk's raw rows (stale data past the last chunk,
+        // never used): a burst of 28 would stall on the 15-deep LDS counter and the LDS bandwidth of four waves at once
+        const unsigned xb = xa_b + (unsigned)slot * (BUF * 4u), zb = za_b + (unsigned)slot * (BUF * 4u);
+#pragma unroll
+        for (int n = 0; n < 64; ++n) {
+            acc[n & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n >> 4][n & 15], M[n >> 4][n & 15], acc[n & 15], 0, 0, 0);
+            if (n < 28) READ_K(n, xb, zb, V[(n + 1) >> 4][(n + 1) & 15], acc[n & 15]);
+        }
     }
+    // retire the last read batch (its registers are dead to the compiler, not to the LDS) and the dummy tail DMAs
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : ALL_PAIRS :: "memory");
+#undef READ_PAIR
+#undef READ_K
+#undef ALL_PAIRS
+#if UNET_ABLATE == 7
+    if (blockIdx.x == 0 && tid == 0) {
+        long long* o = reinterpret_cast<long long*>(p.ws + (size_t)p.splits * 9 * p.Ci * p.Co);
+        for (int i = 0; i < 5; ++i) o[i] = tl[i];
+    }
+#endif
 
     // epilogue: dw[a][b] = (G^T dU G)[a][b], lane-local per (ci, co)
 #pragma unroll
