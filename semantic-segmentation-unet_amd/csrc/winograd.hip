@@ -287,29 +287,140 @@ int wgrad_splits(long T, int Ci, int Co) {
     return (int)s;
 }
 
-// ---- fully fused Winograd F(2x2,3x3) for the narrow (64/128-channel) layers ---------------------------------------------
+// ---- fully fused Winograd F(2x2,3x3) forward / data-gradient convolution ------------------------------------------------
 // One workgroup = 8x8 Winograd tiles (16x16 output pixels) x 64 output channels; wave (mi, ni) owns [32 tiles x 32 channels]
 // for ALL 16 Winograd points (16 x f32x16 = 256 AGPRs, one wave per SIMD).  K is streamed in chunks of 8 input channels:
-//   D  raw input patch 18x18 px x 8 ch   <- LDS-DMA from x (zero page outside the image)            2 buffers x 11 KB
-//   V  [xi][tile][8] = B^T d B           <- waves 0,1 transform D(c+1) while all waves run chunk c   2 buffers x 32 KB
-//   U  [xi][n][8] transformed weights    <- LDS-DMA from Uc[xi][K/8][N][8] (L2-resident)             2 buffers x 32 KB
+//   D  raw input patch 18x18 px x 8 ch   <- LDS-DMA from x (zero page outside the image)                 2 buffers x 12 KB
+//   V  [xi][tile][8] = B^T d B           <- every lane transforms one (tile, channel pair) per chunk      2 buffers x 32 KB
+//   U  [xi][n][8] transformed weights    <- LDS-DMA from Uc[xi][K/8][N][8] (L2-resident)                  2 buffers x 32 KB
 // A lane's 4 consecutive k (lane half picks the quad) are one ds_read_b128 for both operands; the quad slot is XOR-ed with
 // bit 3 of the row (on the DMA source side for U, on the transform's write side for V) so the 16-lane read groups hit 16
 // distinct 16-B slots.  The output transform A^T m A is lane-local in the epilogue.  HBM sees the input once (x1.27 halo)
 // and the output once; the 4x-expanded V / M planes of the unfused route never exist.
+//
+// Schedule.  With one wave per SIMD nothing but asynchronous work hides under the MFMAs: measured on gfx950
+// (scripts/micro/mfma_issue_cost.hip) a VALU instruction between two MFMAs of the same wave costs its own ~4 cycles plus
+// ~10 per matrix-pipe <-> VALU switch, while LDS reads and DMA issue cost ~1 and ~15.  So all four waves share the transform
+// (32 packed-fp32 VALU instructions per lane per chunk, one block) and the DMA issue (11 per wave per chunk, addresses from
+// scalar bases / running pointers), and the chunk loop is written as an explicit instruction stream (inline asm; the
+// compiler would re-sink the LDS reads next to their uses and wait on each):
+//   barrier | DMA U(c+1), D(c+3) | operand reads for points 0,1 | transform D(c+1) regs -> V(c+1) | 16 x { wait operands(xi);
+//   4 MFMAs; operand reads for xi+2; one LDS read of D(c+2) into registers } | wait all | barrier
+// D is pipelined DMA -> LDS -> registers -> V, one chunk per stage, so everything a chunk needs was issued a full chunk
+// earlier.  Operand registers form a 3-deep ring.  lgkmcnt immediates below count the LDS instructions issued after the one
+// waited for (LDS instructions retire in order).
 struct WinoFusedArgs {
     const float* x; const float* Uc; const float* bias; float* out;
     int ldx, ldo, N, H, W, K, Nout, relu;
     int tbx, tby, nt;            // tile-block grid
 };
 typedef __attribute__((address_space(3))) void lds_void_f;
-__device__ __attribute__((aligned(256))) float g_zero_page_f[8];
+constexpr int kWinoFusedMaxK = 4096;
+__device__ __attribute__((aligned(256))) float g_zero_page_f[kWinoFusedMaxK + 8];   // zero source that out-of-image halo pointers walk over
+
+#define WF_RD128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
+#define WF_RD64(dst, base, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
+#define WF_WR64(base, off, val) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(val), "n"(off) : "memory")
+#define WF_MFMA(accv, av, bv) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(accv) : "v"(av), "v"(bv) : "memory")
+#define WF_ALL_D \
+    "+v"(dd[0][0]), "+v"(dd[0][1]), "+v"(dd[0][2]), "+v"(dd[0][3]), "+v"(dd[1][0]), "+v"(dd[1][1]), "+v"(dd[1][2]), "+v"(dd[1][3]), \
+    "+v"(dd[2][0]), "+v"(dd[2][1]), "+v"(dd[2][2]), "+v"(dd[2][3]), "+v"(dd[3][0]), "+v"(dd[3][1]), "+v"(dd[3][2]), "+v"(dd[3][3])
+
+#if UNET_ABLATE == 8
+__device__ long long g_wf_timeline[8];
+#endif
+constexpr int kWfDB = 12 * 256 * 4, kWfIB = 16 * 64 * 8 * 4;      // bytes of one D buffer (18x18 px x 8 ch in 12 1-KB pieces) / one V or U image
+
+// (template functions rather than generic lambdas: clang rejects captured variables as asm operands inside generic lambdas)
+// raw patch D buffer PAR -> registers: 16 LDS reads, not waited for
+template <int PAR> __device__ __forceinline__ void wf_read_D(f32x2 (&dd)[4][4], unsigned d_base) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) WF_RD64(dd[j >> 2][j & 3], d_base, PAR * kWfDB + ((j >> 2) * 18 + (j & 3)) * 32);
+}
+
+// B^T d B of the raw patch in dd -> V image PAR (16 LDS writes).  In the chunk loop 4 operand reads are issued ahead of the
+// writes: with 8 writes behind them lgkmcnt(8) means the reads are back (the counter is 4 bits, so 16 writes cannot be
+// counted past in one go).
+template <int PAR> __device__ __forceinline__ void wf_transform_to(const f32x2 (&dd)[4][4], unsigned v_base) {
+    f32x2 tt[4][4], vv[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        tt[0][c] = dd[0][c] - dd[2][c]; tt[1][c] = dd[1][c] + dd[2][c];
+        tt[2][c] = dd[2][c] - dd[1][c]; tt[3][c] = dd[1][c] - dd[3][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        vv[4 * r + 0] = tt[r][0] - tt[r][2]; vv[4 * r + 1] = tt[r][1] + tt[r][2];
+        vv[4 * r + 2] = tt[r][2] - tt[r][1]; vv[4 * r + 3] = tt[r][1] - tt[r][3];
+    }
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi) WF_WR64(v_base, PAR * kWfIB + xi * 2048, vv[xi]);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+#pragma unroll
+    for (int xi = 8; xi < 16; ++xi) WF_WR64(v_base, PAR * kWfIB + xi * 2048, vv[xi]);
+}
+
+// One chunk after its DMAs were issued; PAR = chunk parity = buffer of V(c), U(c), D(c+2); the other buffers take V(c+1).
+#if UNET_ABLATE == 8
+#define WF_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
+#define WF_TL_ARG , long long (&tl)[6]
+#else
+#define WF_STAMP(t)
+#define WF_TL_ARG
+#endif
+// One chunk; PAR = chunk parity = buffer of V(c), U(c), D(c+2); the other buffers take V(c+1), U(c+1), D(c+3).  usrc / dsrc
+// are this lane's DMA sources for U(c+1) (8 pieces) and D(c+3) (3 pieces); sUw / sDw the wave's first piece of buffer 0.
+// A global_load_lds occupies the vector-memory issue path for ~64 cycles, during which the wave can run MFMAs but not issue
+// another one: eleven in a row stall ~900 cycles, one per MFMA group costs ~15 each (measured, scripts/micro/mfma_issue_cost).
+template <int PAR> __device__ __forceinline__ void wf_chunk(f32x16 (&acc)[16], f32x2 (&dd)[4][4], unsigned a_base, unsigned b_base,
+                                                            unsigned d_base, unsigned v_base, const float* (&usrc)[8],
+                                                            const float* (&dsrc)[3], float* sUw, float* sDw WF_TL_ARG) {
+    constexpr int IMG = 16 * 64 * 8, DFL = 12 * 256;
+    f32x4 A[3], B[3];
+#if UNET_ABLATE == 8
+    long long s0, s1, s2, s3;
+    WF_STAMP(s0);
+    tl[0] += s0 - tl[5];          // address arithmetic (since the previous barrier)
+#endif
+    WF_RD128(A[0], a_base, PAR * kWfIB); WF_RD128(B[0], b_base, PAR * kWfIB);
+    WF_RD128(A[1], a_base, PAR * kWfIB + 2048); WF_RD128(B[1], b_base, PAR * kWfIB + 2048);
+    wf_transform_to<PAR ^ 1>(dd, v_base);
+    asm volatile("" : "+v"(A[0]), "+v"(B[0]), "+v"(A[1]), "+v"(B[1]));
+    WF_STAMP(s1);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+        if (xi >= 2) {
+            // issued after the reads for xi: D read of group xi-2, then group xi-1's operand reads (if any) and D read
+            if (xi + 1 < 16) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(A[xi % 3]), "+v"(B[xi % 3]));
+            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[xi % 3]), "+v"(B[xi % 3]));
+        }
+        WF_MFMA(acc[xi], A[xi % 3][0], B[xi % 3][0]);
+        if (xi < 8) __builtin_amdgcn_global_load_lds(usrc[xi], (lds_void_f*)(sUw + (PAR ^ 1) * IMG + 4 * xi * 256), 16, 0, 0);
+        else if (xi < 11) __builtin_amdgcn_global_load_lds(dsrc[xi - 8], (lds_void_f*)(sDw + (PAR ^ 1) * DFL + 4 * (xi - 8) * 256), 16, 0, 0);
+        WF_MFMA(acc[xi], A[xi % 3][1], B[xi % 3][1]);
+        WF_MFMA(acc[xi], A[xi % 3][2], B[xi % 3][2]);
+        WF_MFMA(acc[xi], A[xi % 3][3], B[xi % 3][3]);
+        if (xi + 2 < 16) {
+            WF_RD128(A[(xi + 2) % 3], a_base, PAR * kWfIB + (xi + 2) * 2048);
+            WF_RD128(B[(xi + 2) % 3], b_base, PAR * kWfIB + (xi + 2) * 2048);
+        }
+        WF_RD64(dd[xi >> 2][xi & 3], d_base, PAR * kWfDB + ((xi >> 2) * 18 + (xi & 3)) * 32);      // D(c+2) -> registers
+    }
+    WF_STAMP(s2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : WF_ALL_D : : "memory");
+#if UNET_ABLATE == 8
+    WF_STAMP(s3);
+    tl[1] += s1 - s0; tl[2] += s2 - s1; tl[3] += s3 - s2; tl[5] = s3;
+#endif
+}
 
 __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
-    constexpr int DPIX = 18 * 18, DPIECES = 11, DFL = DPIECES * 256;       // D image padded to whole 1-KB pieces
+    constexpr int DPIX = 18 * 18, DPIECES = 12, DFL = DPIECES * 256;       // D image padded to 3 1-KB DMA pieces per wave
     constexpr int IMG = 16 * 64 * 8;
+    constexpr int DB = kWfDB, IB = kWfIB;
+    static_assert(DB == DFL * 4 && IB == IMG * 4, "buffer sizes");
     __shared__ __attribute__((aligned(1024))) float smem[2 * DFL + 4 * IMG];
-    float* sD = smem; float* sV = smem + 2 * DFL; float* sU = sV + 2 * IMG;
+    float* sD = smem; float* sU = smem + 2 * DFL + 2 * IMG;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mi = wv & 1, ni = wv >> 1;
@@ -328,111 +439,97 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
+    // --- DMA duty of this wave: D pieces wv, wv+4, wv+8 (32 pixels each, lane -> pixel lane/2, channel quad lane&1) and
+    //     U pieces wv + 4k, k = 0..7 (point xi = 2k + wv/2, rows 32*(wv&1) + lane/2; quad slot swizzled by bit 3 of the row)
     const int drow = lane >> 1, dh = lane & 1;
-    // D piece id (0..10): pixels 32*id + lane/2 of the 18x18 patch
-    auto issue_D = [&](int id, int chunk, float* dst) {
-        const int pix = 32 * id + drow;
+    const float* dptr[3];                 // chunk 0 source of the lane's D pixels; advanced 8 channels per chunk
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pix = 32 * (wv + 4 * k) + drow;
         const int py = pix / 18, px = pix - py * 18;
         const int gy = gy0 + py, gx = gx0 + px;
         const bool ok = pix < DPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        const float* src = ok ? p.x + ((size_t)(img * p.H + gy) * p.W + gx) * p.ldx + chunk * 8 + 4 * dh : g_zero_page_f + 4 * dh;
-        __builtin_amdgcn_global_load_lds(src, (lds_void_f*)(dst + id * 256), 16, 0, 0);
-    };
-    // U piece id (0..31): xi = id>>1, rows 32*(id&1) + lane/2; quad slot swizzled by bit 3 of the row
-    auto issue_U = [&](int id, int chunk, float* dst) {
-        const int xi = id >> 1, row = 32 * (id & 1) + drow;
-        const int hs = dh ^ ((row >> 3) & 1);
-        const float* src = p.Uc + (((size_t)xi * nchunks + chunk) * p.Nout + n0 + row) * 8 + 4 * hs;
-        __builtin_amdgcn_global_load_lds(src, (lds_void_f*)(dst + id * 256), 16, 0, 0);
-    };
-    // DMA duty: waves 2,3 issue everything (waves 0,1 run the transform)
-    auto issue_all = [&](int chunkU, bool doU, int chunkD, bool doD, int bufU, int bufD) {
-        if (wv >= 2) {
-            const int w2 = wv - 2;
-            if (doU) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) issue_U(2 * k + w2, chunkU, sU + bufU * IMG);
-            }
-            if (doD) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { const int id = 2 * k + w2; if (id < DPIECES) issue_D(id, chunkD, sD + bufD * DFL); }
-            }
-        }
-    };
-
-    // transform of one chunk by waves 0,1: lane -> (tile lt = 32*wv + lane/2, channel quad q = lane&1), so a 16-lane
-    // ds_read_b128 group touches 8 distinct 16-B slots of the raw patch (2-way; tile-per-lane would be 4-way) and the V
-    // writes of a tile's two quads are adjacent.  V[xi][lt][slot] = (B^T d B)[xi], slot = q ^ bit3(lt).
-    const int t_lt = 32 * (wv & 1) + (lane >> 1), t_q = lane & 1;
-    const int ty_l = t_lt >> 3, tx_l = t_lt & 7;
-    const int d_base = ((2 * ty_l) * 18 + 2 * tx_l) * 8 + 4 * t_q;
-    const int v_base = t_lt * 8 + 4 * (t_q ^ ((t_lt >> 3) & 1));
-    f32x4 dd[4][4], tt[4][4];
-    auto transform_step = [&](int step, const float* D, float* V) {
-        if (wv >= 2) return;
-        if (step < 4) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dd[step][c] = *reinterpret_cast<const f32x4*>(D + d_base + (step * 18 + c) * 8);
-        } else if (step < 8) {
-            const int c = step - 4;
-            tt[0][c] = dd[0][c] - dd[2][c]; tt[1][c] = dd[1][c] + dd[2][c];
-            tt[2][c] = dd[2][c] - dd[1][c]; tt[3][c] = dd[1][c] - dd[3][c];
-        } else {
-            const int r = (step - 8) >> 1;
-            if (((step - 8) & 1) == 0) {
-                *reinterpret_cast<f32x4*>(V + (4 * r + 0) * 512 + v_base) = tt[r][0] - tt[r][2];
-                *reinterpret_cast<f32x4*>(V + (4 * r + 1) * 512 + v_base) = tt[r][1] + tt[r][2];
-            } else {
-                *reinterpret_cast<f32x4*>(V + (4 * r + 2) * 512 + v_base) = tt[r][2] - tt[r][1];
-                *reinterpret_cast<f32x4*>(V + (4 * r + 3) * 512 + v_base) = tt[r][1] - tt[r][3];
-            }
-        }
-    };
-
-    // prologue: D(0), U(0), D(1) in flight; V(0) from D(0)
-    issue_all(0, true, 0, true, 0, 0);
-    if (nchunks > 1) issue_all(0, false, 1, true, 0, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int st = 0; st < 16; ++st) transform_step(st, sD, sV);
-    __syncthreads();
-
-    const int arow = 32 * mi + li, brow = 32 * ni + li;
-    const int a_off = arow * 8 + 4 * (lh ^ ((arow >> 3) & 1));
-    const int b_off = brow * 8 + 4 * (lh ^ ((brow >> 3) & 1));
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int cur = chunk & 1;
-        const float* cV = sV + cur * IMG; const float* cU = sU + cur * IMG;
-        // next chunk's weights and the chunk-after-next's raw patch (its buffer was consumed by the previous transform)
-#if UNET_ABLATE == 1        /* diagnostics only: no weight DMA in the loop */
-        issue_all(chunk + 1, false, chunk + 2, chunk + 2 < nchunks, cur ^ 1, cur);
-#elif UNET_ABLATE == 3      /* no DMA at all in the loop */
-#else
-        issue_all(chunk + 1, chunk + 1 < nchunks, chunk + 2, chunk + 2 < nchunks, cur ^ 1, cur);
-#endif
-#if UNET_ABLATE >= 2        /* no in-loop transform */
-        const bool tr = false;
-#else
-        const bool tr = chunk + 1 < nchunks;
-#endif
-        const float* nD = sD + (cur ^ 1) * DFL; float* nV = sV + (cur ^ 1) * IMG;
-        f32x4 af = *reinterpret_cast<const f32x4*>(cV + a_off), bf = *reinterpret_cast<const f32x4*>(cU + b_off);
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            f32x4 an = af, bn = bf;
-            if (xi + 1 < 16) {
-                an = *reinterpret_cast<const f32x4*>(cV + a_off + (xi + 1) * 512);
-                bn = *reinterpret_cast<const f32x4*>(cU + b_off + (xi + 1) * 512);
-            }
-            if (tr) transform_step(xi, nD, nV);
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sidx], bf[sidx], acc[xi], 0, 0, 0);
-            af = an; bf = bn;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        dptr[k] = ok ? p.x + ((size_t)(img * p.H + gy) * p.W + gx) * p.ldx + 4 * dh : g_zero_page_f + 4 * dh;
     }
+    const int urow = 32 * (wv & 1) + drow;
+    const unsigned uoff = (unsigned)((urow * 8 + 4 * (dh ^ ((urow >> 3) & 1))) * 4);        // bytes, same for all 8 pieces
+    const size_t ustride_xi = (size_t)nchunks * p.Nout * 32;                                // bytes between points
+    const char* ubase0 = reinterpret_cast<const char*>(p.Uc) + (size_t)n0 * 32 + (size_t)(wv >> 1) * ustride_xi;
+    auto issue_D = [&](int chunk, int par) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            __builtin_amdgcn_global_load_lds(dptr[k] + chunk * 8, (lds_void_f*)(sD + par * DFL + (wv + 4 * k) * 256), 16, 0, 0);
+    };
+    auto issue_U = [&](int chunk, int par) {
+        const char* ub = ubase0 + (size_t)chunk * p.Nout * 32;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(ub + 2 * k * ustride_xi + uoff),
+                                             (lds_void_f*)(sU + par * IMG + (wv + 4 * k) * 256), 16, 0, 0);
+    };
+
+    // --- LDS byte addresses (everything else is an immediate offset)
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_f*)smem;
+    const unsigned ldsV = lds0 + 2 * DB, ldsU = ldsV + 2 * IB;
+    const int arow = 32 * mi + li, brow = 32 * ni + li;
+    const unsigned a_base = ldsV + 4u * (arow * 8 + 4 * (lh ^ ((arow >> 3) & 1)));
+    const unsigned b_base = ldsU + 4u * (brow * 8 + 4 * (lh ^ ((brow >> 3) & 1)));
+    // transform duty: lane -> (tile t_lt = 16*wv + lane/4, channel pair t_q = lane&3); V slot = quad ^ bit3(tile)
+    const int t_lt = 16 * wv + (lane >> 2), t_q = lane & 3;
+    const unsigned d_base = lds0 + 4u * (((2 * (t_lt >> 3)) * 18 + 2 * (t_lt & 7)) * 8 + 2 * t_q);
+    const unsigned v_base = ldsV + 4u * (t_lt * 8 + 4 * ((t_q >> 1) ^ ((t_lt >> 3) & 1)) + 2 * (t_q & 1));
+
+    f32x2 dd[4][4];
+    const int last = nchunks - 1;
+#if UNET_ABLATE == 8        /* diagnostics only: s_memtime at the phase boundaries of workgroup 0 */
+    long long wf_t0, wf_t1, wf_t2;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wf_t0) :: "memory");
+#endif
+
+    // prologue: D(0), D(1), U(0) -> LDS; V(0) from D(0); D(1) into registers; D(2) -> LDS
+    issue_D(0, 0); issue_D(min(1, last), 1); issue_U(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    wf_read_D<0>(dd, d_base);
+    asm volatile("s_waitcnt lgkmcnt(0)" : WF_ALL_D);
+    wf_transform_to<0>(dd, v_base);
+    wf_read_D<1>(dd, d_base);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : WF_ALL_D : : "memory");
+    issue_D(min(2, last), 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+#if UNET_ABLATE == 8
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wf_t1) :: "memory");
+    long long tl[6] = {0, 0, 0, 0, 0, wf_t1};
+#define WF_TL , tl
+#else
+#define WF_TL
+#endif
+    // (prefetches past the last chunk re-read it; nothing consumes them)
+    const float* usrc[8]; const float* dsrc[3];
+    float* const sUw = sU + wv * 256; float* const sDw = sD + wv * 256;
+    auto sources = [&](int cu, int cd) {          // this lane's DMA sources for U(cu) and D(cd): 11 64-bit adds, pinned here
+        const char* ub = ubase0 + (size_t)cu * p.Nout * 32;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) usrc[k] = reinterpret_cast<const float*>(ub + 2 * k * ustride_xi + uoff);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dsrc[k] = dptr[k] + cd * 8;
+        asm volatile("" : "+v"(usrc[0]), "+v"(usrc[1]), "+v"(usrc[2]), "+v"(usrc[3]), "+v"(usrc[4]), "+v"(usrc[5]), "+v"(usrc[6]),
+                          "+v"(usrc[7]), "+v"(dsrc[0]), "+v"(dsrc[1]), "+v"(dsrc[2]));
+    };
+    for (int c = 0; c + 1 < nchunks; c += 2) {
+        sources(min(c + 1, last), min(c + 3, last));
+        wf_chunk<0>(acc, dd, a_base, b_base, d_base, v_base, usrc, dsrc, sUw, sDw WF_TL);
+        sources(min(c + 2, last), min(c + 4, last));
+        wf_chunk<1>(acc, dd, a_base, b_base, d_base, v_base, usrc, dsrc, sUw, sDw WF_TL);
+    }
+    if (nchunks & 1) {                // odd tail outside the loop: inside it the extra control flow made the allocator spill
+        sources(last, last);
+        wf_chunk<0>(acc, dd, a_base, b_base, d_base, v_base, usrc, dsrc, sUw, sDw WF_TL);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the inline-asm MFMAs are invisible to the compiler's hazard recogniser
+#if UNET_ABLATE == 8
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wf_t2) :: "memory");
+#endif
 
     // epilogue: lane-local output transform, + bias, ReLU
     const int Th = p.H >> 1, Tw = p.W >> 1;
@@ -458,6 +555,14 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
             o[(size_t)i * p.W * p.ldo + p.ldo] = y1;
         }
     }
+#if UNET_ABLATE == 8
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 0 && tid == 0) {
+        long long t3; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3) :: "memory");
+        g_wf_timeline[0] = wf_t1 - wf_t0; g_wf_timeline[1] = wf_t2 - wf_t1; g_wf_timeline[2] = t3 - wf_t2; g_wf_timeline[3] = nchunks;
+        for (int i = 0; i < 4; ++i) g_wf_timeline[4 + i] = tl[i];
+    }
+#endif
 }
 
 // ---- fully fused Winograd weight gradient ----------------------------------------------------------------------------
@@ -745,6 +850,7 @@ int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, 
 extern "C" int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
         int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
     UNET_CHECK_ARG(x && Uc && out && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 8 == 0 && Cout % 64 == 0);
+    UNET_CHECK_ARG(Cin <= kWinoFusedMaxK);
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(Uc));
     return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
 }
@@ -752,9 +858,16 @@ extern "C" int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const fl
 extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
         int N, int H, int W, int Cin, int Cout, void* stream) {
     UNET_CHECK_ARG(dz && Ucd && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
+    UNET_CHECK_ARG(Cout <= kWinoFusedMaxK);
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd));
     return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream);
 }
+
+#if UNET_ABLATE == 8
+extern "C" int unet_debug_wf_timeline(long long* out4) {
+    return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_wf_timeline), 64);
+}
+#endif
 
 extern "C" int unet_winograd_wgrad_fused_supported(int N, int H, int W, int Cin, int Cout) {
     return (N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 64 == 0 && Cout % 64 == 0) ? 1 : 0;
