@@ -643,7 +643,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
     int ic = split, i_txb, i_ty, i_img;
     { int t = ic; i_txb = t % p.tbx; t /= p.tbx; i_ty = t % Th; i_img = t / Th; }
     const int d_txb = p.splits % p.tbx, d_ty = (p.splits / p.tbx) % Th, d_img = p.splits / (p.tbx * Th);
-    auto issue_next = [&](float* dst) {
+    const float* dsrc[KPW];              // this lane's sources for the next batch
+    auto next_sources = [&]() {
         const bool cv = ic < p.nchunks;                                           // past the end: re-read chunk 0, never used
         const int txb = cv ? i_txb : 0, ty = cv ? i_ty : 0, img = cv ? i_img : 0;
 #if UNET_ABLATE == 5        /* diagnostics only: every DMA reads the same few KB (always an L2 hit) */
@@ -659,17 +660,25 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
         for (int k = 0; k < KPW; ++k) {
             const char* src = (g_isx[k] ? bx : bz) + g_off[k];
             src = (hit & (0xFu << (4 * k))) ? reinterpret_cast<const char*>(zpage) : src;
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void_g*)(dst + (4 * k + wv) * 256), 16, 0, 0);
+            dsrc[k] = reinterpret_cast<const float*>(src);
         }
+        asm volatile("" : "+v"(dsrc[0]), "+v"(dsrc[1]), "+v"(dsrc[2]), "+v"(dsrc[3]), "+v"(dsrc[4]), "+v"(dsrc[5]), "+v"(dsrc[6]));
         ic += p.splits;
         i_txb += d_txb; const int c1 = i_txb >= p.tbx; i_txb -= c1 ? p.tbx : 0;
         i_ty += d_ty + c1; const int c2 = i_ty >= Th; i_ty -= c2 ? Th : 0;
         i_img += d_img + c2;
     };
+    auto dma = [&](int k, float* dst) {
+        __builtin_amdgcn_global_load_lds(dsrc[k], (lds_void_g*)(dst + (4 * k + wv) * 256), 16, 0, 0);
+    };
 
     int c = split;
 #pragma unroll
-    for (int k = 0; k < LEAD; ++k) issue_next(smem + k * BUF);
+    for (int k = 0; k < LEAD; ++k) {
+        next_sources();
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) dma(j, smem + k * BUF);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int xa = (8 * lh) * 64 + 32 * mi + li;                    // + (row*18 + cc)*64
@@ -683,8 +692,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
     f32x2 xp[4][5], zp[2][4];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_g*)smem;
     const unsigned xa_b = lds0 + 4u * xa, za_b = lds0 + 4u * za;
-#define READ_PAIR(dst, base, off, tie, tieacc) \
-    asm volatile("ds_read2st64_b32 %0, %3 offset0:%4 offset1:%5" : "=&v"(dst), "+v"(tie), "+a"(tieacc) : "v"(base), "n"(off), "n"((off) + 1))
+#define READ_PAIR(dst, base, off) \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(dst) : "v"(base), "n"(off), "n"((off) + 1))
 #define ALL_PAIRS \
     "+v"(xp[0][0]), "+v"(xp[0][1]), "+v"(xp[0][2]), "+v"(xp[0][3]), "+v"(xp[0][4]), "+v"(xp[1][0]), "+v"(xp[1][1]), \
     "+v"(xp[1][2]), "+v"(xp[1][3]), "+v"(xp[1][4]), "+v"(xp[2][0]), "+v"(xp[2][1]), "+v"(xp[2][2]), "+v"(xp[2][3]), \
@@ -693,18 +702,15 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
     float V[4][16], M[4][16];
 #pragma unroll
     for (int i = 0; i < 32; ++i) { V[i >> 4][i & 15] = 0.f; M[i >> 4][i & 15] = 0.f; }
-    // read number k (0..27) of a batch; `tie` / `tieacc` are an operand of the MFMA that must follow it and the accumulator of
-    // the MFMA that must precede it (fake in/out operands: they only order the read inside the MFMA stream)
-#define READ_K(k, xb, zb, tie, tieacc) do { \
-        if ((k) < 20) READ_PAIR(xp[(k) / 5][(k) % 5], xb, ((k) / 5) * 18 + 2 * ((k) % 5), tie, tieacc); \
-        else READ_PAIR(zp[((k) - 20) / 4][((k) - 20) % 4], zb, (((k) - 20) / 4) * 16 + 2 * (((k) - 20) % 4), tie, tieacc); \
+    // read number k (0..27) of a batch
+#define READ_K(k, xb, zb) do { \
+        if ((k) < 20) READ_PAIR(xp[(k) / 5][(k) % 5], xb, ((k) / 5) * 18 + 2 * ((k) % 5)); \
+        else READ_PAIR(zp[((k) - 20) / 4][((k) - 20) % 4], zb, (((k) - 20) / 4) * 16 + 2 * (((k) - 20) % 4)); \
     } while (0)
     {
 #pragma unroll
-        for (int k = 0; k < 28; ++k) READ_K(k, xa_b, za_b, V[0][0], acc[0]);
+        for (int k = 0; k < 28; ++k) READ_K(k, xa_b, za_b);
     }
-    auto xr = [&](int r, int cc) -> float { return (cc & 1) ? xp[r][cc >> 1].y : xp[r][cc >> 1].x; };
-    auto zr = [&](int r, int cc) -> float { return (cc & 1) ? zp[r][cc >> 1].y : zp[r][cc >> 1].x; };
     int slot = 0;
 #if UNET_ABLATE == 7        /* diagnostics only: s_memtime stamps around the phases of one iteration (block 0, wave 0) */
     long long tl[5] = {0, 0, 0, 0, 0}, ts0, ts1, ts2, ts3, ts4 = 0;
@@ -721,30 +727,36 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
         STAMP(ts0);
         asm volatile("s_waitcnt lgkmcnt(0)" : ALL_PAIRS);
         STAMP(ts1);
+        // Packed-fp32 transforms: a register pair holds two adjacent columns.  Row 3 and column 3 of both B^T d B and
+        // A dY A^T are produced with flipped sign (the products V*M are unchanged), which makes every step one v_pk_add_f32:
+        // plain adds / subs for the row stage, two op_sel / neg forms for the column stage (inline asm: the compiler does
+        // not form them; their distance to the MFMAs that read the results is the barrier below, so no hazard NOPs are owed).
+        {
+            f32x2 T[4][5];
 #pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            float tt[4][4];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const float d0 = xr(0, 2 * sidx + cc), d1 = xr(1, 2 * sidx + cc), d2 = xr(2, 2 * sidx + cc), d3 = xr(3, 2 * sidx + cc);
-                tt[0][cc] = d0 - d2; tt[1][cc] = d1 + d2; tt[2][cc] = d2 - d1; tt[3][cc] = d1 - d3;
+            for (int j = 0; j < 5; ++j) {
+                T[0][j] = xp[0][j] - xp[2][j]; T[1][j] = xp[1][j] + xp[2][j];
+                T[2][j] = xp[2][j] - xp[1][j]; T[3][j] = xp[3][j] - xp[1][j];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                V[sidx][4 * r + 0] = tt[r][0] - tt[r][2]; V[sidx][4 * r + 1] = tt[r][1] + tt[r][2];
-                V[sidx][4 * r + 2] = tt[r][2] - tt[r][1]; V[sidx][4 * r + 3] = tt[r][1] - tt[r][3];
-            }
-            const float y00 = zr(0, 2 * sidx), y01 = zr(0, 2 * sidx + 1), y10 = zr(1, 2 * sidx), y11 = zr(1, 2 * sidx + 1);
-            const float ra[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+            for (int sidx = 0; sidx < 4; ++sidx) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                M[sidx][4 * a + 0] = ra[a][0]; M[sidx][4 * a + 1] = ra[a][0] + ra[a][1];
-                M[sidx][4 * a + 2] = ra[a][0] - ra[a][1]; M[sidx][4 * a + 3] = -ra[a][1];
+                for (int i = 0; i < 4; ++i) {
+                    f32x2 v03, v12;
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v03) : "v"(T[i][sidx]), "v"(T[i][sidx + 1]));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(v12) : "v"(T[i][sidx + 1]), "v"(T[i][sidx]));
+                    V[sidx][4 * i + 0] = v03.x; V[sidx][4 * i + 3] = v03.y; V[sidx][4 * i + 1] = v12.x; V[sidx][4 * i + 2] = v12.y;
+                }
+                const f32x2 R[4] = {zp[0][sidx], zp[0][sidx] + zp[1][sidx], zp[0][sidx] - zp[1][sidx], zp[1][sidx]};
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f32x2 m12;
+                    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(m12) : "v"(R[a]));
+                    M[sidx][4 * a + 0] = R[a].x; M[sidx][4 * a + 1] = m12.x; M[sidx][4 * a + 2] = m12.y; M[sidx][4 * a + 3] = R[a].y;
+                }
             }
         }
-        // The chunk after this one must have landed; the LEAD-1 newest batches (KPW DMAs each) may stay in flight.  A bare
-        // s_barrier, not __syncthreads(): its fence makes the compiler drain vmcnt to 0, i.e. the whole ring.  (No LDS read
-        // is outstanding here: the only ones are read_raw's, retired at the top of this iteration.)
+        next_sources();                               // 7 DMA sources for the chunk LEAD ahead: VALU work, so it belongs here
         __builtin_amdgcn_sched_barrier(0);            // keep the VALU block out of the MFMA block
         STAMP(ts2);
         asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
@@ -755,20 +767,21 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
         tl[0] += ts1 - ts0; tl[1] += ts2 - ts1; tl[2] += ts3 - ts2; tl[4] += 1; ts4 = ts3;
 #endif
         slot = (slot + 1) % NSLOT;
-        issue_next(smem + ((slot + LEAD - 1) % NSLOT) * BUF);
-        __builtin_amdgcn_sched_barrier(0);
-        // 64 MFMAs; behind each of the first 28 one LDS read of the next chunk's raw rows (stale data past the last chunk,
-        // never used): a burst of 28 would stall on the 15-deep LDS counter and the LDS bandwidth of four waves at once
+        // 64 MFMAs as an explicit stream.  Behind each of the first 28: one LDS read of the next chunk's raw rows (stale data
+        // past the last chunk, never used; a burst of 28 would stall on the 15-deep LDS counter).  Behind every 8th: one DMA
+        // (a global_load_lds holds the vector-memory issue path ~64 cycles: back to back they stall, spread out they are free).
         const unsigned xb = xa_b + (unsigned)slot * (BUF * 4u), zb = za_b + (unsigned)slot * (BUF * 4u);
+        float* const dst = smem + ((slot + LEAD - 1) % NSLOT) * BUF;
 #pragma unroll
         for (int n = 0; n < 64; ++n) {
-            acc[n & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[n >> 4][n & 15], M[n >> 4][n & 15], acc[n & 15], 0, 0, 0);
-            if (n < 28) READ_K(n, xb, zb, V[(n + 1) >> 4][(n + 1) & 15], acc[n & 15]);
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[n & 15]) : "v"(V[n >> 4][n & 15]), "v"(M[n >> 4][n & 15]) : "memory");
+            if (n < 28) READ_K(n, xb, zb);
+            if (n >= 30 && ((n - 30) & 3) == 0 && ((n - 30) >> 2) < KPW) dma((n - 30) >> 2, dst);
         }
     }
     // retire the last read batch (its registers are dead to the compiler, not to the LDS) and the dummy tail DMAs
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : ALL_PAIRS :: "memory");
-#undef READ_PAIR
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" : ALL_PAIRS :: "memory");       // (+ MFMA -> accumulator read distance:
+#undef READ_PAIR                                                                                           //  inline-asm MFMAs are invisible to the hazard recogniser)
 #undef READ_K
 #undef ALL_PAIRS
 #if UNET_ABLATE == 7
