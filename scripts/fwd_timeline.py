@@ -19,7 +19,7 @@ for name, h, ci, co in [("1b", 512, 64, 64), ("2b", 256, 128, 128), ("4b", 64, 5
     t = (ctypes.c_longlong * 8)()
     raw.unet_debug_wf_timeline(t)
     n = max(t[3], 1)
-    print("%-7s chunks %4d | cycles: prologue %6d  loop %7d (%5.0f per chunk)  epilogue %6d | loop share %.2f"
+    print("%-7s chunks %4d | cycles: prologue-or-gap %6d  loop %7d (%5.0f per chunk)  epilogue %6d | loop share %.2f"
           % (name, n, t[0], t[1], t[1] / n, t[2], t[1] / float(t[0] + t[1] + t[2])))
     print("        per chunk: DMA issue %5.0f | operand reads + transform + V writes %5.0f | 64 MFMAs + reads %5.0f | wait + barrier %5.0f"
           % (t[4] / n, t[5] / n, t[6] / n, t[7] / n))

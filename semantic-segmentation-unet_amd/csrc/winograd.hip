@@ -10,6 +10,7 @@
 //
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
 #include "common.h"
+#include <cstdlib>
 #ifndef UNET_ABLATE
 #define UNET_ABLATE 0
 #endif
@@ -372,8 +373,9 @@ template <int PAR> __device__ __forceinline__ void wf_transform_to(const f32x2 (
 // are this lane's DMA sources for U(c+1) (8 pieces) and D(c+3) (3 pieces); sUw / sDw the wave's first piece of buffer 0.
 // A global_load_lds occupies the vector-memory issue path for ~64 cycles, during which the wave can run MFMAs but not issue
 // another one: eleven in a row stall ~900 cycles, one per MFMA group costs ~15 each (measured, scripts/micro/mfma_issue_cost).
-template <int PAR> __device__ __forceinline__ void wf_chunk(f32x16 (&acc)[16], f32x2 (&dd)[4][4], unsigned a_base, unsigned b_base,
-                                                            unsigned d_base, unsigned v_base, const float* (&usrc)[8],
+// FIRST: the chunk opens a new output tile - the first MFMA of every point starts from C = 0 instead of the accumulator.
+template <int PAR, bool FIRST = false, class SRC> __device__ __forceinline__ void wf_chunk(f32x16 (&acc)[16], f32x2 (&dd)[4][4], unsigned a_base, unsigned b_base,
+                                                            unsigned d_base, unsigned v_base, SRC&& sources, const float* (&usrc)[8],
                                                             const float* (&dsrc)[3], float* sUw, float* sDw WF_TL_ARG) {
     constexpr int IMG = 16 * 64 * 8, DFL = 12 * 256;
     f32x4 A[3], B[3];
@@ -384,6 +386,7 @@ template <int PAR> __device__ __forceinline__ void wf_chunk(f32x16 (&acc)[16], f
 #endif
     WF_RD128(A[0], a_base, PAR * kWfIB); WF_RD128(B[0], b_base, PAR * kWfIB);
     WF_RD128(A[1], a_base, PAR * kWfIB + 2048); WF_RD128(B[1], b_base, PAR * kWfIB + 2048);
+    sources();                                     // DMA source addresses (VALU) while those four reads are in flight
     wf_transform_to<PAR ^ 1>(dd, v_base);
     asm volatile("" : "+v"(A[0]), "+v"(B[0]), "+v"(A[1]), "+v"(B[1]));
     WF_STAMP(s1);
@@ -394,12 +397,19 @@ template <int PAR> __device__ __forceinline__ void wf_chunk(f32x16 (&acc)[16], f
             if (xi + 1 < 16) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(A[xi % 3]), "+v"(B[xi % 3]));
             else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[xi % 3]), "+v"(B[xi % 3]));
         }
-        WF_MFMA(acc[xi], A[xi % 3][0], B[xi % 3][0]);
-        if (xi < 8) __builtin_amdgcn_global_load_lds(usrc[xi], (lds_void_f*)(sUw + (PAR ^ 1) * IMG + 4 * xi * 256), 16, 0, 0);
-        else if (xi < 11) __builtin_amdgcn_global_load_lds(dsrc[xi - 8], (lds_void_f*)(sDw + (PAR ^ 1) * DFL + 4 * (xi - 8) * 256), 16, 0, 0);
-        WF_MFMA(acc[xi], A[xi % 3][1], B[xi % 3][1]);
-        WF_MFMA(acc[xi], A[xi % 3][2], B[xi % 3][2]);
-        WF_MFMA(acc[xi], A[xi % 3][3], B[xi % 3][3]);
+        // srcA = weights (rows of the result = output channels), srcB = data (columns = tiles): a lane then holds 16 channels of
+        // ONE tile, in runs of 4 consecutive channels - the epilogue stores dwordx4 and does its arithmetic packed
+        if (FIRST) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc[xi]) : "v"(B[xi % 3][0]), "v"(A[xi % 3][0]) : "memory");
+        else WF_MFMA(acc[xi], B[xi % 3][0], A[xi % 3][0]);
+        // DMA number j of this chunk: U pieces 0..7, then D pieces 0..2; two per group (behind the 1st and 3rd MFMA), so all
+        // eleven are on their way after 6 of the 16 groups and have the rest of the chunk to land
+        if (2 * xi < 8) __builtin_amdgcn_global_load_lds(usrc[2 * xi], (lds_void_f*)(sUw + (PAR ^ 1) * IMG + 4 * (2 * xi) * 256), 16, 0, 0);
+        else if (2 * xi < 11) __builtin_amdgcn_global_load_lds(dsrc[2 * xi - 8], (lds_void_f*)(sDw + (PAR ^ 1) * DFL + 4 * (2 * xi - 8) * 256), 16, 0, 0);
+        WF_MFMA(acc[xi], B[xi % 3][1], A[xi % 3][1]);
+        WF_MFMA(acc[xi], B[xi % 3][2], A[xi % 3][2]);
+        if (2 * xi + 1 < 8) __builtin_amdgcn_global_load_lds(usrc[2 * xi + 1], (lds_void_f*)(sUw + (PAR ^ 1) * IMG + 4 * (2 * xi + 1) * 256), 16, 0, 0);
+        else if (2 * xi + 1 < 11) __builtin_amdgcn_global_load_lds(dsrc[2 * xi + 1 - 8], (lds_void_f*)(sDw + (PAR ^ 1) * DFL + 4 * (2 * xi + 1 - 8) * 256), 16, 0, 0);
+        WF_MFMA(acc[xi], B[xi % 3][3], A[xi % 3][3]);
         if (xi + 2 < 16) {
             WF_RD128(A[(xi + 2) % 3], a_base, PAR * kWfIB + (xi + 2) * 2048);
             WF_RD128(B[(xi + 2) % 3], b_base, PAR * kWfIB + (xi + 2) * 2048);
@@ -414,6 +424,69 @@ template <int PAR> __device__ __forceinline__ void wf_chunk(f32x16 (&acc)[16], f
 #endif
 }
 
+// Epilogue of one output tile block: lane (li, lh) of wave (mi, ni) holds tile 32*mi + li and channels
+// n0 + 32*ni + 8*g + 4*lh + {0..3}, g = 0..3, in accumulator elements 4g..4g+3 of every point.  Output transform A^T m A,
+// bias and ReLU on channel pairs (packed fp32; the subtractions as inline asm - the compiler splits them into scalar
+// v_sub_f32), then one 16-byte store per pixel and channel quad.  `bias4` = the lane's 16 bias values, loaded by the
+// caller before the chunk loop so their latency is not paid here.
+__device__ __forceinline__ f32x2 wf_pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ void wf_load_bias(const WinoFusedArgs& p, int n0, int ni, int lh, f32x4 (&bias4)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bias4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4[g] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * ni + 4 * lh + 8 * g);
+    }
+}
+__device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[16], const WinoFusedArgs& p, int img, int by, int bx, int n0,
+                                            int mi, int ni, int li, int lh, const f32x4 (&bias4)[4]) {
+    const int lt = 32 * mi + li;
+    const int ty = 8 * by + (lt >> 3), tx = 8 * bx + (lt & 7);
+    if (ty >= (p.H >> 1) || tx >= (p.W >> 1)) return;
+    float* o = p.out + ((size_t)(img * p.H + 2 * ty) * p.W + 2 * tx) * p.ldo + n0 + 32 * ni + 4 * lh;
+    const size_t rowstride = (size_t)p.W * p.ldo;
+    const float lo = p.relu ? 0.f : -__builtin_inff();        // one code path: max(y, -inf) = y  (two instantiations made the
+#pragma unroll                                                 //  compiler stage all 256 accumulators through scratch)
+    for (int g = 0; g < 4; ++g) {
+        f32x2 y[2][2][2];                         // [out row][out col][channel pair]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x2 m[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                // explicit accumulator reads: element extraction left to the compiler round-trips whole accumulators
+                // through VGPRs and back (~270 extra moves per tile at ~8 cycles each)
+                float e0, e1;
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(e0) : "a"(acc[xi][4 * g + 2 * h]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(e1) : "a"(acc[xi][4 * g + 2 * h + 1]));
+                m[xi] = f32x2{e0, e1};
+            }
+            const f32x2 b2 = h ? f32x2{bias4[g][2], bias4[g][3]} : f32x2{bias4[g][0], bias4[g][1]};
+            f32x2 rr[2][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x2 s48 = m[4 + c] + m[8 + c], d48 = wf_pk_sub(m[4 + c], m[8 + c]);
+                rr[0][c] = m[0 + c] + s48;
+                rr[1][c] = wf_pk_sub(d48, m[12 + c]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x2 s12 = rr[i][1] + rr[i][2], d12 = wf_pk_sub(rr[i][1], rr[i][2]);
+                f32x2 y0 = (rr[i][0] + b2) + s12, y1 = wf_pk_sub(d12 + b2, rr[i][3]);
+                y[i][0][h] = f32x2{fmaxf(y0.x, lo), fmaxf(y0.y, lo)}; y[i][1][h] = f32x2{fmaxf(y1.x, lo), fmaxf(y1.y, lo)};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<f32x4*>(o + i * rowstride + (size_t)j * p.ldo + 8 * g) = f32x4{y[i][j][0].x, y[i][j][0].y, y[i][j][1].x, y[i][j][1].y};
+        __builtin_amdgcn_sched_barrier(0);        // one channel quad at a time: hoisting all 256 accumulator reads costs spills
+    }
+}
 __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
     constexpr int DPIX = 18 * 18, DPIECES = 12, DFL = DPIECES * 256;       // D image padded to 3 1-KB DMA pieces per wave
     constexpr int IMG = 16 * 64 * 8;
@@ -480,6 +553,8 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
     const unsigned v_base = ldsV + 4u * (t_lt * 8 + 4 * ((t_q >> 1) ^ ((t_lt >> 3) & 1)) + 2 * (t_q & 1));
 
     f32x2 dd[4][4];
+    f32x4 bias4[4];
+    wf_load_bias(p, n0, ni, lh, bias4);
     const int last = nchunks - 1;
 #if UNET_ABLATE == 8        /* diagnostics only: s_memtime at the phase boundaries of workgroup 0 */
     long long wf_t0, wf_t1, wf_t2;
@@ -517,49 +592,169 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
                           "+v"(usrc[7]), "+v"(dsrc[0]), "+v"(dsrc[1]), "+v"(dsrc[2]));
     };
     for (int c = 0; c + 1 < nchunks; c += 2) {
-        sources(min(c + 1, last), min(c + 3, last));
-        wf_chunk<0>(acc, dd, a_base, b_base, d_base, v_base, usrc, dsrc, sUw, sDw WF_TL);
-        sources(min(c + 2, last), min(c + 4, last));
-        wf_chunk<1>(acc, dd, a_base, b_base, d_base, v_base, usrc, dsrc, sUw, sDw WF_TL);
+        wf_chunk<0>(acc, dd, a_base, b_base, d_base, v_base, [&] { sources(min(c + 1, last), min(c + 3, last)); }, usrc, dsrc, sUw, sDw WF_TL);
+        wf_chunk<1>(acc, dd, a_base, b_base, d_base, v_base, [&] { sources(min(c + 2, last), min(c + 4, last)); }, usrc, dsrc, sUw, sDw WF_TL);
     }
     if (nchunks & 1) {                // odd tail outside the loop: inside it the extra control flow made the allocator spill
-        sources(last, last);
-        wf_chunk<0>(acc, dd, a_base, b_base, d_base, v_base, usrc, dsrc, sUw, sDw WF_TL);
+        wf_chunk<0>(acc, dd, a_base, b_base, d_base, v_base, [&] { sources(last, last); }, usrc, dsrc, sUw, sDw WF_TL);
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the inline-asm MFMAs are invisible to the compiler's hazard recogniser
 #if UNET_ABLATE == 8
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wf_t2) :: "memory");
 #endif
 
-    // epilogue: lane-local output transform, + bias, ReLU
-    const int Th = p.H >> 1, Tw = p.W >> 1;
-    const int co = n0 + 32 * ni + li;
-    const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int lt = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int ty = 8 * by + (lt >> 3), tx = 8 * bx + (lt & 7);
-        if (ty >= Th || tx >= Tw) continue;
-        float rr[2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            rr[0][c] = acc[0 + c][r] + acc[4 + c][r] + acc[8 + c][r];
-            rr[1][c] = acc[4 + c][r] - acc[8 + c][r] - acc[12 + c][r];
-        }
-        float* o = p.out + ((size_t)(img * p.H + 2 * ty) * p.W + 2 * tx) * p.ldo + co;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float y0 = rr[i][0] + rr[i][1] + rr[i][2] + bv, y1 = rr[i][1] - rr[i][2] - rr[i][3] + bv;
-            if (p.relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
-            o[(size_t)i * p.W * p.ldo] = y0;
-            o[(size_t)i * p.W * p.ldo + p.ldo] = y1;
-        }
-    }
+    wf_epilogue(acc, p, img, by, bx, n0, mi, ni, li, lh, bias4);
 #if UNET_ABLATE == 8
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (blockIdx.x == 0 && tid == 0) {
         long long t3; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t3) :: "memory");
         g_wf_timeline[0] = wf_t1 - wf_t0; g_wf_timeline[1] = wf_t2 - wf_t1; g_wf_timeline[2] = t3 - wf_t2; g_wf_timeline[3] = nchunks;
+        for (int i = 0; i < 4; ++i) g_wf_timeline[4 + i] = tl[i];
+    }
+#endif
+}
+
+// Persistent form of the kernel above for K % 16 == 0, K >= 32: a workgroup walks output tiles blockIdx.x, +gridDim.x, ... and
+// the chunk stream runs straight across tile boundaries - the last chunks of a tile prefetch U(0), D(0..2) of the next one
+// instead of idling, so only the first tile of a workgroup pays the two DMA round trips of the prologue, and there is no
+// launch gap between tiles (with 152 KB of LDS a CU holds one workgroup, so nothing else would hide either).  A tile's first
+// chunk starts its accumulators from C = 0.
+__global__ __launch_bounds__(256, 1) void wino_fused_stream_kernel(WinoFusedArgs p, int ntiles) {
+    constexpr int DPIX = 18 * 18, DPIECES = 12, DFL = DPIECES * 256;
+    constexpr int IMG = 16 * 64 * 8;
+    constexpr int DB = kWfDB, IB = kWfIB;
+    __shared__ __attribute__((aligned(1024))) float smem[2 * DFL + 4 * IMG];
+    float* sD = smem; float* sU = smem + 2 * DFL + 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = wv & 1, ni = wv >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nchunks = p.K / 8;
+    const int drow = lane >> 1, dh = lane & 1;
+    const int urow = 32 * (wv & 1) + drow;
+    const unsigned uoff = (unsigned)((urow * 8 + 4 * (dh ^ ((urow >> 3) & 1))) * 4);
+    const size_t ustride_xi = (size_t)nchunks * p.Nout * 32;
+    const size_t ustep = (size_t)p.Nout * 32;                                               // bytes between chunks
+
+    // Per-tile DMA sources: this lane's three D pixels at channel 0 and the wave's U base at chunk 0.  The lane's patch
+    // pixels are tile-invariant; a tile contributes a scalar base and the image-border test.  Tile coordinates advance by
+    // gridDim.x tiles with carries instead of being decoded by division each time (per-tile VALU work is matrix-pipe time).
+    int ppy[3], ppx[3], poff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pix = 32 * (wv + 4 * k) + drow;
+        ppy[k] = pix < DPIX ? pix / 18 : (1 << 20);                 // beyond the 18x18 patch: never in the image
+        ppx[k] = pix % 18;
+        poff[k] = ((pix / 18) * p.W + ppx[k]) * p.ldx + 4 * dh;
+    }
+    struct TileCoord { int tn, bx, by, img; };
+    auto decode = [&](int t) { TileCoord c; c.tn = t % p.nt; t /= p.nt; c.bx = t % p.tbx; t /= p.tbx; c.by = t % p.tby; c.img = t / p.tby; return c; };
+    const TileCoord dstep = decode((int)gridDim.x);
+    auto advance = [&](TileCoord c) {
+        c.tn += dstep.tn; int cy = c.tn >= p.nt; c.tn -= cy ? p.nt : 0;
+        c.bx += dstep.bx + cy; cy = c.bx >= p.tbx; c.bx -= cy ? p.tbx : 0;
+        c.by += dstep.by + cy; cy = c.by >= p.tby; c.by -= cy ? p.tby : 0;
+        c.img += dstep.img + cy;
+        return c;
+    };
+    auto tile_sources = [&](const TileCoord& c, const float* (&dp)[3], const char*& ub0) {
+        const int gy0 = 16 * c.by - 1, gx0 = 16 * c.bx - 1;
+        const float* xb = p.x + ((long long)(c.img * p.H + gy0) * p.W + gx0) * p.ldx;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool ok = (unsigned)(gy0 + ppy[k]) < (unsigned)p.H && (unsigned)(gx0 + ppx[k]) < (unsigned)p.W;
+            dp[k] = ok ? xb + poff[k] : g_zero_page_f + 4 * dh;
+        }
+        ub0 = reinterpret_cast<const char*>(p.Uc) + (size_t)c.tn * 64 * 32 + (size_t)(wv >> 1) * ustride_xi;
+    };
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_f*)smem;
+    const unsigned ldsV = lds0 + 2 * DB, ldsU = ldsV + 2 * IB;
+    const int arow = 32 * mi + li, brow = 32 * ni + li;
+    const unsigned a_base = ldsV + 4u * (arow * 8 + 4 * (lh ^ ((arow >> 3) & 1)));
+    const unsigned b_base = ldsU + 4u * (brow * 8 + 4 * (lh ^ ((brow >> 3) & 1)));
+    const int t_lt = 16 * wv + (lane >> 2), t_q = lane & 3;
+    const unsigned d_base = lds0 + 4u * (((2 * (t_lt >> 3)) * 18 + 2 * (t_lt & 7)) * 8 + 2 * t_q);
+    const unsigned v_base = ldsV + 4u * (t_lt * 8 + 4 * ((t_q >> 1) ^ ((t_lt >> 3) & 1)) + 2 * (t_q & 1));
+    float* const sUw = sU + wv * 256; float* const sDw = sD + wv * 256;
+
+    f32x16 acc[16];
+    f32x2 dd[4][4];
+    const float* dcur[3]; const float* dnxt[3]; const char* ucur; const char* unxt;
+    int t = blockIdx.x;
+    TileCoord tc = decode(t);
+    tile_sources(tc, dcur, ucur);
+
+    // prologue of the workgroup's first tile: D(0), D(1), U(0) -> LDS; V(0) from D(0); D(1) into registers; D(2) -> LDS
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        __builtin_amdgcn_global_load_lds(dcur[k], (lds_void_f*)(sDw + 4 * k * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(dcur[k] + 8, (lds_void_f*)(sDw + DFL + 4 * k * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(ucur + 2 * k * ustride_xi + uoff), (lds_void_f*)(sUw + 4 * k * 256), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    wf_read_D<0>(dd, d_base);
+    asm volatile("s_waitcnt lgkmcnt(0)" : WF_ALL_D);
+    wf_transform_to<0>(dd, v_base);
+    wf_read_D<1>(dd, d_base);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : WF_ALL_D : : "memory");
+#pragma unroll
+    for (int k = 0; k < 3; ++k) __builtin_amdgcn_global_load_lds(dcur[k] + 16, (lds_void_f*)(sDw + 4 * k * 256), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const float* usrc[8]; const float* dsrc[3];
+    // this lane's DMA sources for chunk c of the current tile: U(c+1) and D(c+3), continuing into the next tile
+    auto sources = [&](int c) {
+        const int cu = c + 1, cd = c + 3;
+        const char* ub = cu < nchunks ? ucur + (size_t)cu * ustep : unxt;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) usrc[k] = reinterpret_cast<const float*>(ub + 2 * k * ustride_xi + uoff);
+        const bool same = cd < nchunks;
+        const int doff = (same ? cd : cd - nchunks) * 8;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dsrc[k] = (same ? dcur[k] : dnxt[k]) + doff;
+        asm volatile("" : "+v"(usrc[0]), "+v"(usrc[1]), "+v"(usrc[2]), "+v"(usrc[3]), "+v"(usrc[4]), "+v"(usrc[5]), "+v"(usrc[6]),
+                          "+v"(usrc[7]), "+v"(dsrc[0]), "+v"(dsrc[1]), "+v"(dsrc[2]));
+    };
+
+#if UNET_ABLATE == 8
+    long long q0, q1, q2, q3, qa[4] = {0, 0, 0, 0};
+    long long tl[6] = {0, 0, 0, 0, 0, 0};
+    WF_STAMP(q3);
+#endif
+    for (; t < ntiles; t += gridDim.x) {
+#if UNET_ABLATE == 8
+        WF_STAMP(q0); tl[5] = q0;
+#endif
+        const TileCoord tcn = t + (int)gridDim.x < ntiles ? advance(tc) : tc;            // the last tile prefetches itself again
+        tile_sources(tcn, dnxt, unxt);
+        f32x4 bias4[4];
+        wf_load_bias(p, tc.tn * 64, ni, lh, bias4);
+        wf_chunk<0, true>(acc, dd, a_base, b_base, d_base, v_base, [&] { sources(0); }, usrc, dsrc, sUw, sDw WF_TL);
+        wf_chunk<1>(acc, dd, a_base, b_base, d_base, v_base, [&] { sources(1); }, usrc, dsrc, sUw, sDw WF_TL);
+        for (int c = 2; c < nchunks; c += 2) {
+            wf_chunk<0>(acc, dd, a_base, b_base, d_base, v_base, [&] { sources(c); }, usrc, dsrc, sUw, sDw WF_TL);
+            wf_chunk<1>(acc, dd, a_base, b_base, d_base, v_base, [&] { sources(c + 1); }, usrc, dsrc, sUw, sDw WF_TL);
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMAs are invisible to the compiler's hazard recogniser
+#if UNET_ABLATE == 8
+        WF_STAMP(q1);
+#endif
+
+        wf_epilogue(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, bias4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dcur[k] = dnxt[k];
+        ucur = unxt; tc = tcn;
+#if UNET_ABLATE == 8
+        WF_STAMP(q2);
+        qa[0] += q0 - q3; qa[1] += q1 - q0; qa[2] += q2 - q1; qa[3] += 1; q3 = q2;
+#endif
+    }
+#if UNET_ABLATE == 8
+    if (blockIdx.x == 0 && tid == 0) {
+        g_wf_timeline[0] = qa[0]; g_wf_timeline[1] = qa[1]; g_wf_timeline[2] = qa[2]; g_wf_timeline[3] = nchunks * qa[3];
         for (int i = 0; i < 4; ++i) g_wf_timeline[4 + i] = tl[i];
     }
 #endif
@@ -853,7 +1048,13 @@ int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, 
     a.tby = (H / 2 + 7) / 8; a.tbx = (W / 2 + 7) / 8; a.nt = Nout / 64;
     const long blocks = (long)N * a.tby * a.tbx * a.nt;
     if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
-    wino_fused_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(a);
+    static const bool stream_ok = [] { const char* e = getenv("UNET_WINO_STREAM"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (stream_ok && K % 16 == 0 && K >= 32) {
+        static const int cus = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256; return n; }();
+        wino_fused_stream_kernel<<<dim3((unsigned)(blocks < cus ? blocks : cus)), 256, 0, st>>>(a, (int)blocks);
+    } else {
+        wino_fused_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(a);
+    }
     return UNET_LAUNCH_STATUS();
 }
 
@@ -864,7 +1065,8 @@ extern "C" int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const fl
         int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
     UNET_CHECK_ARG(x && Uc && out && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 8 == 0 && Cout % 64 == 0);
     UNET_CHECK_ARG(Cin <= kWinoFusedMaxK);
-    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(Uc));
+    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(Uc) && unet_aligned16(out));
+    UNET_CHECK_ARG(!bias || unet_aligned16(bias));
     return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
 }
 
@@ -872,7 +1074,7 @@ extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, cons
         int N, int H, int W, int Cin, int Cout, void* stream) {
     UNET_CHECK_ARG(dz && Ucd && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
     UNET_CHECK_ARG(Cout <= kWinoFusedMaxK);
-    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd));
+    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && lddx % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd) && unet_aligned16(dx));
     return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream);
 }
 

@@ -132,7 +132,7 @@ class Engine:
         self.winograd_wgrad_min_channels = int(os.environ.get("UNET_WINOGRAD_WGRAD_MIN_C", "128"))
         # weight-gradient route: "fused" = fused Winograd wgrad wherever it applies; "hybrid" = unfused planes + TN GEMM from
         # `wgrad_unfused_from` channels up, fused below; "unfused" = the previous policy (unfused >= 128, direct below)
-        self.wgrad_route = os.environ.get("UNET_WGRAD_ROUTE", "hybrid")
+        self.wgrad_route = os.environ.get("UNET_WGRAD_ROUTE", "fused")
         self.wgrad_unfused_from = int(os.environ.get("UNET_WGRAD_UNFUSED_FROM", "512"))
         self.wino_U = {}
         self._wino_dirty = True
