@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs p) {
     constexpr int TILE_FLOATS = TILE_PIX * CT;
     constexpr int STEPS = TH * (TW / 2);
     static_assert(KP <= STEPS, "one DMA issue per MFMA step at most");
-    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE_FLOATS];
+    constexpr int NBUF = 3;                           // tile i+2 is in flight while tile i multiplies: one tile of MFMAs (~2-8 us) does
+                                                      // not always cover the DMA latency under load
+    static_assert(NBUF * TILE_FLOATS * 4 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) float smem[NBUF * TILE_FLOATS];
 
     int bid = blockIdx.x;
     const int tmn = bid % (p.mt * p.nt);
@@ -117,23 +120,30 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs p) {
         }
     };
 
+    // prologue: tiles 0 and 1 of this split in flight (a missing tile still issues its KP pieces, from the zero page, so the
+    // vmcnt arithmetic below is uniform)
     int tile = split;
-    if (tile < p.n_tiles) {
-        set_tile(tile);
+    auto issue_tile = [&](int t, float* dst) {
+        const bool valid = t < p.n_tiles;
+        set_tile(valid ? t : 0);
+        if (!valid) t_oy0 = 1 << 20;                  // every pixel out of the image -> zero page
 #pragma unroll
-        for (int k = 0; k < KP; ++k) issue_piece(k, smem);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+        for (int k = 0; k < KP; ++k) issue_piece(k, dst);
+    };
+    issue_tile(tile, smem);
+    issue_tile(tile + p.splits, smem + TILE_FLOATS);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(KP) : "memory");      // tile 0 landed; tile 1 may still be in flight
     int cur = 0;
     for (; tile < p.n_tiles; tile += p.splits) {
         const float* sA = smem + cur * TILE_FLOATS;
         const float* sB = sA + A_PIX_PAD * CT;
-        float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
-        const bool more = tile + p.splits < p.n_tiles;       // wave-uniform
-        if (more) set_tile(tile + p.splits);
+        float* nxt = smem + ((cur + 2) % NBUF) * TILE_FLOATS;
+        const int t2 = tile + 2 * p.splits;
+        const bool valid2 = t2 < p.n_tiles;            // wave-uniform
+        set_tile(valid2 ? t2 : 0);
+        if (!valid2) t_oy0 = 1 << 20;
 
-        // fragments of step st+1 are read while step st's MFMAs issue; the next tile's DMA pieces are issued
+        // fragments of step st+1 are read while step st's MFMAs issue; the DMA pieces of the tile after next are issued
         // one per step so their address arithmetic hides under matrix-pipe time
         float ac[NT], an[NT], bc, bn;
         auto load_frag = [&](int st, float (&av)[NT], float& bv) {
@@ -151,17 +161,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             if (st + 1 < STEPS) load_frag(st + 1, an, bn);
-            if (st < KP && more) issue_piece(st, nxt);
+            if (st < KP) issue_piece(st, nxt);
 #pragma unroll
             for (int tap = 0; tap < NT; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[tap], bc, acc[tap], 0, 0, 0);
 #pragma unroll
             for (int tap = 0; tap < NT; ++tap) ac[tap] = an[tap];
             bc = bn;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next tile landed (this wave's pieces)
-        __syncthreads();                                       // ... everyone's pieces; everyone done with `cur`
-        cur ^= 1;
+        // the next tile (issued one iteration ago) has landed; the newest batch may stay in flight.  A bare s_barrier: the
+        // fence in __syncthreads() would make the compiler drain vmcnt to 0.  lgkmcnt(0): this wave is done reading `cur`.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(KP) : "memory");
+        cur = (cur + 1) % NBUF;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the tail DMAs before the LDS is released
 
     // partial block -> workspace [split][tap][Cm][Cn]
 #pragma unroll

@@ -362,9 +362,11 @@ def test_conv3x3_winograd_wgrad(hip, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (2, 32, 48, 64, 128), (1, 6, 10, 72, 64),
-                                   (1, 20, 36, 256, 128)])
+                                   (1, 20, 36, 256, 128), (1, 16, 16, 32, 64), (5, 104, 136, 64, 64)])
 def test_conv3x3_winograd_fully_fused_fwd_dgrad(hip, shape):
-    # raw patch -> LDS, in-kernel transform, 16-point MFMA, output transform in the epilogue; ragged tile grids included
+    # raw patch -> LDS, in-kernel transform, 16-point MFMA, output transform in the epilogue; ragged tile grids included.
+    # 72 channels = odd chunk count (one-tile-per-workgroup kernel); 32 channels = the shortest chunk stream the persistent
+    # kernel takes; the last shape has 630 tile blocks, so persistent workgroups walk 2-3 tiles each across image borders
     n, h, w, ci, co = shape
     rng = np.random.default_rng(ci + 7 * co + h)
     x = rng.standard_normal((n, ci, h, w))
