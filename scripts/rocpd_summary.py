@@ -1,6 +1,9 @@
 """Summarise a rocprofv3 rocpd database (kernel trace) as a per-kernel table: calls, total / average duration, share.
 
 usage: python scripts/rocpd_summary.py gpurun_out/prof/x_results.db [steps] > profiles/rNN_bench_kernel_stats.txt
+
+The 3x3 forward/dgrad kernel is launched 34 times per step (17 forward, then 17 dgrad); the header splits its launches by that
+position, because only the forward launches run alone on the GPU (bench.py's roofline uses them).
 """
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -10,3 +13,10 @@ print("# rocprofv3 --kernel-trace, %d kernels, %.3f ms of kernel time in total (
 print("%-100s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct"))
 for n, c, t, a, mn, mx in rows:
     print("%-100s %8d %12.3f %10.1f %10.1f %10.1f %6.2f" % (n[:100], c, t / 1e6, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * t / tot))
+
+for kname in ("wino_fused_stream_kernel", "wino_fused_kernel"):
+    ev = [r for r in db.execute("select start, end from kernels where name like ? order by start", ("%" + kname + "(%",))]
+    if len(ev) >= 34 and len(ev) % 34 == 0:
+        fwd = [e - s0 for i, (s0, e) in enumerate(ev) if i % 34 < 17]; bwd = [e - s0 for i, (s0, e) in enumerate(ev) if i % 34 >= 17]
+        print("# %s FORWARD launches (exclusive on the GPU): %d, average %.1f us;  dgrad launches (share the GPU with the side-stream weight gradients): %d, average %.1f us"
+              % (kname, len(fwd), sum(fwd) / len(fwd) / 1e3, len(bwd), sum(bwd) / len(bwd) / 1e3))
