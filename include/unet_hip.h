@@ -140,6 +140,10 @@ int unet_adam_keras(float* theta, const float* grad, float* m, float* v, long n,
 
 /* ---- reference input contract is NCHW (UNet/model.py:73; UNet/imagereader.py:298) -------------------------------- */
 int unet_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
+/* reader output contract, UNet/imagereader.py:302-312,353-355: class map [P] (uint8) -> one-hot int32 [P][K] on the device,
+ * so the feed ships 1 byte per pixel instead of 4K; *out_of_range (may be NULL, else zeroed by the caller) counts labels >= K,
+ * the condition the reference raises IndexError for */
+int unet_labels_onehot(const uint8_t* classmap, int* onehot, long P, int K, unsigned* out_of_range, void* stream);
 
 #ifdef __cplusplus
 }

@@ -289,6 +289,27 @@ extern "C" int unet_softmax_ce(const float* logits, int ldz, const int* labels_o
     return rc;
 }
 
+// class map (one uint8 label per pixel) -> int32 one-hot [P][K]; `bad` counts labels >= K (the reader contract's IndexError,
+// UNet/imagereader.py:302-312, raised by the caller)
+__global__ __launch_bounds__(256) void onehot_kernel(const uint8_t* __restrict__ cls, int* __restrict__ onehot, long P, int K,
+                                                     unsigned* __restrict__ bad) {
+    const long total = P * K, stride = (long)gridDim.x * 256;
+    unsigned nbad = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const long px = i / K; const int k = (int)(i - px * K);
+        const int c = cls[px];
+        onehot[i] = c == k ? 1 : 0;
+        if (k == 0 && c >= K) ++nbad;
+    }
+    if (nbad && bad) atomicAdd(bad, nbad);
+}
+
+extern "C" int unet_labels_onehot(const uint8_t* classmap, int* onehot, long P, int K, unsigned* out_of_range, void* stream) {
+    UNET_CHECK_ARG(classmap && onehot && P > 0 && K > 0 && K <= 256);
+    onehot_kernel<<<grid_for(P * K, 4096), 256, 0, (hipStream_t)stream>>>(classmap, onehot, P, K, out_of_range);
+    return UNET_LAUNCH_STATUS();
+}
+
 extern "C" int unet_argmax(const float* p, int ldp, int* out, long P, int K, void* stream) {
     UNET_CHECK_ARG(p && out && P > 0 && K > 0 && ldp >= K);
     argmax_kernel<<<grid_for(P, 4096), 256, 0, (hipStream_t)stream>>>(p, ldp, out, P, K);

@@ -9,6 +9,8 @@ one-hot [H,W,K].  Two small sources implement that contract here so the CLIs run
 Both expose the reader surface train.py uses: startup(), shutdown(), get_image_count(), get_image_size() -> (H, W, C),
 batches(batch_size) -> iterator of (images [B,C,H,W] fp32, labels [B,H,W,K] int32) that never ends (like the reference's
 generator, UNet/imagereader.py:338-343).  Batches are pinned host tensors so the H2D copy is asynchronous.
+`batches(batch_size, classmap=True, pin=False)` yields the uint8 class map [B,H,W] instead of the one-hot, unpinned: the
+form `feed.DeviceFeed` stages itself and expands to the same one-hot on the device.
 """
 import os
 
@@ -54,13 +56,17 @@ class SyntheticReader(_Base):
     def get_image_size(self):
         return (self.h, self.w, self.c)
 
-    def batches(self, batch_size):
+    def batches(self, batch_size, classmap=False, pin=True):
         g = torch.Generator().manual_seed(self.seed)
+        pin_ = _pin if pin else (lambda t: t)
         while True:
             img = torch.randn(batch_size, self.c, self.h, self.w, generator=g)
             cls = torch.randint(0, self.k, (batch_size, (self.h + 7) // 8, (self.w + 7) // 8), generator=g)
             cls = cls.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :self.h, :self.w]
-            yield _pin(img), _pin(torch.nn.functional.one_hot(cls, self.k).to(torch.int32))
+            if classmap:
+                yield pin_(img), pin_(cls.to(torch.uint8).contiguous())
+            else:
+                yield pin_(img), pin_(torch.nn.functional.one_hot(cls, self.k).to(torch.int32))
 
 
 class TileFolderReader(_Base):
@@ -81,13 +87,18 @@ class TileFolderReader(_Base):
     def get_image_size(self):
         return (self.h, self.w, self.c)
 
-    def _load(self, name):
+    def _load(self, name, classmap=False):
         im = np.load(os.path.join(self.folder, name + ".npy"))
         im = im[..., None] if im.ndim == 2 else im
         mk = np.load(os.path.join(self.folder, name + "_mask.npy"))
+        if classmap:
+            if mk.max(initial=0) >= self.k or mk.min(initial=0) < 0:
+                raise IndexError("Number of classes specified differs from number of observed classes in data")
+            return zscore_normalize(im.transpose(2, 0, 1)), mk.astype(np.uint8)
         return zscore_normalize(im.transpose(2, 0, 1)), one_hot(mk, self.k)
 
-    def batches(self, batch_size):
+    def batches(self, batch_size, classmap=False, pin=True):
+        pin_ = _pin if pin else (lambda t: t)
         rng = np.random.default_rng(self.seed)
         pos = 0
         order = np.arange(len(self.names))
@@ -96,7 +107,7 @@ class TileFolderReader(_Base):
             for _ in range(batch_size):
                 if pos == 0 and self.shuffle:
                     rng.shuffle(order)
-                i, l = self._load(self.names[order[pos]])
+                i, l = self._load(self.names[order[pos]], classmap)
                 imgs.append(i); labs.append(l)
                 pos = (pos + 1) % len(order)
-            yield _pin(torch.as_tensor(np.stack(imgs))), _pin(torch.as_tensor(np.stack(labs)))
+            yield pin_(torch.as_tensor(np.stack(imgs))), pin_(torch.as_tensor(np.stack(labs)))

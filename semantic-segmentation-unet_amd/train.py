@@ -77,11 +77,22 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
         test_reader = readers.TileFolderReader(test_lmdb_filepath, number_classes, shuffle=False)
     say("Test Reader has {} images".format(test_reader.get_image_count()))
     say("Train Reader has {} images".format(train_reader.get_image_count()))
+    feeds = []
     try:
         train_reader.startup()
         test_reader.startup()
-        train_batches = train_reader.batches(batch_size)
-        test_batches = test_reader.batches(batch_size)
+        # device feed (feed.py): reader batches are staged and copied on a copy stream while the previous step runs, labels
+        # travel as uint8 class maps and become the one-hot on the device; UNET_FEED=0 restores the synchronous hand-over
+        use_feed = os.environ.get("UNET_FEED", "1") != "0"
+        if use_feed:
+            from .feed import DeviceFeed
+            dev_ = torch.device("cuda", local)
+            train_batches = DeviceFeed(train_reader.batches(batch_size, classmap=True, pin=False), dev_, classmap=True, number_classes=number_classes)
+            test_batches = DeviceFeed(test_reader.batches(batch_size, classmap=True, pin=False), dev_, classmap=True, number_classes=number_classes)
+            feeds = [train_batches, test_batches]
+        else:
+            train_batches = train_reader.batches(batch_size)
+            test_batches = test_reader.batches(batch_size)
         number_channels = train_reader.get_image_size()[2]
         net = unet_model_module.UNet(number_classes, global_batch_size, number_channels, learning_rate,
                                      device=torch.device("cuda", local))
@@ -156,6 +167,8 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
                 break
         return test_loss
     finally:
+        for f in feeds:
+            f.close()
         train_reader.shutdown()
         test_reader.shutdown()
 
