@@ -97,6 +97,31 @@ def test_conv3x3_mfma_linearity_at_full_size(hip):
     assert o[0][:, 0].abs().max().item() == 0 and o[0][:, :, -1].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("shape", [(8, 512, 512, 64, 64), (8, 512, 512, 128, 64), (8, 32, 32, 1024, 1024)])
+def test_fused_winograd_trio_properties_at_full_size(hip, shape):
+    # BASELINE config-2 layer shapes (the oracle is too slow here): (1) the fused Winograd forward agrees with the direct
+    # MFMA kernel - two independent implementations; (2) the three kernels are mutually adjoint:
+    #     <conv(x, w), dz> == <x, dgrad(dz, w)> == <w, wgrad(x, dz)>        (no bias, no ReLU; inner products in fp64)
+    # 8192 / 8192 / 512 tile blocks on 256 persistent workgroups, image borders included.
+    n, h, w, ci, co = shape
+    g = torch.Generator(device=DEV); g.manual_seed(ci + co)
+    x = torch.randn(n, h, w, ci, device=DEV, generator=g); dz = torch.randn(n, h, w, co, device=DEV, generator=g)
+    wt = torch.randn(3, 3, ci, co, device=DEV, generator=g) / float(np.sqrt(9 * ci))
+    Uc = torch.empty(16 * ci * co, device=DEV); Ucd = torch.empty(16 * ci * co, device=DEV)
+    hip.unet_winograd_weight_transform(P(wt), P(Uc), ci, co, 2, ST()); hip.unet_winograd_weight_transform(P(wt), P(Ucd), ci, co, 3, ST())
+    y = torch.empty(n, h, w, co, device=DEV); yd = torch.empty_like(y); dx = torch.empty_like(x); dw = torch.empty_like(wt)
+    hip.unet_conv3x3_fwd_winograd_fused(P(x), ci, P(Uc), None, P(y), co, n, h, w, ci, co, 0, ST())
+    hip.unet_conv3x3_fwd_mfma(P(x), ci, P(wt), None, P(yd), co, n, h, w, ci, co, 0, ST())
+    assert ((y - yd).abs().max() / yd.abs().max()).item() < 2e-5
+    hip.unet_conv3x3_dgrad_winograd_fused(P(dz), co, P(Ucd), P(dx), ci, n, h, w, ci, co, ST())
+    nb = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co); ws = ws_bytes(nb)
+    hip.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+    dot = lambda a, b: (a.double() * b.double()).sum().item()
+    a0, a1, a2 = dot(y, dz), dot(x, dx), dot(wt, dw)
+    scale = float(np.sqrt(dot(y, y) * dot(dz, dz)))
+    assert abs(a0 - a1) < 1e-5 * scale and abs(a0 - a2) < 1e-5 * scale
+
+
 @pytest.mark.parametrize("shape", [(2, 4, 32, 128, 64), (1, 6, 20, 64, 128), (2, 2, 2, 1024, 512)])
 def test_convT2x2_fwd_dgrad_wgrad(hip, shape):
     n, h, w, ci, co = shape
