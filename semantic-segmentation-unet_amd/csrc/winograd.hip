@@ -55,6 +55,54 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     }
 }
 
+// All fused-route weight transforms of a step in ONE launch (34 tiny launches otherwise: ~0.5 ms of launch bubbles per
+// step).  jobs[j] = { w, Uc forward (mode 2), Uc dgrad (mode 3), Ci | Co << 32, first block, unused }.  The data-gradient
+// kernel uses the 180-degree rotated filter, whose transform is the forward one with points 0 and 3 swapped in both
+// directions (G flip(g) G^T = P (G g G^T) P, P = (3,1,2,0)): computed once, written twice.
+__global__ __launch_bounds__(256) void wino_weight_batch_kernel(const long long* __restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)jobs[(j + 1) * 6 + 4] <= (int)blockIdx.x) ++j;
+    const float* __restrict__ w = reinterpret_cast<const float*>(jobs[j * 6 + 0]);
+    float* __restrict__ uf = reinterpret_cast<float*>(jobs[j * 6 + 1]);
+    float* __restrict__ ud = reinterpret_cast<float*>(jobs[j * 6 + 2]);
+    const int Ci = (int)(jobs[j * 6 + 3] & 0xffffffffll), Co = (int)(jobs[j * 6 + 3] >> 32);
+    const long total = (long)Ci * Co;
+    const size_t plane = (size_t)total;
+    const long base = ((long)blockIdx.x - (int)jobs[j * 6 + 4]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int ci = (int)(i / Co), co = (int)(i % Co);
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = w[((size_t)(a * 3 + b) * Ci + ci) * Co + co];
+        float s[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            s[0][b] = g[0][b];
+            s[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            s[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            s[3][b] = g[2][b];
+        }
+        const size_t offf = ((size_t)(ci >> 3) * Co + co) * 8 + (ci & 7);             // [k/8][n=co][k%8]
+        const size_t offd = ((size_t)(co >> 3) * Ci + ci) * 8 + (co & 7);             // [k/8][n=ci][k%8]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t[4] = {s[r][0], 0.5f * (s[r][0] + s[r][1] + s[r][2]), 0.5f * (s[r][0] - s[r][1] + s[r][2]), s[r][2]};
+            const int rp = r == 0 ? 3 : (r == 3 ? 0 : r);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int cp = c == 0 ? 3 : (c == 3 ? 0 : c);
+                uf[(size_t)(4 * r + c) * plane + offf] = t[c];
+                ud[(size_t)(4 * rp + cp) * plane + offd] = t[c];
+            }
+        }
+    }
+}
+
 // V[xi][tile][c] = (B^T d B)[xi]; thread = (tile, channel quad); patch rows 2ty-1..2ty+2, zero outside the image
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V,
                                                          int N, int H, int W, int C) {
@@ -1119,6 +1167,12 @@ extern "C" int unet_winograd_supported(int N, int H, int W, int Cin, int Cout) {
 extern "C" int unet_winograd_weight_transform(const float* w, float* U, int Cin, int Cout, int mode, void* stream) {
     UNET_CHECK_ARG(w && U && Cin > 0 && Cout > 0 && mode >= 0 && mode <= 3 && (mode < 2 || (Cin % 8 == 0 && Cout % 8 == 0)));
     wino_weight_kernel<<<grid_for((long)Cin * Cout, 4096), 256, 0, (hipStream_t)stream>>>(w, U, Cin, Cout, mode);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_winograd_weight_transform_batch(const void* jobs, int njobs, int total_blocks, void* stream) {
+    UNET_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0);
+    wino_weight_batch_kernel<<<dim3((unsigned)total_blocks), 256, 0, (hipStream_t)stream>>>((const long long*)jobs, njobs);
     return UNET_LAUNCH_STATUS();
 }
 

@@ -136,6 +136,7 @@ class Engine:
         self.wgrad_unfused_from = int(os.environ.get("UNET_WGRAD_UNFUSED_FROM", "512"))
         self.wino_U = {}
         self._wino_dirty = True
+        self._fused_U, self._fused_dirty = None, True
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -182,20 +183,25 @@ class Engine:
                 and k % 8 == 0 and nn % 64 == 0)
 
     def _fused_kernels(self, name):
-        """(Uc forward, Uc dgrad) in the chunked layout of the fused kernel, cached until the next parameter change."""
-        if self._wino_dirty:
-            self.wino_U.clear()
-            self._wino_dirty = False
-        u = self.wino_U.get("f/" + name)
-        if u is None:
-            cin, cout = self.cin[name], self.cout[name]
-            u = (torch.empty(16 * cin * cout, dtype=torch.float32, device=self.dev),
-                 torch.empty(16 * cin * cout, dtype=torch.float32, device=self.dev))
-            st = self._stream()
-            self.L.unet_winograd_weight_transform(_p(self.p[name + "/kernel"]), _p(u[0]), cin, cout, 2, st)
-            self.L.unet_winograd_weight_transform(_p(self.p[name + "/kernel"]), _p(u[1]), cin, cout, 3, st)
-            self.wino_U["f/" + name] = u
-        return u
+        """(Uc forward, Uc dgrad) in the chunked layout of the fused kernel.  The buffers are persistent; after a parameter
+        change ALL fused-route layers are re-transformed by one batched launch at the first use."""
+        if self._fused_U is None:
+            names = [n for n, _, _, _ in self.layers if self.kind[n] == "conv3" and self.cin[n] % 8 == 0 and self.cout[n] % 64 == 0]
+            self._fused_U, rows, blk = {}, [], 0
+            for n in names:
+                cin, cout = self.cin[n], self.cout[n]
+                u = (torch.empty(16 * cin * cout, dtype=torch.float32, device=self.dev),
+                     torch.empty(16 * cin * cout, dtype=torch.float32, device=self.dev))
+                self._fused_U[n] = u
+                rows.append([self.p[n + "/kernel"].data_ptr(), u[0].data_ptr(), u[1].data_ptr(), cin | (cout << 32), blk, 0])
+                blk += (cin * cout + 1023) // 1024
+            self._fused_jobs = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+            self._fused_blocks = blk
+            self._fused_dirty = True
+        if self._fused_dirty:
+            self.L.unet_winograd_weight_transform_batch(_p(self._fused_jobs), self._fused_jobs.shape[0], self._fused_blocks, self._stream())
+            self._fused_dirty = False
+        return self._fused_U[name]
 
     def _winograd_kernels(self, name):
         """(U forward, U dgrad) for a layer; all cached transforms are recomputed lazily after a parameter change."""
@@ -216,6 +222,7 @@ class Engine:
     def load_parameters(self, values):
         """values: {keras-style name: array in the Keras layout}.  Resets nothing else."""
         self._wino_dirty = True
+        self._fused_dirty = True
         for k, v in values.items():
             t = torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float32)))
             if k in self.p:
@@ -515,6 +522,7 @@ class Engine:
         """Keras Adam on the flat buffers (reference UNet/model.py:79,223)."""
         self.iterations += 1
         self._wino_dirty = True
+        self._fused_dirty = True
         t = self.iterations
         alpha = learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
         self.L.unet_adam_keras(_p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v), self.n_flat, alpha,

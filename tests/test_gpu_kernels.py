@@ -386,6 +386,24 @@ def test_conv3x3_winograd_wgrad(hip, shape):
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 3e-5
 
 
+def test_winograd_weight_transform_batch_matches_single(hip):
+    # one launch for several layers == the per-layer transforms: mode 2 bit for bit; mode 3 (rotated filter) is obtained by
+    # permuting the forward transform's points, which sums the taps in the other order -> equal to rounding
+    shapes = [(64, 64), (128, 64), (8, 192), (72, 64)]
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    ws = [torch.randn(3, 3, ci, co, device=DEV, generator=g) for ci, co in shapes]
+    uf = [torch.empty(16 * ci * co, device=DEV) for ci, co in shapes]; ud = [torch.empty(16 * ci * co, device=DEV) for ci, co in shapes]
+    rows, blk = [], 0
+    for (ci, co), w_, a, b in zip(shapes, ws, uf, ud):
+        rows.append([w_.data_ptr(), a.data_ptr(), b.data_ptr(), ci | (co << 32), blk, 0]); blk += (ci * co + 1023) // 1024
+    jobs = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    hip.unet_winograd_weight_transform_batch(P(jobs), len(shapes), blk, ST())
+    for (ci, co), w_, a, b in zip(shapes, ws, uf, ud):
+        ra = torch.empty_like(a); rb = torch.empty_like(b)
+        hip.unet_winograd_weight_transform(P(w_), P(ra), ci, co, 2, ST()); hip.unet_winograd_weight_transform(P(w_), P(rb), ci, co, 3, ST())
+        assert torch.equal(a, ra) and torch.allclose(b, rb, rtol=2e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (2, 32, 48, 64, 128), (1, 6, 10, 72, 64),
                                    (1, 20, 36, 256, 128), (1, 16, 16, 32, 64), (5, 104, 136, 64, 64)])
 def test_conv3x3_winograd_fully_fused_fwd_dgrad(hip, shape):
