@@ -11,6 +11,59 @@ namespace {
 constexpr int CI_CHUNK = 8;
 
 // ---- 3x3 'same' conv, small Cin, forward ---------------------------------------------------------------------
+// Cin = 1..4 (the first layer): the 9*Cin weight quads live in registers and a thread walks a strip of 4 consecutive
+// pixels of one image row, so the 3x6 input window is loaded once per strip and each output quad costs 9*Cin FMAs x 4 plus
+// its store (the generic kernel below spends ~100 instructions per output quad on tap addressing and LDS weight reads,
+// which capped it at 1.5 TB/s of the 6.3 the output stream could take).
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_direct_fwd_strip_kernel(const float* __restrict__ x, int ldx,
+        const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int ldo,
+        int N, int H, int W, int Cout, int relu) {
+    const int tpp = Cout >> 2, spb = 256 / tpp;                   // strips per block pass
+    const int q = threadIdx.x % tpp, sl = threadIdx.x / tpp;
+    f32x4 wr[9][CIN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) wr[t][ci] = *reinterpret_cast<const f32x4*>(w + ((size_t)t * CIN + ci) * Cout + 4 * q);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    const int SW = W >> 2;                                        // strips per row (W % 4 == 0)
+    const long strips = (long)N * H * SW;
+    const float lo = relu ? 0.f : -__builtin_inff();
+    for (long s = (long)blockIdx.x * spb + sl; s < strips; s += (long)gridDim.x * spb) {
+        long t = s; const int sx = (int)(t % SW); t /= SW; const int y = (int)(t % H); const int n = (int)(t / H);
+        const int x0 = 4 * sx;
+        float v[3][6][CIN];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int gy = y + r - 1;
+            const bool rok = (unsigned)gy < (unsigned)H;
+            const float* row = x + ((size_t)(n * H + (rok ? gy : y)) * W) * ldx;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int gx = x0 + c - 1;
+                const bool ok = rok && (unsigned)gx < (unsigned)W;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) v[r][c][ci] = ok ? row[(size_t)gx * ldx + ci] : 0.f;
+            }
+        }
+        float* o = out + ((size_t)(n * H + y) * W + x0) * ldo + 4 * q;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            f32x4 acc = bv;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) acc += v[r][px + c][ci] * wr[3 * r + c][ci];
+            acc[0] = fmaxf(acc[0], lo); acc[1] = fmaxf(acc[1], lo); acc[2] = fmaxf(acc[2], lo); acc[3] = fmaxf(acc[3], lo);
+            *reinterpret_cast<f32x4*>(o + (size_t)px * ldo) = acc;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conv3x3_direct_fwd_kernel(const float* __restrict__ x, int ldx,
         const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int ldo,
         int N, int H, int W, int Cin, int Cout, int relu) {
@@ -90,15 +143,42 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const float* 
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long pix = p0 + pl; pix < p1; pix += npl) {
-        long t = pix; const int xx = (int)(t % W); t /= W; const int y = (int)(t % H); const int n = (int)(t / H);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dz + (size_t)pix * lddz + 4 * q);
+    if ((W & 3) == 0 && (p0 & 3) == 0 && ((p1 - p0) & 3) == 0) {
+        // strips of 4 consecutive pixels of a row: the 3x6 input window is loaded once per strip (the per-pixel form below
+        // spends most of its instructions on tap addressing: 2.2 TB/s of dz instead of ~4.5)
+        for (long pix = p0 + 4 * pl; pix < p1; pix += 4 * npl) {
+            long t = pix; const int x0 = (int)(t % W); t /= W; const int y = (int)(t % H); const int n = (int)(t / H);
+            f32x4 g[4];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int gy = y + tap / 3 - 1, gx = xx + tap % 3 - 1;
-            float xv = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) xv = x[((size_t)(n * H + gy) * W + gx) * ldx + ci];
-            acc[tap] += xv * g;
+            for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const f32x4*>(dz + (size_t)(pix + u) * lddz + 4 * q);
+            float v[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int gy = y + r - 1;
+                const bool rok = (unsigned)gy < (unsigned)H;
+                const float* row = x + ((size_t)(n * H + (rok ? gy : y)) * W) * ldx + ci;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const int gx = x0 + c - 1;
+                    v[r][c] = (rok && (unsigned)gx < (unsigned)W) ? row[(size_t)gx * ldx] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acc[tap] += v[tap / 3][u + tap % 3] * g[u];
+        }
+    } else {
+        for (long pix = p0 + pl; pix < p1; pix += npl) {
+            long t = pix; const int xx = (int)(t % W); t /= W; const int y = (int)(t % H); const int n = (int)(t / H);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dz + (size_t)pix * lddz + 4 * q);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int gy = y + tap / 3 - 1, gx = xx + tap % 3 - 1;
+                float xv = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) xv = x[((size_t)(n * H + gy) * W + gx) * ldx + ci];
+                acc[tap] += xv * g;
+            }
         }
     }
 #pragma unroll
@@ -263,6 +343,15 @@ extern "C" int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, 
     const size_t smem = (size_t)9 * CI_CHUNK * Cout * sizeof(float);
     UNET_CHECK_ARG(smem <= 64 * 1024);
     long blocks = (P + ppb - 1) / ppb; if (blocks > 4096) blocks = 4096;
+    if (Cin <= 4 && W % 4 == 0 && unet_aligned16(w)) {
+        long b1 = (P / 4 + ppb - 1) / ppb; if (b1 > 4096) b1 = 4096;
+        hipStream_t st = (hipStream_t)stream;
+        if (Cin == 1)      conv3x3_direct_fwd_strip_kernel<1><<<(int)b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu);
+        else if (Cin == 2) conv3x3_direct_fwd_strip_kernel<2><<<(int)b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu);
+        else if (Cin == 3) conv3x3_direct_fwd_strip_kernel<3><<<(int)b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu);
+        else               conv3x3_direct_fwd_strip_kernel<4><<<(int)b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu);
+        return UNET_LAUNCH_STATUS();
+    }
     conv3x3_direct_fwd_kernel<<<(int)blocks, 256, smem, (hipStream_t)stream>>>(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, relu);
     return UNET_LAUNCH_STATUS();
 }
@@ -281,7 +370,7 @@ extern "C" int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float*
     const long P = (long)N * H * W;
     const int blocks = direct_wgrad_blocks(P);
     if (ws_bytes < unet_conv3x3_wgrad_direct_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
-    const long ppb = (P + blocks - 1) / blocks;
+    const long ppb = ((P + blocks - 1) / blocks + 3) & ~3L;         // multiple of 4: a block's range is whole 4-pixel strips
     const size_t smem = (size_t)(256 / tpp) * 9 * Cout * sizeof(float);
     UNET_CHECK_ARG(smem <= 64 * 1024);
     conv3x3_direct_wgrad_kernel<<<dim3(blocks, Cin), 256, smem, (hipStream_t)stream>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cin, Cout, ppb);

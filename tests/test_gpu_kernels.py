@@ -149,9 +149,10 @@ def test_convT2x2_fwd_dgrad_wgrad(hip, shape):
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 2e-5
 
 
-@pytest.mark.parametrize("cin", [1, 3])
-def test_first_layer_direct_conv(hip, cin):
-    n, h, w, co = 2, 18, 21, 64
+@pytest.mark.parametrize("cin,w", [(1, 21), (3, 21), (1, 24), (2, 24), (3, 24), (4, 24), (5, 24)])
+def test_first_layer_direct_conv(hip, cin, w):
+    # w % 4 == 0 with cin <= 4 takes the strip kernels (4 pixels per thread, weights in registers), the rest the generic ones
+    n, h, co = 2, 18, 64
     rng = np.random.default_rng(cin)
     x = rng.standard_normal((n, cin, h, w)); wt = rng.standard_normal((3, 3, cin, co)); b = rng.standard_normal(co)
     dz = rng.standard_normal((n, co, h, w))
