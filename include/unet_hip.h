@@ -45,7 +45,7 @@ int unet_winograd_supported(int N, int H, int W, int Cin, int Cout);
 int unet_winograd_weight_transform(const float* w, float* U, int Cin, int Cout, int mode, void* stream);
 /* every fused-route layer's forward (mode 2) and data-gradient (mode 3) transform in one launch.  jobs: device array of
  * njobs x 6 int64 = { w, Uc_fwd, Uc_dgrad, Cin | Cout << 32, first_block, 0 }, first_block = running sum of
- * ceil(Cin*Cout / 1024); total_blocks = that sum over all jobs.  Cin, Cout multiples of 8. */
+ * ceil(Cin*Cout / 2048); total_blocks = that sum over all jobs.  Cin, Cout multiples of 8. */
 int unet_winograd_weight_transform_batch(const void* jobs, int njobs, int total_blocks, void* stream);
 size_t unet_conv3x3_winograd_workspace(int N, int H, int W, int Cin, int Cout);
 /* V_keep (nullable, 16*T*Cin floats, T = N*H/2*W/2): where to leave the transformed input for the weight gradient */

@@ -66,14 +66,17 @@ __global__ __launch_bounds__(256) void wino_weight_batch_kernel(const long long*
     float* __restrict__ uf = reinterpret_cast<float*>(jobs[j * 6 + 1]);
     float* __restrict__ ud = reinterpret_cast<float*>(jobs[j * 6 + 2]);
     const int Ci = (int)(jobs[j * 6 + 3] & 0xffffffffll), Co = (int)(jobs[j * 6 + 3] >> 32);
-    const long total = (long)Ci * Co;
-    const size_t plane = (size_t)total;
-    const long base = ((long)blockIdx.x - (int)jobs[j * 6 + 4]) * 1024;
+    const size_t plane = (size_t)Ci * Co;
+    // one thread = 8 consecutive input channels x one output channel: the forward layout [ci/8][co][8] gets 32-byte runs
+    // (adjacent threads = adjacent co = adjacent runs), the data-gradient layout [co/8][ci][8] gets 8 lanes x 4 bytes
+    const long items = (long)(Ci >> 3) * Co;
+    const long it = ((long)blockIdx.x - (int)jobs[j * 6 + 4]) * 256 + threadIdx.x;
+    if (it >= items) return;
+    const int c8 = (int)(it / Co), co = (int)(it % Co);
+    float t[16][8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const long i = base + u * 256 + threadIdx.x;
-        if (i >= total) break;
-        const int ci = (int)(i / Co), co = (int)(i % Co);
+    for (int e = 0; e < 8; ++e) {
+        const int ci = 8 * c8 + e;
         float g[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -87,19 +90,23 @@ __global__ __launch_bounds__(256) void wino_weight_batch_kernel(const long long*
             s[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
             s[3][b] = g[2][b];
         }
-        const size_t offf = ((size_t)(ci >> 3) * Co + co) * 8 + (ci & 7);             // [k/8][n=co][k%8]
-        const size_t offd = ((size_t)(co >> 3) * Ci + ci) * 8 + (co & 7);             // [k/8][n=ci][k%8]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float t[4] = {s[r][0], 0.5f * (s[r][0] + s[r][1] + s[r][2]), 0.5f * (s[r][0] - s[r][1] + s[r][2]), s[r][2]};
-            const int rp = r == 0 ? 3 : (r == 3 ? 0 : r);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int cp = c == 0 ? 3 : (c == 3 ? 0 : c);
-                uf[(size_t)(4 * r + c) * plane + offf] = t[c];
-                ud[(size_t)(4 * rp + cp) * plane + offd] = t[c];
-            }
+            t[4 * r + 0][e] = s[r][0]; t[4 * r + 1][e] = 0.5f * (s[r][0] + s[r][1] + s[r][2]);
+            t[4 * r + 2][e] = 0.5f * (s[r][0] - s[r][1] + s[r][2]); t[4 * r + 3][e] = s[r][2];
         }
+    }
+    const size_t offf = ((size_t)c8 * Co + co) * 8;                                   // [k/8][n=co][k%8]
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+        float* o = uf + (size_t)xi * plane + offf;
+        *reinterpret_cast<f32x4*>(o) = f32x4{t[xi][0], t[xi][1], t[xi][2], t[xi][3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{t[xi][4], t[xi][5], t[xi][6], t[xi][7]};
+        const int r = xi >> 2, c = xi & 3;
+        const int xp = 4 * (r == 0 ? 3 : (r == 3 ? 0 : r)) + (c == 0 ? 3 : (c == 3 ? 0 : c));
+        float* od = ud + (size_t)xp * plane + ((size_t)(co >> 3) * Ci + 8 * c8) * 8 + (co & 7);     // [k/8][n=ci][k%8]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) od[e * 8] = t[xi][e];
     }
 }
 

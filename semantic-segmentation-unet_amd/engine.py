@@ -194,7 +194,7 @@ class Engine:
                      torch.empty(16 * cin * cout, dtype=torch.float32, device=self.dev))
                 self._fused_U[n] = u
                 rows.append([self.p[n + "/kernel"].data_ptr(), u[0].data_ptr(), u[1].data_ptr(), cin | (cout << 32), blk, 0])
-                blk += (cin * cout + 1023) // 1024
+                blk += (cin * cout + 2047) // 2048
             self._fused_jobs = torch.tensor(rows, dtype=torch.int64, device=self.dev)
             self._fused_blocks = blk
             self._fused_dirty = True

@@ -396,7 +396,7 @@ def test_winograd_weight_transform_batch_matches_single(hip):
     uf = [torch.empty(16 * ci * co, device=DEV) for ci, co in shapes]; ud = [torch.empty(16 * ci * co, device=DEV) for ci, co in shapes]
     rows, blk = [], 0
     for (ci, co), w_, a, b in zip(shapes, ws, uf, ud):
-        rows.append([w_.data_ptr(), a.data_ptr(), b.data_ptr(), ci | (co << 32), blk, 0]); blk += (ci * co + 1023) // 1024
+        rows.append([w_.data_ptr(), a.data_ptr(), b.data_ptr(), ci | (co << 32), blk, 0]); blk += (ci * co + 2047) // 2048
     jobs = torch.tensor(rows, dtype=torch.int64, device=DEV)
     hip.unet_winograd_weight_transform_batch(P(jobs), len(shapes), blk, ST())
     for (ci, co), w_, a, b in zip(shapes, ws, uf, ud):
