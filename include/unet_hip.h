@@ -91,6 +91,11 @@ int unet_conv1x1_wgrad(const float* xin, int ldx, const float* dz, int lddz, flo
 /* N,H,W = INPUT dims of the layer; output is [N,2H,2W,Cout].  Needs Cin % 64 == 0 and Cout % 64 == 0. */
 int unet_convT2x2_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                       int N, int H, int W, int Cin, int Cout, void* stream);
+/* same result from the persistent stream kernel (convt_stream.hip): Cin % 32 == 0, Cout % 64 == 0, N*H*W a multiple of the
+ * 128 (Cout % 128 == 0) or 256 pixel tile, ldo % 4 == 0 */
+int unet_convT2x2_fwd_stream_supported(int N, int H, int W, int Cin, int Cout);
+int unet_convT2x2_fwd_stream(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                             int N, int H, int W, int Cin, int Cout, void* stream);
 int unet_convT2x2_dgrad(const float* dz, int lddz, const float* w, float* dx, int lddx,
                         int N, int H, int W, int Cin, int Cout, void* stream);
 size_t unet_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);

@@ -271,7 +271,10 @@ class Engine:
         w_, b_ = self.p[name + "/kernel"], self.p[name + "/bias"]
         if kind == "deconv":
             r = self._buf("r_" + name, (n, 2 * h, 2 * w, cout))
-            L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, st)
+            if L.unet_convT2x2_fwd_stream_supported(n, h, w, cin, cout) == 1 and _ld(x) <= 4096:
+                L.unet_convT2x2_fwd_stream(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, st)    # persistent stream kernel
+            else:
+                L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, st)
         elif kind == "conv1":
             r = self._buf("r_" + name, (n, h, w, cout))
             L.unet_conv1x1_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)

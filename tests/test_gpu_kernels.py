@@ -149,6 +149,28 @@ def test_convT2x2_fwd_dgrad_wgrad(hip, shape):
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 16, 128, 128), (1, 16, 16, 64, 64), (4, 8, 16, 32, 192), (8, 32, 32, 1024, 512), (8, 256, 256, 128, 64)])
+def test_convT2x2_fwd_stream_matches_igemm_and_oracle(hip, shape):
+    # persistent stream kernel for the transposed-conv forward: bit-level agreement is not expected (different summation
+    # order), so compare with the first kernel at 2e-5 and, on the small shapes, with the fp64 oracle; the last two shapes are
+    # BASELINE config-2 layers (up_4, up_1): 2-8 tiles per workgroup, 128 / 16 chunks per tile
+    n, h, w, ci, co = shape
+    assert hip.unet_convT2x2_fwd_stream_supported(n, h, w, ci, co) == 1
+    g = torch.Generator(device=DEV); g.manual_seed(ci + co + h)
+    x = torch.randn(n, h, w, ci + 4, device=DEV, generator=g)[..., :ci]                  # ld = ci + 4
+    wt = torch.randn(2, 2, co, ci, device=DEV, generator=g) / float(np.sqrt(ci)); b = torch.randn(co, device=DEV, generator=g)
+    cat = torch.zeros(n, 2 * h, 2 * w, 2 * co, device=DEV)
+    out = cat[..., co:]
+    hip.unet_convT2x2_fwd_stream(P(x), ci + 4, P(wt), P(b), P(out), 2 * co, n, h, w, ci, co, ST())
+    ref = torch.empty(n, 2 * h, 2 * w, co, device=DEV)
+    hip.unet_convT2x2_fwd(P(x), ci + 4, P(wt), P(b), P(ref), co, n, h, w, ci, co, ST())
+    assert ((out - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    assert cat[..., :co].abs().max().item() == 0
+    if n * h * w * ci * co < 5e7:
+        z_ref = on.deconv2x2_fwd(from_nhwc(x.contiguous()), wt.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64))
+        assert relerr(from_nhwc(out), z_ref) < 2e-5
+
+
 @pytest.mark.parametrize("cin,w", [(1, 21), (3, 21), (1, 24), (2, 24), (3, 24), (4, 24), (5, 24)])
 def test_first_layer_direct_conv(hip, cin, w):
     # w % 4 == 0 with cin <= 4 takes the strip kernels (4 pixels per thread, weights in registers), the rest the generic ones
