@@ -149,6 +149,25 @@ int unet_adam_keras(float* theta, const float* grad, float* m, float* v, long n,
 
 /* ---- reference input contract is NCHW (UNet/model.py:73; UNet/imagereader.py:298) -------------------------------- */
 int unet_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
+/* ---- augmentation stage, UNet/augment.py:19-174, batched over N images [N][H][W][C] fp32 ------------
+ * warp: skimage rotate / warp(order 1, mode='reflect') -- output pixel (r, c) samples src at mats[n] . (c, r, 1), mats = N x 6
+ *       floats (rows 0 and 1 of the output->input matrix); flips[n] bit 0 = left-right, bit 1 = up-down flip of the warped image
+ *       (NULL = none); round_output = np.round of the result (the mask path).  src != dst.
+ * gaussian_blur: scipy.ndimage.gaussian_filter(sigma, mode='reflect') along H, W and C (in place, tmp same size); sigmas[n] <= 0
+ *       leaves image n unchanged.
+ * minmax: per-image (min, max) -> minmax[N][2].
+ * noise_intensity: img += field * (coef_noise[n] * range_n) + coef_add[n] * range_n, range_n = max - min from minmax. */
+int unet_augment_warp(const float* src, float* dst, int N, int H, int W, int C, const float* mats, const int* flips,
+                      int round_output, void* stream);
+int unet_augment_gaussian_blur(float* img, float* tmp, int N, int H, int W, int C, const float* sigmas, void* stream);
+size_t unet_augment_minmax_workspace(int N);
+int unet_augment_minmax(const float* img, int N, long elems_per_image, float* minmax, void* ws, size_t ws_bytes, void* stream);
+int unet_augment_noise_intensity(float* img, const float* field, int N, long elems_per_image, const float* minmax,
+                                 const float* coef_noise, const float* coef_add, void* stream);
+/* reader contract, UNet/imagereader.py:33-49,298-301: per-(image, channel) z-score ((x - mean) / std, only x - mean when
+ * std <= 1) of img [N][H][W][C], written as the network's [N][C][H][W] input */
+size_t unet_zscore_workspace(int N, int C);
+int unet_zscore_nhwc_to_nchw(const float* img, float* out, int N, int H, int W, int C, void* ws, size_t ws_bytes, void* stream);
 /* reader output contract, UNet/imagereader.py:302-312,353-355: class map [P] (uint8) -> one-hot int32 [P][K] on the device,
  * so the feed ships 1 byte per pixel instead of 4K; *out_of_range (may be NULL, else zeroed by the caller) counts labels >= K,
  * the condition the reference raises IndexError for */

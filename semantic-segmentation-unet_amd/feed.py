@@ -27,11 +27,12 @@ import torch
 
 
 class DeviceFeed:
-    def __init__(self, batches, device, depth=3, classmap=False, number_classes=None):
+    def __init__(self, batches, device, depth=3, classmap=False, number_classes=None, onehot=True):
         assert depth >= 2
         self.dev = torch.device(device)
         self.cuda = self.dev.type == "cuda"
         self.depth, self.classmap, self.k = depth, classmap, number_classes
+        self.onehot = onehot                      # False (classmap feeds only): hand out the uint8 class map itself
         if classmap:
             assert number_classes is not None and 0 < number_classes <= 256
         self._its = [iter(b) for b in batches] if isinstance(batches, (list, tuple)) else [iter(batches)]
@@ -66,7 +67,7 @@ class DeviceFeed:
                 sl["pin_img"] = sl["pin_img"].pin_memory(); sl["pin_lab"] = sl["pin_lab"].pin_memory()
                 sl["dev_img"] = torch.empty(img.shape, dtype=torch.float32, device=self.dev)
                 sl["dev_lab"] = torch.empty(lab.shape, dtype=lab.dtype, device=self.dev)
-                if self.classmap:
+                if self.classmap and self.onehot:
                     sl["dev_onehot"] = torch.empty(tuple(lab.shape) + (self.k,), dtype=torch.int32, device=self.dev)
                 sl["ready"] = torch.cuda.Event(); sl["done"] = None
             self._slots[s] = sl
@@ -104,7 +105,7 @@ class DeviceFeed:
                     with torch.cuda.stream(self._copy):
                         sl["dev_img"].copy_(sl["pin_img"], non_blocking=True)
                         sl["dev_lab"].copy_(sl["pin_lab"], non_blocking=True)
-                        if self.classmap:
+                        if self.classmap and self.onehot:
                             n = sl["dev_lab"].numel()
                             self._L.unet_labels_onehot(ctypes.c_void_p(sl["dev_lab"].data_ptr()), ctypes.c_void_p(sl["dev_onehot"].data_ptr()),
                                                        n, self.k, ctypes.c_void_p(self._bad.data_ptr()),
@@ -135,13 +136,13 @@ class DeviceFeed:
         sl = self._slots[s]
         if not self.cuda:
             lab = sl["pin_lab"]
-            if self.classmap:
+            if self.classmap and self.onehot:
                 if int(lab.max()) >= self.k:
                     raise IndexError("Number of classes specified differs from number of observed classes in data")
                 lab = torch.nn.functional.one_hot(lab.long(), self.k).to(torch.int32)
             return sl["pin_img"].clone(), lab.clone()
         torch.cuda.current_stream(self.dev).wait_event(sl["ready"])
-        return sl["dev_img"], (sl["dev_onehot"] if self.classmap else sl["dev_lab"])
+        return sl["dev_img"], (sl["dev_onehot"] if self.classmap and self.onehot else sl["dev_lab"])
 
     def out_of_range_labels(self):
         """Number of class-map pixels >= number_classes seen so far (host sync; the reference raises IndexError per batch)."""

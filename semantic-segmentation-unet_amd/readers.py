@@ -56,7 +56,7 @@ class SyntheticReader(_Base):
     def get_image_size(self):
         return (self.h, self.w, self.c)
 
-    def batches(self, batch_size, classmap=False, pin=True):
+    def batches(self, batch_size, classmap=False, pin=True, raw=False):       # (raw: the synthetic tiles are N(0,1) either way)
         g = torch.Generator().manual_seed(self.seed)
         pin_ = _pin if pin else (lambda t: t)
         while True:
@@ -87,17 +87,19 @@ class TileFolderReader(_Base):
     def get_image_size(self):
         return (self.h, self.w, self.c)
 
-    def _load(self, name, classmap=False):
+    def _load(self, name, classmap=False, raw=False):
         im = np.load(os.path.join(self.folder, name + ".npy"))
         im = im[..., None] if im.ndim == 2 else im
         mk = np.load(os.path.join(self.folder, name + "_mask.npy"))
         if classmap:
             if mk.max(initial=0) >= self.k or mk.min(initial=0) < 0:
                 raise IndexError("Number of classes specified differs from number of observed classes in data")
-            return zscore_normalize(im.transpose(2, 0, 1)), mk.astype(np.uint8)
+            chw = im.transpose(2, 0, 1)
+            return (np.ascontiguousarray(chw, dtype=np.float32) if raw else zscore_normalize(chw)), mk.astype(np.uint8)
         return zscore_normalize(im.transpose(2, 0, 1)), one_hot(mk, self.k)
 
-    def batches(self, batch_size, classmap=False, pin=True):
+    def batches(self, batch_size, classmap=False, pin=True, raw=False):
+        """raw=True (with classmap=True): un-normalised pixel values, for the device pipeline that augments before z-scoring"""
         pin_ = _pin if pin else (lambda t: t)
         rng = np.random.default_rng(self.seed)
         pos = 0
@@ -107,7 +109,7 @@ class TileFolderReader(_Base):
             for _ in range(batch_size):
                 if pos == 0 and self.shuffle:
                     rng.shuffle(order)
-                i, l = self._load(self.names[order[pos]], classmap)
+                i, l = self._load(self.names[order[pos]], classmap, raw)
                 imgs.append(i); labs.append(l)
                 pos = (pos + 1) % len(order)
             yield pin_(torch.as_tensor(np.stack(imgs))), pin_(torch.as_tensor(np.stack(labs)))

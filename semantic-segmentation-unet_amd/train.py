@@ -87,7 +87,18 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
         if use_feed:
             from .feed import DeviceFeed
             dev_ = torch.device("cuda", local)
-            train_batches = DeviceFeed(train_reader.batches(batch_size, classmap=True, pin=False), dev_, classmap=True, number_classes=number_classes)
+            if use_augmentation:
+                # the reference augments inside its reader processes (UNet/imagereader.py:283-301, settings :79-85), ~31 images/s
+                # per host core; here the raw tiles go to the device and the same sequence runs as HIP kernels (augment.py)
+                from .augment import AugmentingFeed, DeviceAugmenter
+                raw_feed = DeviceFeed(train_reader.batches(batch_size, classmap=True, pin=False, raw=True), dev_, classmap=True,
+                                      number_classes=number_classes, onehot=False)
+                train_batches = AugmentingFeed(raw_feed, DeviceAugmenter(
+                    rotation_flag=True, reflection_flag=True, jitter_augmentation_severity=0.1, noise_augmentation_severity=0.02,
+                    scale_augmentation_severity=0.1, blur_augmentation_max_sigma=2, intensity_augmentation_severity=None,
+                    seed=rank, device=dev_), number_classes)
+            else:
+                train_batches = DeviceFeed(train_reader.batches(batch_size, classmap=True, pin=False), dev_, classmap=True, number_classes=number_classes)
             test_batches = DeviceFeed(test_reader.batches(batch_size, classmap=True, pin=False), dev_, classmap=True, number_classes=number_classes)
             feeds = [train_batches, test_batches]
         else:
