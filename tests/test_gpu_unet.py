@@ -181,3 +181,33 @@ def test_input_gradient_and_estimate_radius_match_oracle():
     r_hip = net.estimate_radius(probe)
     r_ref = ref.estimate_radius(probe)
     assert r_hip % 16 == 0 and r_hip == r_ref, (r_hip, r_ref)
+
+
+def test_full_size_train_step_properties():
+    # BASELINE config 2 (512x512x1, 2 classes, batch 8) is too large for the oracle; size-independent properties instead:
+    #  * two engines with the same seed and the same device-RNG dropout stream run bit-identical steps (every reduction has a
+    #    fixed order, the side-stream weight gradients included);
+    #  * the eval-mode forward of the trained net gives a proper softmax whose argmax (device kernel) equals torch's on the
+    #    same probabilities;
+    #  * the loss of a fixed batch falls; the loss equals the mean pixel cross-entropy recomputed from the softmax
+    n, c, k, hw = 8, 1, 2, 512
+    model = pkg("model")
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(n, c, hw, hw, generator=g)
+    cls = torch.randint(0, k, (n, hw // 8, hw // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    lab = torch.nn.functional.one_hot(cls, k).to(torch.int32)
+    runs = []
+    for _ in range(2):
+        net = model.UNet(k, n, c, learning_rate=1e-3, seed=0)
+        losses = [float(net.train_step((img.cuda(), lab.cuda(), None, None)).numpy()) for _ in range(6)]
+        runs.append((losses, net.engine.theta.clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    losses = runs[0][0]
+    assert all(np.isfinite(losses)) and min(losses[-2:]) < losses[0]
+    e = net.engine
+    prob = e.forward(img.cuda(), training=False, labels=lab.cuda(), global_batch_size=n)
+    assert tuple(prob.shape) == (n, hw, hw, k)
+    assert (prob.sum(-1) - 1).abs().max().item() < 1e-5 and prob.min().item() >= 0
+    assert torch.equal(e.argmax(prob).long(), prob.argmax(-1))
+    ce = -(torch.log(prob.double().clamp_min(1e-30)) * lab.cuda().double()).sum(-1).mean().item()
+    assert abs(float(e.loss_buf[0].item()) - ce) < 1e-5 * max(1.0, abs(ce))
