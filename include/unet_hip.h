@@ -59,6 +59,12 @@ int unet_conv3x3_dgrad_winograd(const float* dz, int lddz, const float* Ud, floa
  * output channels % 64 */
 int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
                                     int N, int H, int W, int Cin, int Cout, int relu, void* stream);
+/* forward + BatchNorm statistics of its output in one kernel (saves one full read of the activation per layer): rows > 0 when the
+ * persistent kernel takes the shape; stat_part holds (Cout/64) * rows * 128 floats; finish with unet_bn_train_finalize_partials */
+int unet_conv3x3_fwd_winograd_fused_stats_rows(int N, int H, int W, int Cin, int Cout);
+int unet_conv3x3_fwd_winograd_fused_stats(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
+                                          int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes,
+                                          void* stream);
 int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
                                       int N, int H, int W, int Cin, int Cout, void* stream);
 /* fused Winograd weight gradient: raw rows through LDS, per-lane transforms in registers, G^T dU G in the epilogue;
@@ -109,6 +115,10 @@ size_t unet_bn_workspace(long P, int C);
 int unet_bn_train_stats(const float* r, int ldr, long P, int C, const float* gamma, const float* beta,
                         float eps, float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
                         float* mean, float* invstd, float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
+/* the same outputs as unet_bn_train_stats from the partial sums written by unet_conv3x3_fwd_winograd_fused_stats */
+int unet_bn_train_finalize_partials(const float* part, int rows, long P, int C, const float* gamma, const float* beta,
+                                    float eps, float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
+                                    float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* training=False (UNet/model.py:239, UNet/inference.py:105,164): coefficients from the moving statistics */
 int unet_bn_eval_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                         float eps, int C, float* scale, float* shift, void* stream);

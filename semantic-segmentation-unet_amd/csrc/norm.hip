@@ -106,6 +106,30 @@ __global__ __launch_bounds__(64) void bn_train_finalize_kernel(const double* __r
     }
 }
 
+// training statistics from the partials the fused conv kernel wrote (winograd.hip, wf_write_stats): part[C/64][rows][64][2]
+__global__ __launch_bounds__(64) void bn_train_finalize_partials_kernel(const float* __restrict__ part, int rows, long P, int C,
+        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, int unbiased,
+        float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x;
+    const float* base = part + ((size_t)(c >> 6) * rows * 64 + (c & 63)) * 2;
+    double s = 0.0, ss = 0.0;
+    for (int k = threadIdx.x; k < rows; k += 64) { s += (double)base[(size_t)k * 128]; ss += (double)base[(size_t)k * 128 + 1]; }
+    s = wave_sum(s); ss = wave_sum(ss);
+    if (threadIdx.x != 0) return;
+    const double m = s / (double)P;
+    double var = ss / (double)P - m * m;
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    mean[c] = (float)m; invstd[c] = (float)inv;
+    const double a = (double)gamma[c] * inv;
+    scale[c] = (float)a; shift[c] = (float)((double)beta[c] - m * a);
+    if (moving_mean) {
+        const double uv = (unbiased && P > 1) ? var * ((double)P / (double)(P - 1)) : var;
+        moving_mean[c] = (float)((double)moving_mean[c] * momentum + m * (1.0 - (double)momentum));
+        moving_var[c] = (float)((double)moving_var[c] * momentum + uv * (1.0 - (double)momentum));
+    }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float eps,
                                       int C, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,6 +305,16 @@ extern "C" int unet_bn_train_stats(const float* r, int ldr, long P, int C, const
     else             bn_stats_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(r, ldr, P, C, pl.tpp, pl.ppb, part);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     bn_train_finalize_kernel<<<C, 64, 0, st>>>(part, pl.nblk, P, C, gamma, beta, eps, momentum,
+        unbiased_moving_var, moving_mean, moving_var, mean, invstd, scale, shift);
+    return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_bn_train_finalize_partials(const float* part, int rows, long P, int C, const float* gamma, const float* beta,
+        float eps, float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
+        float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    UNET_CHECK_ARG(part && rows > 0 && P > 0 && C > 0 && C % 64 == 0 && gamma && beta && mean && invstd && scale && shift);
+    UNET_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
+    bn_train_finalize_partials_kernel<<<C, 64, 0, (hipStream_t)stream>>>(part, rows, P, C, gamma, beta, eps, momentum,
         unbiased_moving_var, moving_mean, moving_var, mean, invstd, scale, shift);
     return UNET_LAUNCH_STATUS();
 }

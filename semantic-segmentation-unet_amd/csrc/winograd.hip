@@ -369,6 +369,7 @@ struct WinoFusedArgs {
     const float* x; const float* Uc; const float* bias; float* out;
     int ldx, ldo, N, H, W, K, Nout, relu;
     int tbx, tby, nt;            // tile-block grid
+    float* stat_part;            // BatchNorm statistics of the output (persistent kernel only), see wf_write_stats; or null
 };
 typedef __attribute__((address_space(3))) void lds_void_f;
 constexpr int kWinoFusedMaxK = 4096;
@@ -496,8 +497,12 @@ __device__ __forceinline__ void wf_load_bias(const WinoFusedArgs& p, int n0, int
         if (p.bias) bias4[g] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * ni + 4 * lh + 8 * g);
     }
 }
+// STATS: also accumulate, per lane, the sum and the sum of squares of the stored values per channel pair (s1 / s2 [2g + h]):
+// the BatchNorm that follows the layer (UNet/model.py:36) needs exactly these over all pixels, and this is the only place
+// the values pass through registers anyway (saves a full read of the activation tensor per layer).
+template <bool STATS>
 __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[16], const WinoFusedArgs& p, int img, int by, int bx, int n0,
-                                            int mi, int ni, int li, int lh, const f32x4 (&bias4)[4]) {
+                                            int mi, int ni, int li, int lh, const f32x4 (&bias4)[4], f32x2 (&s1)[8], f32x2 (&s2)[8]) {
     const int lt = 32 * mi + li;
     const int ty = 8 * by + (lt >> 3), tx = 8 * bx + (lt & 7);
     if (ty >= (p.H >> 1) || tx >= (p.W >> 1)) return;
@@ -533,6 +538,10 @@ __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[16], const WinoF
                 f32x2 y0 = (rr[i][0] + b2) + s12, y1 = wf_pk_sub(d12 + b2, rr[i][3]);
                 y[i][0][h] = f32x2{fmaxf(y0.x, lo), fmaxf(y0.y, lo)}; y[i][1][h] = f32x2{fmaxf(y1.x, lo), fmaxf(y1.y, lo)};
             }
+            if (STATS) {
+                s1[2 * g + h] += (y[0][0][h] + y[0][1][h]) + (y[1][0][h] + y[1][1][h]);
+                s2[2 * g + h] += (y[0][0][h] * y[0][0][h] + y[0][1][h] * y[0][1][h]) + (y[1][0][h] * y[1][0][h] + y[1][1][h] * y[1][1][h]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -542,6 +551,28 @@ __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[16], const WinoF
         __builtin_amdgcn_sched_barrier(0);        // one channel quad at a time: hoisting all 256 accumulator reads costs spills
     }
 }
+// Per-lane running sums -> one row of partials per wave.  A persistent workgroup only ever sees ONE 64-channel output tile
+// (tile ids advance by gridDim.x, a multiple of nt), so the sums run over all its tiles and are reduced across the 32 lanes
+// of a half-wave once, at the end.  Layout: stat_part[tn][row][64 channels][2], row = 2 * (first tile / nt) + mi.
+__device__ __forceinline__ void wf_write_stats(const WinoFusedArgs& p, int t0, int rows_per_tn, int mi, int ni, int li, int lh,
+                                               f32x2 (&s1)[8], f32x2 (&s2)[8]) {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[4 * i] = s1[i].x; v[4 * i + 1] = s1[i].y; v[4 * i + 2] = s2[i].x; v[4 * i + 3] = s2[i].y; }
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) v[i] += __shfl_xor(v[i], m, 32);
+    if (li != 0) return;
+    const int tn = t0 % p.nt, row = 2 * (t0 / p.nt) + mi;
+    float* o = p.stat_part + ((size_t)tn * rows_per_tn + row) * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                       // pair i = 2g + h -> channels 32*ni + 8g + 4lh + 2h + {0,1}
+        const int ch = 32 * ni + 8 * (i >> 1) + 4 * lh + 2 * (i & 1);
+        o[2 * ch] = v[4 * i]; o[2 * ch + 1] = v[4 * i + 2]; o[2 * ch + 2] = v[4 * i + 1]; o[2 * ch + 3] = v[4 * i + 3];
+    }
+}
+
 __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
     constexpr int DPIX = 18 * 18, DPIECES = 12, DFL = DPIECES * 256;       // D image padded to 3 1-KB DMA pieces per wave
     constexpr int IMG = 16 * 64 * 8;
@@ -658,7 +689,8 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wf_t2) :: "memory");
 #endif
 
-    wf_epilogue(acc, p, img, by, bx, n0, mi, ni, li, lh, bias4);
+    f32x2 s1u[8], s2u[8];
+    wf_epilogue<false>(acc, p, img, by, bx, n0, mi, ni, li, lh, bias4, s1u, s2u);
 #if UNET_ABLATE == 8
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (blockIdx.x == 0 && tid == 0) {
@@ -674,7 +706,8 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
 // instead of idling, so only the first tile of a workgroup pays the two DMA round trips of the prologue, and there is no
 // launch gap between tiles (with 152 KB of LDS a CU holds one workgroup, so nothing else would hide either).  A tile's first
 // chunk starts its accumulators from C = 0.
-__global__ __launch_bounds__(256, 1) void wino_fused_stream_kernel(WinoFusedArgs p, int ntiles) {
+template <bool STATS>
+__device__ __forceinline__ void wino_fused_stream_body(const WinoFusedArgs& p, int ntiles) {
     constexpr int DPIX = 18 * 18, DPIECES = 12, DFL = DPIECES * 256;
     constexpr int IMG = 16 * 64 * 8;
     constexpr int DB = kWfDB, IB = kWfIB;
@@ -745,6 +778,10 @@ __global__ __launch_bounds__(256, 1) void wino_fused_stream_kernel(WinoFusedArgs
 #if UNET_ABLATE != 9
     if ((gridDim.x & 7) == 0 && (p.nt & 7) != 0) t = (t & 7) * (int)(gridDim.x >> 3) + (t >> 3);
 #endif
+    const int t_first = t;
+    f32x2 s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = f32x2{0.f, 0.f}; s2[i] = f32x2{0.f, 0.f}; }
     TileCoord tc = decode(t);
     tile_sources(tc, dcur, ucur);
 
@@ -806,7 +843,7 @@ __global__ __launch_bounds__(256, 1) void wino_fused_stream_kernel(WinoFusedArgs
         WF_STAMP(q1);
 #endif
 
-        wf_epilogue(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, bias4);
+        wf_epilogue<STATS>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, bias4, s1, s2);
 #pragma unroll
         for (int k = 0; k < 3; ++k) dcur[k] = dnxt[k];
         ucur = unxt; tc = tcn;
@@ -821,7 +858,11 @@ __global__ __launch_bounds__(256, 1) void wino_fused_stream_kernel(WinoFusedArgs
         for (int i = 0; i < 4; ++i) g_wf_timeline[4 + i] = tl[i];
     }
 #endif
+    if (STATS) wf_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), mi, ni, li, lh, s1, s2);
 }
+// (plain kernels around the templated body: the host-side stub of a kernel TEMPLATE containing this inline asm is not emitted)
+__global__ __launch_bounds__(256, 1) void wino_fused_stream_kernel(WinoFusedArgs p, int ntiles) { wino_fused_stream_body<false>(p, ntiles); }
+__global__ __launch_bounds__(256, 1) void wino_fused_stream_stats_kernel(WinoFusedArgs p, int ntiles) { wino_fused_stream_body<true>(p, ntiles); }
 
 // ---- fully fused Winograd weight gradient ----------------------------------------------------------------------------
 //   dW = G^T [ sum_tiles (B^T d B)[xi][ci] * (A dY A^T)[xi][co] ] G
@@ -1104,18 +1145,38 @@ int run_wino(const float* x, int ldx, const float* U, const float* bias, float* 
     return UNET_LAUNCH_STATUS();
 }
 
+int wino_stream_cus() {
+    static const int cus = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256; return n; }();
+    return cus;
+}
+bool wino_stream_enabled() {
+    static const bool ok = [] { const char* e = getenv("UNET_WINO_STREAM"); return !(e && e[0] == '0'); }();   // A/B switch
+    return ok;
+}
+// rows of statistics partials per 64-channel tile the persistent kernel would write (0: shape not taken by it / grid not a
+// multiple of the n-tile count)
+int wino_stats_rows(int N, int H, int W, int K, int Nout) {
+    if (!(wino_stream_enabled() && K % 16 == 0 && K >= 32 && H % 2 == 0 && W % 2 == 0 && Nout % 64 == 0)) return 0;
+    const int nt = Nout / 64;
+    const long blocks = (long)N * ((H / 2 + 7) / 8) * ((W / 2 + 7) / 8) * nt;
+    const long grid = blocks < wino_stream_cus() ? blocks : wino_stream_cus();
+    return grid % nt == 0 ? (int)(2 * (grid / nt)) : 0;
+}
+
 int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo, int N, int H, int W,
-                   int K, int Nout, int relu, hipStream_t st) {
+                   int K, int Nout, int relu, float* stat_part, hipStream_t st) {
     WinoFusedArgs a{};
     a.x = x; a.Uc = Uc; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo; a.N = N; a.H = H; a.W = W; a.K = K; a.Nout = Nout; a.relu = relu;
-    a.tby = (H / 2 + 7) / 8; a.tbx = (W / 2 + 7) / 8; a.nt = Nout / 64;
+    a.tby = (H / 2 + 7) / 8; a.tbx = (W / 2 + 7) / 8; a.nt = Nout / 64; a.stat_part = stat_part;
     const long blocks = (long)N * a.tby * a.tbx * a.nt;
     if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
-    static const bool stream_ok = [] { const char* e = getenv("UNET_WINO_STREAM"); return !(e && e[0] == '0'); }();   // A/B switch
-    if (stream_ok && K % 16 == 0 && K >= 32) {
-        static const int cus = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256; return n; }();
-        wino_fused_stream_kernel<<<dim3((unsigned)(blocks < cus ? blocks : cus)), 256, 0, st>>>(a, (int)blocks);
+    if (wino_stream_enabled() && K % 16 == 0 && K >= 32) {
+        const int cus = wino_stream_cus();
+        const dim3 grid((unsigned)(blocks < cus ? blocks : cus));
+        if (stat_part) wino_fused_stream_stats_kernel<<<grid, 256, 0, st>>>(a, (int)blocks);
+        else           wino_fused_stream_kernel<<<grid, 256, 0, st>>>(a, (int)blocks);
     } else {
+        if (stat_part) return UNET_EINVAL;
         wino_fused_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(a);
     }
     return UNET_LAUNCH_STATUS();
@@ -1130,7 +1191,27 @@ extern "C" int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const fl
     UNET_CHECK_ARG(Cin <= kWinoFusedMaxK);
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(Uc) && unet_aligned16(out));
     UNET_CHECK_ARG(!bias || unet_aligned16(bias));
-    return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
+    return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, nullptr, (hipStream_t)stream);
+}
+
+// Same, plus the BatchNorm statistics of the output: stat_part[Cout/64][rows][64][2] floats (sum, sum of squares per channel
+// over the pixels each row's workgroup-half produced), rows = unet_conv3x3_fwd_winograd_fused_stats_rows(...) > 0;
+// consumed by unet_bn_train_finalize_partials.
+extern "C" int unet_conv3x3_fwd_winograd_fused_stats_rows(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || Cout % 64 != 0 || Cin > kWinoFusedMaxK) return 0;
+    return wino_stats_rows(N, H, W, Cin, Cout);
+}
+
+extern "C" int unet_conv3x3_fwd_winograd_fused_stats(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
+        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(x && Uc && out && stat_part && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 8 == 0 && Cout % 64 == 0);
+    UNET_CHECK_ARG(Cin <= kWinoFusedMaxK);
+    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(Uc) && unet_aligned16(out));
+    UNET_CHECK_ARG(!bias || unet_aligned16(bias));
+    const int rows = wino_stats_rows(N, H, W, Cin, Cout);
+    UNET_CHECK_ARG(rows > 0);
+    if (stat_bytes < (size_t)(Cout / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
+    return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, (hipStream_t)stream);
 }
 
 extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
@@ -1138,7 +1219,7 @@ extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, cons
     UNET_CHECK_ARG(dz && Ucd && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
     UNET_CHECK_ARG(Cout <= kWinoFusedMaxK);
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && lddx % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd) && unet_aligned16(dx));
-    return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream);
+    return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, nullptr, (hipStream_t)stream);
 }
 
 #if UNET_ABLATE == 8

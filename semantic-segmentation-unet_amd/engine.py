@@ -137,6 +137,7 @@ class Engine:
         self.wino_U = {}
         self._wino_dirty = True
         self._fused_U, self._fused_dirty = None, True
+        self.fuse_bn_stats = os.environ.get("UNET_FUSE_BN_STATS", "1") != "0"      # BN sums from the conv epilogue (A/B switch)
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -269,6 +270,7 @@ class Engine:
         kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
         n, h, w, _ = x.shape
         w_, b_ = self.p[name + "/kernel"], self.p[name + "/bias"]
+        fused_stats = None
         if kind == "deconv":
             r = self._buf("r_" + name, (n, 2 * h, 2 * w, cout))
             if L.unet_convT2x2_fwd_stream_supported(n, h, w, cin, cout) == 1 and _ld(x) <= 4096:
@@ -282,8 +284,17 @@ class Engine:
             r = self._buf("r_" + name, (n, h, w, cout))
             if self._use_fused(name, h, w):
                 self.saved_V[name] = None
-                self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused,
-                            _p(x), _ld(x), _p(self._fused_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+                rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
+                if rows > 0:
+                    # the conv kernel also leaves the BatchNorm sums of its output (one activation read less per layer)
+                    stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
+                    self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused_stats,
+                                _p(x), _ld(x), _p(self._fused_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1,
+                                _p(stat_part), stat_part.numel() * 4, st)
+                    fused_stats = (stat_part, rows)
+                else:
+                    self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused,
+                                _p(x), _ld(x), _p(self._fused_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
             elif self._use_winograd(name, n, h, w):
                 nbw = L.unet_conv3x3_winograd_workspace(n, h, w, cin, cout)
                 vk = None
@@ -303,7 +314,10 @@ class Engine:
         s = self.stat[name]
         gm, bt = self.p[name + "/gamma"], self.p[name + "/beta"]
         mm, mv = self.moving[name + "/moving_mean"], self.moving[name + "/moving_var"]
-        if training:
+        if training and fused_stats is not None:
+            L.unet_bn_train_finalize_partials(_p(fused_stats[0]), fused_stats[1], P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM,
+                                              BN_MOVING_VAR_UNBIASED, _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), st)
+        elif training:
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
             L.unet_bn_train_stats(_p(r), cout, P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM, BN_MOVING_VAR_UNBIASED,

@@ -459,6 +459,39 @@ def test_conv3x3_winograd_fully_fused_fwd_dgrad(hip, shape):
         assert relerr(from_nhwc(dx), dx_ref) < 3e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (5, 104, 136, 64, 64), (2, 32, 48, 64, 192)])
+def test_fused_conv_bn_stats_match_bn_train_stats(hip, shape):
+    # BatchNorm sums written by the conv epilogue -> finalize == the separate statistics pass over the stored activation
+    # (mean / invstd / scale / shift / moving statistics), ragged tile grids and multi-tile workgroups included
+    n, h, w, ci, co = shape
+    rows = hip.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, ci, co)
+    if co // 64 == 3:
+        assert rows == 0 or (n * ((h // 2 + 7) // 8) * ((w // 2 + 7) // 8) * 3) % 3 == 0
+    if rows == 0:
+        pytest.skip("persistent grid not a multiple of the n-tile count for this shape")
+    g = torch.Generator(device=DEV); g.manual_seed(co + h)
+    x = torch.randn(n, h, w, ci, device=DEV, generator=g); wt = torch.randn(3, 3, ci, co, device=DEV, generator=g) / float(np.sqrt(9 * ci))
+    b = torch.randn(co, device=DEV, generator=g); gm = torch.rand(co, device=DEV, generator=g) + 0.5; bt = torch.randn(co, device=DEV, generator=g)
+    Uc = torch.empty(16 * ci * co, device=DEV)
+    hip.unet_winograd_weight_transform(P(wt), P(Uc), ci, co, 2, ST())
+    r = torch.empty(n, h, w, co, device=DEV)
+    part = torch.zeros((co // 64) * rows * 128, device=DEV)
+    hip.unet_conv3x3_fwd_winograd_fused_stats(P(x), ci, P(Uc), P(b), P(r), co, n, h, w, ci, co, 1, P(part), part.numel() * 4, ST())
+    r2 = torch.empty_like(r)
+    hip.unet_conv3x3_fwd_winograd_fused(P(x), ci, P(Uc), P(b), P(r2), co, n, h, w, ci, co, 1, ST())
+    assert torch.equal(r, r2)
+    npx = n * h * w
+    outs = [[torch.zeros(co, device=DEV) for _ in range(4)] for _ in range(2)]
+    mm = [torch.zeros(co, device=DEV) for _ in range(2)]; mv = [torch.ones(co, device=DEV) for _ in range(2)]
+    hip.unet_bn_train_finalize_partials(P(part), rows, npx, co, P(gm), P(bt), 1e-3, 0.99, 1, P(mm[0]), P(mv[0]),
+                                        P(outs[0][0]), P(outs[0][1]), P(outs[0][2]), P(outs[0][3]), ST())
+    nb = hip.unet_bn_workspace(npx, co); ws = ws_bytes(nb)
+    hip.unet_bn_train_stats(P(r), co, npx, co, P(gm), P(bt), 1e-3, 0.99, 1, P(mm[1]), P(mv[1]),
+                            P(outs[1][0]), P(outs[1][1]), P(outs[1][2]), P(outs[1][3]), P(ws), nb, ST())
+    for a_, b_ in list(zip(outs[0], outs[1])) + [(mm[0], mm[1]), (mv[0], mv[1])]:
+        assert torch.allclose(a_, b_, rtol=2e-5, atol=2e-6), (a_ - b_).abs().max().item()
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 64), (3, 8, 24, 64, 192), (1, 6, 10, 64, 64), (2, 32, 48, 128, 128)])
 def test_conv3x3_winograd_fused_wgrad(hip, shape):
     # raw rows through LDS, per-lane Winograd transforms in registers, G^T dU G in the epilogue; ragged tile rows included
