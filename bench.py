@@ -168,7 +168,7 @@ def main():
             fl = sum(f for _, _, f in evs)
             extra[key] = {"launches_per_step": len(evs) // args.steps, "ms_per_step": round(ms / args.steps, 3),
                           "avg_launch_ms": round(ms / len(evs), 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
-        # Dominant kernel = the 3x3 conv forward kernel of the active route: wino_fused_stream_kernel (fully fused, persistent
+        # Dominant kernel = the 3x3 conv forward kernel of the active route: wino_fused_stream_stats_kernel (fully fused, persistent
         # Winograd F(2x2,3x3), default) or igemm_kernel<0,*,*,false> (UNET_CONV_ROUTE=direct).  Forward launches run alone on the
         # GPU, so their event durations are the kernel's own; backward launches (dgrad / wgrad on two streams) overlap and
         # are listed under `kernels` with shared time included.  `achieved` is ALGORITHMIC (direct-convolution) FLOP/s as
@@ -176,7 +176,7 @@ def main():
         # the rate the matrix cores actually run at and `achieved` may exceed the MFMA peak.
         kf, kd = extra.get("conv3x3_fwd_winograd_fused"), extra.get("conv3x3_fwd")
         if kf:
-            roofline = {"bound": "mfma", "kernel": "wino_fused_stream_kernel (3x3 conv forward, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
+            roofline = {"bound": "mfma", "kernel": "wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
                         "achieved": kf["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(kf["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
                         "executed": round(kf["tflops"] / 2.25, 2), "executed_frac": round(kf["tflops"] / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4),

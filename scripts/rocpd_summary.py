@@ -14,9 +14,9 @@ print("%-100s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_ms", "av
 for n, c, t, a, mn, mx in rows:
     print("%-100s %8d %12.3f %10.1f %10.1f %10.1f %6.2f" % (n[:100], c, t / 1e6, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * t / tot))
 
-for kname in ("wino_fused_stream_kernel", "wino_fused_kernel"):
-    ev = [r for r in db.execute("select start, end from kernels where name like ? order by start", ("%" + kname + "(%",))]
-    if len(ev) >= 34 and len(ev) % 34 == 0:
-        fwd = [e - s0 for i, (s0, e) in enumerate(ev) if i % 34 < 17]; bwd = [e - s0 for i, (s0, e) in enumerate(ev) if i % 34 >= 17]
-        print("# %s FORWARD launches (exclusive on the GPU): %d, average %.1f us;  dgrad launches (share the GPU with the side-stream weight gradients): %d, average %.1f us"
-              % (kname, len(fwd), sum(fwd) / len(fwd) / 1e3, len(bwd), sum(bwd) / len(bwd) / 1e3))
+# forward launches run the statistics variant (training), dgrad launches the plain persistent kernel
+for kname, what in (("wino_fused_stream_stats_kernel", "FORWARD launches (exclusive on the GPU; bench.py's roofline uses them)"),
+                    ("wino_fused_stream_kernel", "dgrad launches (share the GPU with the side-stream weight gradients)")):
+    ev = [e - s0 for s0, e in db.execute("select start, end from kernels where name like ?", ("%" + kname + "(%",))]
+    if ev:
+        print("# %s %s: %d, average %.1f us" % (kname, what, len(ev), sum(ev) / len(ev) / 1e3))
