@@ -102,6 +102,10 @@ int unet_convT2x2_fwd(const float* x, int ldx, const float* w, const float* bias
 int unet_convT2x2_fwd_stream_supported(int N, int H, int W, int Cin, int Cout);
 int unet_convT2x2_fwd_stream(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                              int N, int H, int W, int Cin, int Cout, void* stream);
+/* + BatchNorm sums of the output (UNet/model.py:47); rows / layout / finalize as for unet_conv3x3_fwd_winograd_fused_stats */
+int unet_convT2x2_fwd_stream_stats_rows(int N, int H, int W, int Cin, int Cout);
+int unet_convT2x2_fwd_stream_stats(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                   int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream);
 int unet_convT2x2_dgrad(const float* dz, int lddz, const float* w, float* dx, int lddx,
                         int N, int H, int W, int Cin, int Cout, void* stream);
 size_t unet_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);

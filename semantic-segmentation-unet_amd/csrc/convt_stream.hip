@@ -26,6 +26,7 @@ struct ConvtFwdArgs {
     int ldx, ldo, N, H, W, Cin, Cout;
     long P;              // N*H*W input pixels
     int npt, nct, ntiles;
+    float* stat_part;    // BatchNorm sums of the output (UNet/model.py:47), see the end of the kernel; or null
 };
 
 #define CT_RD128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
@@ -64,7 +65,7 @@ __device__ __forceinline__ void ct_chunk(f32x16 (&acc)[16], const CtFrags& cur, 
     }
 }
 
-template <int PW>
+template <int PW, bool STATS>
 __device__ __forceinline__ void convt_fwd_stream_body(const ConvtFwdArgs& p) {
     constexpr int CW = 4 / PW, XP = 2 * PW, NP = XP + 8 * CW, PPW = NP / 4;
     constexpr int SLOTB = NP * 1024, SLOTF = SLOTB / 4;
@@ -137,6 +138,11 @@ __device__ __forceinline__ void convt_fwd_stream_body(const ConvtFwdArgs& p) {
 
     f32x16 acc[16];
     const int Wo = 2 * p.W;
+    // STATS: per-lane running sum / sum of squares of the stored values for the lane's 32 channels.  A persistent workgroup
+    // only ever sees one channel tile (tile ids advance by gridDim.x, a multiple of nct), so they run over all its tiles.
+    f32x4 st1[2][4], st2[2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
         // the wave's 16 bias values (latency hidden under the chunk loop)
         const int ptile = t / p.nct, ctile = t % p.nct;
@@ -197,17 +203,51 @@ __device__ __forceinline__ void convt_fwd_stream_body(const ConvtFwdArgs& p) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             asm("v_accvgpr_read_b32 %0, %1" : "=v"(e[k]) : "a"(acc[(tap * 2 + pt) * 2 + c2][4 * g + k]));
-                        *reinterpret_cast<f32x4*>(o + 32 * c2 + 8 * g) = f32x4{e[0], e[1], e[2], e[3]} + bias4[c2][g];
+                        const f32x4 v = f32x4{e[0], e[1], e[2], e[3]} + bias4[c2][g];
+                        *reinterpret_cast<f32x4*>(o + 32 * c2 + 8 * g) = v;
+                        if (STATS) { st1[c2][g] += v; st2[c2][g] += v * v; }
                     }
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : CT_ALL(fa) : : "memory");      // retire the tail prefetches
+    if (STATS) {
+        // reduce over the 32 pixel lanes of each half-wave; row layout as unet_bn_train_finalize_partials expects:
+        // stat_part[64-channel block][row][64][2], block = ctile*CW + cw, row = (first tile / nct) * PW + pi
+        float v[64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[8 * i + 2 * k] = st1[i >> 2][i & 3][k]; v[8 * i + 2 * k + 1] = st2[i >> 2][i & 3][k]; }
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) v[i] += __shfl_xor(v[i], m, 32);
+        if (li == 0) {
+            const int t0 = blockIdx.x, ctile0 = t0 % p.nct;
+            const int rows = ((int)gridDim.x / p.nct) * PW;
+            float* o = p.stat_part + ((size_t)(ctile0 * CW + cw) * rows + (t0 / p.nct) * PW + pi) * 128;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ch = 32 * (i >> 2) + 8 * (i & 3) + 4 * lh + k;
+                    o[2 * ch] = v[8 * i + 2 * k]; o[2 * ch + 1] = v[8 * i + 2 * k + 1];
+                }
+        }
+    }
 }
 
 // (plain kernels around the templated body: the host-side stub of a kernel TEMPLATE containing this inline asm is not emitted)
-__global__ __launch_bounds__(256, 1) void convt_fwd_stream_kernel_2x2(ConvtFwdArgs p) { convt_fwd_stream_body<2>(p); }
-__global__ __launch_bounds__(256, 1) void convt_fwd_stream_kernel_4x1(ConvtFwdArgs p) { convt_fwd_stream_body<4>(p); }
+__global__ __launch_bounds__(256, 1) void convt_fwd_stream_kernel_2x2(ConvtFwdArgs p) { convt_fwd_stream_body<2, false>(p); }
+__global__ __launch_bounds__(256, 1) void convt_fwd_stream_kernel_4x1(ConvtFwdArgs p) { convt_fwd_stream_body<4, false>(p); }
+__global__ __launch_bounds__(256, 1) void convt_fwd_stream_stats_kernel_2x2(ConvtFwdArgs p) { convt_fwd_stream_body<2, true>(p); }
+__global__ __launch_bounds__(256, 1) void convt_fwd_stream_stats_kernel_4x1(ConvtFwdArgs p) { convt_fwd_stream_body<4, true>(p); }
+
+int convt_cus() {
+    static const int cus = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256; return n; }();
+    return cus;
+}
 
 }  // namespace
 
@@ -218,22 +258,54 @@ extern "C" int unet_convT2x2_fwd_stream_supported(int N, int H, int W, int Cin, 
     return (P % tpx == 0 && (long)4 * Cout * Cin * 4 < (1L << 31) && (long)tpx * 4096 * 4 < (1L << 31)) ? 1 : 0;
 }
 
-extern "C" int unet_convT2x2_fwd_stream(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
-                                        int N, int H, int W, int Cin, int Cout, void* stream) {
+extern "C" int unet_convT2x2_fwd_stream_stats_rows(int N, int H, int W, int Cin, int Cout);
+
+static int convt_fwd_stream_launch(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                   int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(x && w && out && unet_convT2x2_fwd_stream_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0 && ldx <= 4096);
     UNET_CHECK_ARG(unet_aligned16(x) && unet_aligned16(w) && unet_aligned16(out) && (!bias || unet_aligned16(bias)));
     ConvtFwdArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.P = (long)N * H * W;
+    a.P = (long)N * H * W; a.stat_part = stat_part;
     const bool wide = Cout % 128 == 0;
     a.npt = (int)(a.P / (wide ? 128 : 256)); a.nct = Cout / (wide ? 128 : 64);
     const long tiles = (long)a.npt * a.nct;
     if (tiles > 0x7fffffffL) return UNET_EINVAL;
     a.ntiles = (int)tiles;
-    static const int cus = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256; return n; }();
-    const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
-    if (wide) convt_fwd_stream_kernel_2x2<<<dim3(grid), 256, 0, (hipStream_t)stream>>>(a);
-    else      convt_fwd_stream_kernel_4x1<<<dim3(grid), 256, 0, (hipStream_t)stream>>>(a);
+    const unsigned grid = (unsigned)(tiles < convt_cus() ? tiles : convt_cus());
+    hipStream_t st = (hipStream_t)stream;
+    if (stat_part) {
+        const int rows = unet_convT2x2_fwd_stream_stats_rows(N, H, W, Cin, Cout);
+        UNET_CHECK_ARG(rows > 0);
+        if (stat_bytes < (size_t)(Cout / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
+        if (wide) convt_fwd_stream_stats_kernel_2x2<<<dim3(grid), 256, 0, st>>>(a);
+        else      convt_fwd_stream_stats_kernel_4x1<<<dim3(grid), 256, 0, st>>>(a);
+    } else {
+        if (wide) convt_fwd_stream_kernel_2x2<<<dim3(grid), 256, 0, st>>>(a);
+        else      convt_fwd_stream_kernel_4x1<<<dim3(grid), 256, 0, st>>>(a);
+    }
     return UNET_LAUNCH_STATUS();
+}
+
+// rows of statistics partials per 64-channel block (0: shape not supported / grid not a multiple of the channel-tile count)
+extern "C" int unet_convT2x2_fwd_stream_stats_rows(int N, int H, int W, int Cin, int Cout) {
+    if (!unet_convT2x2_fwd_stream_supported(N, H, W, Cin, Cout)) return 0;
+    const bool wide = Cout % 128 == 0;
+    const long tiles = ((long)N * H * W / (wide ? 128 : 256)) * (Cout / (wide ? 128 : 64));
+    const long grid = tiles < convt_cus() ? tiles : convt_cus();
+    const int nct = Cout / (wide ? 128 : 64);
+    return grid % nct == 0 ? (int)((grid / nct) * (wide ? 2 : 4)) : 0;
+}
+
+extern "C" int unet_convT2x2_fwd_stream(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                        int N, int H, int W, int Cin, int Cout, void* stream) {
+    return convt_fwd_stream_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, nullptr, 0, stream);
+}
+
+// + BatchNorm sums of the output (layout and finalize as for unet_conv3x3_fwd_winograd_fused_stats)
+extern "C" int unet_convT2x2_fwd_stream_stats(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                              int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(stat_part);
+    return convt_fwd_stream_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, stat_part, stat_bytes, stream);
 }

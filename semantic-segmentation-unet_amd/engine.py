@@ -273,8 +273,15 @@ class Engine:
         fused_stats = None
         if kind == "deconv":
             r = self._buf("r_" + name, (n, 2 * h, 2 * w, cout))
-            if L.unet_convT2x2_fwd_stream_supported(n, h, w, cin, cout) == 1 and _ld(x) <= 4096:
-                L.unet_convT2x2_fwd_stream(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, st)    # persistent stream kernel
+            if L.unet_convT2x2_fwd_stream_supported(n, h, w, cin, cout) == 1 and _ld(x) <= 4096:           # persistent stream kernel
+                rows = L.unet_convT2x2_fwd_stream_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
+                if rows > 0:
+                    stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
+                    L.unet_convT2x2_fwd_stream_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout,
+                                                     _p(stat_part), stat_part.numel() * 4, st)
+                    fused_stats = (stat_part, rows)
+                else:
+                    L.unet_convT2x2_fwd_stream(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, st)
             else:
                 L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, st)
         elif kind == "conv1":

@@ -492,6 +492,32 @@ def test_fused_conv_bn_stats_match_bn_train_stats(hip, shape):
         assert torch.allclose(a_, b_, rtol=2e-5, atol=2e-6), (a_ - b_).abs().max().item()
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 16, 128, 128), (1, 16, 16, 64, 64), (8, 64, 64, 512, 256), (8, 256, 256, 128, 64)])
+def test_convT_stream_bn_stats_match_bn_train_stats(hip, shape):
+    # BatchNorm sums from the transposed-conv stream kernel's epilogue == the separate statistics pass
+    n, h, w, ci, co = shape
+    rows = hip.unet_convT2x2_fwd_stream_stats_rows(n, h, w, ci, co)
+    assert rows > 0
+    g = torch.Generator(device=DEV); g.manual_seed(co + h)
+    x = torch.randn(n, h, w, ci, device=DEV, generator=g); wt = torch.randn(2, 2, co, ci, device=DEV, generator=g) / float(np.sqrt(ci))
+    b = torch.randn(co, device=DEV, generator=g); gm = torch.rand(co, device=DEV, generator=g) + 0.5; bt = torch.randn(co, device=DEV, generator=g)
+    r = torch.empty(n, 2 * h, 2 * w, co, device=DEV); r2 = torch.empty_like(r)
+    part = torch.zeros((co // 64) * rows * 128, device=DEV)
+    hip.unet_convT2x2_fwd_stream_stats(P(x), ci, P(wt), P(b), P(r), co, n, h, w, ci, co, P(part), part.numel() * 4, ST())
+    hip.unet_convT2x2_fwd_stream(P(x), ci, P(wt), P(b), P(r2), co, n, h, w, ci, co, ST())
+    assert torch.equal(r, r2)
+    npx = n * 4 * h * w
+    outs = [[torch.zeros(co, device=DEV) for _ in range(4)] for _ in range(2)]
+    mm = [torch.zeros(co, device=DEV) for _ in range(2)]; mv = [torch.ones(co, device=DEV) for _ in range(2)]
+    hip.unet_bn_train_finalize_partials(P(part), rows, npx, co, P(gm), P(bt), 1e-3, 0.99, 1, P(mm[0]), P(mv[0]),
+                                        P(outs[0][0]), P(outs[0][1]), P(outs[0][2]), P(outs[0][3]), ST())
+    nb = hip.unet_bn_workspace(npx, co); ws = ws_bytes(nb)
+    hip.unet_bn_train_stats(P(r), co, npx, co, P(gm), P(bt), 1e-3, 0.99, 1, P(mm[1]), P(mv[1]),
+                            P(outs[1][0]), P(outs[1][1]), P(outs[1][2]), P(outs[1][3]), P(ws), nb, ST())
+    for a_, b_ in list(zip(outs[0], outs[1])) + [(mm[0], mm[1]), (mv[0], mv[1])]:
+        assert torch.allclose(a_, b_, rtol=2e-5, atol=2e-6), (a_ - b_).abs().max().item()
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 64), (3, 8, 24, 64, 192), (1, 6, 10, 64, 64), (2, 32, 48, 128, 128)])
 def test_conv3x3_winograd_fused_wgrad(hip, shape):
     # raw rows through LDS, per-lane Winograd transforms in registers, G^T dU G in the epilogue; ragged tile rows included
