@@ -70,6 +70,12 @@ int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Uc
 /* fused Winograd weight gradient: raw rows through LDS, per-lane transforms in registers, G^T dU G in the epilogue;
  * needs H, W even and Cin, Cout multiples of 64 */
 int unet_winograd_wgrad_fused_supported(int N, int H, int W, int Cin, int Cout);
+/* data gradient + the BatchNorm-backward sums (sum dy, sum dy*r) of the layer that produced this layer's input: dx channels
+ * [c0, c1) are that layer's dy, r_prev its saved activation; rows = unet_conv3x3_fwd_winograd_fused_stats_rows(N,H,W,Cout,Cin);
+ * the sums replace the reduction pass of unet_bn_bwd (unet_bn_bwd_from_partials, part = stat_part + (c0/64)*rows*128) */
+int unet_conv3x3_dgrad_winograd_fused_bnstats(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
+                                              int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+                                              float* stat_part, size_t stat_bytes, void* stream);
 size_t unet_conv3x3_wgrad_winograd_fused_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                                       int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
@@ -131,6 +137,10 @@ int unet_bn_apply(const float* r, int ldr, const float* scale, const float* shif
 int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
                 const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,
                 float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+int unet_bn_bwd_from_partials(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
+                              const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,
+                              float* dbias, const float* part_sums, int rows, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- MaxPool2D(2), UNet/model.py:50-53; Dropout(0.5), UNet/model.py:60-63 ---------------------------------------- */
 int unet_maxpool2x2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C, void* stream);

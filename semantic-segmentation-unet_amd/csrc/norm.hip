@@ -130,6 +130,18 @@ __global__ __launch_bounds__(64) void bn_train_finalize_partials_kernel(const fl
     }
 }
 
+// dgamma / dbeta from the sums a fused data-gradient kernel left (winograd.hip, STATS == 2): part[C/64][rows][64][2] holds
+// sum(dy) and sum(dy * r) per channel; dbeta = sum dy, dgamma = sum dy xhat = invstd * (sum dy r - mean * sum dy)
+__global__ __launch_bounds__(64) void bn_bwd_finalize_partials_kernel(const float* __restrict__ part, int rows, int C,
+        const float* __restrict__ mean, const float* __restrict__ invstd, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x;
+    const float* base = part + ((size_t)(c >> 6) * rows * 64 + (c & 63)) * 2;
+    double s = 0.0, sr = 0.0;
+    for (int k = threadIdx.x; k < rows; k += 64) { s += (double)base[(size_t)k * 128]; sr += (double)base[(size_t)k * 128 + 1]; }
+    s = wave_sum(s); sr = wave_sum(sr);
+    if (threadIdx.x == 0) { dbeta[c] = (float)s; dgamma[c] = (float)((double)invstd[c] * (sr - (double)mean[c] * s)); }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float eps,
                                       int C, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,6 +368,29 @@ extern "C" int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, c
     bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(part, pl.nblk, C, dgamma, dbeta);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     double* part2 = part + (size_t)2 * pl.nblk * C;
+    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
+    else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
+    rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    colsum_finalize_kernel<<<C, 64, 0, st>>>(part2, pl.nblk, C, dbias);
+    return UNET_LAUNCH_STATUS();
+}
+
+// unet_bn_bwd with the reduction pass replaced by the partial sums of a fused data-gradient kernel
+// (unet_conv3x3_dgrad_winograd_fused_bnstats): part holds (C/64) * rows * 128 floats for exactly these C channels.
+extern "C" int unet_bn_bwd_from_partials(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
+        const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta, float* dbias,
+        const float* part_sums, int rows, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(dy && r && gamma && mean && invstd && dz && dgamma && dbeta && dbias && ws && part_sums && rows > 0 && P > 0 && C > 0 && C % 64 == 0);
+    UNET_CHECK_ARG(lddy >= C && ldr >= C && lddz >= C);
+    Plan pl;
+    const bool al = unet_aligned16(dy) && unet_aligned16(r) && unet_aligned16(dz) && unet_aligned16(gamma) && unet_aligned16(mean) &&
+                    unet_aligned16(invstd) && unet_aligned16(dgamma) && unet_aligned16(dbeta);
+    UNET_CHECK_ARG(make_plan(P, C, lddy, ldr, lddz, al, &pl));
+    if (ws_bytes < unet_bn_workspace(P, C)) return UNET_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    bn_bwd_finalize_partials_kernel<<<C, 64, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    double* part2 = (double*)ws + (size_t)2 * pl.nblk * C;
     if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
     else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;

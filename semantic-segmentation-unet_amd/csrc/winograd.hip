@@ -370,6 +370,7 @@ struct WinoFusedArgs {
     int ldx, ldo, N, H, W, K, Nout, relu;
     int tbx, tby, nt;            // tile-block grid
     float* stat_part;            // BatchNorm statistics of the output (persistent kernel only), see wf_write_stats; or null
+    const float* bn_r; int bn_ldr, bn_c0, bn_c1;      // STATS == 2 (data gradient): saved activation of the producer layer, channels [c0, c1)
 };
 typedef __attribute__((address_space(3))) void lds_void_f;
 constexpr int kWinoFusedMaxK = 4096;
@@ -500,9 +501,13 @@ __device__ __forceinline__ void wf_load_bias(const WinoFusedArgs& p, int n0, int
 // STATS: also accumulate, per lane, the sum and the sum of squares of the stored values per channel pair (s1 / s2 [2g + h]):
 // the BatchNorm that follows the layer (UNet/model.py:36) needs exactly these over all pixels, and this is the only place
 // the values pass through registers anyway (saves a full read of the activation tensor per layer).
-template <bool STATS>
+// STATS == 2 (data gradient whose output is the dy of a BatchNorm layer): the sums are sum(dy) and sum(dy * r) with r the saved
+// activation of that layer at the same pixels (rv, loaded by the caller before the chunk loop) -- what the BatchNorm backward
+// reduction needs (dbeta = sum dy, dgamma = invstd (sum dy r - mean sum dy)), again one full read of two tensors saved.
+template <int STATS>
 __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[16], const WinoFusedArgs& p, int img, int by, int bx, int n0,
-                                            int mi, int ni, int li, int lh, const f32x4 (&bias4)[4], f32x2 (&s1)[8], f32x2 (&s2)[8]) {
+                                            int mi, int ni, int li, int lh, const f32x4 (&bias4)[4], f32x2 (&s1)[8], f32x2 (&s2)[8],
+                                            const f32x4 (&rv)[4][4]) {
     const int lt = 32 * mi + li;
     const int ty = 8 * by + (lt >> 3), tx = 8 * bx + (lt & 7);
     if (ty >= (p.H >> 1) || tx >= (p.W >> 1)) return;
@@ -538,9 +543,18 @@ __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[16], const WinoF
                 f32x2 y0 = (rr[i][0] + b2) + s12, y1 = wf_pk_sub(d12 + b2, rr[i][3]);
                 y[i][0][h] = f32x2{fmaxf(y0.x, lo), fmaxf(y0.y, lo)}; y[i][1][h] = f32x2{fmaxf(y1.x, lo), fmaxf(y1.y, lo)};
             }
-            if (STATS) {
+            if (STATS == 1) {
                 s1[2 * g + h] += (y[0][0][h] + y[0][1][h]) + (y[1][0][h] + y[1][1][h]);
                 s2[2 * g + h] += (y[0][0][h] * y[0][0][h] + y[0][1][h] * y[0][1][h]) + (y[1][0][h] * y[1][0][h] + y[1][1][h] * y[1][1][h]);
+            }
+            if (STATS == 2) {
+                s1[2 * g + h] += (y[0][0][h] + y[0][1][h]) + (y[1][0][h] + y[1][1][h]);
+                f32x2 q = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) q += y[i][j][h] * (h ? f32x2{rv[2 * i + j][g][2], rv[2 * i + j][g][3]} : f32x2{rv[2 * i + j][g][0], rv[2 * i + j][g][1]});
+                s2[2 * g + h] += q;
             }
         }
 #pragma unroll
@@ -551,6 +565,25 @@ __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[16], const WinoF
         __builtin_amdgcn_sched_barrier(0);        // one channel quad at a time: hoisting all 256 accumulator reads costs spills
     }
 }
+// STATS == 2: the lane's 4 pixels x 16 channels of the producer layer's saved activation (zero for lanes outside the image or
+// for channel tiles outside [bn_c0, bn_c1), whose sums are never read)
+__device__ __forceinline__ void wf_load_r(const WinoFusedArgs& p, int img, int by, int bx, int n0, int mi, int ni, int li, int lh,
+                                          f32x4 (&rv)[4][4]) {
+    const int lt = 32 * mi + li;
+    const int ty = 8 * by + (lt >> 3), tx = 8 * bx + (lt & 7);
+    const bool ok = ty < (p.H >> 1) && tx < (p.W >> 1) && n0 >= p.bn_c0 && n0 < p.bn_c1;
+    const float* r = p.bn_r + ((size_t)(img * p.H + 2 * ty) * p.W + 2 * tx) * p.bn_ldr + (n0 - p.bn_c0) + 32 * ni + 4 * lh;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                rv[2 * i + j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) rv[2 * i + j][g] = *reinterpret_cast<const f32x4*>(r + ((size_t)i * p.W + j) * p.bn_ldr + 8 * g);
+            }
+}
+
 // Per-lane running sums -> one row of partials per wave.  A persistent workgroup only ever sees ONE 64-channel output tile
 // (tile ids advance by gridDim.x, a multiple of nt), so the sums run over all its tiles and are reduced across the 32 lanes
 // of a half-wave once, at the end.  Layout: stat_part[tn][row][64 channels][2], row = 2 * (first tile / nt) + mi.
@@ -689,8 +722,8 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wf_t2) :: "memory");
 #endif
 
-    f32x2 s1u[8], s2u[8];
-    wf_epilogue<false>(acc, p, img, by, bx, n0, mi, ni, li, lh, bias4, s1u, s2u);
+    f32x2 s1u[8], s2u[8]; f32x4 rvu[4][4];
+    wf_epilogue<0>(acc, p, img, by, bx, n0, mi, ni, li, lh, bias4, s1u, s2u, rvu);
 #if UNET_ABLATE == 8
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (blockIdx.x == 0 && tid == 0) {
@@ -706,7 +739,7 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
 // instead of idling, so only the first tile of a workgroup pays the two DMA round trips of the prologue, and there is no
 // launch gap between tiles (with 152 KB of LDS a CU holds one workgroup, so nothing else would hide either).  A tile's first
 // chunk starts its accumulators from C = 0.
-template <bool STATS>
+template <int STATS>
 __device__ __forceinline__ void wino_fused_stream_body(const WinoFusedArgs& p, int ntiles) {
     constexpr int DPIX = 18 * 18, DPIECES = 12, DFL = DPIECES * 256;
     constexpr int IMG = 16 * 64 * 8;
@@ -832,6 +865,8 @@ __device__ __forceinline__ void wino_fused_stream_body(const WinoFusedArgs& p, i
         tile_sources(tcn, dnxt, unxt);
         f32x4 bias4[4];
         wf_load_bias(p, tc.tn * 64, ni, lh, bias4);
+        f32x4 rv[4][4];
+        if (STATS == 2) wf_load_r(p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, rv);
         wf_chunk<0, true>(acc, dd, a_base, b_base, d_base, v_base, [&] { sources(0); }, usrc, dsrc, sUw, sDw WF_TL);
         wf_chunk<1>(acc, dd, a_base, b_base, d_base, v_base, [&] { sources(1); }, usrc, dsrc, sUw, sDw WF_TL);
         for (int c = 2; c < nchunks; c += 2) {
@@ -843,7 +878,7 @@ __device__ __forceinline__ void wino_fused_stream_body(const WinoFusedArgs& p, i
         WF_STAMP(q1);
 #endif
 
-        wf_epilogue<STATS>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, bias4, s1, s2);
+        wf_epilogue<STATS>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, bias4, s1, s2, rv);
 #pragma unroll
         for (int k = 0; k < 3; ++k) dcur[k] = dnxt[k];
         ucur = unxt; tc = tcn;
@@ -861,8 +896,9 @@ __device__ __forceinline__ void wino_fused_stream_body(const WinoFusedArgs& p, i
     if (STATS) wf_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), mi, ni, li, lh, s1, s2);
 }
 // (plain kernels around the templated body: the host-side stub of a kernel TEMPLATE containing this inline asm is not emitted)
-__global__ __launch_bounds__(256, 1) void wino_fused_stream_kernel(WinoFusedArgs p, int ntiles) { wino_fused_stream_body<false>(p, ntiles); }
-__global__ __launch_bounds__(256, 1) void wino_fused_stream_stats_kernel(WinoFusedArgs p, int ntiles) { wino_fused_stream_body<true>(p, ntiles); }
+__global__ __launch_bounds__(256, 1) void wino_fused_stream_kernel(WinoFusedArgs p, int ntiles) { wino_fused_stream_body<0>(p, ntiles); }
+__global__ __launch_bounds__(256, 1) void wino_fused_stream_stats_kernel(WinoFusedArgs p, int ntiles) { wino_fused_stream_body<1>(p, ntiles); }
+__global__ __launch_bounds__(256, 1) void wino_fused_stream_bnbwd_kernel(WinoFusedArgs p, int ntiles) { wino_fused_stream_body<2>(p, ntiles); }
 
 // ---- fully fused Winograd weight gradient ----------------------------------------------------------------------------
 //   dW = G^T [ sum_tiles (B^T d B)[xi][ci] * (A dY A^T)[xi][co] ] G
@@ -1163,8 +1199,10 @@ int wino_stats_rows(int N, int H, int W, int K, int Nout) {
     return grid % nt == 0 ? (int)(2 * (grid / nt)) : 0;
 }
 
+struct WinoBnBwd { const float* r; int ldr, c0, c1; };
+
 int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo, int N, int H, int W,
-                   int K, int Nout, int relu, float* stat_part, hipStream_t st) {
+                   int K, int Nout, int relu, float* stat_part, hipStream_t st, const WinoBnBwd* bb = nullptr) {
     WinoFusedArgs a{};
     a.x = x; a.Uc = Uc; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo; a.N = N; a.H = H; a.W = W; a.K = K; a.Nout = Nout; a.relu = relu;
     a.tby = (H / 2 + 7) / 8; a.tbx = (W / 2 + 7) / 8; a.nt = Nout / 64; a.stat_part = stat_part;
@@ -1173,8 +1211,12 @@ int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, 
     if (wino_stream_enabled() && K % 16 == 0 && K >= 32) {
         const int cus = wino_stream_cus();
         const dim3 grid((unsigned)(blocks < cus ? blocks : cus));
-        if (stat_part) wino_fused_stream_stats_kernel<<<grid, 256, 0, st>>>(a, (int)blocks);
-        else           wino_fused_stream_kernel<<<grid, 256, 0, st>>>(a, (int)blocks);
+        if (bb) {
+            a.bn_r = bb->r; a.bn_ldr = bb->ldr; a.bn_c0 = bb->c0; a.bn_c1 = bb->c1;
+            wino_fused_stream_bnbwd_kernel<<<grid, 256, 0, st>>>(a, (int)blocks);
+        }
+        else if (stat_part) wino_fused_stream_stats_kernel<<<grid, 256, 0, st>>>(a, (int)blocks);
+        else                wino_fused_stream_kernel<<<grid, 256, 0, st>>>(a, (int)blocks);
     } else {
         if (stat_part) return UNET_EINVAL;
         wino_fused_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(a);
@@ -1227,6 +1269,23 @@ extern "C" int unet_debug_wf_timeline(long long* out4) {
     return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_wf_timeline), 64);
 }
 #endif
+
+// Data gradient + the BatchNorm-backward sums of the layer that PRODUCED this layer's input: dx channels [c0, c1) (multiples of
+// 64) are that layer's dy, r_prev its saved activation (c1 - c0 channels, pixel stride ldr).  stat_part = (Cin/64) * rows * 128
+// floats, rows = unet_conv3x3_fwd_winograd_fused_stats_rows(N, H, W, Cout, Cin); blocks c0/64 .. c1/64 - 1 hold sum(dy) and
+// sum(dy * r) per channel, consumed by unet_bn_bwd_from_partials.
+extern "C" int unet_conv3x3_dgrad_winograd_fused_bnstats(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
+        int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+        float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(dz && Ucd && dx && r_prev && stat_part && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
+    UNET_CHECK_ARG(Cout <= kWinoFusedMaxK && c0 >= 0 && c1 > c0 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0 && ldr % 4 == 0);
+    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && lddx % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd) && unet_aligned16(dx) && unet_aligned16(r_prev));
+    const int rows = wino_stats_rows(N, H, W, Cout, Cin);
+    UNET_CHECK_ARG(rows > 0);
+    if (stat_bytes < (size_t)(Cin / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
+    const WinoBnBwd bb{r_prev, ldr, c0, c1};
+    return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, stat_part, (hipStream_t)stream, &bb);
+}
 
 extern "C" int unet_winograd_wgrad_fused_supported(int N, int H, int W, int Cin, int Cout) {
     return (N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 64 == 0 && Cout % 64 == 0) ? 1 : 0;

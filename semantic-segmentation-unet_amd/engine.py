@@ -60,6 +60,15 @@ BACKWARD_ORDER = ["logits", "dec_1b", "dec_1a", "up_1", "dec_2b", "dec_2a", "up_
                   "conv_2b", "conv_2a", "conv_1b", "conv_1a"]
 
 
+# layer -> (producer, first, last, parts): the layer's input channels [first/parts, last/parts) of its Cin are EXACTLY the BatchNorm
+# output of `producer` and feed nothing else, so the layer's data gradient over that range is the producer's dy
+PRODUCER = {"bott_b": ("bott_a", 0, 1, 1)}
+for _l in (1, 2, 3, 4):
+    PRODUCER["conv_%db" % _l] = ("conv_%da" % _l, 0, 1, 1)
+    PRODUCER["dec_%db" % _l] = ("dec_%da" % _l, 0, 1, 1)
+    PRODUCER["dec_%da" % _l] = ("up_%d" % _l, 1, 2, 2)          # concat [skip, upsampled] (UNet/model.py:55-58): upper half
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -138,6 +147,7 @@ class Engine:
         self._wino_dirty = True
         self._fused_U, self._fused_dirty = None, True
         self.fuse_bn_stats = os.environ.get("UNET_FUSE_BN_STATS", "1") != "0"      # BN sums from the conv epilogue (A/B switch)
+        self.bnbwd_part = {}
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -431,8 +441,18 @@ class Engine:
         P = n * ho * wo
         s = self.stat[name]
         dz = self._buf("dz_" + name, tuple(r.shape))
+        pre = self.bnbwd_part.pop(name, None) if not eval_mode else None
         if eval_mode:
             L.unet_bn_eval_bwd(_p(dy), _ld(dy), _p(r), cout, _p(s[2]), _p(dz), cout, P, cout, 0 if kind == "deconv" else 1, st)
+        elif pre is not None:
+            # sum(dy), sum(dy*r) already came out of the consumer layer's data-gradient kernel: no reduction pass
+            part, rows, c0 = pre
+            nb = L.unet_bn_workspace(P, cout)
+            ws = self._workspace(nb)
+            L.unet_bn_bwd_from_partials(_p(dy), _ld(dy), _p(r), cout, _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
+                                        0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
+                                        _p(self.g[name + "/bias"]), ctypes.c_void_p(part.data_ptr() + (c0 // 64) * rows * 128 * 4), rows,
+                                        _p(ws), nb, st)
         else:
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
@@ -485,8 +505,20 @@ class Engine:
             elif kind == "conv1":
                 L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
             elif self._use_fused(name, ho, wo, dgrad=True):
-                self._timed("conv3x3_dgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd_fused,
-                            _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout, st)
+                prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
+                rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, ho, wo, cout, cin) if prod else 0
+                if rows > 0:
+                    # dx (or a channel range of it) is the dy of the producer layer's BatchNorm: leave its backward sums too
+                    pname, c0, c1 = prod[0], prod[1] * (cin // prod[3]), prod[2] * (cin // prod[3])
+                    r_prev = self.saved[pname][1]
+                    part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
+                    self._timed("conv3x3_dgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd_fused_bnstats,
+                                _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
+                                _p(r_prev), r_prev.shape[-1], c0, c1, _p(part), part.numel() * 4, st)
+                    self.bnbwd_part[pname] = (part, rows, c0)
+                else:
+                    self._timed("conv3x3_dgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd_fused,
+                                _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout, st)
             elif self._use_winograd(name, n, ho, wo):
                 nbw = L.unet_conv3x3_winograd_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_dgrad_winograd", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd,

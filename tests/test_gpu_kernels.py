@@ -518,6 +518,47 @@ def test_convT_stream_bn_stats_match_bn_train_stats(hip, shape):
         assert torch.allclose(a_, b_, rtol=2e-5, atol=2e-6), (a_ - b_).abs().max().item()
 
 
+@pytest.mark.parametrize("shape,crange", [((2, 16, 16, 64, 64), (0, 64)), ((1, 16, 32, 128, 64), (64, 128)), ((5, 104, 136, 64, 64), (0, 64)),
+                                          ((2, 32, 32, 256, 128), (128, 256))])
+def test_dgrad_bn_backward_sums_match_reduction(hip, shape, crange):
+    # data gradient + (sum dy, sum dy*r) of the producer layer's BatchNorm from the epilogue -> bn_bwd_from_partials ==
+    # the plain data gradient followed by the full unet_bn_bwd (dz, dgamma, dbeta, dbias), for a channel sub-range too
+    n, h, w, ci, co = shape
+    c0, c1 = crange
+    cp = c1 - c0
+    rows = hip.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, co, ci)
+    assert rows > 0
+    g = torch.Generator(device=DEV); g.manual_seed(ci + co + h)
+    dzin = torch.randn(n, h, w, co, device=DEV, generator=g); wt = torch.randn(3, 3, ci, co, device=DEV, generator=g) / float(np.sqrt(9 * co))
+    r_prev = torch.relu(torch.randn(n, h, w, cp, device=DEV, generator=g))
+    gm = torch.rand(cp, device=DEV, generator=g) + 0.5
+    mean = r_prev.mean((0, 1, 2)).contiguous(); invstd = (1.0 / torch.sqrt(r_prev.var((0, 1, 2), unbiased=False) + 1e-3)).contiguous()
+    Ucd = torch.empty(16 * ci * co, device=DEV)
+    hip.unet_winograd_weight_transform(P(wt), P(Ucd), ci, co, 3, ST())
+    dx = torch.empty(n, h, w, ci, device=DEV); dx2 = torch.empty_like(dx)
+    part = torch.zeros((ci // 64) * rows * 128, device=DEV)
+    hip.unet_conv3x3_dgrad_winograd_fused_bnstats(P(dzin), co, P(Ucd), P(dx), ci, n, h, w, ci, co, P(r_prev), cp, c0, c1,
+                                                  P(part), part.numel() * 4, ST())
+    hip.unet_conv3x3_dgrad_winograd_fused(P(dzin), co, P(Ucd), P(dx2), ci, n, h, w, ci, co, ST())
+    assert torch.equal(dx, dx2)
+    npx = n * h * w
+    dy = dx[..., c0:c1]
+    nb = hip.unet_bn_workspace(npx, cp); ws = ws_bytes(nb)
+    res = []
+    for fused in (True, False):
+        dz = torch.empty(n, h, w, cp, device=DEV); dg, db, dbias = [torch.empty(cp, device=DEV) for _ in range(3)]
+        if fused:
+            import ctypes
+            hip.unet_bn_bwd_from_partials(P(dy), ci, P(r_prev), cp, P(gm), P(mean), P(invstd), npx, cp, 1, P(dz), cp, P(dg), P(db), P(dbias),
+                                          ctypes.c_void_p(part.data_ptr() + (c0 // 64) * rows * 128 * 4), rows, P(ws), nb, ST())
+        else:
+            hip.unet_bn_bwd(P(dy), ci, P(r_prev), cp, P(gm), P(mean), P(invstd), npx, cp, 1, P(dz), cp, P(dg), P(db), P(dbias), P(ws), nb, ST())
+        res.append((dz, dg, db, dbias))
+    for a_, b_ in zip(res[0], res[1]):
+        scale = b_.abs().max().item() + 1e-30
+        assert (a_ - b_).abs().max().item() < 2e-5 * scale + 1e-6, (a_ - b_).abs().max().item() / scale
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 64), (3, 8, 24, 64, 192), (1, 6, 10, 64, 64), (2, 32, 48, 128, 128)])
 def test_conv3x3_winograd_fused_wgrad(hip, shape):
     # raw rows through LDS, per-lane Winograd transforms in registers, G^T dU G in the epilogue; ragged tile rows included
