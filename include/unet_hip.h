@@ -87,6 +87,10 @@ int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* V_saved,
 /* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
 int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                             int N, int H, int W, int Cin, int Cout, int relu, void* stream);
+/* + BatchNorm sums of the output from the strip kernel (Cin <= 4, W % 4 == 0, Cout % 64 == 0): rows > 0 when it applies */
+int unet_conv3x3_fwd_direct_stats_rows(int N, int H, int W, int Cin, int Cout);
+int unet_conv3x3_fwd_direct_stats(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                  int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
 size_t unet_conv3x3_wgrad_direct_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);

@@ -18,7 +18,8 @@ constexpr int CI_CHUNK = 8;
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_direct_fwd_strip_kernel(const float* __restrict__ x, int ldx,
         const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int ldo,
-        int N, int H, int W, int Cout, int relu) {
+        int N, int H, int W, int Cout, int relu, float* __restrict__ stat_part) {
+    extern __shared__ __attribute__((aligned(16))) float sStat[];  // [spb][Cout][2] when stat_part != null
     const int tpp = Cout >> 2, spb = 256 / tpp;                   // strips per block pass
     const int q = threadIdx.x % tpp, sl = threadIdx.x / tpp;
     f32x4 wr[9][CIN];
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_fwd_strip_kernel(const flo
     const int SW = W >> 2;                                        // strips per row (W % 4 == 0)
     const long strips = (long)N * H * SW;
     const float lo = relu ? 0.f : -__builtin_inff();
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};     // BatchNorm sums of the thread's channel quad (UNet/model.py:36)
     for (long s = (long)blockIdx.x * spb + sl; s < strips; s += (long)gridDim.x * spb) {
         long t = s; const int sx = (int)(t % SW); t /= SW; const int y = (int)(t % H); const int n = (int)(t / H);
         const int x0 = 4 * sx;
@@ -60,6 +62,18 @@ __global__ __launch_bounds__(256) void conv3x3_direct_fwd_strip_kernel(const flo
                     for (int ci = 0; ci < CIN; ++ci) acc += v[r][px + c][ci] * wr[3 * r + c][ci];
             acc[0] = fmaxf(acc[0], lo); acc[1] = fmaxf(acc[1], lo); acc[2] = fmaxf(acc[2], lo); acc[3] = fmaxf(acc[3], lo);
             *reinterpret_cast<f32x4*>(o + (size_t)px * ldo) = acc;
+            st1 += acc; st2 += acc * acc;
+        }
+    }
+    if (stat_part) {            // one row of partials per block, layout of unet_bn_train_finalize_partials: [C/64][rows][64][2]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sStat[(sl * Cout + 4 * q + e) * 2] = st1[e]; sStat[(sl * Cout + 4 * q + e) * 2 + 1] = st2[e]; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * Cout; i += 256) {
+            float t = 0.f;
+            for (int l = 0; l < spb; ++l) t += sStat[l * 2 * Cout + i];
+            const int c = i >> 1;
+            stat_part[((size_t)(c >> 6) * gridDim.x + blockIdx.x) * 128 + (c & 63) * 2 + (i & 1)] = t;
         }
     }
 }
@@ -332,8 +346,8 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_wgrad_kernel(const float* 
 
 }  // namespace
 
-extern "C" int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
-                                       int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
+static int direct_fwd_launch(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                             int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(x && w && out && N > 0 && H > 0 && W > 0 && Cin > 0 && ldx >= Cin && ldo >= Cout);
     const int tpp = Cout / 4;
     UNET_CHECK_ARG(Cout % 4 == 0 && tpp >= 1 && tpp <= 256 && 256 % tpp == 0 && ldo % 4 == 0 && unet_aligned16(out));
@@ -346,14 +360,41 @@ extern "C" int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, 
     if (Cin <= 4 && W % 4 == 0 && unet_aligned16(w)) {
         long b1 = (P / 4 + ppb - 1) / ppb; if (b1 > 4096) b1 = 4096;
         hipStream_t st = (hipStream_t)stream;
-        if (Cin == 1)      conv3x3_direct_fwd_strip_kernel<1><<<(int)b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu);
-        else if (Cin == 2) conv3x3_direct_fwd_strip_kernel<2><<<(int)b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu);
-        else if (Cin == 3) conv3x3_direct_fwd_strip_kernel<3><<<(int)b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu);
-        else               conv3x3_direct_fwd_strip_kernel<4><<<(int)b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu);
+        size_t sm = 0;
+        if (stat_part) {
+            UNET_CHECK_ARG(Cout % 64 == 0);
+            if (stat_bytes < (size_t)(Cout / 64) * b1 * 128 * sizeof(float)) return UNET_ENOSPC;
+            sm = (size_t)ppb * Cout * 2 * sizeof(float);
+        }
+        if (Cin == 1)      conv3x3_direct_fwd_strip_kernel<1><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part);
+        else if (Cin == 2) conv3x3_direct_fwd_strip_kernel<2><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part);
+        else if (Cin == 3) conv3x3_direct_fwd_strip_kernel<3><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part);
+        else               conv3x3_direct_fwd_strip_kernel<4><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part);
         return UNET_LAUNCH_STATUS();
     }
+    if (stat_part) return UNET_EINVAL;
     conv3x3_direct_fwd_kernel<<<(int)blocks, 256, smem, (hipStream_t)stream>>>(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, relu);
     return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                       int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    return direct_fwd_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, relu, nullptr, 0, stream);
+}
+
+// rows of BatchNorm partial sums the strip kernel would write per 64-channel block (0: the generic kernel would run)
+extern "C" int unet_conv3x3_fwd_direct_stats_rows(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 1 || Cin > 4 || W % 4 != 0 || Cout % 64 != 0 || Cout > 1024) return 0;
+    const int ppb = 256 / (Cout / 4);
+    long b1 = ((long)N * H * W / 4 + ppb - 1) / ppb; if (b1 > 4096) b1 = 4096;
+    return (int)b1;
+}
+
+// forward + BatchNorm sums of the output (stat_part: (Cout/64) * rows * 128 floats; finish with unet_bn_train_finalize_partials)
+extern "C" int unet_conv3x3_fwd_direct_stats(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(stat_part && unet_conv3x3_fwd_direct_stats_rows(N, H, W, Cin, Cout) > 0 && unet_aligned16(w));
+    return direct_fwd_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, stat_bytes, stream);
 }
 
 static int direct_wgrad_blocks(long P) { long b = (P + 1023) / 1024; if (b > 1024) b = 1024; if (b < 1) b = 1; return (int)b; }

@@ -326,7 +326,14 @@ class Engine:
                 self._timed("conv3x3_fwd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
                             _p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
             else:
-                L.unet_conv3x3_fwd_direct(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+                rows = L.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
+                if rows > 0:
+                    stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
+                    L.unet_conv3x3_fwd_direct_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1,
+                                                    _p(stat_part), stat_part.numel() * 4, st)
+                    fused_stats = (stat_part, rows)
+                else:
+                    L.unet_conv3x3_fwd_direct(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
         P = r.shape[0] * r.shape[1] * r.shape[2]
         s = self.stat[name]
         gm, bt = self.p[name + "/gamma"], self.p[name + "/beta"]
