@@ -16,7 +16,8 @@ for n, c, t, a, mn, mx in rows:
 
 # forward launches run the statistics variant (training), dgrad launches the plain persistent kernel
 for kname, what in (("wino_fused_stream_stats_kernel", "FORWARD launches (exclusive on the GPU; bench.py's roofline uses them)"),
-                    ("wino_fused_stream_kernel", "dgrad launches (share the GPU with the side-stream weight gradients)")):
+                    ("wino_fused_stream_bnbwd_kernel", "dgrad launches that also leave the producer's BatchNorm-backward sums (share the GPU with the side-stream weight gradients)"),
+                    ("wino_fused_stream_kernel", "other dgrad launches (same sharing)")):
     ev = [e - s0 for s0, e in db.execute("select start, end from kernels where name like ?", ("%" + kname + "(%",))]
     if ev:
         print("# %s %s: %d, average %.1f us" % (kname, what, len(ev), sum(ev) / len(ev) / 1e3))
