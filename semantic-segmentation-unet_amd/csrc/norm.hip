@@ -166,6 +166,37 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
+// BN apply fused with the 2x2 max pool that follows the encoder's second conv of a level (UNet/model.py:36,50-53): one thread =
+// one pooled pixel x channel quad: reads the 4 r values, writes the 4 normalised values (the skip tensor) and their first-max
+// (row-major window order, the reference's tie rule) + its index -- the skip tensor is not read back for pooling.
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
+        const float* __restrict__ shift, float* __restrict__ y, int ldy, float* __restrict__ pooled, int ldp, uint8_t* __restrict__ idx,
+        int N, int H, int W, int C) {
+    const int H2 = H / 2, W2 = W / 2, nq = C / 4;
+    const long total = (long)N * H2 * W2 * nq, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        long t = i; const int cq = (int)(t % nq); t /= nq;
+        const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const int n = (int)(t / H2);
+        const long opix = ((long)n * H2 + oy) * W2 + ox;
+        float a[4], b[4], best[4]; uint8_t bi[4];
+        vload<4>(a, scale + 4 * cq); vload<4>(b, shift + 4 * cq);
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            const size_t pix = (size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1);
+            float v[4];
+            vload<4>(v, r + pix * ldr + 4 * cq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaf(a[e], v[e], b[e]);
+                if (pos == 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)pos; }
+            }
+            vstore<4>(y + pix * ldy + 4 * cq, v);
+        }
+        vstore<4>(pooled + (size_t)opix * ldp + 4 * cq, best);
+        *reinterpret_cast<uint32_t*>(idx + (size_t)opix * C + 4 * cq) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    }
+}
+
 // backward pass 1: per-channel sum(dy) and sum(dy * xhat)
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
@@ -347,6 +378,19 @@ extern "C" int unet_bn_apply(const float* r, int ldr, const float* scale, const 
     long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
     if (v4) bn_apply_kernel<4><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C);
     else    bn_apply_kernel<1><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C);
+    return UNET_LAUNCH_STATUS();
+}
+
+// y = scale * r + shift (as unet_bn_apply) and, in the same pass, pooled = MaxPool2D(2)(y) with the first-max index
+extern "C" int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy,
+                                     float* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    UNET_CHECK_ARG(r && scale && shift && y && pooled && idx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0);
+    UNET_CHECK_ARG(ldr >= C && ldy >= C && ldp >= C && ldr % 4 == 0 && ldy % 4 == 0 && ldp % 4 == 0);
+    UNET_CHECK_ARG(unet_aligned16(r) && unet_aligned16(y) && unet_aligned16(pooled) && unet_aligned16(scale) && unet_aligned16(shift) &&
+                   (reinterpret_cast<uintptr_t>(idx) & 3u) == 0);
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    bn_apply_pool_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C);
     return UNET_LAUNCH_STATUS();
 }
 

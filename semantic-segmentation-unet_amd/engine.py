@@ -148,6 +148,7 @@ class Engine:
         self._fused_U, self._fused_dirty = None, True
         self.fuse_bn_stats = os.environ.get("UNET_FUSE_BN_STATS", "1") != "0"      # BN sums from the conv epilogue (A/B switch)
         self.bnbwd_part = {}
+        self.fuse_pool = os.environ.get("UNET_FUSE_POOL", "1") != "0"             # BN apply + max pool in one pass (A/B switch)
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -274,7 +275,7 @@ class Engine:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def _block_fwd(self, name, x, y_out, training):
+    def _block_fwd(self, name, x, y_out, training, pool=None):
         """x: NHWC view (input of the layer), y_out: NHWC view the BN output is written to."""
         L, st = self.L, self._stream()
         kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
@@ -348,7 +349,11 @@ class Engine:
                                   _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(ws), nb, st)
         else:
             L.unet_bn_eval_coeffs(_p(gm), _p(bt), _p(mm), _p(mv), BN_EPS, cout, _p(s[2]), _p(s[3]), st)
-        L.unet_bn_apply(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), P, cout, st)
+        if pool is not None:           # (pooled, idx): BN apply and the level's max pool in one pass
+            L.unet_bn_apply_maxpool(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
+                                    r.shape[0], r.shape[1], r.shape[2], cout, st)
+        else:
+            L.unet_bn_apply(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), P, cout, st)
         self.saved[name] = (x, r)
         return y_out
 
@@ -400,12 +405,14 @@ class Engine:
             ya = f("conv_%da" % lvl, cur, self._buf("y_conv_%da" % lvl, (n, hh, ww, ch)), training)
             cat = self._buf("cat_%d" % lvl, (n, hh, ww, 2 * ch))
             self.cat[lvl] = cat
-            skip = f("conv_%db" % lvl, ya, cat[..., :ch], training)
-            if lvl == 4 and training:
-                self._dropout(skip, "drop_4", self.masks)
             pooled = self._buf("pool_%d" % lvl, (n, hh // 2, ww // 2, ch))
             idx = self._buf("idx_%d" % lvl, (n, hh // 2, ww // 2, ch), torch.uint8)
-            L.unet_maxpool2x2_fwd(_p(skip), _ld(skip), _p(pooled), ch, _p(idx), n, hh, ww, ch, st)
+            fuse_pool = self.fuse_pool and not (lvl == 4 and training)   # level 4 drops out between BN and pool (UNet/model.py:105-107)
+            skip = f("conv_%db" % lvl, ya, cat[..., :ch], training, pool=(pooled, idx) if fuse_pool else None)
+            if not fuse_pool:
+                if lvl == 4 and training:
+                    self._dropout(skip, "drop_4", self.masks)
+                L.unet_maxpool2x2_fwd(_p(skip), _ld(skip), _p(pooled), ch, _p(idx), n, hh, ww, ch, st)
             self.idx[lvl] = idx
             cur = pooled
         hh, ww = cur.shape[1], cur.shape[2]

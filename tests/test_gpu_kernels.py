@@ -271,6 +271,23 @@ def test_batchnorm_train_eval_backward(hip, c, relu):
     assert np.abs(gr[2, :c].cpu().numpy() - dz_ref.sum(axis=(0, 2, 3))).max() < 1e-4 * np.abs(dz_ref).sum(axis=(0, 2, 3)).max()
 
 
+def test_bn_apply_maxpool_fused_equals_separate(hip):
+    # one pass == unet_bn_apply followed by unet_maxpool2x2_fwd, bit for bit (values, pooled, first-max indices incl. ties)
+    n, h, w, c = 2, 12, 20, 64
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    r = torch.relu(torch.randn(n, h, w, c, device=DEV, generator=g))          # post-ReLU: plenty of exact ties at 0
+    sc = torch.rand(c, device=DEV, generator=g) + 0.5; sh = torch.zeros(c, device=DEV)
+    cat1 = torch.zeros(n, h, w, 2 * c, device=DEV); cat2 = torch.zeros_like(cat1)
+    p1 = torch.empty(n, h // 2, w // 2, c, device=DEV); p2 = torch.empty_like(p1)
+    i1 = torch.empty(n, h // 2, w // 2, c, dtype=torch.uint8, device=DEV); i2 = torch.empty_like(i1)
+    y1, y2 = cat1[..., :c], cat2[..., :c]
+    hip.unet_bn_apply_maxpool(P(r), c, P(sc), P(sh), P(y1), 2 * c, P(p1), c, P(i1), n, h, w, c, ST())
+    hip.unet_bn_apply(P(r), c, P(sc), P(sh), P(y2), 2 * c, n * h * w, c, ST())
+    hip.unet_maxpool2x2_fwd(P(y2), 2 * c, P(p2), c, P(i2), n, h, w, c, ST())
+    assert torch.equal(cat1, cat2) and torch.equal(p1, p2) and torch.equal(i1, i2)
+    assert (i1 == 0).float().mean().item() > 0.3                               # ties resolved to the first position
+
+
 def test_maxpool_fwd_bwd_with_ties(hip):
     n, h, w, c = 2, 8, 12, 64
     rng = np.random.default_rng(0)
