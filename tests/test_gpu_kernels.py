@@ -285,7 +285,7 @@ def test_bn_apply_maxpool_fused_equals_separate(hip):
     hip.unet_bn_apply(P(r), c, P(sc), P(sh), P(y2), 2 * c, n * h * w, c, ST())
     hip.unet_maxpool2x2_fwd(P(y2), 2 * c, P(p2), c, P(i2), n, h, w, c, ST())
     assert torch.equal(cat1, cat2) and torch.equal(p1, p2) and torch.equal(i1, i2)
-    assert (i1 == 0).float().mean().item() > 0.3                               # ties resolved to the first position
+    assert (i1 == 0).float().mean().item() > 0.27                              # 0.234 strict wins + 1/16 all-zero windows (ties -> first position)
 
 
 def test_maxpool_fwd_bwd_with_ties(hip):
