@@ -145,6 +145,10 @@ int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float*
                 const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,
                 float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* the layer's output also fed MaxPool2D(2): dy = dy_skip + unpool(pooled_dy, idx) formed on the fly (no pool-backward pass) */
+int unet_bn_bwd_pooled(const float* dy_skip, int lddy, const float* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
+                       const float* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
+                       float* dz, int lddz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, void* stream);
 int unet_bn_bwd_from_partials(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
                               const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,
                               float* dbias, const float* part_sums, int rows, void* ws, size_t ws_bytes, void* stream);

@@ -26,6 +26,22 @@ template <int VEC> __device__ __forceinline__ Lay make_lay(int C, int tpp) {
     l.c0 = l.q * VEC; l.active = l.c0 < C; return l;
 }
 
+// Optional second gradient source for the BatchNorm-backward kernels: the layer's output also went through MaxPool2D(2)
+// (encoder levels, UNet/model.py:50-53,89-91), so dy(pixel) = dy_skip(pixel) + [pixel is its window's first max] * pooled_dy.
+// Reading it here saves the separate pool-backward pass that would read-modify-write the whole skip gradient.
+struct PoolGrad { const float* pdy; int ldp; const uint8_t* idx; int H, W, C; };
+
+template <int VEC> __device__ __forceinline__ void add_pool_grad(float (&g)[VEC], const PoolGrad& pg, long pix, int c0) {
+    if (!pg.pdy) return;
+    const int x = (int)(pix % pg.W); const long t = pix / pg.W; const int y = (int)(t % pg.H); const long n = t / pg.H;
+    const long opix = (n * (pg.H >> 1) + (y >> 1)) * (pg.W >> 1) + (x >> 1);
+    const int pos = ((y & 1) << 1) | (x & 1);
+    float q[VEC];
+    vload<VEC>(q, pg.pdy + (size_t)opix * pg.ldp + c0);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) if (pg.idx[(size_t)opix * pg.C + c0 + e] == pos) g[e] += q[e];
+}
+
 // block-level combine of NV per-lane fp64 vectors (each VEC wide) over the pixel lanes; result to part[v][blk][C]
 template <int VEC, int NV>
 __device__ __forceinline__ void block_combine(double (&acc)[NV][VEC], const Lay& l, int C, double* part, int nblk, double* sR) {
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
         int ldr, const float* __restrict__ mean, const float* __restrict__ invstd, long P, int C, int tpp, long ppb,
-        double* __restrict__ part) {
+        double* __restrict__ part, PoolGrad pg) {
     extern __shared__ __attribute__((aligned(16))) double sRd[];
     const Lay l = make_lay<VEC>(C, tpp);
     const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P) p1 = P;
@@ -217,6 +233,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 vload<VEC>(g[u], dy + (size_t)(pix + u * st) * lddy + l.c0); vload<VEC>(v[u], r + (size_t)(pix + u * st) * ldr + l.c0);
+                add_pool_grad<VEC>(g[u], pg, pix + u * st, l.c0);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -229,6 +246,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         for (; pix < p1; pix += st) {
             float g[VEC], v[VEC];
             vload<VEC>(g, dy + (size_t)pix * lddy + l.c0); vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
+            add_pool_grad<VEC>(g, pg, pix, l.c0);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xh = (v[e] - mu[e]) * is[e];
@@ -252,7 +270,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
         int ldr, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
         const float* __restrict__ dgamma, const float* __restrict__ dbeta, long P, int C, int tpp, long ppb, int relu,
-        float* __restrict__ dz, int lddz, double* __restrict__ part) {
+        float* __restrict__ dz, int lddz, double* __restrict__ part, PoolGrad pg) {
     extern __shared__ __attribute__((aligned(16))) double sRd[];
     const Lay l = make_lay<VEC>(C, tpp);
     const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P) p1 = P;
@@ -274,6 +292,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 vload<VEC>(g[u], dy + (size_t)(pix + u * st) * lddy + l.c0); vload<VEC>(v[u], r + (size_t)(pix + u * st) * ldr + l.c0);
+                add_pool_grad<VEC>(g[u], pg, pix + u * st, l.c0);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -291,6 +310,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         for (; pix < p1; pix += st) {
             float g[VEC], v[VEC], o[VEC];
             vload<VEC>(g, dy + (size_t)pix * lddy + l.c0); vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
+            add_pool_grad<VEC>(g, pg, pix, l.c0);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xh = (v[e] - mu[e]) * is[e];
@@ -394,29 +414,51 @@ extern "C" int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale
     return UNET_LAUNCH_STATUS();
 }
 
-extern "C" int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
+static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
         const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta, float* dbias,
-        void* ws, size_t ws_bytes, void* stream) {
+        const float* part_sums, int rows, PoolGrad pg, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(dy && r && gamma && mean && invstd && dz && dgamma && dbeta && dbias && ws && P > 0 && C > 0);
     UNET_CHECK_ARG(lddy >= C && ldr >= C && lddz >= C);
     Plan pl;
     const bool al = unet_aligned16(dy) && unet_aligned16(r) && unet_aligned16(dz) && unet_aligned16(gamma) && unet_aligned16(mean) &&
-                    unet_aligned16(invstd) && unet_aligned16(dgamma) && unet_aligned16(dbeta);
+                    unet_aligned16(invstd) && unet_aligned16(dgamma) && unet_aligned16(dbeta) && (!pg.pdy || (unet_aligned16(pg.pdy) && pg.ldp % 4 == 0));
     UNET_CHECK_ARG(make_plan(P, C, lddy, ldr, lddz, al, &pl));
     if (ws_bytes < unet_bn_workspace(P, C)) return UNET_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)ws;
-    if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part);
-    else             bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part);
-    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(part, pl.nblk, C, dgamma, dbeta);
+    int rc;
+    if (part_sums) {
+        bn_bwd_finalize_partials_kernel<<<C, 64, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
+    } else {
+        if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg);
+        else             bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg);
+        rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+        bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(part, pl.nblk, C, dgamma, dbeta);
+    }
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     double* part2 = part + (size_t)2 * pl.nblk * C;
-    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
-    else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
+    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg);
+    else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     colsum_finalize_kernel<<<C, 64, 0, st>>>(part2, pl.nblk, C, dbias);
     return UNET_LAUNCH_STATUS();
+}
+
+extern "C" int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
+        const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta, float* dbias,
+        void* ws, size_t ws_bytes, void* stream) {
+    return bn_bwd_launch(dy, lddy, r, ldr, gamma, mean, invstd, P, C, relu, dz, lddz, dgamma, dbeta, dbias, nullptr, 0,
+                         PoolGrad{nullptr, 0, nullptr, 0, 0, 0}, ws, ws_bytes, stream);
+}
+
+// unet_bn_bwd for a layer whose output also feeds MaxPool2D(2): the gradient is dy_skip + unpool(pooled_dy) (first-max indices
+// idx from the forward pool), formed on the fly -- no separate pool-backward pass.  dy_skip / r / dz are [N,H,W,C].
+extern "C" int unet_bn_bwd_pooled(const float* dy_skip, int lddy, const float* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
+        const float* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
+        float* dz, int lddz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(pooled_dy && idx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ldp >= C);
+    return bn_bwd_launch(dy_skip, lddy, r, ldr, gamma, mean, invstd, (long)N * H * W, C, relu, dz, lddz, dgamma, dbeta, dbias, nullptr, 0,
+                         PoolGrad{pooled_dy, ldp, idx, H, W, C}, ws, ws_bytes, stream);
 }
 
 // unet_bn_bwd with the reduction pass replaced by the partial sums of a fused data-gradient kernel
@@ -424,20 +466,7 @@ extern "C" int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, c
 extern "C" int unet_bn_bwd_from_partials(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
         const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta, float* dbias,
         const float* part_sums, int rows, void* ws, size_t ws_bytes, void* stream) {
-    UNET_CHECK_ARG(dy && r && gamma && mean && invstd && dz && dgamma && dbeta && dbias && ws && part_sums && rows > 0 && P > 0 && C > 0 && C % 64 == 0);
-    UNET_CHECK_ARG(lddy >= C && ldr >= C && lddz >= C);
-    Plan pl;
-    const bool al = unet_aligned16(dy) && unet_aligned16(r) && unet_aligned16(dz) && unet_aligned16(gamma) && unet_aligned16(mean) &&
-                    unet_aligned16(invstd) && unet_aligned16(dgamma) && unet_aligned16(dbeta);
-    UNET_CHECK_ARG(make_plan(P, C, lddy, ldr, lddz, al, &pl));
-    if (ws_bytes < unet_bn_workspace(P, C)) return UNET_ENOSPC;
-    hipStream_t st = (hipStream_t)stream;
-    bn_bwd_finalize_partials_kernel<<<C, 64, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
-    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    double* part2 = (double*)ws + (size_t)2 * pl.nblk * C;
-    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
-    else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2);
-    rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    colsum_finalize_kernel<<<C, 64, 0, st>>>(part2, pl.nblk, C, dbias);
-    return UNET_LAUNCH_STATUS();
+    UNET_CHECK_ARG(part_sums && rows > 0 && C % 64 == 0);
+    return bn_bwd_launch(dy, lddy, r, ldr, gamma, mean, invstd, P, C, relu, dz, lddz, dgamma, dbeta, dbias, part_sums, rows,
+                         PoolGrad{nullptr, 0, nullptr, 0, 0, 0}, ws, ws_bytes, stream);
 }

@@ -445,7 +445,7 @@ class Engine:
         return prob
 
     # ------------------------------------------------------------------------------------------------ backward
-    def _block_bwd(self, name, dy, need_dx=True, eval_mode=False):
+    def _block_bwd(self, name, dy, need_dx=True, eval_mode=False, pool_grad=None):
         """dy: NHWC view = gradient w.r.t. the layer's BN output.  Returns gradient w.r.t. the layer input (or None).
         eval_mode: BN used its moving statistics (an affine map) and no parameter gradients are wanted."""
         L, st = self.L, self._stream()
@@ -467,6 +467,14 @@ class Engine:
                                         0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
                                         _p(self.g[name + "/bias"]), ctypes.c_void_p(part.data_ptr() + (c0 // 64) * rows * 128 * 4), rows,
                                         _p(ws), nb, st)
+        elif pool_grad is not None:
+            # dy = skip gradient + un-pooled gradient of the level below, formed inside the BatchNorm-backward kernels
+            pdy, pidx = pool_grad
+            nb = L.unet_bn_workspace(P, cout)
+            ws = self._workspace(nb)
+            L.unet_bn_bwd_pooled(_p(dy), _ld(dy), _p(pdy), _ld(pdy), _p(pidx), n, ho, wo, _p(r), cout, _p(self.p[name + "/gamma"]),
+                                 _p(s[0]), _p(s[1]), cout, 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
+                                 _p(self.g[name + "/bias"]), _p(ws), nb, st)
         else:
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
@@ -579,10 +587,13 @@ class Engine:
             dcat = self.bufs["dcat_%d" % lvl]
             ds = dcat[..., :ch]
             n, hh, ww, _ = ds.shape
-            L.unet_maxpool2x2_bwd(_p(d), _ld(d), _p(self.idx[lvl]), _p(ds), _ld(ds), n, hh, ww, ch, 1, st)
-            if lvl == 4 and not eval_mode:
-                self._dropout(ds, "drop_4", self.masks)
-            d = b("conv_%db" % lvl, ds)
+            if self.fuse_pool and not eval_mode and lvl != 4 and ch % 4 == 0:
+                d = self._block_bwd("conv_%db" % lvl, ds, pool_grad=(d, self.idx[lvl]))       # no separate pool-backward pass
+            else:
+                L.unet_maxpool2x2_bwd(_p(d), _ld(d), _p(self.idx[lvl]), _p(ds), _ld(ds), n, hh, ww, ch, 1, st)
+                if lvl == 4 and not eval_mode:
+                    self._dropout(ds, "drop_4", self.masks)
+                d = b("conv_%db" % lvl, ds)
             d = b("conv_%da" % lvl, d, need_dx=(lvl != 1 or eval_mode))
         if self.overlap_wgrad and not eval_mode:
             torch.cuda.current_stream().wait_stream(self.side)        # every weight gradient done before Adam

@@ -288,6 +288,36 @@ def test_bn_apply_maxpool_fused_equals_separate(hip):
     assert (i1 == 0).float().mean().item() > 0.27                              # 0.234 strict wins + 1/16 all-zero windows (ties -> first position)
 
 
+def test_bn_bwd_pooled_equals_pool_backward_then_bn_bwd(hip):
+    # dy = skip gradient + un-pooled gradient formed inside the BatchNorm-backward kernels == the separate pool-backward pass
+    # (accumulating into the skip gradient) followed by unet_bn_bwd
+    n, h, w, c = 2, 12, 20, 64
+    g = torch.Generator(device=DEV); g.manual_seed(4)
+    r = torch.relu(torch.randn(n, h, w, c, device=DEV, generator=g))
+    y = r * 1.3
+    pooled = torch.empty(n, h // 2, w // 2, c, device=DEV); idx = torch.empty(n, h // 2, w // 2, c, dtype=torch.uint8, device=DEV)
+    hip.unet_maxpool2x2_fwd(P(y), c, P(pooled), c, P(idx), n, h, w, c, ST())
+    dcat = torch.randn(n, h, w, 2 * c, device=DEV, generator=g); dskip = dcat[..., :c]
+    pdy = torch.randn(n, h // 2, w // 2, c, device=DEV, generator=g)
+    gm = torch.rand(c, device=DEV, generator=g) + 0.5
+    mean = r.mean((0, 1, 2)).contiguous(); invstd = (1.0 / torch.sqrt(r.var((0, 1, 2), unbiased=False) + 1e-3)).contiguous()
+    npx = n * h * w
+    nb = hip.unet_bn_workspace(npx, c); ws = ws_bytes(nb)
+    out = []
+    for fused in (True, False):
+        dz = torch.empty(n, h, w, c, device=DEV); dg, db, dbias = [torch.empty(c, device=DEV) for _ in range(3)]
+        if fused:
+            hip.unet_bn_bwd_pooled(P(dskip), 2 * c, P(pdy), c, P(idx), n, h, w, P(r), c, P(gm), P(mean), P(invstd), c, 1,
+                                   P(dz), c, P(dg), P(db), P(dbias), P(ws), nb, ST())
+        else:
+            d2 = dcat.clone(); ds2 = d2[..., :c]
+            hip.unet_maxpool2x2_bwd(P(pdy), c, P(idx), P(ds2), 2 * c, n, h, w, c, 1, ST())
+            hip.unet_bn_bwd(P(ds2), 2 * c, P(r), c, P(gm), P(mean), P(invstd), npx, c, 1, P(dz), c, P(dg), P(db), P(dbias), P(ws), nb, ST())
+        out.append((dz, dg, db, dbias))
+    for a_, b_ in zip(out[0], out[1]):
+        assert torch.equal(a_, b_)
+
+
 def test_maxpool_fwd_bwd_with_ties(hip):
     n, h, w, c = 2, 8, 12, 64
     rng = np.random.default_rng(0)
