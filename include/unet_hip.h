@@ -121,6 +121,12 @@ int unet_convT2x2_dgrad(const float* dz, int lddz, const float* w, float* dx, in
 size_t unet_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_convT2x2_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* same result from the wide-tile persistent kernel (convt_stream.hip): W % 16 == 0, Cin % 128 == 0, Cout % 64 == 0; its own
+ * workspace size (split partials [splits][2][2][Cout][Cin], summed in fixed order) */
+int unet_convT2x2_wgrad_wide_supported(int N, int H, int W, int Cin, int Cout);
+size_t unet_convT2x2_wgrad_wide_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_convT2x2_wgrad_wide(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                             int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- BatchNormalization(axis=1), UNet/model.py:36,47 ------------------------------------------------------------- */
 size_t unet_bn_workspace(long P, int C);

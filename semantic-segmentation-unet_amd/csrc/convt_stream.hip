@@ -309,3 +309,218 @@ extern "C" int unet_convT2x2_fwd_stream_stats(const float* x, int ldx, const flo
     UNET_CHECK_ARG(stat_part);
     return convt_fwd_stream_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, stat_part, stat_bytes, stream);
 }
+
+// ---- transposed-conv weight gradient, wide tiles ---------------------------------------------------------------------------
+//   dw[a][b][co][ci] = sum_{n,i,j} dz[n,2i+a,2j+b,co] * x[n,i,j,ci]
+// The contraction runs over pixels, so operands are read from LDS images in their natural [pixel][channel] layout
+// (conflict-free ds_read_b32, the lane half picks the pixel of the k pair) like conv_wgrad.hip's kernel -- but a wave owns
+// 4 taps x (64 or 32 co) x 64 ci = 16 (8) accumulators instead of 4, which doubles the MFMA work per LDS-filled byte (the
+// narrow kernel sat at busy x clock = 1.35-1.48 GHz against the 1.85-1.9 every other MFMA kernel here reaches).  Workgroup =
+// CTM (128, or 64 when Cout % 128 != 0) output channels x 128 input channels, persistent over a split of the pixel tiles
+// (16 input pixels of one row = 2 x 32 dz pixels); 3-slot LDS-DMA ring; per tile 8 k-steps of 16 (8) MFMAs as an explicit
+// stream with the next step's operand reads and the DMAs of the tile after next behind them.
+namespace {
+
+struct ConvtWgArgs {
+    const float* x; const float* dz; float* ws;
+    int ldx, lddz, N, H, W, Cin, Cout;
+    int mt, nt, splits, n_tiles;
+};
+
+#define CW_RD32(dst, base, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
+
+template <int TM>
+__device__ __forceinline__ void convt_wgrad_wide_body(const ConvtWgArgs& p) {
+    constexpr int CTM = 64 * TM, CTN = 128;
+    constexpr int QA = CTM / 4, PPA = 64 / QA;               // lanes per dz pixel, dz pixels per 1-KB piece
+    constexpr int NPA = QA, NPB = 8, NP = NPA + NPB, PPW = NP / 4;
+    constexpr int SLOTB = NP * 1024, SLOTF = SLOTB / 4;
+    constexpr int NMF = 4 * TM * 2;                          // MFMAs per k-step
+    __shared__ __attribute__((aligned(1024))) float smem[3 * SLOTF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = wv & 1, ni = wv >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tmn = bid % (p.mt * p.nt), split = bid / (p.mt * p.nt);
+    const int m0 = (tmn / p.nt) * CTM, n0 = (tmn % p.nt) * CTN;
+    const int tpr = p.W >> 4;                                // tiles per image row
+
+    // DMA duty: pieces wv + 4k; k < KAW are dz pieces for every wave (NPA is a multiple of 4), the rest x pieces
+    unsigned doff[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int id = wv + 4 * k;
+        if (id < NPA) { const int pix = id * PPA + lane / QA; doff[k] = (unsigned)((((pix >> 5) * 2 * p.W + (pix & 31)) * p.lddz + 4 * (lane % QA)) * 4); }
+        else          { const int pix = (id - NPA) * 2 + (lane >> 5); doff[k] = (unsigned)((pix * p.ldx + 4 * (lane & 31)) * 4); }
+    }
+    // tile t = (image row `row` = t / tpr, 16-pixel segment t % tpr):  x pixel offset = 16 t,  dz pixel offset = 32 t + 2W row
+    const float* src_next[PPW];
+    auto sources = [&](int t, int row) {
+        const bool ok = t < p.n_tiles;                       // past the end: re-read the first tile, never used
+        const int tc = ok ? t : split, rc = ok ? row : split / tpr;
+        const char* dzb = reinterpret_cast<const char*>(p.dz + ((size_t)32 * tc + (size_t)2 * p.W * rc) * p.lddz + m0);
+        const char* xb = reinterpret_cast<const char*>(p.x + (size_t)16 * tc * p.ldx + n0);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) src_next[k] = reinterpret_cast<const float*>(((wv + 4 * k) < NPA ? dzb : xb) + doff[k]);
+    };
+    auto issue_tile = [&](int t, int slot) {
+        sources(t, t / tpr);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k)
+            __builtin_amdgcn_global_load_lds(src_next[k], (lds_void_t*)(smem + slot * SLOTF + (wv + 4 * k) * 256), 16, 0, 0);
+    };
+
+    f32x16 acc[4][TM][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
+    const unsigned a_lane = lds0 + 4u * (2 * lh * CTM + 32 * TM * mi + li);
+    const unsigned b_lane = lds0 + NPA * 1024 + 4u * (lh * CTN + 64 * ni + li);
+
+    int tile = split;
+    issue_tile(tile, 0);
+    issue_tile(tile + p.splits, 1);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PPW) : "memory");
+    int slot = 0;
+    // look-ahead tile (two splits on), advanced incrementally: no division in the loop
+    const int dtx = p.splits % tpr, drow = p.splits / tpr;
+    int t2 = tile + 2 * p.splits, tx2 = t2 % tpr, row2 = t2 / tpr;
+    for (; tile < p.n_tiles; tile += p.splits) {
+        const unsigned ab = a_lane + (unsigned)slot * SLOTB, bb = b_lane + (unsigned)slot * SLOTB;
+        float* const dst = smem + ((slot + 2) % 3) * SLOTF;
+        float fa[2][4][TM], fb[2][2];
+        // operand reads of k-step 0 (exposed once per tile), then 8 steps; reads of step s+1 ride behind step s's MFMAs
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int a = 0; a < TM; ++a) CW_RD32(fa[0][t][a], ab, (((t >> 1) * 32 + (t & 1)) * CTM + 32 * a) * 4);
+        CW_RD32(fb[0][0], bb, 0); CW_RD32(fb[0][1], bb, 128);
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int cur = st & 1, nx = cur ^ 1;
+            if (TM == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0][0]), "+v"(fa[cur][1][0]), "+v"(fa[cur][2][0]), "+v"(fa[cur][3][0]),
+                                       "+v"(fa[cur][0][TM - 1]), "+v"(fa[cur][1][TM - 1]), "+v"(fa[cur][2][TM - 1]), "+v"(fa[cur][3][TM - 1]),
+                                       "+v"(fb[cur][0]), "+v"(fb[cur][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0][0]), "+v"(fa[cur][1][0]), "+v"(fa[cur][2][0]), "+v"(fa[cur][3][0]),
+                              "+v"(fb[cur][0]), "+v"(fb[cur][1]));
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) {
+                const int t = m / (2 * TM), a = (m / 2) % TM, b = m & 1;
+                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[t][a][b]) : "v"(fa[cur][t][a]), "v"(fb[cur][b]) : "memory");
+                if (st == 0 && m == 0) {
+                    sources(t2, row2);
+                    t2 += p.splits; tx2 += dtx; row2 += drow;
+                    if (tx2 >= tpr) { tx2 -= tpr; ++row2; }
+                }
+                if (st + 1 < 8) {
+                    if (m < 4 * TM) {
+                        const int t2 = m / TM, a2 = m % TM;
+                        CW_RD32(fa[nx][t2][a2], ab, (((t2 >> 1) * 32 + (t2 & 1) + 4 * (st + 1)) * CTM + 32 * a2) * 4);
+                    } else if (m < 4 * TM + 2) {
+                        CW_RD32(fb[nx][m - 4 * TM], bb, (2 * (st + 1) * CTN + 32 * (m - 4 * TM)) * 4);
+                    }
+                }
+                // DMAs of the tile after next: PPW pieces over the 8 steps (at most 2 per step, behind MFMAs NMF-4 and NMF-2)
+                if (m == NMF - 4 && 2 * st < PPW) __builtin_amdgcn_global_load_lds(src_next[2 * st], (lds_void_t*)(dst + (wv + 4 * (2 * st)) * 256), 16, 0, 0);
+                if (m == NMF - 2 && 2 * st + 1 < PPW) __builtin_amdgcn_global_load_lds(src_next[2 * st + 1], (lds_void_t*)(dst + (wv + 4 * (2 * st + 1)) * 256), 16, 0, 0);
+            }
+        }
+        // the next tile has landed (only the newest batch may be in flight; loads retire in order); everyone is done with `slot`
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(PPW) : "memory");
+        slot = (slot + 1) % 3;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+    // partial block -> workspace [split][tap][Cout][Cin]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float e;
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(e) : "a"(acc[t][a][b][r]));
+                    p.ws[(((size_t)split * 4 + t) * p.Cout + m0 + 32 * TM * mi + 32 * a + row) * p.Cin + n0 + 64 * ni + 32 * b + li] = e;
+                }
+}
+
+__global__ __launch_bounds__(256, 1) void convt_wgrad_wide_kernel_128(ConvtWgArgs p) { convt_wgrad_wide_body<2>(p); }
+__global__ __launch_bounds__(256, 1) void convt_wgrad_wide_kernel_64(ConvtWgArgs p) { convt_wgrad_wide_body<1>(p); }
+
+// dw = sum over the split partials, in a fixed order: a block covers 256/SL consecutive float4 outputs x SL slices of the split
+// range (SL a power of two <= 16, chosen on the host so that small weight tensors with many splits still fill the chip); each
+// thread sums its slice front to back, thread 0 of each output adds the slice sums front to back.
+__global__ __launch_bounds__(256) void convt_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits, int sl) {
+    __shared__ f32x4 part[256];
+    const int per = 256 / sl;
+    const int o = threadIdx.x % per, sj = threadIdx.x / per;
+    const long i = (long)blockIdx.x * per + o;
+    const int k0 = (int)((long)splits * sj / sl), k1 = (int)((long)splits * (sj + 1) / sl);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int k = k0; k < k1; ++k) s += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
+    if (sl == 1) { if (i < n4) reinterpret_cast<f32x4*>(dw)[i] = s; return; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (sj == 0 && i < n4) {
+        for (int j = 1; j < sl; ++j) s += part[j * per + o];
+        reinterpret_cast<f32x4*>(dw)[i] = s;
+    }
+}
+
+int convt_wg_splits(int N, int H, int W, int Cin, int Cout) {
+    const int ctm = Cout % 128 == 0 ? 128 : 64;
+    const int mn = (Cout / ctm) * (Cin / 128);
+    const long tiles = (long)N * H * (W / 16);
+    long s = convt_cus() / mn; if (s < 1) s = 1; if (s > tiles) s = tiles;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" int unet_convT2x2_wgrad_wide_supported(int N, int H, int W, int Cin, int Cout) {
+    return (N > 0 && H > 0 && W > 0 && W % 16 == 0 && Cin % 128 == 0 && Cout % 64 == 0 &&
+            (long)2 * W * 4096 * 4 < (1L << 31)) ? 1 : 0;
+}
+
+extern "C" size_t unet_convT2x2_wgrad_wide_workspace(int N, int H, int W, int Cin, int Cout) {
+    if (!unet_convT2x2_wgrad_wide_supported(N, H, W, Cin, Cout)) return 0;
+    return (size_t)convt_wg_splits(N, H, W, Cin, Cout) * 4 * Cout * Cin * sizeof(float);
+}
+
+// dw[a][b][co][ci] = sum_{n,i,j} dz[n,2i+a,2j+b,co] * xin[n,i,j,ci]      (H, W are the INPUT dims of the layer)
+extern "C" int unet_convT2x2_wgrad_wide(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                        int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(xin && dz && dw && ws && unet_convT2x2_wgrad_wide_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && ldx <= 4096 && lddz <= 4096);
+    UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
+    if (ws_bytes < unet_convT2x2_wgrad_wide_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
+    ConvtWgArgs a{};
+    a.x = xin; a.dz = dz; a.ws = (float*)ws; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    const bool wide = Cout % 128 == 0;
+    a.mt = Cout / (wide ? 128 : 64); a.nt = Cin / 128;
+    a.splits = convt_wg_splits(N, H, W, Cin, Cout);
+    a.n_tiles = N * H * (W / 16);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(a.mt * a.nt * a.splits));
+    if (wide) convt_wgrad_wide_kernel_128<<<grid, 256, 0, st>>>(a);
+    else      convt_wgrad_wide_kernel_64<<<grid, 256, 0, st>>>(a);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    const long n4 = (long)4 * Cout * Cin / 4;
+    int sl = 1;
+    while (sl < 16 && 2 * sl <= a.splits && n4 * sl < 256 * 1024) sl *= 2;
+    const long blocks = (n4 * sl + 255) / 256;
+    convt_wgrad_reduce_kernel<<<(unsigned)blocks, 256, 0, st>>>((const float*)ws, dw, n4, a.splits, sl);
+    return UNET_LAUNCH_STATUS();
+}

@@ -149,6 +149,7 @@ class Engine:
         self.fuse_bn_stats = os.environ.get("UNET_FUSE_BN_STATS", "1") != "0"      # BN sums from the conv epilogue (A/B switch)
         self.bnbwd_part = {}
         self.fuse_pool = os.environ.get("UNET_FUSE_POOL", "1") != "0"             # BN apply + max pool in one pass (A/B switch)
+        self.convt_wgrad_wide = os.environ.get("UNET_CONVT_WGRAD_WIDE", "0") == "1"  # wide-tile kernel: 22% faster alone, no gain next to the dgrad stream
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -489,8 +490,12 @@ class Engine:
             sd = self.overlap_wgrad
             st2 = self._stream()
             if kind == "deconv":
-                nb2 = L.unet_convT2x2_wgrad_workspace(n, hi, wi, cin, cout)
-                L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                if self.convt_wgrad_wide and L.unet_convT2x2_wgrad_wide_supported(n, hi, wi, cin, cout) == 1:
+                    nb2 = L.unet_convT2x2_wgrad_wide_workspace(n, hi, wi, cin, cout)
+                    L.unet_convT2x2_wgrad_wide(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                else:
+                    nb2 = L.unet_convT2x2_wgrad_workspace(n, hi, wi, cin, cout)
+                    L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
                 L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)

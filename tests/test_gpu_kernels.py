@@ -149,6 +149,39 @@ def test_convT2x2_fwd_dgrad_wgrad(hip, shape):
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(1, 2, 16, 128, 64), (2, 3, 32, 128, 128), (1, 5, 48, 256, 192), (3, 1, 16, 384, 256),
+                                   (8, 32, 32, 1024, 512), (8, 256, 256, 128, 64)])
+def test_convT2x2_wgrad_wide_matches_first_kernel_and_oracle(hip, shape):
+    # wide-tile persistent weight-gradient kernel: fp64 oracle on the small shapes (1..12 tiles per workgroup, odd tile
+    # counts, both channel-tile widths, padded leading dimensions); the two BASELINE config-2 layers (up_4, up_1) against
+    # the first kernel
+    n, h, w, ci, co = shape
+    assert hip.unet_convT2x2_wgrad_wide_supported(n, h, w, ci, co) == 1
+    g = torch.Generator(device=DEV); g.manual_seed(ci + co + h)
+    x = torch.randn(n, h, w, ci + 8, device=DEV, generator=g)[..., :ci]
+    dz = torch.randn(n, 2 * h, 2 * w, co + 4, device=DEV, generator=g)[..., :co]
+    nb = hip.unet_convT2x2_wgrad_wide_workspace(n, h, w, ci, co)
+    ws = ws_bytes(nb)
+    dw = torch.full((2, 2, co, ci), float("nan"), device=DEV)
+    hip.unet_convT2x2_wgrad_wide(P(x), ci + 8, P(dz), co + 4, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+    nb0 = hip.unet_convT2x2_wgrad_workspace(n, h, w, ci, co)
+    ws0 = ws_bytes(nb0)
+    dw0 = torch.empty(2, 2, co, ci, device=DEV)
+    hip.unet_convT2x2_wgrad(P(x), ci + 8, P(dz), co + 4, P(dw0), n, h, w, ci, co, P(ws0), nb0, ST())
+    assert relerr(dw.cpu().numpy().astype(np.float64), dw0.cpu().numpy().astype(np.float64)) < 2e-5
+    if n * h * w <= 512:
+        xr = x.permute(0, 3, 1, 2).cpu().numpy().astype(np.float64)
+        dzr = dz.permute(0, 3, 1, 2).cpu().numpy().astype(np.float64)
+        _, dw_ref, _ = on.deconv2x2_bwd(xr, np.zeros((2, 2, co, ci)), dzr)
+        assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 2e-5
+    # run-to-run determinism (fixed split order)
+    dw2 = torch.empty_like(dw)
+    hip.unet_convT2x2_wgrad_wide(P(x), ci + 8, P(dz), co + 4, P(dw2), n, h, w, ci, co, P(ws), nb, ST())
+    assert torch.equal(dw, dw2)
+    assert hip.unet_convT2x2_wgrad_wide_supported(n, h, w + 1, ci, co) == 0
+    assert hip.unet_convT2x2_wgrad_wide_supported(n, h, w, ci + 64, co) == 0
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 16, 128, 128), (1, 16, 16, 64, 64), (4, 8, 16, 32, 192), (8, 32, 32, 1024, 512), (8, 256, 256, 128, 64)])
 def test_convT2x2_fwd_stream_matches_igemm_and_oracle(hip, shape):
     # persistent stream kernel for the transposed-conv forward: bit-level agreement is not expected (different summation
