@@ -84,6 +84,18 @@ size_t unet_conv3x3_wgrad_winograd_workspace(int N, int H, int W, int Cin, int C
 /* V_saved (nullable): the V_keep of the forward call on the same xin; when given, xin is not read */
 int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* V_saved, const float* dz, int lddz, float* dw,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* ---- bf16 matrix-core 3x3 convolution (BASELINE config 4: bf16 forward/backward, fp32 master weights; the reference keeps
+ * its mixed-precision policy commented out, UNet/train.py:52-54) ------------------------------------------------------
+ * Operands rounded to bf16 (nearest-even), exact products, fp32 accumulation; activations / gradients stay fp32 in memory.
+ * Cin % 64 == 0, Cout % 64 == 0, tensors < 2 GiB.  Weights are packed on the device once per step from the fp32 master copy
+ * (HWIO, UNet/model.py:31): mode 0 for the forward, mode 1 for the data gradient. */
+int unet_conv3x3_bf16_supported(int N, int H, int W, int Cin, int Cout);
+size_t unet_conv3x3_bf16_packed_bytes(int Cin, int Cout);
+int unet_conv3x3_bf16_pack_weights(const float* w, void* packed, int Cin, int Cout, int mode, void* stream);
+int unet_conv3x3_fwd_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
+                          int N, int H, int W, int Cin, int Cout, int relu, void* stream);
+int unet_conv3x3_dgrad_bf16(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
+                            int N, int H, int W, int Cin, int Cout, void* stream);
 /* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
 int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                             int N, int H, int W, int Cin, int Cout, int relu, void* stream);

@@ -1,0 +1,318 @@
+// 3x3 convolution on the bf16 matrix cores (BASELINE config 4: "bf16 forward/backward with fp32 master weights").
+//
+// Reference semantics: the same UNet._conv_layer convolution as the fp32 kernels (UNet/model.py:28-37); the reference keeps a
+// mixed-precision policy in comments only (UNet/train.py:52-54), so the contract here is the usual one of that policy: the
+// operands of the contraction (activations, weights) are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32), products
+// are exact and accumulated in fp32 (v_mfma_f32_32x32x16_bf16), bias / ReLU / BatchNorm / loss / Adam stay fp32 on fp32
+// master weights.  Activations stay fp32 in HBM in this stage: the kernel converts while it stages its input patch.
+//
+// Implicit GEMM, one workgroup (4 waves, one per SIMD, 256 accumulator registers) = 16 x 32 output pixels x CT = 128 (or 64)
+// output channels; the reduction runs in chunks of 16 input channels x 9 taps:
+//   * input patch 18 x 34 pixels x 16 channels: fp32 buffer loads (out-of-image lanes return 0 through the buffer's range
+//     check, no branches) into registers one chunk ahead, converted and written as two bf16 planes [k half][pixel][8] -- an
+//     MFMA A fragment (32 consecutive pixels of a row, 8 channels per lane) is one conflict-free ds_read_b128 whose address
+//     differs between taps by an immediate;
+//   * weights pre-packed on the device as [chunk][tap][k half][Cout][8] bf16, so a chunk's share is 1-KB pieces that LDS-DMA
+//     copies verbatim and a B fragment is again one linear ds_read_b128;
+//   * per chunk and wave 144 (72) MFMAs from 18 A + 36 (18) B fragment reads: every A fragment (patch row q, column shift b)
+//     feeds the up to three taps a with output row q - a, every B fragment four output rows; the stream is explicit
+//     (asm volatile) with the next group's reads issued behind the current group's MFMAs and counted lgkmcnt waits.
+// The data gradient is the same kernel on dz with weights packed flipped / transposed (mode 1).
+#include "common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_b;
+
+struct ConvBf16Args {
+    const float* x; const uint16_t* wp; const float* bias; float* out;
+    int ldx, ldo, N, H, W, Cin, Cout, relu;
+    int tby, tbx, n_px, n_co;
+    unsigned x_bytes;
+};
+
+constexpr int kPW = 34, kPlane = 640 * 16, kXP = 2 * kPlane;        // patch row length (pixels), bytes of one k-half plane, of the patch
+
+#define CB_RD128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
+#define CB_MFMA(accv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(accv) : "v"(av), "v"(bv) : "memory")
+
+template <int NCO> struct CbFrags { bf16x8 a[2]; bf16x8 b[2][3][NCO]; };
+
+__device__ __forceinline__ unsigned cb_pack2(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// wait until at most `n` LDS operations are outstanding; ties every fragment the following MFMAs read to the wait (each
+// register exactly once: a repeated "+v" operand would be copied BEFORE the wait)
+#define CB_WAIT_TIED(n, ...) asm volatile("s_waitcnt lgkmcnt(" #n ")" : __VA_ARGS__)
+#define CB_TIES4(a, b) "+v"(a), "+v"(b[0][0]), "+v"(b[1][0]), "+v"(b[2][0]), "+v"(b[0][1]), "+v"(b[1][1]), "+v"(b[2][1]), \
+                       "+v"(b[0][2]), "+v"(b[1][2]), "+v"(b[2][2]), "+v"(b[0][3]), "+v"(b[1][3]), "+v"(b[2][3])
+#define CB_TIES2(a, b) "+v"(a), "+v"(b[0][0]), "+v"(b[1][0]), "+v"(b[2][0]), "+v"(b[0][1]), "+v"(b[1][1]), "+v"(b[2][1])
+template <int NCO> __device__ __forceinline__ void cb_wait_ab(int issued, bf16x8& a, bf16x8 (&b)[3][NCO]);
+template <> __device__ __forceinline__ void cb_wait_ab<4>(int issued, bf16x8& a, bf16x8 (&b)[3][4]) {
+    if (issued == 3) CB_WAIT_TIED(3, CB_TIES4(a, b)); else if (issued == 2) CB_WAIT_TIED(2, CB_TIES4(a, b)); else CB_WAIT_TIED(1, CB_TIES4(a, b));
+}
+template <> __device__ __forceinline__ void cb_wait_ab<2>(int issued, bf16x8& a, bf16x8 (&b)[3][2]) {
+    if (issued == 3) CB_WAIT_TIED(3, CB_TIES2(a, b)); else if (issued == 2) CB_WAIT_TIED(2, CB_TIES2(a, b)); else CB_WAIT_TIED(1, CB_TIES2(a, b));
+}
+
+// one chunk (16 input channels x 9 taps) from LDS stage ST: 36 * NCO MFMAs per wave.  Groups (bs, q) = (column shift, patch
+// row); group g issues the A fragment of group g + 1 and its share of the next column shift's B fragments, waits for its own
+// (counted: LDS operations retire in order) and runs its MFMAs.
+template <int NCO, int ST, int STAGE_BYTES>
+__device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_base0, unsigned b_base0) {
+    constexpr int CT = 32 * NCO;
+    constexpr int AO = 0, BO = 0;                                   // (the stage offset does not fit the 16-bit immediate)
+    const unsigned a_base = a_base0 + ST * STAGE_BYTES, b_base = b_base0 + ST * STAGE_BYTES;
+    constexpr int BPG = NCO / 2;                                   // next-shift B reads per group: 3 * NCO over 6 groups
+    CbFrags<NCO> fr;
+#pragma unroll
+    for (int k = 0; k < 3 * NCO; ++k)
+        CB_RD128(fr.b[0][k / NCO][k % NCO], b_base, BO + (3 * (k / NCO) + 0) * 2 * CT * 16 + (k % NCO) * 512);
+    CB_RD128(fr.a[0], a_base, AO + 0);
+#pragma unroll
+    for (int g = 0; g < 18; ++g) {
+        const int bs = g / 6, q = g % 6;
+        int issued = 0;
+        if (g + 1 < 18) {
+            const int bs2 = (g + 1) / 6, q2 = (g + 1) % 6;
+            CB_RD128(fr.a[(g + 1) & 1], a_base, AO + (q2 * kPW + bs2) * 16);
+            ++issued;
+        }
+        if (bs < 2) {
+#pragma unroll
+            for (int k = q * BPG; k < (q + 1) * BPG; ++k) {
+                CB_RD128(fr.b[(bs + 1) & 1][k / NCO][k % NCO], b_base, BO + (3 * (k / NCO) + bs + 1) * 2 * CT * 16 + (k % NCO) * 512);
+                ++issued;
+            }
+        }
+        // everything issued before this group has landed once at most `issued` operations are outstanding
+        if (q == 0) cb_wait_ab<NCO>(issued, fr.a[g & 1], fr.b[bs & 1]);
+        else {
+            if (issued == 3)      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fr.a[g & 1]));
+            else if (issued == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr.a[g & 1]));
+            else if (issued == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fr.a[g & 1]));
+            else                  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr.a[g & 1]));
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int r = q - a;
+            if (r < 0 || r > 3) continue;
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) CB_MFMA(acc[r][c], fr.a[g & 1], fr.b[bs & 1][a][c]);
+        }
+    }
+}
+
+template <int NCO>
+__device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
+    constexpr int CT = 32 * NCO;
+    constexpr int WB = 18 * CT * 16;                                // bytes of a chunk's weights for this tile
+    constexpr int STAGE = kXP + WB;
+    constexpr int NPIECE = WB / 1024, KW = (NPIECE + 3) / 4;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    // tile: consecutive ids stay on one XCD (workgroups are dealt round-robin over the 8 XCDs), output-channel tile slowest,
+    // so an XCD's L2 holds few weight tiles at a time
+    int t = blockIdx.x;
+    const int total = p.n_px * p.n_co;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
+    const int cot = t / p.n_px; int px = t % p.n_px;
+    const int bx = px % p.tbx; px /= p.tbx;
+    const int by = px % p.tby; const int img = px / p.tby;
+    const int co0 = cot * CT, ty0 = 16 * by, tx0 = 32 * bx;
+    const int nchunks = p.Cin / 16;
+
+    // staging duty: float4 quad f of patch pixels (tid >> 2) + 64 j; out-of-image (and past-the-patch) lanes get an offset the
+    // buffer's range check rejects, so they load zeros
+    unsigned voff[10];
+    const int f = tid & 3;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const int pp = (tid >> 2) + 64 * j;
+        const int gy = ty0 - 1 + pp / kPW, gx = tx0 - 1 + pp % kPW;
+        const bool ok = pp < 18 * kPW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        voff[j] = ok ? (unsigned)((((size_t)(img * p.H + gy) * p.W + gx) * p.ldx) * 4 + f * 16) : 0x80000000u;
+    }
+    i32x4 srd;
+    {
+        const uint64_t base = (uint64_t)(uintptr_t)p.x;
+        srd.x = (int)(unsigned)base; srd.y = (int)(unsigned)((base >> 32) & 0xffffu); srd.z = (int)p.x_bytes; srd.w = 0x00020000;
+        srd.x = __builtin_amdgcn_readfirstlane(srd.x); srd.y = __builtin_amdgcn_readfirstlane(srd.y);
+        srd.z = __builtin_amdgcn_readfirstlane(srd.z); srd.w = __builtin_amdgcn_readfirstlane(srd.w);
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
+    const unsigned wr_base = lds0 + (unsigned)((f >> 1) * kPlane + (tid >> 2) * 16 + (f & 1) * 8);
+    const unsigned a_base = lds0 + (unsigned)(lh * kPlane + (4 * wv * kPW + li) * 16);
+    const unsigned b_base = lds0 + (unsigned)(kXP + lh * CT * 16 + li * 16);
+
+    // weight pieces wv + 4k of a chunk: piece = 64 channels x 16 B of one (tap, k half); [tap][half][Cout][8] in memory
+    unsigned woff[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int id = wv + 4 * k;
+        const int row = id / (CT / 64), blk = id % (CT / 64);
+        woff[k] = (unsigned)((row * p.Cout + co0 + 64 * blk) * 16 + lane * 16);
+    }
+    const size_t wchunk = (size_t)18 * p.Cout * 16;
+    const char* wsrc = reinterpret_cast<const char*>(p.wp);
+
+    f32x4 stg[10];
+    auto issue_x = [&](int chunk) {
+        const int so = chunk * 64;
+#pragma unroll
+        for (int j = 0; j < 10; ++j)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(stg[j]) : "v"(voff[j]), "s"(srd), "s"(so) : "memory");
+    };
+    auto issue_w = [&](int chunk, int stage) {
+        const char* src = wsrc + (size_t)chunk * wchunk;
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (NPIECE % 4 == 0 || wv + 4 * k < NPIECE)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + woff[k]),
+                                                 (lds_void_b*)(smem + stage * STAGE + kXP + (wv + 4 * k) * 1024), 16, 0, 0);
+    };
+    auto write_x = [&](int stage) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]),
+                     "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]), "+v"(stg[8]), "+v"(stg[9]) :: "memory");
+        const unsigned wb = wr_base + (unsigned)(stage * STAGE);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            uint2 v; v.x = cb_pack2(stg[j].x, stg[j].y); v.y = cb_pack2(stg[j].z, stg[j].w);
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(j * 1024) : "memory");
+        }
+    };
+
+    f32x16 acc[4][NCO];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+
+    issue_x(0); issue_w(0, 0);
+    write_x(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int c = 0; c < nchunks; c += 2) {                            // Cin % 32 == 0: an even number of chunks
+        issue_x(c + 1); issue_w(c + 1, 1);
+        cb_compute<NCO, 0, STAGE>(acc, a_base, b_base);
+        write_x(1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int cn = c + 2 < nchunks ? c + 2 : c;                  // past the end: refill with a valid chunk, never read
+        issue_x(cn); issue_w(cn, 0);
+        cb_compute<NCO, 1, STAGE>(acc, a_base, b_base);
+        write_x(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    // epilogue: accumulator register e of (row r, sub-tile c) = pixel (ty0 + 4 wv + r, tx0 + (e&3) + 8 (e>>2) + 4 lh), channel co0 + 32 c + li
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+        const int co = co0 + 32 * c + li;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+        const float lo = p.relu ? 0.f : -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = ty0 + 4 * wv + r;
+            float* orow = p.out + ((size_t)(img * p.H + gy) * p.W + tx0) * p.ldo + co;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float v;
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[r][c][e]));
+                v = fmaxf(v + bv, lo);
+                if (gy < p.H && tx0 + col < p.W) orow[(size_t)col * p.ldo] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void conv_bf16_kernel_128(ConvBf16Args p) { conv_bf16_body<4>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_kernel_64(ConvBf16Args p) { conv_bf16_body<2>(p); }
+
+// fp32 HWIO weights -> bf16 [chunk][tap][k half][out channel][8]: mode 0 forward (reduce over Cin), mode 1 data gradient
+// (reduce over Cout, taps flipped, output channel = the layer's input channel)
+__global__ void conv_bf16_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int Cin, int Cout, int mode) {
+    const int red = mode ? Cout : Cin, outc = mode ? Cin : Cout;
+    const long n = (long)(red / 8) * 9 * outc;                       // one thread = 8 reduce channels of one (tap, output channel)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int o = (int)(i % outc); long rest = i / outc;
+    const int kh = (int)(rest % 2); rest /= 2;
+    const int tap = (int)(rest % 9); const int chunk = (int)(rest / 9);
+    const int k0 = chunk * 16 + kh * 8;
+    unsigned v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a, b;
+        if (mode == 0) { a = w[((size_t)tap * Cin + k0 + 2 * e) * Cout + o]; b = w[((size_t)tap * Cin + k0 + 2 * e + 1) * Cout + o]; }
+        else           { a = w[((size_t)(8 - tap) * Cin + o) * Cout + k0 + 2 * e]; b = w[((size_t)(8 - tap) * Cin + o) * Cout + k0 + 2 * e + 1]; }
+        v[e] = cb_pack2(a, b);
+    }
+    reinterpret_cast<uint4*>(wp)[i] = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+int conv_bf16_cus() {
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+    return cus;
+}
+
+int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
+                  int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+    ConvBf16Args a{};
+    a.x = x; a.wp = (const uint16_t*)wp; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
+    a.tby = (H + 15) / 16; a.tbx = (W + 31) / 32; a.n_px = N * a.tby * a.tbx;
+    a.x_bytes = (unsigned)((size_t)N * H * W * ldx * 4);
+    // 128-channel tiles halve the input traffic; 64-channel tiles when they would leave compute units idle
+    const bool wide = Cout % 128 == 0 && (long)a.n_px * (Cout / 128) >= conv_bf16_cus();
+    a.n_co = Cout / (wide ? 128 : 64);
+    const dim3 grid((unsigned)(a.n_px * a.n_co));
+    if (wide) conv_bf16_kernel_128<<<grid, 256, 0, st>>>(a);
+    else      conv_bf16_kernel_64<<<grid, 256, 0, st>>>(a);
+    return UNET_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+extern "C" int unet_conv3x3_bf16_supported(int N, int H, int W, int Cin, int Cout) {
+    return (N > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout % 64 == 0 && (size_t)N * H * W * Cin * 4 < ((size_t)1 << 31)) ? 1 : 0;
+}
+
+extern "C" size_t unet_conv3x3_bf16_packed_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * 2; }
+
+// mode 0: forward operand; mode 1: data-gradient operand (call unet_conv3x3_dgrad_bf16 with it)
+extern "C" int unet_conv3x3_bf16_pack_weights(const float* w, void* packed, int Cin, int Cout, int mode, void* stream) {
+    UNET_CHECK_ARG(w && packed && Cin % 64 == 0 && Cout % 64 == 0 && (mode == 0 || mode == 1) && unet_aligned16(packed));
+    const long n = (long)9 * Cin * Cout / 8;
+    conv_bf16_pack_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, (uint16_t*)packed, Cin, Cout, mode);
+    return UNET_LAUNCH_STATUS();
+}
+
+// out[n,i,j,co] = relu?(bias[co] + sum_{a,b,ci} bf16(x[n,i+a-1,j+b-1,ci]) * bf16(W[a,b,ci,co])), fp32 accumulation
+extern "C" int unet_conv3x3_fwd_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
+                                     int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    UNET_CHECK_ARG(x && wp && out && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
+    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31));
+    return run_conv_bf16(x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
+}
+
+// dx[n,i,j,ci] = sum_{a,b,co} bf16(dz[n,i+1-a,j+1-b,co]) * bf16(W[a,b,ci,co]);  wpd from pack_weights(mode 1)
+extern "C" int unet_conv3x3_dgrad_bf16(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
+                                       int N, int H, int W, int Cin, int Cout, void* stream) {
+    UNET_CHECK_ARG(dz && wpd && dx && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));
+    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
+    UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31));
+    return run_conv_bf16(dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream);
+}

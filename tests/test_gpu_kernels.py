@@ -655,3 +655,46 @@ def test_conv3x3_winograd_fused_wgrad(hip, shape):
     dw = torch.full((3, 3, ci, co), 7.0, device=DEV)
     hip.unet_conv3x3_wgrad_winograd_fused(P(xv), ci + 4, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 3e-5
+
+
+def bf16_round(a):
+    """round-to-nearest-even to bf16, returned as float64 (what v_cvt_pk_bf16_f32 does to finite values)"""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return u.view(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 64), (2, 20, 40, 64, 128), (1, 32, 32, 128, 64), (1, 48, 64, 192, 256), (2, 7, 9, 64, 64)])
+def test_conv3x3_bf16_fwd_dgrad_match_oracle_on_rounded_operands(hip, shape):
+    # bf16 matrix-core path: with both operands rounded to bf16 the products are exact, so the fp64 oracle on the ROUNDED
+    # operands must agree to fp32-accumulation accuracy (2e-5 of the output range); against the unrounded oracle the
+    # difference is the rounding itself (2^-9 per operand, checked loosely).  Ragged tiles, padded leading dimensions, both
+    # channel-tile widths.
+    n, h, w, ci, co = shape
+    assert hip.unet_conv3x3_bf16_supported(n, h, w, ci, co) == 1
+    rng = np.random.default_rng(ci + co + h)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, ci, co)) / np.sqrt(9 * ci)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    dz = rng.standard_normal((n, co, h, w)).astype(np.float32)
+    z_ref = on.conv_same_fwd(bf16_round(x), bf16_round(wt), b.astype(np.float64))
+    z_full = on.conv_same_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    dx_ref, _, _ = on.conv_same_bwd(bf16_round(x), bf16_round(wt), bf16_round(dz))
+    xd = torch.zeros(n, h, w, ci + 8, device=DEV); xd[..., :ci] = to_nhwc(x); xv = xd[..., :ci]
+    dzd = to_nhwc(dz)
+    wd, bd = dev(wt), dev(b)
+    nb = hip.unet_conv3x3_bf16_packed_bytes(ci, co)
+    wp, wpd = ws_bytes(nb), ws_bytes(nb)
+    hip.unet_conv3x3_bf16_pack_weights(P(wd), P(wp), ci, co, 0, ST())
+    hip.unet_conv3x3_bf16_pack_weights(P(wd), P(wpd), ci, co, 1, ST())
+    cat = torch.full((n, h, w, co + 4), float("nan"), device=DEV)
+    hip.unet_conv3x3_fwd_bf16(P(xv), ci + 8, P(wp), P(bd), P(cat), co + 4, n, h, w, ci, co, 0, ST())
+    z = from_nhwc(cat[..., :co])
+    assert relerr(z, z_ref) < 2e-5
+    assert relerr(z, z_full) < 2e-2
+    assert torch.isnan(cat[..., co:]).all()
+    hip.unet_conv3x3_fwd_bf16(P(xv), ci + 8, P(wp), P(bd), P(cat), co + 4, n, h, w, ci, co, 1, ST())
+    assert relerr(from_nhwc(cat[..., :co]), np.maximum(z_ref, 0)) < 2e-5
+    dx = torch.empty(n, h, w, ci, device=DEV)
+    hip.unet_conv3x3_dgrad_bf16(P(dzd), co, P(wpd), P(dx), ci, n, h, w, ci, co, ST())
+    assert relerr(from_nhwc(dx), dx_ref) < 2e-5
