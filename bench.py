@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 PKG = "semantic-segmentation-unet_amd"
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, chip table (dense, spec)
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table: ~2.5 PF dense bf16 (spec)
 TRAIN_GFLOP_PER_IMG = {(512, 1, 2): 1154.00}
 
 
@@ -107,6 +108,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="contraction precision of the 3x3 layers; bf16 = BASELINE config 4 (fp32 master weights, fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream (A/B switch)")
@@ -131,7 +134,8 @@ def main():
 
     model = importlib.import_module(PKG + ".model")
     G = args.batch * world
-    net = model.UNet(args.classes, G, args.channels, learning_rate=3e-4, device=dev, seed=0)
+    net = model.UNet(args.classes, G, args.channels, learning_rate=3e-4, device=dev, seed=0,
+                     compute_dtype={"f32": "fp32", "bf16": "bf16"}[args.dtype])
     net.engine.overlap_wgrad = not args.no_overlap
     if world > 1:
         par = importlib.import_module(PKG + ".parallel")
@@ -174,8 +178,14 @@ def main():
         # are listed under `kernels` with shared time included.  `achieved` is ALGORITHMIC (direct-convolution) FLOP/s as
         # SURVEY.md 8(d) defines the work; Winograd executes 2.25x fewer multiplies, so `executed` = achieved / 2.25 is
         # the rate the matrix cores actually run at and `achieved` may exceed the MFMA peak.
-        kf, kd = extra.get("conv3x3_fwd_winograd_fused"), extra.get("conv3x3_fwd")
-        if kf:
+        kf, kd, kb = extra.get("conv3x3_fwd_winograd_fused"), extra.get("conv3x3_fwd"), extra.get("conv3x3_fwd_bf16")
+        tfile = None
+        if kb:
+            roofline = {"bound": "mfma", "kernel": "conv_bf16_kernel_{128,64} (3x3 conv forward, implicit GEMM on v_mfma_f32_32x32x16_bf16)",
+                        "achieved": kb["tflops"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(kb["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": kb["launches_per_step"], "avg_launch_ms": kb["avg_launch_ms"]}
+        elif kf:
             roofline = {"bound": "mfma", "kernel": "wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
                         "achieved": kf["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(kf["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -191,7 +201,7 @@ def main():
         if roofline:
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction,
             # WRITE_SIZE) of this same workload, committed under profiles/; only valid for the default workload.
-            tf = os.path.join(ROOT, "profiles", tfile)
+            tf = os.path.join(ROOT, "profiles", tfile or "none")
             if os.path.exists(tf) and (args.size, args.channels, args.classes, args.batch) == (512, 1, 2, 8):
                 t = json.load(open(tf))
                 if t.get("launches_per_step") == roofline["launches_per_step"]:
@@ -203,7 +213,7 @@ def main():
         out = {
             "metric": "training images/sec", "value": round(ips, 3), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "U-Net train step (fwd + softmax-CE + bwd + Keras-Adam%s), synthetic %dx%dx%d tiles, "
                                    "%d classes, batch %d per GPU, random-init weights, dropout on"
                                    % (" + RCCL gradient all-reduce" if world > 1 else "", args.size, args.size,

@@ -150,6 +150,10 @@ class Engine:
         self.bnbwd_part = {}
         self.fuse_pool = os.environ.get("UNET_FUSE_POOL", "1") != "0"             # BN apply + max pool in one pass (A/B switch)
         self.convt_wgrad_wide = os.environ.get("UNET_CONVT_WGRAD_WIDE", "0") == "1"  # wide-tile kernel: 22% faster alone, no gain next to the dgrad stream
+        # contraction precision of the wide 3x3 layers: "fp32" (the reference's arithmetic) or "bf16" (BASELINE config 4: bf16
+        # forward/backward on fp32 master weights -- operands rounded to bf16, fp32 accumulation, everything else fp32)
+        self.compute_dtype = os.environ.get("UNET_COMPUTE_DTYPE", "fp32")
+        self._bf16_W, self._bf16_dirty = {}, True
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -195,6 +199,31 @@ class Engine:
         return (self.conv_route == "fused" and self.kind[name] == "conv3" and h % 2 == 0 and w % 2 == 0
                 and k % 8 == 0 and nn % 64 == 0)
 
+    def _use_bf16(self, name, n, h, w, dgrad=False):
+        if self.compute_dtype != "bf16" or self.kind[name] != "conv3":
+            return False
+        cin, cout = self.cin[name], self.cout[name]
+        k, nn = (cout, cin) if dgrad else (cin, cout)
+        return self.L.unet_conv3x3_bf16_supported(n, h, w, k, nn) == 1
+
+    def _bf16_kernels(self, name):
+        """(forward operand, data-gradient operand): the layer's fp32 master kernel packed to bf16, refreshed after every
+        parameter change."""
+        if self._bf16_dirty:
+            self._bf16_fresh = set()
+            self._bf16_dirty = False
+        w = self._bf16_W.get(name)
+        if w is None:
+            nb = self.L.unet_conv3x3_bf16_packed_bytes(self.cin[name], self.cout[name])
+            w = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
+            self._bf16_W[name] = w
+        if name not in self._bf16_fresh:
+            st = self._stream()
+            self.L.unet_conv3x3_bf16_pack_weights(_p(self.p[name + "/kernel"]), _p(w[0]), self.cin[name], self.cout[name], 0, st)
+            self.L.unet_conv3x3_bf16_pack_weights(_p(self.p[name + "/kernel"]), _p(w[1]), self.cin[name], self.cout[name], 1, st)
+            self._bf16_fresh.add(name)
+        return w
+
     def _fused_kernels(self, name):
         """(Uc forward, Uc dgrad) in the chunked layout of the fused kernel.  The buffers are persistent; after a parameter
         change ALL fused-route layers are re-transformed by one batched launch at the first use."""
@@ -232,10 +261,15 @@ class Engine:
             self.wino_U[name] = u
         return u
 
-    def load_parameters(self, values):
-        """values: {keras-style name: array in the Keras layout}.  Resets nothing else."""
+    def parameters_changed(self):
+        """theta was written from outside (broadcast, checkpoint): every cached transform of the kernels is stale."""
         self._wino_dirty = True
         self._fused_dirty = True
+        self._bf16_dirty = True
+
+    def load_parameters(self, values):
+        """values: {keras-style name: array in the Keras layout}.  Resets nothing else."""
+        self.parameters_changed()
         for k, v in values.items():
             t = torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float32)))
             if k in self.p:
@@ -301,7 +335,11 @@ class Engine:
             L.unet_conv1x1_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
         else:
             r = self._buf("r_" + name, (n, h, w, cout))
-            if self._use_fused(name, h, w):
+            if self._use_bf16(name, n, h, w):
+                self.saved_V[name] = None
+                self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
+                            _p(x), _ld(x), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+            elif self._use_fused(name, h, w):
                 self.saved_V[name] = None
                 rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
                 if rows > 0:
@@ -531,6 +569,9 @@ class Engine:
                 L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
                 L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
+            elif self._use_bf16(name, n, ho, wo, dgrad=True):
+                self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
+                            _p(dz), cout, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout, st)
             elif self._use_fused(name, ho, wo, dgrad=True):
                 prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
                 rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, ho, wo, cout, cin) if prod else 0
@@ -609,6 +650,7 @@ class Engine:
         self.iterations += 1
         self._wino_dirty = True
         self._fused_dirty = True
+        self._bf16_dirty = True
         t = self.iterations
         alpha = learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
         self.L.unet_adam_keras(_p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v), self.n_flat, alpha,

@@ -91,13 +91,17 @@ class UNet:
     RADIUS = 96
 
     def __init__(self, number_classes, global_batch_size, number_channels, learning_rate=3e-4, label_smoothing=0,
-                 device="cuda", seed=0):
+                 device="cuda", seed=0, compute_dtype=None):
         self.number_channels = number_channels
         self.learning_rate = learning_rate
         self.number_classes = number_classes
         self.global_batch_size = global_batch_size
         self.label_smoothing = label_smoothing
         self.engine = Engine(number_classes, number_channels, device=device, seed=seed)
+        if compute_dtype is not None:        # "fp32" (reference arithmetic) | "bf16" (mixed precision the reference leaves commented
+            if compute_dtype not in ("fp32", "bf16"):                                  # out, UNet/train.py:52-54)
+                raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
+            self.engine.compute_dtype = compute_dtype
         self.model = _KerasLikeModel(self)
         self.optimizer = _Optimizer(learning_rate)
         self.parallel = None         # set by parallel.DataParallel

@@ -48,6 +48,8 @@ class DataParallel:
         e = self.engine
         for t in [e.theta, e.adam_m, e.adam_v] + list(e.moving.values()):
             dist.broadcast(t, src=0, group=self.group)
+        if hasattr(e, "parameters_changed"):
+            e.parameters_changed()
 
     def begin_step(self):
         self._pending = []
