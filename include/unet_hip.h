@@ -96,6 +96,12 @@ int unet_conv3x3_fwd_bf16(const float* x, int ldx, const void* wp, const float* 
                           int N, int H, int W, int Cin, int Cout, int relu, void* stream);
 int unet_conv3x3_dgrad_bf16(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
                             int N, int H, int W, int Cin, int Cout, void* stream);
+/* weight gradient in the same arithmetic (both operands rounded to bf16, fp32 accumulation, split partial sums added in a
+ * fixed order): dw[a,b,ci,co] = sum xin[n,y+a-1,x+b-1,ci] * dz[n,y,x,co] */
+int unet_conv3x3_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout);
+size_t unet_conv3x3_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                            int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
 int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                             int N, int H, int W, int Cin, int Cout, int relu, void* stream);

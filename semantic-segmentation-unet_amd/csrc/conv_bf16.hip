@@ -45,6 +45,13 @@ __device__ __forceinline__ unsigned cb_pack2(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+// the same, pinned in program order: in the staging path the conversion must stay BEHIND the MFMA stream (it carries the
+// compiler's wait for the prefetched loads with it)
+__device__ __forceinline__ unsigned cb_pack2_pinned(float lo, float hi) {
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 
 // wait until at most `n` LDS operations are outstanding; ties every fragment the following MFMAs read to the wait (each
 // register exactly once: a repeated "+v" operand would be copied BEFORE the wait)
@@ -141,13 +148,9 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
         const bool ok = pp < 18 * kPW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         voff[j] = ok ? (unsigned)((((size_t)(img * p.H + gy) * p.W + gx) * p.ldx) * 4 + f * 16) : 0x80000000u;
     }
-    i32x4 srd;
-    {
-        const uint64_t base = (uint64_t)(uintptr_t)p.x;
-        srd.x = (int)(unsigned)base; srd.y = (int)(unsigned)((base >> 32) & 0xffffu); srd.z = (int)p.x_bytes; srd.w = 0x00020000;
-        srd.x = __builtin_amdgcn_readfirstlane(srd.x); srd.y = __builtin_amdgcn_readfirstlane(srd.y);
-        srd.z = __builtin_amdgcn_readfirstlane(srd.z); srd.w = __builtin_amdgcn_readfirstlane(srd.w);
-    }
+    // (compiler-visible buffer loads: it places the vmcnt wait in front of the first use; with inline-asm loads a register copy
+    // of a destination can be scheduled ahead of a hand-written wait)
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
     const unsigned wr_base = lds0 + (unsigned)((f >> 1) * kPlane + (tid >> 2) * 16 + (f & 1) * 8);
     const unsigned a_base = lds0 + (unsigned)(lh * kPlane + (4 * wv * kPW + li) * 16);
@@ -169,7 +172,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
         const int so = chunk * 64;
 #pragma unroll
         for (int j = 0; j < 10; ++j)
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(stg[j]) : "v"(voff[j]), "s"(srd), "s"(so) : "memory");
+            stg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff[j], so, 0));
     };
     auto issue_w = [&](int chunk, int stage) {
         const char* src = wsrc + (size_t)chunk * wchunk;
@@ -180,12 +183,10 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
                                                  (lds_void_b*)(smem + stage * STAGE + kXP + (wv + 4 * k) * 1024), 16, 0, 0);
     };
     auto write_x = [&](int stage) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]),
-                     "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]), "+v"(stg[8]), "+v"(stg[9]) :: "memory");
         const unsigned wb = wr_base + (unsigned)(stage * STAGE);
 #pragma unroll
         for (int j = 0; j < 10; ++j) {
-            uint2 v; v.x = cb_pack2(stg[j].x, stg[j].y); v.y = cb_pack2(stg[j].z, stg[j].w);
+            uint2 v; v.x = cb_pack2_pinned(stg[j].x, stg[j].y); v.y = cb_pack2_pinned(stg[j].z, stg[j].w);
             asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(j * 1024) : "memory");
         }
     };
@@ -315,4 +316,265 @@ extern "C" int unet_conv3x3_dgrad_bf16(const float* dz, int lddz, const void* wp
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
     UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31));
     return run_conv_bf16(dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream);
+}
+
+// ---- weight gradient on the bf16 matrix cores ------------------------------------------------------------------------------
+//   dw[a,b,ci,co] = sum_{n,y,x} bf16(xin[n,y+a-1,x+b-1,ci]) * bf16(dz[n,y,x,co]),   fp32 accumulation
+// The contraction runs over pixels, so both MFMA operands need 8 consecutive PIXELS of one channel per lane while memory (and
+// the LDS images, [32-channel group][pixel][32 channels] bf16) are channel-minor: the fragments are gathered by
+// ds_read_b64_tr_b16 (gfx950's transposing LDS read, two per fragment), which also makes the nine taps free -- a tap is a
+// row slot and a pixel offset in the read address, nothing is staged per tap.
+// Workgroup = 64 input x 64 output channels x 9 taps (wave = one 32 x 32 pair, 9 accumulators) walking down a 32-pixel-wide
+// strip of one image two rows per step: per step 2 new input rows (ring of 6) and 2 new dz rows are staged (fp32 buffer loads
+// one step ahead, zeros outside the image through the buffer range check, converted to bf16 on the way into LDS) and every
+// wave runs 36 MFMAs.  Strips x row chunks are split over workgroups; partial sums are added in a fixed order.
+namespace {
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+struct WgBf16Args {
+    const float* x; const float* dz; float* out;
+    int ldx, lddz, N, H, W, Cin, Cout;
+    int n_ci, n_co, splits, tbx, rpc, cps, n_sc;
+    unsigned x_bytes, dz_bytes;
+};
+
+constexpr int kWgXRow = 2 * 36 * 64, kWgDzRow = 2 * 32 * 64;       // bytes of one staged input row (34 + 2 pad pixels) / dz row
+constexpr int kWgXRing = 6 * kWgXRow;
+
+#define WG_RDTR(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
+#define WG_WAIT_CASE(n) case n: asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void wg_wait_lgkm(int n) {
+    switch (n) { WG_WAIT_CASE(0) WG_WAIT_CASE(1) WG_WAIT_CASE(2) WG_WAIT_CASE(3) WG_WAIT_CASE(4) WG_WAIT_CASE(5) WG_WAIT_CASE(6)
+                 WG_WAIT_CASE(7) WG_WAIT_CASE(8) WG_WAIT_CASE(9) WG_WAIT_CASE(10) WG_WAIT_CASE(11) WG_WAIT_CASE(12)
+                 default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[kWgXRing + 4 * kWgDzRow];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int npairs = p.n_ci * p.n_co;
+    const int pair = blockIdx.x % npairs, split = blockIdx.x / npairs;
+    const int ci0 = (pair / p.n_co) * 64, co0 = (pair % p.n_co) * 64;
+    const int cisub = wv & 1, cosub = wv >> 1;
+
+    // staging roles (wave-uniform): waves 0,1 stage input row rho = wave, waves 2,3 the dz row rho = wave - 2; thread = 4 channels
+    // (quad q) of 9 (input: patch columns 9o..9o+8) or 8 (dz) consecutive pixels
+    const bool is_x = wv < 2;
+    const int rho = wv & 1, o = (lane >> 4) & 3, q = lane & 15;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
+    const unsigned wr_lane = (unsigned)((q >> 3) * (is_x ? 36 * 64 : 32 * 64) + (is_x ? 9 * o : 8 * o) * 64 + (q & 7) * 8);
+    // fragment gathers: 16-lane group g4 = (k half, channel half); lane 4 q4 + pp supplies pixel row q4, channels 4 pp .. 4 pp + 3
+    const int g4 = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned frag_lane = (unsigned)((8 * (g4 >> 1) + q4) * 64 + (16 * (g4 & 1) + 4 * pp) * 2);
+    const unsigned a_lane = lds0 + cisub * (36 * 64) + frag_lane;
+    const unsigned b_lane = lds0 + kWgXRing + cosub * (32 * 64) + frag_lane;
+
+    const float* xb_ptr = p.x + ci0; const float* zb_ptr = p.dz + co0;
+    const int xrec = (int)(p.x_bytes - (unsigned)ci0 * 4), zrec = (int)(p.dz_bytes - (unsigned)co0 * 4);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    f32x4 stg[9];
+    unsigned voff[9];
+    // loads of one staging pass: input rows xrow + rho (when do_x) / dz rows zrow + rho, rows outside [0, H) / [0, y_end) read zeros
+    auto issue = [&](int xrow, int zrow, int y_end, bool do_x, bool do_z) {
+        if (is_x) {
+            if (!do_x) return;
+            const int row = xrow + rho;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)xb_ptr, 0, (row < 0 || row >= p.H) ? 0 : xrec, 0x00020000);
+            const int so = (row < 0 ? 0 : row) * p.W * p.ldx * 4;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) stg[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[t], so, 0));
+        } else {
+            if (!do_z) return;
+            const int row = zrow + rho;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)zb_ptr, 0, row >= y_end ? 0 : zrec, 0x00020000);
+            const int so = row * p.W * p.lddz * 4;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) stg[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[t], so, 0));
+        }
+    };
+    // convert and write what `issue` loaded: input rows into ring slots xslot + rho, dz rows into slots zslot + rho
+    auto commit = [&](int xslot, int zslot, bool do_x, bool do_z) {
+        if (is_x) {
+            if (!do_x) return;
+            int sl = xslot + rho; if (sl >= 6) sl -= 6;
+            const unsigned wb = lds0 + wr_lane + (unsigned)(sl * kWgXRow);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                uint2 v; v.x = cb_pack2_pinned(stg[t].x, stg[t].y); v.y = cb_pack2_pinned(stg[t].z, stg[t].w);
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(t * 64) : "memory");
+            }
+        } else {
+            if (!do_z) return;
+            const unsigned wb = lds0 + kWgXRing + wr_lane + (unsigned)((zslot + rho) * kWgDzRow);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                uint2 v; v.x = cb_pack2_pinned(stg[t].x, stg[t].y); v.y = cb_pack2_pinned(stg[t].z, stg[t].w);
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(t * 64) : "memory");
+            }
+        }
+    };
+
+    for (int sc = split; sc < p.n_sc; sc += p.splits) {
+        const int strip = sc / p.cps, chunk = sc % p.cps;
+        const int img = strip / p.tbx, x0 = 32 * (strip % p.tbx);
+        const int y0 = chunk * p.rpc;
+        const int y_end = y0 + p.rpc < p.H ? y0 + p.rpc : p.H;
+        const int steps = (y_end - y0 + 1) / 2;
+        // per-thread offsets inside a row (the row goes into the scalar offset); columns outside the image / the patch: rejected
+        if (is_x) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int pc = 9 * o + t, gx = x0 - 1 + pc;
+                voff[t] = (pc < 34 && gx >= 0 && gx < p.W) ? (unsigned)((((size_t)img * p.H * p.W + gx) * p.ldx) * 4 + q * 16) : 0x80000000u;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int gx = x0 + 8 * o + t;
+                voff[t] = (t < 8 && gx < p.W) ? (unsigned)((((size_t)img * p.H * p.W + gx) * p.lddz) * 4 + q * 16) : 0x80000000u;
+            }
+        }
+        // prologue: input rows y0-1, y0 -> slots 0,1; then the regular pass for step 0: input rows y0+1, y0+2 -> slots 2,3, dz rows
+        // y0, y0+1 -> dz slots 0,1.  (The previous strip's last step ended with a barrier: every wave is done reading.)
+        issue(y0 - 1, 0, y_end, true, false);
+        commit(0, 0, true, false);
+        issue(y0 + 1, y0, y_end, true, true);
+        commit(2, 0, true, true);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+        int xs = 0;                                                   // ring slot of input row Y - 1
+        for (int s = 0; s < steps; ++s) {
+            const int Y = y0 + 2 * s;
+            issue(Y + 3, Y + 2, y_end, true, true);
+            // slot bases of the four input rows Y-1 .. Y+2 and the two dz rows of this step
+            unsigned xb[4], zb[2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { int sl = xs + r; if (sl >= 6) sl -= 6; xb[r] = a_lane + (unsigned)(sl * kWgXRow); }
+            zb[0] = b_lane + (unsigned)(((s & 1) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
+
+            // 4 groups (output row yy, k-step ks) x 9 taps; A fragments three ahead, the next group's B at the group start
+            i32x2 af[4][2], bf[2][2];
+            int issued = 0, a_mark[36];
+#define WG_ISSUE_A(i) do { const int grp_ = (i) / 9, tap_ = (i) % 9; \
+                WG_RDTR(af[(i) & 3][0], xb[(grp_ >> 1) + tap_ / 3], ((tap_ % 3) + 16 * (grp_ & 1)) * 64); \
+                WG_RDTR(af[(i) & 3][1], xb[(grp_ >> 1) + tap_ / 3], ((tap_ % 3) + 16 * (grp_ & 1)) * 64 + 256); \
+                issued += 2; a_mark[(i)] = issued; } while (0)
+#define WG_ISSUE_B(g) do { WG_RDTR(bf[(g) & 1][0], zb[(g) >> 1], 16 * ((g) & 1) * 64); \
+                WG_RDTR(bf[(g) & 1][1], zb[(g) >> 1], 16 * ((g) & 1) * 64 + 256); issued += 2; } while (0)
+            WG_ISSUE_B(0);
+            WG_ISSUE_A(0); WG_ISSUE_A(1); WG_ISSUE_A(2);
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                const int grp = i / 9, tap = i % 9;
+                if (tap == 0 && grp + 1 < 4) WG_ISSUE_B(grp + 1);
+                if (i + 3 < 36) WG_ISSUE_A(i + 3);
+                wg_wait_lgkm(issued - a_mark[i]);                      // LDS operations retire in order: A(i), and B(grp) before it, are back
+                asm volatile("" : "+v"(af[i & 3][0]), "+v"(af[i & 3][1]), "+v"(bf[grp & 1][0]), "+v"(bf[grp & 1][1]));
+                bf16x8 av, bv;
+                { i32x4 t4; t4.x = af[i & 3][0].x; t4.y = af[i & 3][0].y; t4.z = af[i & 3][1].x; t4.w = af[i & 3][1].y; av = __builtin_bit_cast(bf16x8, t4); }
+                { i32x4 t4; t4.x = bf[grp & 1][0].x; t4.y = bf[grp & 1][0].y; t4.z = bf[grp & 1][1].x; t4.w = bf[grp & 1][1].y; bv = __builtin_bit_cast(bf16x8, t4); }
+                // the operands are assembled from two 64-bit reads each, which can leave compiler-generated v_mov's right in front
+                // of the MFMA; the hazard recogniser does not see into inline asm, so the wait states a VALU write needs before
+                // an MFMA reads the register are supplied here
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[tap]) : "v"(av), "v"(bv) : "memory");
+            }
+#undef WG_ISSUE_A
+#undef WG_ISSUE_B
+            int xn = xs + 4; if (xn >= 6) xn -= 6;
+            commit(xn, ((s + 1) & 1) * 2, true, true);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            xs += 2; if (xs >= 6) xs -= 6;
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    // accumulator register e of tap t = (input channel ci0 + 32 cisub + (e&3) + 8 (e>>2) + 4 lh, output channel co0 + 32 cosub + li)
+    float* o_base = p.out + (size_t)split * 9 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ci = ci0 + 32 * cisub + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float v;
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[t][e]));
+            o_base[((size_t)t * p.Cin + ci) * p.Cout + co0 + 32 * cosub + li] = v;
+        }
+}
+
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits, int sl) {
+    __shared__ f32x4 part[256];
+    const int per = 256 / sl;
+    const int o = threadIdx.x % per, sj = threadIdx.x / per;
+    const long i = (long)blockIdx.x * per + o;
+    const int k0 = (int)((long)splits * sj / sl), k1 = (int)((long)splits * (sj + 1) / sl);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int k = k0; k < k1; ++k) s += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
+    if (sl == 1) { if (i < n4) reinterpret_cast<f32x4*>(dw)[i] = s; return; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (sj == 0 && i < n4) {
+        for (int j = 1; j < sl; ++j) s += part[j * per + o];
+        reinterpret_cast<f32x4*>(dw)[i] = s;
+    }
+}
+
+void wgrad_bf16_plan(WgBf16Args& a) {
+    a.n_ci = a.Cin / 64; a.n_co = a.Cout / 64;
+    const int npairs = a.n_ci * a.n_co;
+    a.tbx = (a.W + 31) / 32;
+    const int strips = a.N * a.tbx;
+    const int target = (conv_bf16_cus() + npairs - 1) / npairs;          // strip-chunks wanted so that every CU has a workgroup
+    int cps = (target + strips - 1) / strips; if (cps < 1) cps = 1;
+    int rpc = (a.H + cps - 1) / cps; rpc += rpc & 1; if (rpc < 2) rpc = 2;
+    a.rpc = rpc; a.cps = (a.H + rpc - 1) / rpc; a.n_sc = strips * a.cps;
+    int splits = conv_bf16_cus() / npairs; if (splits < 1) splits = 1; if (splits > a.n_sc) splits = a.n_sc;
+    a.splits = splits;
+}
+
+}  // namespace
+
+extern "C" int unet_conv3x3_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout) {
+    return (N > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout % 64 == 0 && (size_t)N * H * W * (Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31)) ? 1 : 0;
+}
+
+extern "C" size_t unet_conv3x3_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout) {
+    if (!unet_conv3x3_wgrad_bf16_supported(N, H, W, Cin, Cout)) return 0;
+    WgBf16Args a{}; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    wgrad_bf16_plan(a);
+    return a.splits > 1 ? (size_t)a.splits * 9 * Cin * Cout * sizeof(float) : 16;
+}
+
+// dw[a,b,ci,co] (HWIO, UNet/model.py:31) = sum_{n,y,x} bf16(xin[n,y+a-1,x+b-1,ci]) * bf16(dz[n,y,x,co])
+extern "C" int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                       int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(xin && dz && dw && ws && unet_conv3x3_wgrad_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
+    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddz * 4 < ((size_t)1 << 31));
+    if (ws_bytes < unet_conv3x3_wgrad_bf16_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
+    WgBf16Args a{};
+    a.x = xin; a.dz = dz; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    wgrad_bf16_plan(a);
+    a.out = a.splits > 1 ? (float*)ws : dw;
+    a.x_bytes = (unsigned)((size_t)N * H * W * ldx * 4); a.dz_bytes = (unsigned)((size_t)N * H * W * lddz * 4);
+    hipStream_t st = (hipStream_t)stream;
+    wgrad_bf16_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    if (a.splits > 1) {
+        const long n4 = (long)9 * Cin * Cout / 4;
+        int sl = 1;
+        while (sl < 16 && 2 * sl <= a.splits && n4 * sl < 256 * 1024) sl *= 2;
+        wgrad_bf16_reduce_kernel<<<(unsigned)((n4 * sl + 255) / 256), 256, 0, st>>>((const float*)ws, dw, n4, a.splits, sl);
+        rc = UNET_LAUNCH_STATUS();
+    }
+    return rc;
 }

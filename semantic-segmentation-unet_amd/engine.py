@@ -537,6 +537,10 @@ class Engine:
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
                 L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+            elif self.compute_dtype == "bf16" and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1:
+                nb2 = L.unet_conv3x3_wgrad_bf16_workspace(n, ho, wo, cin, cout)
+                self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16,
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif (self.wgrad_route in ("fused", "hybrid") and L.unet_winograd_wgrad_fused_supported(n, ho, wo, cin, cout) == 1
                   and not (self.wgrad_route == "hybrid" and min(cin, cout) >= self.wgrad_unfused_from
                            and L.unet_winograd_wgrad_supported(n, ho, wo, cin, cout) == 1)):

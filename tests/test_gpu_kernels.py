@@ -698,3 +698,27 @@ def test_conv3x3_bf16_fwd_dgrad_match_oracle_on_rounded_operands(hip, shape):
     dx = torch.empty(n, h, w, ci, device=DEV)
     hip.unet_conv3x3_dgrad_bf16(P(dzd), co, P(wpd), P(dx), ci, n, h, w, ci, co, ST())
     assert relerr(from_nhwc(dx), dx_ref) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 32, 64, 64), (2, 6, 40, 64, 128), (1, 7, 33, 128, 64), (1, 64, 32, 64, 64), (2, 4, 32, 1024, 1024),
+                                   (3, 10, 70, 192, 64)])
+def test_conv3x3_bf16_wgrad_matches_oracle_on_rounded_operands(hip, shape):
+    # weight gradient on the bf16 matrix cores (transposing LDS reads): fp64 oracle on the bf16-rounded operands to
+    # fp32-accumulation accuracy.  Cases: one strip; ragged width; odd height and width; row chunks split over workgroups
+    # (chunk boundaries); one workgroup walking several strips (256 channel pairs); three strips with a ragged last one.
+    n, h, w, ci, co = shape
+    assert hip.unet_conv3x3_wgrad_bf16_supported(n, h, w, ci, co) == 1
+    rng = np.random.default_rng(ci + co + h)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    dz = rng.standard_normal((n, co, h, w)).astype(np.float32)
+    _, dw_ref, _ = on.conv_same_bwd(bf16_round(x), np.zeros((3, 3, ci, co)), bf16_round(dz))
+    xd = torch.zeros(n, h, w, ci + 4, device=DEV); xd[..., :ci] = to_nhwc(x); xv = xd[..., :ci]
+    dzd = torch.zeros(n, h, w, co + 8, device=DEV); dzd[..., :co] = to_nhwc(dz); dzv = dzd[..., :co]
+    nb = hip.unet_conv3x3_wgrad_bf16_workspace(n, h, w, ci, co)
+    ws = ws_bytes(nb)
+    dw = torch.full((3, 3, ci, co), float("nan"), device=DEV)
+    hip.unet_conv3x3_wgrad_bf16(P(xv), ci + 4, P(dzv), co + 8, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+    assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 2e-5
+    dw2 = torch.empty_like(dw)
+    hip.unet_conv3x3_wgrad_bf16(P(xv), ci + 4, P(dzv), co + 8, P(dw2), n, h, w, ci, co, P(ws), nb, ST())
+    assert torch.equal(dw, dw2)
