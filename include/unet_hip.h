@@ -96,6 +96,14 @@ int unet_conv3x3_fwd_bf16(const float* x, int ldx, const void* wp, const float* 
                           int N, int H, int W, int Cin, int Cout, int relu, void* stream);
 int unet_conv3x3_dgrad_bf16(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
                             int N, int H, int W, int Cin, int Cout, void* stream);
+/* the same two kernels leaving BatchNorm sums behind (one row of partials per 16x32-pixel tile, layout and finalize as for
+ * unet_conv3x3_fwd_winograd_fused_stats / unet_conv3x3_dgrad_winograd_fused_bnstats) */
+int unet_conv3x3_bf16_stats_rows(int N, int H, int W, int Cin, int Cout);
+int unet_conv3x3_fwd_bf16_stats(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
+                                int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
+int unet_conv3x3_dgrad_bf16_bnstats(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
+                                    int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+                                    float* stat_part, size_t stat_bytes, void* stream);
 /* weight gradient in the same arithmetic (both operands rounded to bf16, fp32 accumulation, split partial sums added in a
  * fixed order): dw[a,b,ci,co] = sum xin[n,y+a-1,x+b-1,ci] * dz[n,y,x,co] */
 int unet_conv3x3_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout);

@@ -31,6 +31,8 @@ struct ConvBf16Args {
     int ldx, ldo, N, H, W, Cin, Cout, relu;
     int tby, tbx, n_px, n_co;
     unsigned x_bytes;
+    float* stat_part;            // STATS 1: BatchNorm sums of the output (sum y, sum y^2); STATS 2: BatchNorm-backward sums (sum dx, sum dx * r)
+    const float* bn_r; int bn_ldr, bn_c0, bn_c1;     // STATS 2: saved activation of the producer layer, whose dy is dx[..., c0:c1)
 };
 
 constexpr int kPW = 34, kPlane = 640 * 16, kXP = 2 * kPlane;        // patch row length (pixels), bytes of one k-half plane, of the patch
@@ -115,7 +117,7 @@ __device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_bas
     }
 }
 
-template <int NCO>
+template <int NCO, int STATS>
 __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     constexpr int CT = 32 * NCO;
     constexpr int WB = 18 * CT * 16;                                // bytes of a chunk's weights for this tile
@@ -216,29 +218,72 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
     // epilogue: accumulator register e of (row r, sub-tile c) = pixel (ty0 + 4 wv + r, tx0 + (e&3) + 8 (e>>2) + 4 lh), channel co0 + 32 c + li
+    float st1[NCO], st2[NCO];
 #pragma unroll
     for (int c = 0; c < NCO; ++c) {
         const int co = co0 + 32 * c + li;
         const float bv = p.bias ? p.bias[co] : 0.f;
         const float lo = p.relu ? 0.f : -INFINITY;
+        const bool with_r = STATS == 2 && co >= p.bn_c0 && co < p.bn_c1;
+        st1[c] = 0.f; st2[c] = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gy = ty0 + 4 * wv + r;
-            float* orow = p.out + ((size_t)(img * p.H + gy) * p.W + tx0) * p.ldo + co;
+            const size_t pix0 = (size_t)(img * p.H + gy) * p.W + tx0;
+            float* orow = p.out + pix0 * p.ldo + co;
+            // STATS 2: the 16 saved-activation values first, all loads in flight together (the stores below may alias them as far
+            // as the compiler knows, so loads interleaved with the stores would each wait out their full latency)
+            float rv[16];
+            if (STATS == 2) {
+                const float* rrow = p.bn_r + pix0 * p.bn_ldr + (co - p.bn_c0);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    rv[e] = (with_r && gy < p.H && tx0 + col < p.W) ? rrow[(size_t)col * p.bn_ldr] : 0.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
                 float v;
                 asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[r][c][e]));
                 v = fmaxf(v + bv, lo);
-                if (gy < p.H && tx0 + col < p.W) orow[(size_t)col * p.ldo] = v;
+                if (gy < p.H && tx0 + col < p.W) {
+                    orow[(size_t)col * p.ldo] = v;
+                    if (STATS == 1) { st1[c] += v; st2[c] += v * v; }
+                    if (STATS == 2) { st1[c] += v; st2[c] += v * rv[e]; }
+                }
             }
+        }
+    }
+    if (STATS != 0) {
+        // per-channel sums of this tile: the two half-waves (same channels, different pixels), then the four waves through LDS in a
+        // fixed order -> stat_part[channel / 64][row = pixel tile][channel % 64][2]
+        float* red = reinterpret_cast<float*>(smem);                  // free: the last chunk ended with a barrier
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) {
+            st1[c] += __shfl_xor(st1[c], 32); st2[c] += __shfl_xor(st2[c], 32);
+            if (lh == 0) { red[((wv * NCO + c) * 32 + li) * 2] = st1[c]; red[((wv * NCO + c) * 32 + li) * 2 + 1] = st2[c]; }
+        }
+        __syncthreads();
+        if (tid < CT) {
+            const int c = tid >> 5, l = tid & 31;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) { a += red[((w4 * NCO + c) * 32 + l) * 2]; b += red[((w4 * NCO + c) * 32 + l) * 2 + 1]; }
+            const int ch = co0 + tid, row = t % p.n_px;
+            float* o = p.stat_part + (((size_t)(ch >> 6) * p.n_px + row) * 64 + (ch & 63)) * 2;
+            o[0] = a; o[1] = b;
         }
     }
 }
 
-__global__ __launch_bounds__(256, 1) void conv_bf16_kernel_128(ConvBf16Args p) { conv_bf16_body<4>(p); }
-__global__ __launch_bounds__(256, 1) void conv_bf16_kernel_64(ConvBf16Args p) { conv_bf16_body<2>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 0>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 0>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_stats_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 1>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_stats_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 1>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_bnbwd_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 2>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_bnbwd_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 2>(p); }
 
 // fp32 HWIO weights -> bf16 [chunk][tap][k half][out channel][8]: mode 0 forward (reduce over Cin), mode 1 data gradient
 // (reduce over Cout, taps flipped, output channel = the layer's input channel)
@@ -268,8 +313,10 @@ int conv_bf16_cus() {
     return cus;
 }
 
+struct ConvBf16Stats { int mode; float* part; size_t bytes; const float* r; int ldr, c0, c1; };
+
 int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
-                  int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+                  int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st, const ConvBf16Stats* stats = nullptr) {
     ConvBf16Args a{};
     a.x = x; a.wp = (const uint16_t*)wp; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
@@ -278,9 +325,15 @@ int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, fl
     // 128-channel tiles halve the input traffic; 64-channel tiles when they would leave compute units idle
     const bool wide = Cout % 128 == 0 && (long)a.n_px * (Cout / 128) >= conv_bf16_cus();
     a.n_co = Cout / (wide ? 128 : 64);
+    const int mode = stats ? stats->mode : 0;
+    if (mode) {
+        if (stats->bytes < (size_t)(Cout / 64) * a.n_px * 128 * sizeof(float)) return UNET_ENOSPC;
+        a.stat_part = stats->part; a.bn_r = stats->r; a.bn_ldr = stats->ldr; a.bn_c0 = stats->c0; a.bn_c1 = stats->c1;
+    }
     const dim3 grid((unsigned)(a.n_px * a.n_co));
-    if (wide) conv_bf16_kernel_128<<<grid, 256, 0, st>>>(a);
-    else      conv_bf16_kernel_64<<<grid, 256, 0, st>>>(a);
+    if (mode == 0) { if (wide) conv_bf16_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_kernel_64<<<grid, 256, 0, st>>>(a); }
+    else if (mode == 1) { if (wide) conv_bf16_stats_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_stats_kernel_64<<<grid, 256, 0, st>>>(a); }
+    else { if (wide) conv_bf16_bnbwd_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_bnbwd_kernel_64<<<grid, 256, 0, st>>>(a); }
     return UNET_LAUNCH_STATUS();
 }
 
@@ -307,6 +360,35 @@ extern "C" int unet_conv3x3_fwd_bf16(const float* x, int ldx, const void* wp, co
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
     UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31));
     return run_conv_bf16(x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
+}
+
+// rows of the statistics partials of the two calls below (one per 16 x 32 pixel tile)
+extern "C" int unet_conv3x3_bf16_stats_rows(int N, int H, int W, int Cin, int Cout) {
+    if (!unet_conv3x3_bf16_supported(N, H, W, Cin, Cout)) return 0;
+    return N * ((H + 15) / 16) * ((W + 31) / 32);
+}
+
+// forward + BatchNorm sums of the output: stat_part[Cout/64][rows][64][2] = (sum y, sum y^2) per tile, for unet_bn_train_finalize_partials
+extern "C" int unet_conv3x3_fwd_bf16_stats(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
+                                           int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(x && wp && out && stat_part && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
+    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31));
+    const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0};
+    return run_conv_bf16(x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream, &s);
+}
+
+// data gradient + BatchNorm-backward sums of the producer layer (same contract as unet_conv3x3_dgrad_winograd_fused_bnstats):
+// stat_part[Cin/64][rows][64][2] = (sum dx, sum dx * r_prev) with r_prev channel = dx channel - c0, for channels [c0, c1)
+extern "C" int unet_conv3x3_dgrad_bf16_bnstats(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
+                                               int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+                                               float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(dz && wpd && dx && r_prev && stat_part && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));
+    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
+    UNET_CHECK_ARG(c0 >= 0 && c0 < c1 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0);
+    UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31));
+    const ConvBf16Stats s{2, stat_part, stat_bytes, r_prev, ldr, c0, c1};
+    return run_conv_bf16(dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream, &s);
 }
 
 // dx[n,i,j,ci] = sum_{a,b,co} bf16(dz[n,i+1-a,j+1-b,co]) * bf16(W[a,b,ci,co]);  wpd from pack_weights(mode 1)

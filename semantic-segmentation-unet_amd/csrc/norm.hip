@@ -123,15 +123,21 @@ __global__ __launch_bounds__(64) void bn_train_finalize_kernel(const double* __r
 }
 
 // training statistics from the partials the fused conv kernel wrote (winograd.hip, wf_write_stats): part[C/64][rows][64][2]
-__global__ __launch_bounds__(64) void bn_train_finalize_partials_kernel(const float* __restrict__ part, int rows, long P, int C,
+// (256 threads per channel: the bf16 kernels leave one row per 16x32-pixel tile, thousands of rows at full resolution; the four
+// waves' sums are added in a fixed order)
+__global__ __launch_bounds__(256) void bn_train_finalize_partials_kernel(const float* __restrict__ part, int rows, long P, int C,
         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, int unbiased,
         float* moving_mean, float* moving_var, float* mean, float* invstd, float* scale, float* shift) {
+    __shared__ double sh[4][2];
     const int c = blockIdx.x;
     const float* base = part + ((size_t)(c >> 6) * rows * 64 + (c & 63)) * 2;
     double s = 0.0, ss = 0.0;
-    for (int k = threadIdx.x; k < rows; k += 64) { s += (double)base[(size_t)k * 128]; ss += (double)base[(size_t)k * 128 + 1]; }
+    for (int k = threadIdx.x; k < rows; k += 256) { const float2 v = *reinterpret_cast<const float2*>(base + (size_t)k * 128); s += (double)v.x; ss += (double)v.y; }
     s = wave_sum(s); ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = s; sh[threadIdx.x >> 6][1] = ss; }
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    s = ((sh[0][0] + sh[1][0]) + sh[2][0]) + sh[3][0]; ss = ((sh[0][1] + sh[1][1]) + sh[2][1]) + sh[3][1];
     const double m = s / (double)P;
     double var = ss / (double)P - m * m;
     if (var < 0.0) var = 0.0;
@@ -148,14 +154,20 @@ __global__ __launch_bounds__(64) void bn_train_finalize_partials_kernel(const fl
 
 // dgamma / dbeta from the sums a fused data-gradient kernel left (winograd.hip, STATS == 2): part[C/64][rows][64][2] holds
 // sum(dy) and sum(dy * r) per channel; dbeta = sum dy, dgamma = sum dy xhat = invstd * (sum dy r - mean * sum dy)
-__global__ __launch_bounds__(64) void bn_bwd_finalize_partials_kernel(const float* __restrict__ part, int rows, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_partials_kernel(const float* __restrict__ part, int rows, int C,
         const float* __restrict__ mean, const float* __restrict__ invstd, float* dgamma, float* dbeta) {
+    __shared__ double sh[4][2];
     const int c = blockIdx.x;
     const float* base = part + ((size_t)(c >> 6) * rows * 64 + (c & 63)) * 2;
     double s = 0.0, sr = 0.0;
-    for (int k = threadIdx.x; k < rows; k += 64) { s += (double)base[(size_t)k * 128]; sr += (double)base[(size_t)k * 128 + 1]; }
+    for (int k = threadIdx.x; k < rows; k += 256) { const float2 v = *reinterpret_cast<const float2*>(base + (size_t)k * 128); s += (double)v.x; sr += (double)v.y; }
     s = wave_sum(s); sr = wave_sum(sr);
-    if (threadIdx.x == 0) { dbeta[c] = (float)s; dgamma[c] = (float)((double)invstd[c] * (sr - (double)mean[c] * s)); }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = s; sh[threadIdx.x >> 6][1] = sr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = ((sh[0][0] + sh[1][0]) + sh[2][0]) + sh[3][0]; sr = ((sh[0][1] + sh[1][1]) + sh[2][1]) + sh[3][1];
+        dbeta[c] = (float)s; dgamma[c] = (float)((double)invstd[c] * (sr - (double)mean[c] * s));
+    }
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float eps,
@@ -377,7 +389,7 @@ extern "C" int unet_bn_train_finalize_partials(const float* part, int rows, long
         float* mean, float* invstd, float* scale, float* shift, void* stream) {
     UNET_CHECK_ARG(part && rows > 0 && P > 0 && C > 0 && C % 64 == 0 && gamma && beta && mean && invstd && scale && shift);
     UNET_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
-    bn_train_finalize_partials_kernel<<<C, 64, 0, (hipStream_t)stream>>>(part, rows, P, C, gamma, beta, eps, momentum,
+    bn_train_finalize_partials_kernel<<<C, 256, 0, (hipStream_t)stream>>>(part, rows, P, C, gamma, beta, eps, momentum,
         unbiased_moving_var, moving_mean, moving_var, mean, invstd, scale, shift);
     return UNET_LAUNCH_STATUS();
 }
@@ -428,7 +440,7 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     double* part = (double*)ws;
     int rc;
     if (part_sums) {
-        bn_bwd_finalize_partials_kernel<<<C, 64, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
+        bn_bwd_finalize_partials_kernel<<<C, 256, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
     } else {
         if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg);
         else             bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg);

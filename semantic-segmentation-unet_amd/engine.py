@@ -337,8 +337,16 @@ class Engine:
             r = self._buf("r_" + name, (n, h, w, cout))
             if self._use_bf16(name, n, h, w):
                 self.saved_V[name] = None
-                self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
-                            _p(x), _ld(x), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+                rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
+                if rows > 0:
+                    stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
+                    self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16_stats,
+                                _p(x), _ld(x), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1,
+                                _p(stat_part), stat_part.numel() * 4, st)
+                    fused_stats = (stat_part, rows)
+                else:
+                    self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
+                                _p(x), _ld(x), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
             elif self._use_fused(name, h, w):
                 self.saved_V[name] = None
                 rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
@@ -574,8 +582,19 @@ class Engine:
             elif kind == "conv1":
                 L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
             elif self._use_bf16(name, n, ho, wo, dgrad=True):
-                self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
-                            _p(dz), cout, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout, st)
+                prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
+                rows = L.unet_conv3x3_bf16_stats_rows(n, ho, wo, cout, cin) if prod else 0
+                if rows > 0:
+                    pname, c0, c1 = prod[0], prod[1] * (cin // prod[3]), prod[2] * (cin // prod[3])
+                    r_prev = self.saved[pname][1]
+                    part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
+                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16_bnstats,
+                                _p(dz), cout, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
+                                _p(r_prev), r_prev.shape[-1], c0, c1, _p(part), part.numel() * 4, st)
+                    self.bnbwd_part[pname] = (part, rows, c0)
+                else:
+                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
+                                _p(dz), cout, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout, st)
             elif self._use_fused(name, ho, wo, dgrad=True):
                 prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
                 rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, ho, wo, cout, cin) if prod else 0

@@ -722,3 +722,44 @@ def test_conv3x3_bf16_wgrad_matches_oracle_on_rounded_operands(hip, shape):
     dw2 = torch.empty_like(dw)
     hip.unet_conv3x3_wgrad_bf16(P(xv), ci + 4, P(dzv), co + 8, P(dw2), n, h, w, ci, co, P(ws), nb, ST())
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 40, 64, 128), (1, 32, 64, 128, 64), (2, 16, 32, 64, 256)])
+def test_conv3x3_bf16_fused_batchnorm_sums(hip, shape):
+    # the statistics variants of the bf16 kernels: same tensors as the plain kernels, bit for bit, plus per-tile partial sums whose
+    # totals are the BatchNorm forward sums (sum y, sum y^2) / backward sums (sum dx, sum dx * r) of what the kernel wrote
+    n, h, w, ci, co = shape
+    g = torch.Generator(device=DEV); g.manual_seed(ci + co + h)
+    x = torch.randn(n, h, w, ci, device=DEV, generator=g)
+    wt = torch.randn(3, 3, ci, co, device=DEV, generator=g) / (3 * ci ** 0.5)
+    b = torch.randn(co, device=DEV, generator=g)
+    dz = torch.randn(n, h, w, co, device=DEV, generator=g)
+    nb = hip.unet_conv3x3_bf16_packed_bytes(ci, co)
+    wp, wpd = ws_bytes(nb), ws_bytes(nb)
+    hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wp), ci, co, 0, ST())
+    hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wpd), ci, co, 1, ST())
+    y0 = torch.empty(n, h, w, co, device=DEV); y1 = torch.empty_like(y0)
+    hip.unet_conv3x3_fwd_bf16(P(x), ci, P(wp), P(b), P(y0), co, n, h, w, ci, co, 1, ST())
+    rows = hip.unet_conv3x3_bf16_stats_rows(n, h, w, ci, co)
+    assert rows == n * ((h + 15) // 16) * ((w + 31) // 32)
+    part = torch.full(((co // 64) * rows * 128,), float("nan"), device=DEV)
+    hip.unet_conv3x3_fwd_bf16_stats(P(x), ci, P(wp), P(b), P(y1), co, n, h, w, ci, co, 1, P(part), part.numel() * 4, ST())
+    assert torch.equal(y0, y1)
+    pv = part.view(co // 64, rows, 64, 2).double().sum(1)                        # [C/64][64][2]
+    s1 = y0.double().sum((0, 1, 2)).view(co // 64, 64); s2 = (y0.double() ** 2).sum((0, 1, 2)).view(co // 64, 64)
+    assert (pv[..., 0] - s1).abs().max().item() < 1e-4 * s1.abs().max().item() + 1e-3
+    assert (pv[..., 1] - s2).abs().max().item() < 1e-4 * s2.abs().max().item()
+    # data gradient: dx channels [c0, c1) are the dy of a producer whose saved activation r has c1 - c0 channels
+    c0, c1 = (ci // 2, ci) if ci >= 128 else (0, ci)
+    r_prev = torch.randn(n, h, w, c1 - c0, device=DEV, generator=g)
+    dx0 = torch.empty(n, h, w, ci, device=DEV); dx1 = torch.empty_like(dx0)
+    hip.unet_conv3x3_dgrad_bf16(P(dz), co, P(wpd), P(dx0), ci, n, h, w, ci, co, ST())
+    rows2 = hip.unet_conv3x3_bf16_stats_rows(n, h, w, co, ci)
+    part2 = torch.full(((ci // 64) * rows2 * 128,), float("nan"), device=DEV)
+    hip.unet_conv3x3_dgrad_bf16_bnstats(P(dz), co, P(wpd), P(dx1), ci, n, h, w, ci, co, P(r_prev), c1 - c0, c0, c1,
+                                        P(part2), part2.numel() * 4, ST())
+    assert torch.equal(dx0, dx1)
+    pv2 = part2.view(ci // 64, rows2, 64, 2).double().sum(1).view(ci, 2)[c0:c1]
+    t1 = dx0[..., c0:c1].double().sum((0, 1, 2)); t2 = (dx0[..., c0:c1].double() * r_prev.double()).sum((0, 1, 2))
+    assert (pv2[:, 0] - t1).abs().max().item() < 1e-4 * t1.abs().max().item() + 1e-3
+    assert (pv2[:, 1] - t2).abs().max().item() < 1e-4 * t2.abs().max().item() + 1e-3
