@@ -217,42 +217,51 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
-    // epilogue: accumulator register e of (row r, sub-tile c) = pixel (ty0 + 4 wv + r, tx0 + (e&3) + 8 (e>>2) + 4 lh), channel co0 + 32 c + li
+    // epilogue: accumulator register e of (row r, sub-tile c) = pixel (ty0 + 4 wv + r, tx0 + (e&3) + 8 (e>>2) + 4 lh), channel co0 + 32 c + li.
+    // Buffer stores: the 16 per-lane offsets (column, channel lane) are computed once, row / sub-tile go into the scalar offset;
+    // columns past the image edge get an offset the range check drops.
     float st1[NCO], st2[NCO];
+    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.N * p.H * p.W * p.ldo * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? p.bn_r : p.out), 0,
+                                                                            STATS == 2 ? (int)((size_t)p.N * p.H * p.W * p.bn_ldr * 4) : 0, 0x00020000);
+    int ovoff[16], rvoff[16];
+    bool colok[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        colok[e] = tx0 + col < p.W;
+        ovoff[e] = colok[e] ? (col * p.ldo + li) * 4 : (int)0x80000000;
+        rvoff[e] = (STATS == 2 && colok[e]) ? (col * p.bn_ldr + li) * 4 : (int)0x80000000;
+    }
 #pragma unroll
     for (int c = 0; c < NCO; ++c) {
-        const int co = co0 + 32 * c + li;
-        const float bv = p.bias ? p.bias[co] : 0.f;
+        const int cb = co0 + 32 * c;
+        const float bv = p.bias ? p.bias[cb + li] : 0.f;
         const float lo = p.relu ? 0.f : -INFINITY;
-        const bool with_r = STATS == 2 && co >= p.bn_c0 && co < p.bn_c1;
+        const bool with_r = STATS == 2 && cb >= p.bn_c0 && cb < p.bn_c1;            // uniform: c0, c1 are multiples of 64
         st1[c] = 0.f; st2[c] = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gy = ty0 + 4 * wv + r;
-            const size_t pix0 = (size_t)(img * p.H + gy) * p.W + tx0;
-            float* orow = p.out + pix0 * p.ldo + co;
-            // STATS 2: the 16 saved-activation values first, all loads in flight together (the stores below may alias them as far
-            // as the compiler knows, so loads interleaved with the stores would each wait out their full latency)
+            if (gy >= p.H) continue;                                                 // uniform per wave
+            const int pix0 = (img * p.H + gy) * p.W + tx0;
+            const int so = (pix0 * p.ldo + cb) * 4;
+            // STATS 2: the 16 saved-activation values first, all loads in flight together
             float rv[16];
-            if (STATS == 2) {
-                const float* rrow = p.bn_r + pix0 * p.bn_ldr + (co - p.bn_c0);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    rv[e] = (with_r && gy < p.H && tx0 + col < p.W) ? rrow[(size_t)col * p.bn_ldr] : 0.f;
-                }
+            for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+            if (with_r) {
+                const int sr = (pix0 * p.bn_ldr + (cb - p.bn_c0)) * 4;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, rvoff[e], sr, 0));
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
                 float v;
                 asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[r][c][e]));
                 v = fmaxf(v + bv, lo);
-                if (gy < p.H && tx0 + col < p.W) {
-                    orow[(size_t)col * p.ldo] = v;
-                    if (STATS == 1) { st1[c] += v; st2[c] += v * v; }
-                    if (STATS == 2) { st1[c] += v; st2[c] += v * rv[e]; }
-                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd_o, ovoff[e], so, 0);
+                if (STATS != 0 && colok[e]) { st1[c] += v; st2[c] += STATS == 1 ? v * v : v * rv[e]; }
             }
         }
     }
@@ -358,7 +367,7 @@ extern "C" int unet_conv3x3_fwd_bf16(const float* x, int ldx, const void* wp, co
                                      int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
     UNET_CHECK_ARG(x && wp && out && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
-    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31));
+    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * ldo * 4 < ((size_t)1 << 31));
     return run_conv_bf16(x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
 }
 
@@ -373,7 +382,7 @@ extern "C" int unet_conv3x3_fwd_bf16_stats(const float* x, int ldx, const void* 
                                            int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(x && wp && out && stat_part && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
-    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31));
+    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * ldo * 4 < ((size_t)1 << 31));
     const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0};
     return run_conv_bf16(x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream, &s);
 }
@@ -386,7 +395,7 @@ extern "C" int unet_conv3x3_dgrad_bf16_bnstats(const float* dz, int lddz, const 
     UNET_CHECK_ARG(dz && wpd && dx && r_prev && stat_part && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
     UNET_CHECK_ARG(c0 >= 0 && c0 < c1 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0);
-    UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31));
+    UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
     const ConvBf16Stats s{2, stat_part, stat_bytes, r_prev, ldr, c0, c1};
     return run_conv_bf16(dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream, &s);
 }
@@ -396,7 +405,7 @@ extern "C" int unet_conv3x3_dgrad_bf16(const float* dz, int lddz, const void* wp
                                        int N, int H, int W, int Cin, int Cout, void* stream) {
     UNET_CHECK_ARG(dz && wpd && dx && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
-    UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31));
+    UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
     return run_conv_bf16(dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream);
 }
 
