@@ -19,6 +19,7 @@
 //     (asm volatile) with the next group's reads issued behind the current group's MFMAs and counted lgkmcnt waits.
 // The data gradient is the same kernel on dz with weights packed flipped / transposed (mode 1).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -428,9 +429,10 @@ struct WgBf16Args {
     int ldx, lddz, N, H, W, Cin, Cout;
     int n_ci, n_co, splits, tbx, rpc, cps, n_sc;
     unsigned x_bytes, dz_bytes;
+    int ablate;                  // diagnostics (UNET_WGRAD_BF16_ABLATE): 1 = no MFMA stream, 2 = no staging loads (results are wrong)
 };
 
-constexpr int kWgXRow = 2 * 36 * 64, kWgDzRow = 2 * 32 * 64;       // bytes of one staged input row (34 + 2 pad pixels) / dz row
+constexpr int kWgXRow = 2 * 36 * 64, kWgDzRow = kWgXRow;            // bytes of one staged row: 2 channel groups x 36 pixels (34 / 32 used) x 64 B
 constexpr int kWgXRing = 6 * kWgXRow;
 
 #define WG_RDTR(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
@@ -447,7 +449,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int npairs = p.n_ci * p.n_co;
-    const int pair = blockIdx.x % npairs, split = blockIdx.x / npairs;
+    // workgroups are dealt round-robin over the 8 XCDs: keep all channel pairs of one pixel split on one XCD (and adjacent in
+    // launch order), so that its L2 serves the 2..16-fold re-reads of the strip's rows instead of the fabric
+    int pair, split;
+    if ((p.splits & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        pair = idx % npairs; split = xcd + 8 * (idx / npairs);
+    } else {
+        pair = blockIdx.x % npairs; split = blockIdx.x / npairs;
+    }
     const int ci0 = (pair / p.n_co) * 64, co0 = (pair % p.n_co) * 64;
     const int cisub = wv & 1, cosub = wv >> 1;
 
@@ -456,12 +466,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
     const bool is_x = wv < 2;
     const int rho = wv & 1, o = (lane >> 4) & 3, q = lane & 15;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
-    const unsigned wr_lane = (unsigned)((q >> 3) * (is_x ? 36 * 64 : 32 * 64) + (is_x ? 9 * o : 8 * o) * 64 + (q & 7) * 8);
+    const unsigned wr_lane = (unsigned)((q >> 3) * (36 * 64) + 9 * o * 64 + (q & 7) * 8);
     // fragment gathers: 16-lane group g4 = (k half, channel half); lane 4 q4 + pp supplies pixel row q4, channels 4 pp .. 4 pp + 3
     const int g4 = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
     const unsigned frag_lane = (unsigned)((8 * (g4 >> 1) + q4) * 64 + (16 * (g4 & 1) + 4 * pp) * 2);
     const unsigned a_lane = lds0 + cisub * (36 * 64) + frag_lane;
-    const unsigned b_lane = lds0 + kWgXRing + cosub * (32 * 64) + frag_lane;
+    const unsigned b_lane = lds0 + kWgXRing + cosub * (36 * 64) + frag_lane;
 
     const float* xb_ptr = p.x + ci0; const float* zb_ptr = p.dz + co0;
     const int xrec = (int)(p.x_bytes - (unsigned)ci0 * 4), zrec = (int)(p.dz_bytes - (unsigned)co0 * 4);
@@ -472,119 +482,236 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    f32x4 stg[9];
+    // Staging passes.  Pass j of a strip chunk carries input rows y0-1+2j, y0+2j (ring slots 2j, 2j+1 mod 6) and, for j >= 1, dz
+    // rows y0+2(j-1), +1 (dz slots 2((j-1)&1), +1); compute step s needs passes <= s+1.  HBM latency under load is several
+    // thousand cycles against 1152 MFMA cycles per step, so the loads run THREE passes ahead in a register ring
+    // (pass j -> stg[j % 3]): iteration s issues pass s+4, computes step s and commits pass s+2.
+    f32x4 stg[3][9];
     unsigned voff[9];
-    // loads of one staging pass: input rows xrow + rho (when do_x) / dz rows zrow + rho, rows outside [0, H) / [0, y_end) read zeros
-    auto issue = [&](int xrow, int zrow, int y_end, bool do_x, bool do_z) {
-        if (is_x) {
-            if (!do_x) return;
-            const int row = xrow + rho;
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)xb_ptr, 0, (row < 0 || row >= p.H) ? 0 : xrec, 0x00020000);
-            const int so = (row < 0 ? 0 : row) * p.W * p.ldx * 4;
+    int y0 = 0, y_end = 0;
+    // (both roles run the SAME instruction sequence -- 9 loads, 9 conversions and writes per pass, the dz role's ninth column is
+    // padding -- and differ only in scalar operands: with role branches the compiler merged their tails and turned the register
+    // ring into a dynamically indexed scratch array)
+    const float* role_ptr = is_x ? xb_ptr : zb_ptr;
+    const int role_rec = is_x ? xrec : zrec, role_rowbytes = p.W * (is_x ? p.ldx : p.lddz) * 4;
+    auto issue = [&](f32x4 (&sg)[9], int j) {
+        const int row = is_x ? y0 - 1 + 2 * j + rho : y0 + 2 * (j - 1) + rho;
+        const bool ok = is_x ? (row >= 0 && row < p.H) : (row >= y0 && row < y_end);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)role_ptr, 0, ok ? role_rec : 0, 0x00020000);
+        const int so = (row < 0 ? 0 : row) * role_rowbytes;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) stg[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[t], so, 0));
-        } else {
-            if (!do_z) return;
-            const int row = zrow + rho;
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)zb_ptr, 0, row >= y_end ? 0 : zrec, 0x00020000);
-            const int so = row * p.W * p.lddz * 4;
+        for (int t = 0; t < 9; ++t) sg[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[t], so, 0));
+    };
+    // convert and write pass j
+    auto commit = [&](const f32x4 (&sg)[9], int j) {
+        const int slot = is_x ? (2 * j + rho) % 6 : 6 + 2 * ((j + 1) & 1) + rho;       // dz slots follow the 6 input-row slots
+        const unsigned wb = lds0 + wr_lane + (unsigned)(slot * kWgXRow);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) stg[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff[t], so, 0));
+        for (int t = 0; t < 9; ++t) {
+            uint2 v; v.x = cb_pack2_pinned(sg[t].x, sg[t].y); v.y = cb_pack2_pinned(sg[t].z, sg[t].w);
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(t * 64) : "memory");
         }
     };
-    // convert and write what `issue` loaded: input rows into ring slots xslot + rho, dz rows into slots zslot + rho
-    auto commit = [&](int xslot, int zslot, bool do_x, bool do_z) {
-        if (is_x) {
-            if (!do_x) return;
-            int sl = xslot + rho; if (sl >= 6) sl -= 6;
-            const unsigned wb = lds0 + wr_lane + (unsigned)(sl * kWgXRow);
+    // compute step s from LDS: 4 groups (output row yy, k-step ks) x 9 taps; A fragments three ahead, the next group's B at the group start
+    auto compute = [&](int s) {
+        unsigned xb[4], zb[2];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                uint2 v; v.x = cb_pack2_pinned(stg[t].x, stg[t].y); v.y = cb_pack2_pinned(stg[t].z, stg[t].w);
-                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(t * 64) : "memory");
-            }
-        } else {
-            if (!do_z) return;
-            const unsigned wb = lds0 + kWgXRing + wr_lane + (unsigned)((zslot + rho) * kWgDzRow);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                uint2 v; v.x = cb_pack2_pinned(stg[t].x, stg[t].y); v.y = cb_pack2_pinned(stg[t].z, stg[t].w);
-                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(t * 64) : "memory");
-            }
-        }
+        for (int r = 0; r < 4; ++r) xb[r] = a_lane + (unsigned)(((2 * s + r) % 6) * kWgXRow);
+        zb[0] = b_lane + (unsigned)(((s & 1) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
+        // One asm block per step (generated: 80 transposing reads, 36 MFMAs, counted waits; LDS operations retire in order).  The
+        // fragments live in fixed registers v[232:255] -- A buffers four deep, B two -- because a 128-bit MFMA operand has to be
+        // assembled from two 64-bit reads: as separate asm statements that took compiler copies plus s_nop padding in front of
+        // every MFMA (57 cycles per MFMA measured); inside one block nothing can be scheduled between a read and its use.
+        asm volatile(
+            "ds_read_b64_tr_b16 v[248:249], %13 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[250:251], %13 offset:256\n\t"
+            "ds_read_b64_tr_b16 v[232:233], %9 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[234:235], %9 offset:256\n\t"
+            "ds_read_b64_tr_b16 v[236:237], %9 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[238:239], %9 offset:320\n\t"
+            "ds_read_b64_tr_b16 v[240:241], %9 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[242:243], %9 offset:384\n\t"
+            "ds_read_b64_tr_b16 v[252:253], %13 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[254:255], %13 offset:1280\n\t"
+            "ds_read_b64_tr_b16 v[244:245], %10 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[246:247], %10 offset:256\n\t"
+            "s_waitcnt lgkmcnt(8)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[232:235], v[248:251], %0\n\t"
+            "ds_read_b64_tr_b16 v[232:233], %10 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[234:235], %10 offset:320\n\t"
+            "s_waitcnt lgkmcnt(8)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, v[236:239], v[248:251], %1\n\t"
+            "ds_read_b64_tr_b16 v[236:237], %10 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[238:239], %10 offset:384\n\t"
+            "s_waitcnt lgkmcnt(8)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, v[240:243], v[248:251], %2\n\t"
+            "ds_read_b64_tr_b16 v[240:241], %11 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[242:243], %11 offset:256\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, v[244:247], v[248:251], %3\n\t"
+            "ds_read_b64_tr_b16 v[244:245], %11 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[246:247], %11 offset:320\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %4, v[232:235], v[248:251], %4\n\t"
+            "ds_read_b64_tr_b16 v[232:233], %11 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[234:235], %11 offset:384\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %5, v[236:239], v[248:251], %5\n\t"
+            "ds_read_b64_tr_b16 v[236:237], %9 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[238:239], %9 offset:1280\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %6, v[240:243], v[248:251], %6\n\t"
+            "ds_read_b64_tr_b16 v[240:241], %9 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[242:243], %9 offset:1344\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %7, v[244:247], v[248:251], %7\n\t"
+            "ds_read_b64_tr_b16 v[244:245], %9 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[246:247], %9 offset:1408\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %8, v[232:235], v[248:251], %8\n\t"
+            "ds_read_b64_tr_b16 v[248:249], %14 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[250:251], %14 offset:256\n\t"
+            "ds_read_b64_tr_b16 v[232:233], %10 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[234:235], %10 offset:1280\n\t"
+            "s_waitcnt lgkmcnt(8)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[236:239], v[252:255], %0\n\t"
+            "ds_read_b64_tr_b16 v[236:237], %10 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[238:239], %10 offset:1344\n\t"
+            "s_waitcnt lgkmcnt(8)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, v[240:243], v[252:255], %1\n\t"
+            "ds_read_b64_tr_b16 v[240:241], %10 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[242:243], %10 offset:1408\n\t"
+            "s_waitcnt lgkmcnt(8)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, v[244:247], v[252:255], %2\n\t"
+            "ds_read_b64_tr_b16 v[244:245], %11 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[246:247], %11 offset:1280\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, v[232:235], v[252:255], %3\n\t"
+            "ds_read_b64_tr_b16 v[232:233], %11 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[234:235], %11 offset:1344\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %4, v[236:239], v[252:255], %4\n\t"
+            "ds_read_b64_tr_b16 v[236:237], %11 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[238:239], %11 offset:1408\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %5, v[240:243], v[252:255], %5\n\t"
+            "ds_read_b64_tr_b16 v[240:241], %10 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[242:243], %10 offset:256\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %6, v[244:247], v[252:255], %6\n\t"
+            "ds_read_b64_tr_b16 v[244:245], %10 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[246:247], %10 offset:320\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %7, v[232:235], v[252:255], %7\n\t"
+            "ds_read_b64_tr_b16 v[232:233], %10 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[234:235], %10 offset:384\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %8, v[236:239], v[252:255], %8\n\t"
+            "ds_read_b64_tr_b16 v[252:253], %14 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[254:255], %14 offset:1280\n\t"
+            "ds_read_b64_tr_b16 v[236:237], %11 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[238:239], %11 offset:256\n\t"
+            "s_waitcnt lgkmcnt(8)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[240:243], v[248:251], %0\n\t"
+            "ds_read_b64_tr_b16 v[240:241], %11 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[242:243], %11 offset:320\n\t"
+            "s_waitcnt lgkmcnt(8)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, v[244:247], v[248:251], %1\n\t"
+            "ds_read_b64_tr_b16 v[244:245], %11 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[246:247], %11 offset:384\n\t"
+            "s_waitcnt lgkmcnt(8)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, v[232:235], v[248:251], %2\n\t"
+            "ds_read_b64_tr_b16 v[232:233], %12 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[234:235], %12 offset:256\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, v[236:239], v[248:251], %3\n\t"
+            "ds_read_b64_tr_b16 v[236:237], %12 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[238:239], %12 offset:320\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %4, v[240:243], v[248:251], %4\n\t"
+            "ds_read_b64_tr_b16 v[240:241], %12 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[242:243], %12 offset:384\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %5, v[244:247], v[248:251], %5\n\t"
+            "ds_read_b64_tr_b16 v[244:245], %10 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[246:247], %10 offset:1280\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %6, v[232:235], v[248:251], %6\n\t"
+            "ds_read_b64_tr_b16 v[232:233], %10 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[234:235], %10 offset:1344\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %7, v[236:239], v[248:251], %7\n\t"
+            "ds_read_b64_tr_b16 v[236:237], %10 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[238:239], %10 offset:1408\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %8, v[240:243], v[248:251], %8\n\t"
+            "ds_read_b64_tr_b16 v[240:241], %11 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[242:243], %11 offset:1280\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[244:247], v[252:255], %0\n\t"
+            "ds_read_b64_tr_b16 v[244:245], %11 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[246:247], %11 offset:1344\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, v[232:235], v[252:255], %1\n\t"
+            "ds_read_b64_tr_b16 v[232:233], %11 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[234:235], %11 offset:1408\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, v[236:239], v[252:255], %2\n\t"
+            "ds_read_b64_tr_b16 v[236:237], %12 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[238:239], %12 offset:1280\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, v[240:243], v[252:255], %3\n\t"
+            "ds_read_b64_tr_b16 v[240:241], %12 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[242:243], %12 offset:1344\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %4, v[244:247], v[252:255], %4\n\t"
+            "ds_read_b64_tr_b16 v[244:245], %12 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[246:247], %12 offset:1408\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %5, v[232:235], v[252:255], %5\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %6, v[236:239], v[252:255], %6\n\t"
+            "s_waitcnt lgkmcnt(2)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %7, v[240:243], v[252:255], %7\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %8, v[244:247], v[252:255], %8\n\t"
+            : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8])
+            : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(zb[0]), "v"(zb[1])
+            : "memory", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
     };
 
     for (int sc = split; sc < p.n_sc; sc += p.splits) {
         const int strip = sc / p.cps, chunk = sc % p.cps;
         const int img = strip / p.tbx, x0 = 32 * (strip % p.tbx);
-        const int y0 = chunk * p.rpc;
-        const int y_end = y0 + p.rpc < p.H ? y0 + p.rpc : p.H;
-        const int steps = (y_end - y0 + 1) / 2;
+        y0 = chunk * p.rpc;
+        y_end = y0 + p.rpc < p.H ? y0 + p.rpc : p.H;
+        const int steps = ((y_end - y0 + 1) / 2 + 2) / 3 * 3;         // rounded up to the ring depth: the extra steps see zero dz rows
         // per-thread offsets inside a row (the row goes into the scalar offset); columns outside the image / the patch: rejected
-        if (is_x) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int pc = 9 * o + t, gx = x0 - 1 + pc;
-                voff[t] = (pc < 34 && gx >= 0 && gx < p.W) ? (unsigned)((((size_t)img * p.H * p.W + gx) * p.ldx) * 4 + q * 16) : 0x80000000u;
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int gx = x0 + 8 * o + t;
-                voff[t] = (t < 8 && gx < p.W) ? (unsigned)((((size_t)img * p.H * p.W + gx) * p.lddz) * 4 + q * 16) : 0x80000000u;
-            }
+        for (int t = 0; t < 9; ++t) {
+            const int pc = 9 * o + t;                                 // staged column: input patch column (image column x0 - 1 + pc) / dz column x0 + pc
+            const int gx = is_x ? x0 - 1 + pc : x0 + pc;
+            const bool ok = pc < (is_x ? 34 : 32) && gx >= 0 && gx < p.W;
+            voff[t] = ok ? (unsigned)((((size_t)img * p.H * p.W + gx) * (is_x ? p.ldx : p.lddz)) * 4 + q * 16) : 0x80000000u;
         }
-        // prologue: input rows y0-1, y0 -> slots 0,1; then the regular pass for step 0: input rows y0+1, y0+2 -> slots 2,3, dz rows
-        // y0, y0+1 -> dz slots 0,1.  (The previous strip's last step ended with a barrier: every wave is done reading.)
-        issue(y0 - 1, 0, y_end, true, false);
-        commit(0, 0, true, false);
-        issue(y0 + 1, y0, y_end, true, true);
-        commit(2, 0, true, true);
+        // fill: passes 0 and 1 committed, 2 and 3 in flight.  (The previous strip's last step ended with a barrier: every wave is
+        // done reading the rings.)
+        issue(stg[0], 0); issue(stg[1], 1);
+        commit(stg[0], 0); commit(stg[1], 1);
+        issue(stg[2], 2); issue(stg[0], 3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-        int xs = 0;                                                   // ring slot of input row Y - 1
-        for (int s = 0; s < steps; ++s) {
-            const int Y = y0 + 2 * s;
-            issue(Y + 3, Y + 2, y_end, true, true);
-            // slot bases of the four input rows Y-1 .. Y+2 and the two dz rows of this step
-            unsigned xb[4], zb[2];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { int sl = xs + r; if (sl >= 6) sl -= 6; xb[r] = a_lane + (unsigned)(sl * kWgXRow); }
-            zb[0] = b_lane + (unsigned)(((s & 1) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
-
-            // 4 groups (output row yy, k-step ks) x 9 taps; A fragments three ahead, the next group's B at the group start
-            i32x2 af[4][2], bf[2][2];
-            int issued = 0, a_mark[36];
-#define WG_ISSUE_A(i) do { const int grp_ = (i) / 9, tap_ = (i) % 9; \
-                WG_RDTR(af[(i) & 3][0], xb[(grp_ >> 1) + tap_ / 3], ((tap_ % 3) + 16 * (grp_ & 1)) * 64); \
-                WG_RDTR(af[(i) & 3][1], xb[(grp_ >> 1) + tap_ / 3], ((tap_ % 3) + 16 * (grp_ & 1)) * 64 + 256); \
-                issued += 2; a_mark[(i)] = issued; } while (0)
-#define WG_ISSUE_B(g) do { WG_RDTR(bf[(g) & 1][0], zb[(g) >> 1], 16 * ((g) & 1) * 64); \
-                WG_RDTR(bf[(g) & 1][1], zb[(g) >> 1], 16 * ((g) & 1) * 64 + 256); issued += 2; } while (0)
-            WG_ISSUE_B(0);
-            WG_ISSUE_A(0); WG_ISSUE_A(1); WG_ISSUE_A(2);
-#pragma unroll
-            for (int i = 0; i < 36; ++i) {
-                const int grp = i / 9, tap = i % 9;
-                if (tap == 0 && grp + 1 < 4) WG_ISSUE_B(grp + 1);
-                if (i + 3 < 36) WG_ISSUE_A(i + 3);
-                wg_wait_lgkm(issued - a_mark[i]);                      // LDS operations retire in order: A(i), and B(grp) before it, are back
-                asm volatile("" : "+v"(af[i & 3][0]), "+v"(af[i & 3][1]), "+v"(bf[grp & 1][0]), "+v"(bf[grp & 1][1]));
-                bf16x8 av, bv;
-                { i32x4 t4; t4.x = af[i & 3][0].x; t4.y = af[i & 3][0].y; t4.z = af[i & 3][1].x; t4.w = af[i & 3][1].y; av = __builtin_bit_cast(bf16x8, t4); }
-                { i32x4 t4; t4.x = bf[grp & 1][0].x; t4.y = bf[grp & 1][0].y; t4.z = bf[grp & 1][1].x; t4.w = bf[grp & 1][1].y; bv = __builtin_bit_cast(bf16x8, t4); }
-                // the operands are assembled from two 64-bit reads each, which can leave compiler-generated v_mov's right in front
-                // of the MFMA; the hazard recogniser does not see into inline asm, so the wait states a VALU write needs before
-                // an MFMA reads the register are supplied here
-                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[tap]) : "v"(av), "v"(bv) : "memory");
-            }
-#undef WG_ISSUE_A
-#undef WG_ISSUE_B
-            int xn = xs + 4; if (xn >= 6) xn -= 6;
-            commit(xn, ((s + 1) & 1) * 2, true, true);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            xs += 2; if (xs >= 6) xs -= 6;
+        for (int s = 0; s < steps; s += 3) {
+            if (!(p.ablate & 2)) issue(stg[1], s + 4);
+            if (!(p.ablate & 1)) compute(s);
+            commit(stg[2], s + 2); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!(p.ablate & 2)) issue(stg[2], s + 5);
+            if (!(p.ablate & 1)) compute(s + 1);
+            commit(stg[0], s + 3); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!(p.ablate & 2)) issue(stg[0], s + 6);
+            if (!(p.ablate & 1)) compute(s + 2);
+            commit(stg[1], s + 4); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // passes still in flight belong to nobody
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
@@ -656,6 +783,7 @@ extern "C" int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* d
     a.x = xin; a.dz = dz; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     wgrad_bf16_plan(a);
     a.out = a.splits > 1 ? (float*)ws : dw;
+    { const char* e = getenv("UNET_WGRAD_BF16_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     a.x_bytes = (unsigned)((size_t)N * H * W * ldx * 4); a.dz_bytes = (unsigned)((size_t)N * H * W * lddz * 4);
     hipStream_t st = (hipStream_t)stream;
     wgrad_bf16_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
