@@ -185,6 +185,7 @@ def main():
                         "achieved": kb["tflops"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(kb["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
                         "launches_per_step": kb["launches_per_step"], "avg_launch_ms": kb["avg_launch_ms"]}
+            tfile = "r01f_conv_bf16_fwd_pmc_traffic.json"
         elif kf:
             roofline = {"bound": "mfma", "kernel": "wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
                         "achieved": kf["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -202,7 +203,7 @@ def main():
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction,
             # WRITE_SIZE) of this same workload, committed under profiles/; only valid for the default workload.
             tf = os.path.join(ROOT, "profiles", tfile or "none")
-            if os.path.exists(tf) and (args.size, args.channels, args.classes, args.batch) == (512, 1, 2, 8):
+            if os.path.exists(tf) and (args.size, args.channels, args.classes, args.batch) == ((512, 3, 4, 8) if kb else (512, 1, 2, 8)):
                 t = json.load(open(tf))
                 if t.get("launches_per_step") == roofline["launches_per_step"]:
                     roofline["traffic"] = round(t["hbm_bytes_per_launch"])
