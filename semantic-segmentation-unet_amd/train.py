@@ -53,7 +53,7 @@ def best_epoch_index(test_loss):
 
 def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, test_lmdb_filepath, use_augmentation,
                 number_classes, balance_classes, learning_rate, test_every_n_steps, early_stopping_count,
-                train_reader=None, test_reader=None, max_epochs=None, quiet=False):
+                train_reader=None, test_reader=None, max_epochs=None, quiet=False, compute_dtype=None):
     say = (lambda *a: None) if quiet else print
     for k, v in (("batch_size", batch_size), ("number_classes", number_classes), ("learning_rate", learning_rate),
                  ("test_every_n_steps", test_every_n_steps), ("balance_classes", balance_classes),
@@ -106,7 +106,7 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
             test_batches = test_reader.batches(batch_size)
         number_channels = train_reader.get_image_size()[2]
         net = unet_model_module.UNet(number_classes, global_batch_size, number_channels, learning_rate,
-                                     device=torch.device("cuda", local))
+                                     device=torch.device("cuda", local), compute_dtype=compute_dtype)
         strategy = None
         if world > 1:
             from .parallel import DataParallel
@@ -201,6 +201,9 @@ def main(argv=None):
     # opt-in extras (not in the reference)
     ap.add_argument("--synthetic", type=str, default=None, help="HxWxC[xCOUNT] synthetic tiles instead of databases")
     ap.add_argument("--max_epochs", type=int, default=None)
+    ap.add_argument("--compute_dtype", choices=["fp32", "bf16"], default=None,
+                    help="bf16: mixed precision (the policy the reference keeps commented out, UNet/train.py:52-54): bf16 "
+                         "contractions in the wide 3x3 layers, fp32 accumulation and master weights")
     a = ap.parse_args(argv)
     tr = te = None
     if a.synthetic:
@@ -213,7 +216,7 @@ def main(argv=None):
         ap.error("--train_database and --test_database are required unless --synthetic is given")
     train_model(a.output_folder, a.batch_size, a.reader_count, a.train_database_filepath, a.test_database_filepath,
                 a.use_augmentation, a.number_classes, a.balance_classes, a.learning_rate, a.test_every_n_steps,
-                a.early_stopping_count, train_reader=tr, test_reader=te, max_epochs=a.max_epochs)
+                a.early_stopping_count, train_reader=tr, test_reader=te, max_epochs=a.max_epochs, compute_dtype=a.compute_dtype)
 
 
 if __name__ == "__main__":

@@ -56,3 +56,19 @@ def test_train_cli_then_inference_cli(tmp_path):
     whole = inf._inference(zb, net)
     assert whole.shape == big.shape
     assert (whole == m_big).mean() > 0.9999
+
+
+def test_train_cli_bf16(tmp_path):
+    # the same loop in the mixed-precision mode (bf16 contractions, fp32 master weights): runs, writes the same outputs, and the
+    # checkpoint (fp32 master weights) is readable by the fp32 inference path
+    train = pkg("train")
+    out = str(tmp_path / "out16")
+    train.main(["--output_dir", out, "--batch_size", "2", "--number_classes", "3", "--test_every_n_steps", "3",
+                "--early_stopping", "1", "--synthetic", "64x64x3x8", "--max_epochs", "2", "--compute_dtype", "bf16"])
+    losses = [float(v) for v in open(os.path.join(out, "test_loss.csv")).read().split()]
+    assert len(losses) == 2 and all(np.isfinite(losses))
+    net = pkg("model").UNet(3, 1, 3)
+    net.load_checkpoint(os.path.join(out, "checkpoint", "ckpt"))
+    x = torch.randn(1, 3, 64, 64)
+    p = net.get_keras_model()(x, training=False)
+    assert tuple(p.shape) == (1, 64, 64, 3) and torch.isfinite(p).all()
