@@ -104,12 +104,22 @@ int unet_conv3x3_fwd_bf16_stats(const float* x, int ldx, const void* wp, const f
 int unet_conv3x3_dgrad_bf16_bnstats(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
                                     int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
                                     float* stat_part, size_t stat_bytes, void* stream);
+/* general forms: an operand that only bf16 contractions read may be STORED as bf16 (x_bf16 / dz_bf16 != 0; leading dimension in
+ * elements) -- its producer (unet_bn_apply_bf16out, unet_bn_bwd_any) rounds exactly as these kernels' staging would, so the
+ * results are bit-identical to fp32 storage; stat_part (and r_prev) nullable */
+int unet_conv3x3_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
+                             int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
+int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
+                               int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+                               float* stat_part, size_t stat_bytes, void* stream);
 /* weight gradient in the same arithmetic (both operands rounded to bf16, fp32 accumulation, split partial sums added in a
  * fixed order): dw[a,b,ci,co] = sum xin[n,y+a-1,x+b-1,ci] * dz[n,y,x,co] */
 int unet_conv3x3_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_conv3x3_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                             int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int unet_conv3x3_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
 int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                             int N, int H, int W, int Cin, int Cout, int relu, void* stream);
@@ -169,6 +179,9 @@ int unet_bn_train_finalize_partials(const float* part, int rows, long P, int C, 
 int unet_bn_eval_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                         float eps, int C, float* scale, float* shift, void* stream);
 int unet_bn_apply(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy, long P, int C, void* stream);
+/* the same, y stored as bf16 (ldy in elements): for an output read only by bf16 contractions */
+int unet_bn_apply_bf16out(const float* r, int ldr, const float* scale, const float* shift, void* y16, int ldy,
+                          long P, int C, void* stream);
 /* the same plus the MaxPool2D(2) that follows (UNet/model.py:50-53) in one pass: pooled [N,H/2,W/2,C] and first-max indices */
 int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy,
                           float* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream);
@@ -181,6 +194,11 @@ int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float*
 int unet_bn_bwd_pooled(const float* dy_skip, int lddy, const float* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
                        const float* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
                        float* dz, int lddz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, void* stream);
+/* all three forms in one call (pooled_dy/idx nullable, part_sums nullable), dz optionally stored as bf16 (dz_bf16 != 0) */
+int unet_bn_bwd_any(const float* dy, int lddy, const float* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
+                    const float* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
+                    void* dz, int lddz, int dz_bf16, float* dgamma, float* dbeta, float* dbias, const float* part_sums, int rows,
+                    void* ws, size_t ws_bytes, void* stream);
 int unet_bn_bwd_from_partials(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
                               const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,
                               float* dbias, const float* part_sums, int rows, void* ws, size_t ws_bytes, void* stream);

@@ -32,6 +32,7 @@ struct ConvBf16Args {
     int ldx, ldo, N, H, W, Cin, Cout, relu;
     int tby, tbx, n_px, n_co;
     unsigned x_bytes;
+    int in16;                    // the input tensor is stored as bf16 (ldx in elements): staged without conversion
     float* stat_part;            // STATS 1: BatchNorm sums of the output (sum y, sum y^2); STATS 2: BatchNorm-backward sums (sum dx, sum dx * r)
     const float* bn_r; int bn_ldr, bn_c0, bn_c1;     // STATS 2: saved activation of the producer layer, whose dy is dx[..., c0:c1)
 };
@@ -149,7 +150,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
         const int pp = (tid >> 2) + 64 * j;
         const int gy = ty0 - 1 + pp / kPW, gx = tx0 - 1 + pp % kPW;
         const bool ok = pp < 18 * kPW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        voff[j] = ok ? (unsigned)((((size_t)(img * p.H + gy) * p.W + gx) * p.ldx) * 4 + f * 16) : 0x80000000u;
+        voff[j] = ok ? (unsigned)((((size_t)(img * p.H + gy) * p.W + gx) * p.ldx) * (p.in16 ? 2 : 4) + (p.in16 ? (f >> 1) * 16 : f * 16)) : 0x80000000u;
     }
     // (compiler-visible buffer loads: it places the vmcnt wait in front of the first use; with inline-asm loads a register copy
     // of a destination can be scheduled ahead of a hand-written wait)
@@ -171,8 +172,11 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     const char* wsrc = reinterpret_cast<const char*>(p.wp);
 
     f32x4 stg[10];
+    // (a bf16 input goes through the same 16-byte loads -- 16-byte aligned, as the instruction requires: 8 channels, of which the
+    // thread keeps its half, the neighbour thread the other from the same address: the instruction stream stays one and the
+    // HBM traffic halves)
     auto issue_x = [&](int chunk) {
-        const int so = chunk * 64;
+        const int so = chunk * (p.in16 ? 32 : 64);
 #pragma unroll
         for (int j = 0; j < 10; ++j)
             stg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff[j], so, 0));
@@ -190,6 +194,9 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
 #pragma unroll
         for (int j = 0; j < 10; ++j) {
             uint2 v; v.x = cb_pack2_pinned(stg[j].x, stg[j].y); v.y = cb_pack2_pinned(stg[j].z, stg[j].w);
+            if (p.in16) {
+                v.x = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].z : stg[j].x); v.y = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].w : stg[j].y);
+            }
             asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(j * 1024) : "memory");
         }
     };
@@ -326,12 +333,13 @@ int conv_bf16_cus() {
 struct ConvBf16Stats { int mode; float* part; size_t bytes; const float* r; int ldr, c0, c1; };
 
 int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
-                  int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st, const ConvBf16Stats* stats = nullptr) {
+                  int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st, const ConvBf16Stats* stats = nullptr, int in16 = 0) {
     ConvBf16Args a{};
+    a.in16 = in16;
     a.x = x; a.wp = (const uint16_t*)wp; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.tby = (H + 15) / 16; a.tbx = (W + 31) / 32; a.n_px = N * a.tby * a.tbx;
-    a.x_bytes = (unsigned)((size_t)N * H * W * ldx * 4);
+    a.x_bytes = (unsigned)((size_t)N * H * W * ldx * (in16 ? 2 : 4));
     // 128-channel tiles halve the input traffic; 64-channel tiles when they would leave compute units idle
     const bool wide = Cout % 128 == 0 && (long)a.n_px * (Cout / 128) >= conv_bf16_cus();
     a.n_co = Cout / (wide ? 128 : 64);
@@ -429,6 +437,7 @@ struct WgBf16Args {
     int ldx, lddz, N, H, W, Cin, Cout;
     int n_ci, n_co, splits, tbx, rpc, cps, n_sc;
     unsigned x_bytes, dz_bytes;
+    int x16, z16;                // xin / dz stored as bf16 (ldx / lddz in elements)
     int ablate;                  // diagnostics (UNET_WGRAD_BF16_ABLATE): 1 = no MFMA stream, 2 = no staging loads (results are wrong)
 };
 
@@ -473,8 +482,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
     const unsigned a_lane = lds0 + cisub * (36 * 64) + frag_lane;
     const unsigned b_lane = lds0 + kWgXRing + cosub * (36 * 64) + frag_lane;
 
-    const float* xb_ptr = p.x + ci0; const float* zb_ptr = p.dz + co0;
-    const int xrec = (int)(p.x_bytes - (unsigned)ci0 * 4), zrec = (int)(p.dz_bytes - (unsigned)co0 * 4);
+    const int xes = p.x16 ? 2 : 4, zes = p.z16 ? 2 : 4;
+    const char* xb_ptr = reinterpret_cast<const char*>(p.x) + (size_t)ci0 * xes;
+    const char* zb_ptr = reinterpret_cast<const char*>(p.dz) + (size_t)co0 * zes;
+    const int xrec = (int)(p.x_bytes - (unsigned)ci0 * xes), zrec = (int)(p.dz_bytes - (unsigned)co0 * zes);
 
     f32x16 acc[9];
 #pragma unroll
@@ -492,8 +503,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
     // (both roles run the SAME instruction sequence -- 9 loads, 9 conversions and writes per pass, the dz role's ninth column is
     // padding -- and differ only in scalar operands: with role branches the compiler merged their tails and turned the register
     // ring into a dynamically indexed scratch array)
-    const float* role_ptr = is_x ? xb_ptr : zb_ptr;
-    const int role_rec = is_x ? xrec : zrec, role_rowbytes = p.W * (is_x ? p.ldx : p.lddz) * 4;
+    const char* role_ptr = is_x ? xb_ptr : zb_ptr;
+    const bool is16 = is_x ? p.x16 != 0 : p.z16 != 0;                // bf16-stored operand: same 16-byte loads, half of each used as it is
+    const int role_es = is16 ? 2 : 4;
+    const int role_rec = is_x ? xrec : zrec, role_rowbytes = p.W * (is_x ? p.ldx : p.lddz) * role_es;
     auto issue = [&](f32x4 (&sg)[9], int j) {
         const int row = is_x ? y0 - 1 + 2 * j + rho : y0 + 2 * (j - 1) + rho;
         const bool ok = is_x ? (row >= 0 && row < p.H) : (row >= y0 && row < y_end);
@@ -509,6 +522,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             uint2 v; v.x = cb_pack2_pinned(sg[t].x, sg[t].y); v.y = cb_pack2_pinned(sg[t].z, sg[t].w);
+            if (is16) {          // 16-byte aligned load = 8 channels: this thread's quad is the low or the high half
+                v.x = __builtin_bit_cast(unsigned, (q & 1) ? sg[t].z : sg[t].x); v.y = __builtin_bit_cast(unsigned, (q & 1) ? sg[t].w : sg[t].y);
+            }
             asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(t * 64) : "memory");
         }
     };
@@ -692,7 +708,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
             const int pc = 9 * o + t;                                 // staged column: input patch column (image column x0 - 1 + pc) / dz column x0 + pc
             const int gx = is_x ? x0 - 1 + pc : x0 + pc;
             const bool ok = pc < (is_x ? 34 : 32) && gx >= 0 && gx < p.W;
-            voff[t] = ok ? (unsigned)((((size_t)img * p.H * p.W + gx) * (is_x ? p.ldx : p.lddz)) * 4 + q * 16) : 0x80000000u;
+            voff[t] = ok ? (unsigned)((((size_t)img * p.H * p.W + gx) * (is_x ? p.ldx : p.lddz)) * role_es + (is16 ? (q >> 1) * 16 : q * 16)) : 0x80000000u;
         }
         // fill: passes 0 and 1 committed, 2 and 3 in flight.  (The previous strip's last step ended with a barrier: every wave is
         // done reading the rings.)
@@ -772,19 +788,22 @@ extern "C" size_t unet_conv3x3_wgrad_bf16_workspace(int N, int H, int W, int Cin
     return a.splits > 1 ? (size_t)a.splits * 9 * Cin * Cout * sizeof(float) : 16;
 }
 
-// dw[a,b,ci,co] (HWIO, UNet/model.py:31) = sum_{n,y,x} bf16(xin[n,y+a-1,x+b-1,ci]) * bf16(dz[n,y,x,co])
-extern "C" int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* dz, int lddz, float* dw,
-                                       int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+// dw[a,b,ci,co] (HWIO, UNet/model.py:31) = sum_{n,y,x} bf16(xin[n,y+a-1,x+b-1,ci]) * bf16(dz[n,y,x,co]); x_bf16 / dz_bf16: that
+// operand is already stored as bf16 (leading dimension in elements)
+extern "C" int unet_conv3x3_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                                          int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(xin && dz && dw && ws && unet_conv3x3_wgrad_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG((!x_bf16 || ldx % 8 == 0) && (!dz_bf16 || lddz % 8 == 0));        // 16-byte aligned pixels
     UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
     UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddz * 4 < ((size_t)1 << 31));
     if (ws_bytes < unet_conv3x3_wgrad_bf16_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
     WgBf16Args a{};
-    a.x = xin; a.dz = dz; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.x = (const float*)xin; a.dz = (const float*)dz; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.x16 = x_bf16 ? 1 : 0; a.z16 = dz_bf16 ? 1 : 0;
     wgrad_bf16_plan(a);
     a.out = a.splits > 1 ? (float*)ws : dw;
     { const char* e = getenv("UNET_WGRAD_BF16_ABLATE"); a.ablate = e ? atoi(e) : 0; }
-    a.x_bytes = (unsigned)((size_t)N * H * W * ldx * 4); a.dz_bytes = (unsigned)((size_t)N * H * W * lddz * 4);
+    a.x_bytes = (unsigned)((size_t)N * H * W * ldx * (a.x16 ? 2 : 4)); a.dz_bytes = (unsigned)((size_t)N * H * W * lddz * (a.z16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     wgrad_bf16_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
@@ -796,4 +815,34 @@ extern "C" int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* d
         rc = UNET_LAUNCH_STATUS();
     }
     return rc;
+}
+
+extern "C" int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                       int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    return unet_conv3x3_wgrad_bf16_ex(xin, ldx, 0, dz, lddz, 0, dw, N, H, W, Cin, Cout, ws, ws_bytes, stream);
+}
+
+// forward with every option: x_bf16 (input stored as bf16, ldx in elements), stat_part nullable (BatchNorm sums as in _stats)
+extern "C" int unet_conv3x3_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
+                                        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(x && wp && out && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
+    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * ldo * 4 < ((size_t)1 << 31));
+    UNET_CHECK_ARG(!x_bf16 || ldx % 8 == 0);
+    const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0};
+    return run_conv_bf16((const float*)x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream, stat_part ? &s : nullptr, x_bf16 ? 1 : 0);
+}
+
+// data gradient with every option: dz_bf16 (dz stored as bf16), r_prev / stat_part nullable (producer's BatchNorm-backward sums)
+extern "C" int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
+                                          int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+                                          float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(dz && wpd && dx && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));
+    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
+    UNET_CHECK_ARG((r_prev == nullptr) == (stat_part == nullptr));
+    UNET_CHECK_ARG(!r_prev || (c0 >= 0 && c0 < c1 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0));
+    UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
+    UNET_CHECK_ARG(!dz_bf16 || lddz % 8 == 0);
+    const ConvBf16Stats s{2, stat_part, stat_bytes, r_prev, ldr, c0, c1};
+    return run_conv_bf16((const float*)dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream, r_prev ? &s : nullptr, dz_bf16 ? 1 : 0);
 }

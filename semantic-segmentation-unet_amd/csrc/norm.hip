@@ -19,6 +19,17 @@ template <int VEC> __device__ __forceinline__ void vstore(float* p, const float 
     else *p = v[0];
 }
 
+// store to an fp32 tensor or (out16, VEC == 4) to a bf16 tensor of the same logical layout: element index idx, nearest-even
+// rounding by the instruction the bf16 conv kernels use when they stage fp32 operands, so a bf16-stored tensor is bit-for-bit
+// what those kernels would have made of the fp32 one
+__device__ __forceinline__ unsigned bn_pack2(float lo, float hi) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
+template <int VEC> __device__ __forceinline__ void vstore_dt(float* base, size_t idx, const float (&v)[VEC], int out16) {
+    if constexpr (VEC == 4) {
+        if (out16) { uint2 t; t.x = bn_pack2(v[0], v[1]); t.y = bn_pack2(v[2], v[3]); *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + idx) = t; return; }
+    }
+    vstore<VEC>(base + idx, v);
+}
+
 struct Lay { int tpp, npl, q, pl, c0; bool active; };
 
 template <int VEC> __device__ __forceinline__ Lay make_lay(int C, int tpp) {
@@ -181,7 +192,7 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
-        const float* __restrict__ shift, float* __restrict__ y, int ldy, long P, int C) {
+        const float* __restrict__ shift, float* __restrict__ y, int ldy, long P, int C, int out16) {
     const int nq = C / VEC;
     const long total = P * nq, stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         vload<VEC>(v, r + (size_t)pix * ldr + c0); vload<VEC>(a, scale + c0); vload<VEC>(b, shift + c0);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[e] = fmaf(a[e], v[e], b[e]);
-        vstore<VEC>(y + (size_t)pix * ldy + c0, v);
+        vstore_dt<VEC>(y, (size_t)pix * ldy + c0, v, out16);
     }
 }
 
@@ -282,7 +293,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
         int ldr, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
         const float* __restrict__ dgamma, const float* __restrict__ dbeta, long P, int C, int tpp, long ppb, int relu,
-        float* __restrict__ dz, int lddz, double* __restrict__ part, PoolGrad pg) {
+        float* __restrict__ dz, int lddz, double* __restrict__ part, PoolGrad pg, int dz16) {
     extern __shared__ __attribute__((aligned(16))) double sRd[];
     const Lay l = make_lay<VEC>(C, tpp);
     const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P) p1 = P;
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                     if (relu && !(v[u][e] > 0.f)) d = 0.f;
                     o[e] = d; acc[0][e] += (double)d;
                 }
-                vstore<VEC>(dz + (size_t)(pix + u * st) * lddz + l.c0, o);
+                vstore_dt<VEC>(dz, (size_t)(pix + u * st) * lddz + l.c0, o, dz16);
             }
         }
         for (; pix < p1; pix += st) {
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 if (relu && !(v[e] > 0.f)) d = 0.f;
                 o[e] = d; acc[0][e] += (double)d;
             }
-            vstore<VEC>(dz + (size_t)pix * lddz + l.c0, o);
+            vstore_dt<VEC>(dz, (size_t)pix * lddz + l.c0, o, dz16);
         }
     }
     block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
@@ -408,8 +419,19 @@ extern "C" int unet_bn_apply(const float* r, int ldr, const float* scale, const 
                     unet_aligned16(scale) && unet_aligned16(shift);
     const long total = v4 ? P * (C / 4) : P * C;
     long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    if (v4) bn_apply_kernel<4><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C);
-    else    bn_apply_kernel<1><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C);
+    if (v4) bn_apply_kernel<4><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C, 0);
+    else    bn_apply_kernel<1><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C, 0);
+    return UNET_LAUNCH_STATUS();
+}
+
+// the same with the result stored as bf16 (y16: [P][ldy] bf16 elements) for a consumer that contracts in bf16 anyway
+extern "C" int unet_bn_apply_bf16out(const float* r, int ldr, const float* scale, const float* shift, void* y16, int ldy,
+                                     long P, int C, void* stream) {
+    UNET_CHECK_ARG(r && scale && shift && y16 && P > 0 && C > 0 && ldr >= C && ldy >= C);
+    UNET_CHECK_ARG(C % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0 && unet_aligned16(r) && unet_aligned16(y16) && unet_aligned16(scale) && unet_aligned16(shift));
+    const long total = P * (C / 4);
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    bn_apply_kernel<4><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, (float*)y16, ldy, P, C, 1);
     return UNET_LAUNCH_STATUS();
 }
 
@@ -428,7 +450,7 @@ extern "C" int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale
 
 static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
         const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta, float* dbias,
-        const float* part_sums, int rows, PoolGrad pg, void* ws, size_t ws_bytes, void* stream) {
+        const float* part_sums, int rows, PoolGrad pg, void* ws, size_t ws_bytes, void* stream, int dz16 = 0) {
     UNET_CHECK_ARG(dy && r && gamma && mean && invstd && dz && dgamma && dbeta && dbias && ws && P > 0 && C > 0);
     UNET_CHECK_ARG(lddy >= C && ldr >= C && lddz >= C);
     Plan pl;
@@ -449,8 +471,9 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     }
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     double* part2 = part + (size_t)2 * pl.nblk * C;
-    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg);
-    else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg);
+    if (dz16 && pl.vec != 4) return UNET_EINVAL;
+    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, dz16);
+    else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, 0);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     colsum_finalize_kernel<<<C, 64, 0, st>>>(part2, pl.nblk, C, dbias);
     return UNET_LAUNCH_STATUS();
@@ -481,4 +504,19 @@ extern "C" int unet_bn_bwd_from_partials(const float* dy, int lddy, const float*
     UNET_CHECK_ARG(part_sums && rows > 0 && C % 64 == 0);
     return bn_bwd_launch(dy, lddy, r, ldr, gamma, mean, invstd, P, C, relu, dz, lddz, dgamma, dbeta, dbias, part_sums, rows,
                          PoolGrad{nullptr, 0, nullptr, 0, 0, 0}, ws, ws_bytes, stream);
+}
+
+// All three forms of the BatchNorm backward in one call, with the choice of storing dz as bf16 (dz_bf16 != 0: `dz` is a bf16
+// tensor [P][lddz]; its consumers are the bf16 data / weight gradient kernels, which would round the fp32 values the same way):
+// pooled_dy / idx nullable (unet_bn_bwd_pooled when given), part_sums nullable (unet_bn_bwd_from_partials when given).
+extern "C" int unet_bn_bwd_any(const float* dy, int lddy, const float* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
+        const float* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
+        void* dz, int lddz, int dz_bf16, float* dgamma, float* dbeta, float* dbias, const float* part_sums, int rows,
+        void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(N > 0 && H > 0 && W > 0 && (pooled_dy == nullptr) == (idx == nullptr));
+    UNET_CHECK_ARG(!pooled_dy || (H % 2 == 0 && W % 2 == 0 && ldp >= C));
+    UNET_CHECK_ARG(!part_sums || (rows > 0 && C % 64 == 0));
+    const PoolGrad pg = pooled_dy ? PoolGrad{pooled_dy, ldp, idx, H, W, C} : PoolGrad{nullptr, 0, nullptr, 0, 0, 0};
+    return bn_bwd_launch(dy, lddy, r, ldr, gamma, mean, invstd, (long)N * H * W, C, relu, (float*)dz, lddz, dgamma, dbeta, dbias,
+                         part_sums, part_sums ? rows : 0, pg, ws, ws_bytes, stream, dz_bf16 ? 1 : 0);
 }

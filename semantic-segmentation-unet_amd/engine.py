@@ -154,6 +154,10 @@ class Engine:
         # forward/backward on fp32 master weights -- operands rounded to bf16, fp32 accumulation, everything else fp32)
         self.compute_dtype = os.environ.get("UNET_COMPUTE_DTYPE", "fp32")
         self._bf16_W, self._bf16_dirty = {}, True
+        # bf16 mode, stage 2: tensors whose ONLY readers are bf16 contractions are stored as bf16 -- the BatchNorm outputs between
+        # the two convs of a block and every dz.  The producing kernel rounds exactly as the consumers' staging would have, so
+        # results are bit-identical to fp32 storage (tests assert that); only the bytes moved change.
+        self.bf16_storage = os.environ.get("UNET_BF16_STORAGE", "1") != "0"
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -198,6 +202,14 @@ class Engine:
         k, nn = (cout, cin) if dgrad else (cin, cout)
         return (self.conv_route == "fused" and self.kind[name] == "conv3" and h % 2 == 0 and w % 2 == 0
                 and k % 8 == 0 and nn % 64 == 0)
+
+    def _ybuf(self, name, shape, consumer):
+        """BatchNorm-output buffer of `name`, read only by the 3x3 layer `consumer`: bf16 when that layer contracts in bf16."""
+        n, h, w, _ = shape
+        if self.compute_dtype == "bf16" and self.bf16_storage and self._use_bf16(consumer, n, h, w) \
+                and self.L.unet_conv3x3_wgrad_bf16_supported(n, h, w, self.cin[consumer], self.cout[consumer]) == 1:
+            return self._buf("y16_" + name, shape, torch.bfloat16)
+        return self._buf("y_" + name, shape)
 
     def _use_bf16(self, name, n, h, w, dgrad=False):
         if self.compute_dtype != "bf16" or self.kind[name] != "conv3":
@@ -338,15 +350,12 @@ class Engine:
             if self._use_bf16(name, n, h, w):
                 self.saved_V[name] = None
                 rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
+                stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
+                self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16_ex,
+                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout,
+                            n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:
-                    stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
-                    self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16_stats,
-                                _p(x), _ld(x), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1,
-                                _p(stat_part), stat_part.numel() * 4, st)
                     fused_stats = (stat_part, rows)
-                else:
-                    self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
-                                _p(x), _ld(x), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
             elif self._use_fused(name, h, w):
                 self.saved_V[name] = None
                 rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
@@ -399,6 +408,8 @@ class Engine:
         if pool is not None:           # (pooled, idx): BN apply and the level's max pool in one pass
             L.unet_bn_apply_maxpool(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
                                     r.shape[0], r.shape[1], r.shape[2], cout, st)
+        elif y_out.dtype == torch.bfloat16:
+            L.unet_bn_apply_bf16out(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), P, cout, st)
         else:
             L.unet_bn_apply(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), P, cout, st)
         self.saved[name] = (x, r)
@@ -449,7 +460,7 @@ class Engine:
         self.cat = {}
         for lvl, ch in ((1, B), (2, 2 * B), (3, 4 * B), (4, 8 * B)):
             hh, ww = cur.shape[1], cur.shape[2]
-            ya = f("conv_%da" % lvl, cur, self._buf("y_conv_%da" % lvl, (n, hh, ww, ch)), training)
+            ya = f("conv_%da" % lvl, cur, self._ybuf("conv_%da" % lvl, (n, hh, ww, ch), "conv_%db" % lvl), training)
             cat = self._buf("cat_%d" % lvl, (n, hh, ww, 2 * ch))
             self.cat[lvl] = cat
             pooled = self._buf("pool_%d" % lvl, (n, hh // 2, ww // 2, ch))
@@ -463,7 +474,7 @@ class Engine:
             self.idx[lvl] = idx
             cur = pooled
         hh, ww = cur.shape[1], cur.shape[2]
-        ya = f("bott_a", cur, self._buf("y_bott_a", (n, hh, ww, 16 * B)), training)
+        ya = f("bott_a", cur, self._ybuf("bott_a", (n, hh, ww, 16 * B), "bott_b"), training)
         cur = f("bott_b", ya, self._buf("y_bott_b", (n, hh, ww, 16 * B)), training)
         if training:
             self._dropout(cur, "drop_b", self.masks)
@@ -471,7 +482,7 @@ class Engine:
             cat = self.cat[lvl]
             f("up_%d" % lvl, cur, cat[..., ch:], training)
             hh, ww = cat.shape[1], cat.shape[2]
-            ya = f("dec_%da" % lvl, cat, self._buf("y_dec_%da" % lvl, (n, hh, ww, ch)), training)
+            ya = f("dec_%da" % lvl, cat, self._ybuf("dec_%da" % lvl, (n, hh, ww, ch), "dec_%db" % lvl), training)
             cur = f("dec_%db" % lvl, ya, self._buf("y_dec_%db" % lvl, (n, hh, ww, ch)), training)
         yl = f("logits", cur, self._buf("y_logits", (n, h, w, self.K)), training)
         prob = self._buf("softmax", (n, h, w, self.K))
@@ -501,9 +512,26 @@ class Engine:
         n, ho, wo, _ = r.shape
         P = n * ho * wo
         s = self.stat[name]
-        dz = self._buf("dz_" + name, tuple(r.shape))
+        dz16 = (self.compute_dtype == "bf16" and self.bf16_storage and kind == "conv3" and not eval_mode
+                and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1
+                and (not need_dx or self._use_bf16(name, n, ho, wo, dgrad=True)))
+        dz = self._buf("dz16_" + name, tuple(r.shape), torch.bfloat16) if dz16 else self._buf("dz_" + name, tuple(r.shape))
         pre = self.bnbwd_part.pop(name, None) if not eval_mode else None
-        if eval_mode:
+        if dz16:
+            # one entry point for the three forms (plain / pooled / sums from the consumer's data gradient), dz stored as bf16
+            part_ptr, rows = None, 0
+            if pre is not None:
+                part, rows, c0 = pre
+                part_ptr = ctypes.c_void_p(part.data_ptr() + (c0 // 64) * rows * 128 * 4)
+            pdy, pidx = pool_grad if (pool_grad is not None and pre is None) else (None, None)
+            assert not (pool_grad is not None and pre is not None)
+            nb = L.unet_bn_workspace(P, cout)
+            ws = self._workspace(nb)
+            L.unet_bn_bwd_any(_p(dy), _ld(dy), _p(pdy), _ld(pdy) if pdy is not None else 0, _p(pidx), n, ho, wo, _p(r), cout,
+                              _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 1, _p(dz), cout, 1,
+                              _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]), _p(self.g[name + "/bias"]), part_ptr, rows,
+                              _p(ws), nb, st)
+        elif eval_mode:
             L.unet_bn_eval_bwd(_p(dy), _ld(dy), _p(r), cout, _p(s[2]), _p(dz), cout, P, cout, 0 if kind == "deconv" else 1, st)
         elif pre is not None:
             # sum(dy), sum(dy*r) already came out of the consumer layer's data-gradient kernel: no reduction pass
@@ -547,8 +575,9 @@ class Engine:
                 L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif self.compute_dtype == "bf16" and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1:
                 nb2 = L.unet_conv3x3_wgrad_bf16_workspace(n, ho, wo, cin, cout)
-                self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16,
-                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16_ex,
+                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw),
+                            n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif (self.wgrad_route in ("fused", "hybrid") and L.unet_winograd_wgrad_fused_supported(n, ho, wo, cin, cout) == 1
                   and not (self.wgrad_route == "hybrid" and min(cin, cout) >= self.wgrad_unfused_from
                            and L.unet_winograd_wgrad_supported(n, ho, wo, cin, cout) == 1)):
@@ -584,17 +613,19 @@ class Engine:
             elif self._use_bf16(name, n, ho, wo, dgrad=True):
                 prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
                 rows = L.unet_conv3x3_bf16_stats_rows(n, ho, wo, cout, cin) if prod else 0
+                z16 = int(dz.dtype == torch.bfloat16)
                 if rows > 0:
                     pname, c0, c1 = prod[0], prod[1] * (cin // prod[3]), prod[2] * (cin // prod[3])
                     r_prev = self.saved[pname][1]
                     part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
-                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16_bnstats,
-                                _p(dz), cout, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
+                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16_ex,
+                                _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
                                 _p(r_prev), r_prev.shape[-1], c0, c1, _p(part), part.numel() * 4, st)
                     self.bnbwd_part[pname] = (part, rows, c0)
                 else:
-                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
-                                _p(dz), cout, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout, st)
+                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16_ex,
+                                _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
+                                None, 0, 0, 0, None, 0, st)
             elif self._use_fused(name, ho, wo, dgrad=True):
                 prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
                 rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, ho, wo, cout, cin) if prod else 0

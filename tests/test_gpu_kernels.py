@@ -763,3 +763,51 @@ def test_conv3x3_bf16_fused_batchnorm_sums(hip, shape):
     t1 = dx0[..., c0:c1].double().sum((0, 1, 2)); t2 = (dx0[..., c0:c1].double() * r_prev.double()).sum((0, 1, 2))
     assert (pv2[:, 0] - t1).abs().max().item() < 1e-4 * t1.abs().max().item() + 1e-3
     assert (pv2[:, 1] - t2).abs().max().item() < 1e-4 * t2.abs().max().item() + 1e-3
+
+
+def test_bf16_stored_operands_bit_identical(hip):
+    # an operand stored as bf16 must give exactly what the fp32 tensor gives (the kernels round fp32 inputs to the same bf16 values)
+    n, h, w, ci, co = 2, 20, 40, 128, 64
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    x = torch.randn(n, h, w, ci, device=DEV, generator=g); dz = torch.randn(n, h, w, co, device=DEV, generator=g)
+    wt = torch.randn(3, 3, ci, co, device=DEV, generator=g) / (3 * ci ** 0.5); b = torch.randn(co, device=DEV, generator=g)
+    x16, dz16 = x.to(torch.bfloat16), dz.to(torch.bfloat16)                      # torch rounds to nearest even too
+    nb = hip.unet_conv3x3_bf16_packed_bytes(ci, co)
+    wp, wpd = ws_bytes(nb), ws_bytes(nb)
+    hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wp), ci, co, 0, ST())
+    hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wpd), ci, co, 1, ST())
+    y0 = torch.empty(n, h, w, co, device=DEV); y1 = torch.empty_like(y0)
+    hip.unet_conv3x3_fwd_bf16_ex(P(x), ci, 0, P(wp), P(b), P(y0), co, n, h, w, ci, co, 1, None, 0, ST())
+    hip.unet_conv3x3_fwd_bf16_ex(P(x16), ci, 1, P(wp), P(b), P(y1), co, n, h, w, ci, co, 1, None, 0, ST())
+    assert torch.equal(y0, y1)
+    d0 = torch.empty(n, h, w, ci, device=DEV); d1 = torch.empty_like(d0)
+    hip.unet_conv3x3_dgrad_bf16_ex(P(dz), co, 0, P(wpd), P(d0), ci, n, h, w, ci, co, None, 0, 0, 0, None, 0, ST())
+    hip.unet_conv3x3_dgrad_bf16_ex(P(dz16), co, 1, P(wpd), P(d1), ci, n, h, w, ci, co, None, 0, 0, 0, None, 0, ST())
+    assert torch.equal(d0, d1)
+    nbw = hip.unet_conv3x3_wgrad_bf16_workspace(n, h, w, ci, co)
+    ws = ws_bytes(nbw)
+    outs = []
+    for xa, xf, za, zf in ((x, 0, dz, 0), (x16, 1, dz16, 1), (x, 0, dz16, 1), (x16, 1, dz, 0)):
+        dw = torch.empty(3, 3, ci, co, device=DEV)
+        hip.unet_conv3x3_wgrad_bf16_ex(P(xa), ci, xf, P(za), co, zf, P(dw), n, h, w, ci, co, P(ws), nbw, ST())
+        outs.append(dw)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    # producers: BatchNorm apply / backward storing bf16 == rounding their fp32 result
+    r = torch.randn(n, h, w, co, device=DEV, generator=g)
+    sc = torch.rand(co, device=DEV, generator=g) + 0.5; sh = torch.randn(co, device=DEV, generator=g)
+    yf = torch.empty(n, h, w, co, device=DEV); yh = torch.empty(n, h, w, co, device=DEV, dtype=torch.bfloat16)
+    hip.unet_bn_apply(P(r), co, P(sc), P(sh), P(yf), co, n * h * w, co, ST())
+    hip.unet_bn_apply_bf16out(P(r), co, P(sc), P(sh), P(yh), co, n * h * w, co, ST())
+    assert torch.equal(yf.to(torch.bfloat16), yh)
+    gm = torch.rand(co, device=DEV, generator=g) + 0.5
+    mean = r.mean((0, 1, 2)); invstd = 1.0 / torch.sqrt(r.var((0, 1, 2), unbiased=False) + 1e-3)
+    dy = torch.randn(n, h, w, co, device=DEV, generator=g)
+    nbb = hip.unet_bn_workspace(n * h * w, co)
+    wsb = ws_bytes(nbb)
+    zf_ = torch.empty(n, h, w, co, device=DEV); zh = torch.empty(n, h, w, co, device=DEV, dtype=torch.bfloat16)
+    gr = [torch.empty(co, device=DEV) for _ in range(6)]
+    hip.unet_bn_bwd(P(dy), co, P(r), co, P(gm), P(mean), P(invstd), n * h * w, co, 1, P(zf_), co, P(gr[0]), P(gr[1]), P(gr[2]), P(wsb), nbb, ST())
+    hip.unet_bn_bwd_any(P(dy), co, None, 0, None, n, h, w, P(r), co, P(gm), P(mean), P(invstd), co, 1, P(zh), co, 1,
+                        P(gr[3]), P(gr[4]), P(gr[5]), None, 0, P(wsb), nbb, ST())
+    assert torch.equal(zf_.to(torch.bfloat16), zh)
+    assert all(torch.equal(gr[i], gr[i + 3]) for i in range(3))

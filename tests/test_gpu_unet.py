@@ -290,3 +290,29 @@ def test_bf16_full_size_config4_step_properties():
     assert (prob.sum(-1) - 1).abs().max().item() < 1e-5 and prob.min().item() >= 0
     ce = -(torch.log(prob.double().clamp_min(1e-30)) * lab.cuda().double()).sum(-1).mean().item()
     assert abs(float(e.loss_buf[0].item()) - ce) < 1e-5 * max(1.0, abs(ce))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 4, 64), (1, 1, 2, 96)])
+def test_bf16_storage_is_bit_identical_to_fp32_storage(shape):
+    # stage 2 of the bf16 mode stores the tensors that only bf16 contractions read (BatchNorm outputs between the two convs of a
+    # block, every dz) as bf16.  The producer rounds with the instruction the consumers' staging uses, so nothing may change:
+    # losses, gradients, weights after several steps and the eval-mode softmax are compared bit for bit with fp32 storage.
+    n, c, k, hw = shape
+    model = pkg("model")
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(n, c, hw, hw, generator=g)
+    cls = torch.randint(0, k, (n, hw // 8, hw // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    lab = torch.nn.functional.one_hot(cls, k).to(torch.int32)
+    batch = (img.cuda(), lab.cuda(), None, None)
+    res = []
+    for storage in (False, True):
+        net = model.UNet(k, n, c, learning_rate=1e-3, seed=0, compute_dtype="bf16")
+        net.engine.bf16_storage = storage
+        losses = [float(net.train_step(batch).numpy()) for _ in range(3)]
+        g1 = net.engine.grad.clone()
+        prob = net.engine.forward(img.cuda(), training=False).clone()
+        res.append((losses, g1, net.engine.theta.clone(), prob))
+        if storage:
+            assert any(t.dtype == torch.bfloat16 for t in net.engine.bufs.values())
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
