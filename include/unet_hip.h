@@ -185,6 +185,8 @@ int unet_bn_apply_bf16out(const float* r, int ldr, const float* scale, const flo
 /* the same plus the MaxPool2D(2) that follows (UNet/model.py:50-53) in one pass: pooled [N,H/2,W/2,C] and first-max indices */
 int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy,
                           float* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int unet_bn_apply_maxpool_bf16out(const float* r, int ldr, const float* scale, const float* shift, void* y16, int ldy,
+                                  void* pooled16, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream);
 /* backward of [ReLU ->] BN: dz = relu'(r) * d r, plus dgamma, dbeta and dbias = column sums of dz */
 int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
                 const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // (row-major window order, the reference's tie rule) + its index -- the skip tensor is not read back for pooling.
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
         const float* __restrict__ shift, float* __restrict__ y, int ldy, float* __restrict__ pooled, int ldp, uint8_t* __restrict__ idx,
-        int N, int H, int W, int C) {
+        int N, int H, int W, int C, int out16) {
     const int H2 = H / 2, W2 = W / 2, nq = C / 4;
     const long total = (long)N * H2 * W2 * nq, stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
@@ -229,9 +229,9 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
                 v[e] = fmaf(a[e], v[e], b[e]);
                 if (pos == 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)pos; }
             }
-            vstore<4>(y + pix * ldy + 4 * cq, v);
+            vstore_dt<4>(y, pix * ldy + 4 * cq, v, out16);
         }
-        vstore<4>(pooled + (size_t)opix * ldp + 4 * cq, best);
+        vstore_dt<4>(pooled, (size_t)opix * ldp + 4 * cq, best, out16);
         *reinterpret_cast<uint32_t*>(idx + (size_t)opix * C + 4 * cq) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     }
 }
@@ -444,7 +444,21 @@ extern "C" int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale
                    (reinterpret_cast<uintptr_t>(idx) & 3u) == 0);
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    bn_apply_pool_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C);
+    bn_apply_pool_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, 0);
+    return UNET_LAUNCH_STATUS();
+}
+
+// the same with y and pooled stored as bf16 (both read only by bf16 contractions; max commutes with the rounding, the index is
+// taken on the fp32 values)
+extern "C" int unet_bn_apply_maxpool_bf16out(const float* r, int ldr, const float* scale, const float* shift, void* y16, int ldy,
+                                             void* pooled16, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    UNET_CHECK_ARG(r && scale && shift && y16 && pooled16 && idx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0);
+    UNET_CHECK_ARG(ldr >= C && ldy >= C && ldp >= C && ldr % 4 == 0 && ldy % 4 == 0 && ldp % 4 == 0);
+    UNET_CHECK_ARG(unet_aligned16(r) && unet_aligned16(y16) && unet_aligned16(pooled16) && unet_aligned16(scale) && unet_aligned16(shift) &&
+                   (reinterpret_cast<uintptr_t>(idx) & 3u) == 0);
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    bn_apply_pool_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, (float*)y16, ldy, (float*)pooled16, ldp, idx, N, H, W, C, 1);
     return UNET_LAUNCH_STATUS();
 }
 

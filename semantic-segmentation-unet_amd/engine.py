@@ -158,6 +158,7 @@ class Engine:
         # the two convs of a block and every dz.  The producing kernel rounds exactly as the consumers' staging would have, so
         # results are bit-identical to fp32 storage (tests assert that); only the bytes moved change.
         self.bf16_storage = os.environ.get("UNET_BF16_STORAGE", "1") != "0"
+        self.bf16_storage_cat = os.environ.get("UNET_BF16_STORAGE_CAT", "1") != "0"    # ... the concat / pooled tensors too (A/B switch)
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -405,7 +406,10 @@ class Engine:
                                   _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(ws), nb, st)
         else:
             L.unet_bn_eval_coeffs(_p(gm), _p(bt), _p(mm), _p(mv), BN_EPS, cout, _p(s[2]), _p(s[3]), st)
-        if pool is not None:           # (pooled, idx): BN apply and the level's max pool in one pass
+        if pool is not None and y_out.dtype == torch.bfloat16:
+            L.unet_bn_apply_maxpool_bf16out(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
+                                            r.shape[0], r.shape[1], r.shape[2], cout, st)
+        elif pool is not None:         # (pooled, idx): BN apply and the level's max pool in one pass
             L.unet_bn_apply_maxpool(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
                                     r.shape[0], r.shape[1], r.shape[2], cout, st)
         elif y_out.dtype == torch.bfloat16:
@@ -461,9 +465,15 @@ class Engine:
         for lvl, ch in ((1, B), (2, 2 * B), (3, 4 * B), (4, 8 * B)):
             hh, ww = cur.shape[1], cur.shape[2]
             ya = f("conv_%da" % lvl, cur, self._ybuf("conv_%da" % lvl, (n, hh, ww, ch), "conv_%db" % lvl), training)
-            cat = self._buf("cat_%d" % lvl, (n, hh, ww, 2 * ch))
+            # the concat buffer [skip, upsampled] and the pooled tensor feed 3x3 layers only (dec_Na / the next level's first conv):
+            # bf16 storage applies to them as well (levels 1-3; level 4 goes through the dropout and the unfused pool kernels)
+            nxt = "conv_%da" % (lvl + 1) if lvl < 4 else "bott_a"
+            c16 = (self.compute_dtype == "bf16" and self.bf16_storage and self.bf16_storage_cat and self.fuse_pool and lvl < 4
+                   and self._use_bf16("dec_%da" % lvl, n, hh, ww) and self._use_bf16(nxt, n, hh // 2, ww // 2)
+                   and L.unet_conv3x3_wgrad_bf16_supported(n, hh, ww, 2 * ch, ch) == 1)
+            cat = self._buf(("cat16_%d" if c16 else "cat_%d") % lvl, (n, hh, ww, 2 * ch), torch.bfloat16 if c16 else torch.float32)
             self.cat[lvl] = cat
-            pooled = self._buf("pool_%d" % lvl, (n, hh // 2, ww // 2, ch))
+            pooled = self._buf(("pool16_%d" if c16 else "pool_%d") % lvl, (n, hh // 2, ww // 2, ch), torch.bfloat16 if c16 else torch.float32)
             idx = self._buf("idx_%d" % lvl, (n, hh // 2, ww // 2, ch), torch.uint8)
             fuse_pool = self.fuse_pool and not (lvl == 4 and training)   # level 4 drops out between BN and pool (UNet/model.py:105-107)
             skip = f("conv_%db" % lvl, ya, cat[..., :ch], training, pool=(pooled, idx) if fuse_pool else None)
