@@ -452,6 +452,18 @@ __device__ __forceinline__ void wg_wait_lgkm(int n) {
                  default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 }
 
+// counted lgkmcnt wait tied to the fragments about to be consumed (each register once)
+#define WG_TIED_CASE4(n) case n: asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)); break;
+__device__ __forceinline__ void wg_wait_tied4(int n, bf16x8& a, bf16x8& b0, bf16x8& b1, bf16x8& b2, bf16x8& b3) {
+    switch (n) { WG_TIED_CASE4(0) WG_TIED_CASE4(1) WG_TIED_CASE4(2) WG_TIED_CASE4(3) WG_TIED_CASE4(4) WG_TIED_CASE4(5) WG_TIED_CASE4(6) WG_TIED_CASE4(7)
+                 default: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)); }
+}
+#define WG_TIED_CASE2(n) case n: asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b0), "+v"(b1)); break;
+__device__ __forceinline__ void wg_wait_tied2(int n, bf16x8& a, bf16x8& b0, bf16x8& b1) {
+    switch (n) { WG_TIED_CASE2(0) WG_TIED_CASE2(1) WG_TIED_CASE2(2) WG_TIED_CASE2(3) WG_TIED_CASE2(4) WG_TIED_CASE2(5) WG_TIED_CASE2(6) WG_TIED_CASE2(7)
+                 default: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b0), "+v"(b1)); }
+}
+
 __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
     __shared__ __attribute__((aligned(1024))) char smem[kWgXRing + 4 * kWgDzRow];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -845,4 +857,320 @@ extern "C" int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16,
     UNET_CHECK_ARG(!dz_bf16 || lddz % 8 == 0);
     const ConvBf16Stats s{2, stat_part, stat_bytes, r_prev, ldr, c0, c1};
     return run_conv_bf16((const float*)dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream, r_prev ? &s : nullptr, dz_bf16 ? 1 : 0);
+}
+
+// ---- 2x2 / stride-2 transposed convolution on the bf16 matrix cores (forward and data gradient) -----------------------------------
+//   forward  (UNet/model.py:39-48): z[n,2i+a,2j+b,co] = bias[co] + sum_ci bf16(x[n,i,j,ci]) * bf16(W[a,b,co,ci])
+//   gradient:                       dx[n,i,j,ci] = sum_{a,b,co} bf16(dz[n,2i+a,2j+b,co]) * bf16(W[a,b,co,ci])
+// Both are GEMMs over the INPUT-resolution pixels: forward K = Cin, N = 4 taps x Cout with the result scattered to the four
+// sub-lattices of the output; gradient K = 4 taps x Cout (a k-chunk never straddles a tap: its gather is a scalar offset), N = Cin.
+// One body: workgroup = 16 x 32 pixels x CT = 128 (64) columns, k-chunks of 32 (two MFMA k-steps), the staging / LDS images /
+// fragment reads of the 3x3 kernel without the halo and the taps.  With so little arithmetic per byte these kernels live on
+// the LDS fill and HBM, not on the matrix pipe; what bf16 buys is 16x less MFMA time next to that traffic.
+namespace {
+
+struct ConvtBf16Args {
+    const float* x; const uint16_t* wp; const float* bias; float* out;
+    int ldx, ldo, N, H, W, K, Ncol, Cout;          // H, W: input resolution; K, Ncol: GEMM depth / width; Cout: the layer's (tap = column / Cout)
+    int tby, tbx, n_px, n_co;
+    unsigned x_bytes; int in16;
+    float* stat_part;
+    const float* bn_r; int bn_ldr;               // MODE 2 + STATS 2: the producer's saved activation (all Ncol channels)
+};
+
+constexpr int kCtXP = 2 * 2 * 512 * 16;             // [k-step][k half][pixel][8] bf16
+
+template <int NCO, int STATS, int MODE>
+__device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
+    constexpr int CT = 32 * NCO;
+    constexpr int WB = 2 * 2 * CT * 16;
+    constexpr int STAGE = kCtXP + WB;
+    constexpr int NPIECE = WB / 1024, KW = (NPIECE + 3) / 4;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int t = blockIdx.x;
+    const int total = p.n_px * p.n_co;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
+    const int cot = t / p.n_px; int px = t % p.n_px;
+    const int bx = px % p.tbx; px /= p.tbx;
+    const int by = px % p.tby; const int img = px / p.tby;
+    const int n0 = cot * CT, ty0 = 16 * by, tx0 = 32 * bx;
+    const int nchunks = p.K / 32;
+    const int es = p.in16 ? 2 : 4;
+
+    // staging duty: quad f (4 of the chunk's 32 channels) of pixels (tid >> 3) + 32 j
+    unsigned voff[16];
+    const int f = tid & 7;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int pp = (tid >> 3) + 32 * j;
+        const int gy = ty0 + (pp >> 5), gx = tx0 + (pp & 31);
+        const bool ok = gy < p.H && gx < p.W;
+        const size_t pix = MODE == 2 ? ((size_t)(img * 2 * p.H + 2 * gy) * (2 * p.W) + 2 * gx) : ((size_t)(img * p.H + gy) * p.W + gx);
+        voff[j] = ok ? (unsigned)(pix * p.ldx * es + (p.in16 ? (f >> 1) * 16 : f * 16)) : 0x80000000u;
+    }
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
+    // image [k-step = f >> 2][k half = (f >> 1) & 1][pixel][16 B], low / high 8 bytes by f & 1
+    const unsigned wr_base = lds0 + (unsigned)(((f >> 2) * 2 + ((f >> 1) & 1)) * 8192 + (tid >> 3) * 16 + (f & 1) * 8);
+    const unsigned a_base = lds0 + (unsigned)(lh * 8192 + (4 * wv * 32 + li) * 16);
+    const unsigned b_base = lds0 + (unsigned)(kCtXP + lh * CT * 16 + li * 16);
+    unsigned woff[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int id = wv + 4 * k;
+        const int row = id / (CT / 64), blk = id % (CT / 64);      // row = k-step * 2 + k half
+        woff[k] = (unsigned)((row * p.Ncol + n0 + 64 * blk) * 16 + lane * 16);
+    }
+    const size_t wchunk = (size_t)4 * p.Ncol * 16;
+    const char* wsrc = reinterpret_cast<const char*>(p.wp);
+
+    f32x4 stg[16];
+    auto issue_x = [&](int chunk) {
+        int so;
+        if (MODE == 2) {       // chunk = 32 channels of one tap (a, b): the tap's pixel offset and the channel offset are scalars
+            const int k0 = chunk * 32, tap = k0 / p.Cout, c0 = k0 % p.Cout;
+            so = (((tap >> 1) * 2 * p.W + (tap & 1)) * p.ldx + c0) * es;
+        } else so = chunk * 32 * es;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            stg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff[j], so, 0));
+    };
+    auto issue_w = [&](int chunk, int stage) {
+        const char* src = wsrc + (size_t)chunk * wchunk;
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (NPIECE % 4 == 0 || wv + 4 * k < NPIECE)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src + woff[k]),
+                                                 (lds_void_b*)(smem + stage * STAGE + kCtXP + (wv + 4 * k) * 1024), 16, 0, 0);
+    };
+    auto write_x = [&](int stage) {
+        const unsigned wb = wr_base + (unsigned)(stage * STAGE);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            uint2 v; v.x = cb_pack2_pinned(stg[j].x, stg[j].y); v.y = cb_pack2_pinned(stg[j].z, stg[j].w);
+            if (p.in16) {
+                v.x = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].z : stg[j].x); v.y = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].w : stg[j].y);
+            }
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(j * 512) : "memory");
+        }
+    };
+    f32x16 acc[4][NCO];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+    // one chunk from stage ST: 2 k-steps x (4 pixel rows x NCO column tiles); all 8 + 2 NCO fragment reads up front, consumed in order
+    auto compute = [&](unsigned ab, unsigned bb) {
+        bf16x8 fa[2][4], fb[2][NCO];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) CB_RD128(fb[ks][c], bb, ks * 2 * CT * 16 + c * 512);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) CB_RD128(fa[ks][r], ab, ks * 16384 + r * 512);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // reads still allowed in flight when fa[ks][r] is needed: everything issued after it
+                constexpr int dummy = 0; (void)dummy;
+                const int after = (1 - ks) * (NCO + 4) + (3 - r);
+                if (NCO == 4) {
+                    if (after >= 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[ks][r]), "+v"(fb[ks][0]), "+v"(fb[ks][1]), "+v"(fb[ks][2]), "+v"(fb[ks][3]));
+                    else wg_wait_tied4(after, fa[ks][r], fb[ks][0], fb[ks][1], fb[ks][2], fb[ks][3]);
+                } else {
+                    wg_wait_tied2(after, fa[ks][r], fb[ks][0], fb[ks][1]);
+                }
+#pragma unroll
+                for (int c = 0; c < NCO; ++c) CB_MFMA(acc[r][c], fa[ks][r], fb[ks][c]);
+            }
+    };
+
+    issue_x(0); issue_w(0, 0);
+    write_x(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int c = 0; c < nchunks; c += 2) {                            // K % 64 == 0: an even number of chunks
+        issue_x(c + 1); issue_w(c + 1, 1);
+        compute(a_base, b_base);
+        write_x(1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int cn = c + 2 < nchunks ? c + 2 : c;
+        issue_x(cn); issue_w(cn, 0);
+        compute(a_base + STAGE, b_base + STAGE);
+        write_x(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    // epilogue.  Forward: column n = tap * Cout + co -> output pixel (2 y + a, 2 x + b); gradient: plain [pixel][ci].
+    float st1[NCO], st2[NCO];
+    const int oH = MODE == 1 ? 2 * p.H : p.H, oW = MODE == 1 ? 2 * p.W : p.W, pstep = MODE == 1 ? 2 : 1;
+    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.N * oH * oW * p.ldo * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? p.bn_r : p.out), 0,
+                                                                            STATS == 2 ? (int)((size_t)p.N * p.H * p.W * p.bn_ldr * 4) : 0, 0x00020000);
+    int ovoff[16], rvoff[16];
+    bool colok[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        colok[e] = tx0 + col < p.W;
+        ovoff[e] = colok[e] ? (pstep * col * p.ldo + li) * 4 : (int)0x80000000;
+        rvoff[e] = (STATS == 2 && colok[e]) ? (col * p.bn_ldr + li) * 4 : (int)0x80000000;
+    }
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+        const int nb = n0 + 32 * c;                                  // first column of this sub-tile
+        const int tap = MODE == 1 ? nb / p.Cout : 0, cb = MODE == 1 ? nb % p.Cout : nb;
+        const float bv = (MODE == 1 && p.bias) ? p.bias[cb + li] : 0.f;
+        st1[c] = 0.f; st2[c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = ty0 + 4 * wv + r;
+            if (gy >= p.H) continue;
+            const int opix = MODE == 1 ? ((img * oH + 2 * gy + (tap >> 1)) * oW + 2 * tx0 + (tap & 1)) : ((img * p.H + gy) * p.W + tx0);
+            const int so = (opix * p.ldo + cb) * 4;
+            float rv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+            if (STATS == 2) {
+                const int sr = (((img * p.H + gy) * p.W + tx0) * p.bn_ldr + cb) * 4;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, rvoff[e], sr, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v;
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[r][c][e]));
+                v += bv;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd_o, ovoff[e], so, 0);
+                if (STATS != 0 && colok[e]) { st1[c] += v; st2[c] += STATS == 1 ? v * v : v * rv[e]; }
+            }
+        }
+    }
+    if (STATS != 0) {
+        // per-channel sums; forward: one partial row per (pixel tile, tap), so the four taps of a channel are four rows
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) {
+            st1[c] += __shfl_xor(st1[c], 32); st2[c] += __shfl_xor(st2[c], 32);
+            if (lh == 0) { red[((wv * NCO + c) * 32 + li) * 2] = st1[c]; red[((wv * NCO + c) * 32 + li) * 2 + 1] = st2[c]; }
+        }
+        __syncthreads();
+        if (tid < CT) {
+            const int c = tid >> 5, l = tid & 31;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) { a += red[((w4 * NCO + c) * 32 + l) * 2]; b += red[((w4 * NCO + c) * 32 + l) * 2 + 1]; }
+            const int ncol = n0 + tid;
+            const int ch = MODE == 1 ? ncol % p.Cout : ncol, tap = MODE == 1 ? ncol / p.Cout : 0;
+            const int rows = MODE == 1 ? 4 * p.n_px : p.n_px, row = MODE == 1 ? 4 * (t % p.n_px) + tap : t % p.n_px;
+            float* o = p.stat_part + (((size_t)(ch >> 6) * rows + row) * 64 + (ch & 63)) * 2;
+            o[0] = a; o[1] = b;
+        }
+    }
+}
+
+}  // namespace
+
+namespace {
+
+__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 0, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 0, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_stats_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 1, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_stats_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 1, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 0, 2>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 0, 2>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_bnbwd_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 2, 2>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_bnbwd_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 2, 2>(p); }
+
+// B[K][Ncol] of the GEMM -> bf16 [K/32][k-step][k half][Ncol][8]; the Keras kernel [2][2][Cout][Cin] is B^T for the forward
+// (k = ci, column = tap * Cout + co) and B itself for the data gradient (k = tap * Cout + co, column = ci)
+__global__ void convt_bf16_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int K, int Ncol, int transposed) {
+    const long n = (long)(K / 8) * Ncol;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int col = (int)(i % Ncol); const int k0 = (int)(i / Ncol) * 8;       // (chunk, k-step, k half) flattened = k0 / 8
+    unsigned v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = k0 + 2 * e;
+        const float a = transposed ? w[(size_t)col * K + k] : w[(size_t)k * Ncol + col];
+        const float b = transposed ? w[(size_t)col * K + k + 1] : w[(size_t)(k + 1) * Ncol + col];
+        v[e] = cb_pack2(a, b);
+    }
+    reinterpret_cast<uint4*>(wp)[i] = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+int run_convt_bf16(int mode, const void* x, int ldx, int in16, const void* wp, const float* bias, float* out, int ldo,
+                   int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, const float* r_prev, int ldr, hipStream_t st) {
+    ConvtBf16Args a{};
+    a.x = (const float*)x; a.wp = (const uint16_t*)wp; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.in16 = in16;
+    a.K = mode == 1 ? Cin : 4 * Cout; a.Ncol = mode == 1 ? 4 * Cout : Cin;
+    a.tby = (H + 15) / 16; a.tbx = (W + 31) / 32; a.n_px = N * a.tby * a.tbx;
+    a.x_bytes = (unsigned)((size_t)N * H * W * (mode == 2 ? 4 : 1) * ldx * (in16 ? 2 : 4));
+    const bool wide = a.Ncol % 128 == 0 && (long)a.n_px * (a.Ncol / 128) >= conv_bf16_cus();
+    a.n_co = a.Ncol / (wide ? 128 : 64);
+    a.stat_part = stat_part; a.bn_r = r_prev; a.bn_ldr = ldr;
+    if (stat_part) {
+        const int chans = mode == 1 ? Cout : Cin, rows = (mode == 1 ? 4 : 1) * a.n_px;
+        if (stat_bytes < (size_t)(chans / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
+    }
+    const dim3 grid((unsigned)(a.n_px * a.n_co));
+    if (mode == 1) {
+        if (stat_part) { if (wide) convt_bf16_fwd_stats_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_fwd_stats_kernel_64<<<grid, 256, 0, st>>>(a); }
+        else           { if (wide) convt_bf16_fwd_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_fwd_kernel_64<<<grid, 256, 0, st>>>(a); }
+    } else {
+        if (stat_part) { if (wide) convt_bf16_dgrad_bnbwd_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_dgrad_bnbwd_kernel_64<<<grid, 256, 0, st>>>(a); }
+        else           { if (wide) convt_bf16_dgrad_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_dgrad_kernel_64<<<grid, 256, 0, st>>>(a); }
+    }
+    return UNET_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+// Cin, Cout multiples of 64; tensors < 2 GiB
+extern "C" int unet_convT2x2_bf16_supported(int N, int H, int W, int Cin, int Cout) {
+    return (N > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout % 64 == 0 && (size_t)N * H * W * 4 * Cout * 4 < ((size_t)1 << 31) &&
+            (size_t)N * H * W * Cin * 4 < ((size_t)1 << 31)) ? 1 : 0;
+}
+extern "C" size_t unet_convT2x2_bf16_packed_bytes(int Cin, int Cout) { return (size_t)4 * Cin * Cout * 2; }
+// mode 0: forward operand, mode 1: data-gradient operand; w is the Keras kernel [2][2][Cout][Cin] (UNet/model.py:41-46)
+extern "C" int unet_convT2x2_bf16_pack_weights(const float* w, void* packed, int Cin, int Cout, int mode, void* stream) {
+    UNET_CHECK_ARG(w && packed && Cin % 64 == 0 && Cout % 64 == 0 && (mode == 0 || mode == 1) && unet_aligned16(packed));
+    const int K = mode == 0 ? Cin : 4 * Cout, Ncol = mode == 0 ? 4 * Cout : Cin;
+    const long n = (long)(K / 8) * Ncol;
+    convt_bf16_pack_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, (uint16_t*)packed, K, Ncol, mode == 0 ? 1 : 0);
+    return UNET_LAUNCH_STATUS();
+}
+// rows of the statistics partials: forward 4 per 16x32 input-pixel tile (one per tap), data gradient 1
+extern "C" int unet_convT2x2_bf16_stats_rows(int N, int H, int W, int Cin, int Cout, int dgrad) {
+    if (!unet_convT2x2_bf16_supported(N, H, W, Cin, Cout)) return 0;
+    return (dgrad ? 1 : 4) * N * ((H + 15) / 16) * ((W + 31) / 32);
+}
+// z[n,2i+a,2j+b,co] = bias[co] + sum_ci x[n,i,j,ci] W[a,b,co,ci] (operands rounded to bf16, fp32 accumulation); H, W: input size;
+// x_bf16: x stored as bf16; stat_part nullable: BatchNorm sums of z, [Cout/64][rows][64][2]
+extern "C" int unet_convT2x2_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
+                                         int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(x && wp && out && unet_convT2x2_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && (!x_bf16 || ldx % 8 == 0) && unet_aligned16(x) && unet_aligned16(wp));
+    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * 4 * ldo * 4 < ((size_t)1 << 31));
+    return run_convt_bf16(1, x, ldx, x_bf16 ? 1 : 0, wp, bias, out, ldo, N, H, W, Cin, Cout, stat_part, stat_bytes, nullptr, 0, (hipStream_t)stream);
+}
+// dx[n,i,j,ci] = sum_{a,b,co} dz[n,2i+a,2j+b,co] W[a,b,co,ci]; r_prev / stat_part nullable: BatchNorm-backward sums (sum dx, sum dx * r_prev)
+// of the layer that produced x (all Cin channels), [Cin/64][rows][64][2]
+extern "C" int unet_convT2x2_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
+                                           int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr,
+                                           float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(dz && wpd && dx && unet_convT2x2_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && (!dz_bf16 || lddz % 8 == 0) && unet_aligned16(dz) && unet_aligned16(wpd));
+    UNET_CHECK_ARG((r_prev == nullptr) == (stat_part == nullptr) && (!r_prev || ldr >= Cin));
+    UNET_CHECK_ARG((size_t)N * H * W * 4 * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
+    return run_convt_bf16(2, dz, lddz, dz_bf16 ? 1 : 0, wpd, nullptr, dx, lddx, N, H, W, Cin, Cout, stat_part, stat_bytes, r_prev, ldr, (hipStream_t)stream);
 }

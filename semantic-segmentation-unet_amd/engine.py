@@ -67,6 +67,8 @@ for _l in (1, 2, 3, 4):
     PRODUCER["conv_%db" % _l] = ("conv_%da" % _l, 0, 1, 1)
     PRODUCER["dec_%db" % _l] = ("dec_%da" % _l, 0, 1, 1)
     PRODUCER["dec_%da" % _l] = ("up_%d" % _l, 1, 2, 2)          # concat [skip, upsampled] (UNet/model.py:55-58): upper half
+for _l in (1, 2, 3):
+    PRODUCER["up_%d" % _l] = ("dec_%db" % (_l + 1), 0, 1, 1)   # (up_4's input went through the dropout: no direct producer)
 
 
 def _p(t):
@@ -227,15 +229,21 @@ class Engine:
             self._bf16_dirty = False
         w = self._bf16_W.get(name)
         if w is None:
-            nb = self.L.unet_conv3x3_bf16_packed_bytes(self.cin[name], self.cout[name])
+            nbytes = self.L.unet_convT2x2_bf16_packed_bytes if self.kind[name] == "deconv" else self.L.unet_conv3x3_bf16_packed_bytes
+            nb = nbytes(self.cin[name], self.cout[name])
             w = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
             self._bf16_W[name] = w
         if name not in self._bf16_fresh:
             st = self._stream()
-            self.L.unet_conv3x3_bf16_pack_weights(_p(self.p[name + "/kernel"]), _p(w[0]), self.cin[name], self.cout[name], 0, st)
-            self.L.unet_conv3x3_bf16_pack_weights(_p(self.p[name + "/kernel"]), _p(w[1]), self.cin[name], self.cout[name], 1, st)
+            pack = self.L.unet_convT2x2_bf16_pack_weights if self.kind[name] == "deconv" else self.L.unet_conv3x3_bf16_pack_weights
+            pack(_p(self.p[name + "/kernel"]), _p(w[0]), self.cin[name], self.cout[name], 0, st)
+            pack(_p(self.p[name + "/kernel"]), _p(w[1]), self.cin[name], self.cout[name], 1, st)
             self._bf16_fresh.add(name)
         return w
+
+    def _use_bf16_convt(self, name, n, h, w):
+        return (self.compute_dtype == "bf16" and self.kind[name] == "deconv"
+                and self.L.unet_convT2x2_bf16_supported(n, h, w, self.cin[name], self.cout[name]) == 1)
 
     def _fused_kernels(self, name):
         """(Uc forward, Uc dgrad) in the chunked layout of the fused kernel.  The buffers are persistent; after a parameter
@@ -332,7 +340,14 @@ class Engine:
         fused_stats = None
         if kind == "deconv":
             r = self._buf("r_" + name, (n, 2 * h, 2 * w, cout))
-            if L.unet_convT2x2_fwd_stream_supported(n, h, w, cin, cout) == 1 and _ld(x) <= 4096:           # persistent stream kernel
+            if self._use_bf16_convt(name, n, h, w):
+                rows = L.unet_convT2x2_bf16_stats_rows(n, h, w, cin, cout, 0) if (training and self.fuse_bn_stats) else 0
+                stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
+                L.unet_convT2x2_fwd_bf16_ex(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout,
+                                            n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+                if rows > 0:
+                    fused_stats = (stat_part, rows)
+            elif L.unet_convT2x2_fwd_stream_supported(n, h, w, cin, cout) == 1 and _ld(x) <= 4096:           # persistent stream kernel
                 rows = L.unet_convT2x2_fwd_stream_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
                 if rows > 0:
                     stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
@@ -616,7 +631,17 @@ class Engine:
                 wgrad()
         if need_dx:
             dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
-            if kind == "deconv":
+            if kind == "deconv" and self._use_bf16_convt(name, n, hi, wi):
+                prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
+                rows = L.unet_convT2x2_bf16_stats_rows(n, hi, wi, cin, cout, 1) if prod else 0
+                r_prev = self.saved[prod[0]][1] if rows > 0 else None
+                part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,)) if rows > 0 else None
+                L.unet_convT2x2_dgrad_bf16_ex(_p(dz), cout, int(dz.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[1]), _p(dx), cin,
+                                              n, hi, wi, cin, cout, _p(r_prev), r_prev.shape[-1] if rows > 0 else 0,
+                                              _p(part), part.numel() * 4 if rows > 0 else 0, st)
+                if rows > 0:
+                    self.bnbwd_part[prod[0]] = (part, rows, 0)
+            elif kind == "deconv":
                 L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
                 L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)

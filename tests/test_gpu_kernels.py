@@ -811,3 +811,53 @@ def test_bf16_stored_operands_bit_identical(hip):
                         P(gr[3]), P(gr[4]), P(gr[5]), None, 0, P(wsb), nbb, ST())
     assert torch.equal(zf_.to(torch.bfloat16), zh)
     assert all(torch.equal(gr[i], gr[i + 3]) for i in range(3))
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 64), (2, 10, 20, 128, 64), (1, 8, 40, 64, 128), (2, 4, 8, 256, 128)])
+def test_convT2x2_bf16_fwd_dgrad_match_oracle_on_rounded_operands(hip, shape):
+    # bf16 transposed conv (forward, data gradient): fp64 oracle on the bf16-rounded operands to fp32-accumulation accuracy; ragged
+    # tiles, padded leading dimensions, both column-tile widths, the fused BatchNorm sums, a bf16-stored input
+    n, h, w, ci, co = shape
+    assert hip.unet_convT2x2_bf16_supported(n, h, w, ci, co) == 1
+    rng = np.random.default_rng(ci + co + h)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((2, 2, co, ci)) / np.sqrt(ci)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    dz = rng.standard_normal((n, co, 2 * h, 2 * w)).astype(np.float32)
+    z_ref = on.deconv2x2_fwd(bf16_round(x), bf16_round(wt), b.astype(np.float64))
+    dx_ref, _, _ = on.deconv2x2_bwd(bf16_round(x), bf16_round(wt), bf16_round(dz))
+    xd = torch.zeros(n, h, w, ci + 8, device=DEV); xd[..., :ci] = to_nhwc(x); xv = xd[..., :ci]
+    dzd, wd, bd = to_nhwc(dz), dev(wt), dev(b)
+    nb = hip.unet_convT2x2_bf16_packed_bytes(ci, co)
+    wp, wpd = ws_bytes(nb), ws_bytes(nb)
+    hip.unet_convT2x2_bf16_pack_weights(P(wd), P(wp), ci, co, 0, ST())
+    hip.unet_convT2x2_bf16_pack_weights(P(wd), P(wpd), ci, co, 1, ST())
+    cat = torch.full((n, 2 * h, 2 * w, 2 * co), float("nan"), device=DEV)
+    outv = cat[..., co:]                                               # the upper half of a concat buffer
+    rows = hip.unet_convT2x2_bf16_stats_rows(n, h, w, ci, co, 0)
+    part = torch.full(((co // 64) * rows * 128,), float("nan"), device=DEV)
+    hip.unet_convT2x2_fwd_bf16_ex(P(xv), ci + 8, 0, P(wp), P(bd), P(outv), 2 * co, n, h, w, ci, co, P(part), part.numel() * 4, ST())
+    z = from_nhwc(outv)
+    assert relerr(z, z_ref) < 2e-5
+    assert torch.isnan(cat[..., :co]).all()
+    pv = part.view(co // 64, rows, 64, 2).double().sum(1).view(co, 2)
+    s1 = outv.double().sum((0, 1, 2)); s2 = (outv.double() ** 2).sum((0, 1, 2))
+    assert (pv[:, 0] - s1).abs().max().item() < 1e-4 * s1.abs().max().item() + 1e-3
+    assert (pv[:, 1] - s2).abs().max().item() < 1e-4 * s2.abs().max().item()
+    out2 = torch.empty(n, 2 * h, 2 * w, co, device=DEV)
+    hip.unet_convT2x2_fwd_bf16_ex(P(xv.contiguous().to(torch.bfloat16)), ci, 1, P(wp), P(bd), P(out2), co, n, h, w, ci, co, None, 0, ST())
+    assert torch.equal(out2, outv.contiguous())
+    # data gradient (+ the producer's BatchNorm-backward sums)
+    dx = torch.empty(n, h, w, ci, device=DEV); dx2 = torch.empty_like(dx)
+    hip.unet_convT2x2_dgrad_bf16_ex(P(dzd), co, 0, P(wpd), P(dx), ci, n, h, w, ci, co, None, 0, None, 0, ST())
+    assert relerr(from_nhwc(dx), dx_ref) < 2e-5
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    r_prev = torch.randn(n, h, w, ci, device=DEV, generator=g)
+    rows2 = hip.unet_convT2x2_bf16_stats_rows(n, h, w, ci, co, 1)
+    part2 = torch.full(((ci // 64) * rows2 * 128,), float("nan"), device=DEV)
+    hip.unet_convT2x2_dgrad_bf16_ex(P(dzd.to(torch.bfloat16)), co, 1, P(wpd), P(dx2), ci, n, h, w, ci, co, P(r_prev), ci, P(part2), part2.numel() * 4, ST())
+    assert torch.equal(dx, dx2)
+    pv2 = part2.view(ci // 64, rows2, 64, 2).double().sum(1).view(ci, 2)
+    t1 = dx.double().sum((0, 1, 2)); t2 = (dx.double() * r_prev.double()).sum((0, 1, 2))
+    assert (pv2[:, 0] - t1).abs().max().item() < 1e-4 * t1.abs().max().item() + 1e-3
+    assert (pv2[:, 1] - t2).abs().max().item() < 1e-4 * t2.abs().max().item() + 1e-3
