@@ -178,6 +178,11 @@ int unet_convT2x2_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp
 int unet_convT2x2_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
                                 int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr,
                                 float* stat_part, size_t stat_bytes, void* stream);
+/* weight gradient in the same arithmetic (additionally Cin % 128 == 0): dw[a,b,co,ci] = sum dz[n,2i+a,2j+b,co] * xin[n,i,j,ci] */
+int unet_convT2x2_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout);
+size_t unet_convT2x2_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_convT2x2_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                                int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- BatchNormalization(axis=1), UNet/model.py:36,47 ------------------------------------------------------------- */
 size_t unet_bn_workspace(long P, int C);

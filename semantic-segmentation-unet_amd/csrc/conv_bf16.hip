@@ -1174,3 +1174,226 @@ extern "C" int unet_convT2x2_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16
     UNET_CHECK_ARG((size_t)N * H * W * 4 * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
     return run_convt_bf16(2, dz, lddz, dz_bf16 ? 1 : 0, wpd, nullptr, dx, lddx, N, H, W, Cin, Cout, stat_part, stat_bytes, r_prev, ldr, (hipStream_t)stream);
 }
+
+// ---- transposed-conv weight gradient on the bf16 matrix cores -------------------------------------------------------------------
+//   dw[a,b,co,ci] = sum_{n,i,j} bf16(dz[n,2i+a,2j+b,co]) * bf16(x[n,i,j,ci])        (Keras kernel layout [2][2][Cout][Cin])
+// Contraction over input pixels, operands gathered by the transposing LDS read as in wgrad_bf16_kernel; the four taps are the
+// four stride-2 sub-lattices of dz, i.e. a row slot plus a pixel offset with DOUBLED pixel stride in the read address.
+// Workgroup = CO_T (128 / 64) output x 128 input channels x 4 taps; unit of work = one input row segment of 32 pixels (+ its two
+// dz rows of 64 pixels): every thread stages the same 4 + CO_T/8 loads per unit (no roles), one unit ahead; units are dealt to the
+// workgroups of a channel tile round-robin and the partial sums added in a fixed order.  Per unit 32 (16) MFMAs per wave against
+// 80 (48) KB of fp32 operands: the kernel runs on HBM / L2 bandwidth, which is the point -- the fp32 kernel ran on the matrix pipe.
+namespace {
+
+struct CtWgBf16Args {
+    const float* x; const float* dz; float* out;
+    int ldx, lddz, N, H, W, Cin, Cout;
+    int n_co, n_ci, splits, tbx, n_units;
+    unsigned x_bytes, dz_bytes; int x16, z16;
+};
+
+template <int MT>      // 32-channel blocks of dz per wave; the workgroup covers CO_T = 64 * MT output channels
+__device__ __forceinline__ void convt_wgrad_bf16_body(const CtWgBf16Args& p) {
+    constexpr int CO_T = 64 * MT, ZG = CO_T / 32;                    // dz channel groups of 32
+    constexpr int XROW = 4 * 32 * 64, ZROW = ZG * 64 * 64;           // bytes of the staged x row (4 groups x 32 px) / one dz row (ZG groups x 64 px)
+    constexpr int STAGE = XROW + 2 * ZROW;
+    constexpr int XL = 4, ZL = 2 * 64 * (CO_T / 4) / 256;            // loads per thread: x 32 px x 32 quads, dz 2 rows x 64 px x CO_T/4 quads
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wv & 1, wn = wv >> 1;
+    const int npairs = p.n_co * p.n_ci;
+    const int pair = blockIdx.x % npairs, split = blockIdx.x / npairs;
+    const int co0 = (pair / p.n_ci) * CO_T, ci0 = (pair % p.n_ci) * 128;
+    const int xes = p.x16 ? 2 : 4, zes = p.z16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.x) + (size_t)ci0 * xes), 0,
+                                                                            (int)(p.x_bytes - (unsigned)ci0 * xes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_z = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.dz) + (size_t)co0 * zes), 0,
+                                                                            (int)(p.dz_bytes - (unsigned)co0 * zes), 0x00020000);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
+    // staging: x load j covers quad xq of pixel xp + 8 j; dz load j covers quad zq of (row, pixel) index zi + (256 / ZQ) j
+    constexpr int ZQ = CO_T / 4;
+    const int xq = tid & 31, xp = tid >> 5, zq = tid % ZQ, zi = tid / ZQ;
+    const unsigned xw = lds0 + (unsigned)((xq >> 3) * (32 * 64) + xp * 64 + (xq & 7) * 8);
+    const unsigned zw = lds0 + XROW + (unsigned)((zq >> 3) * (64 * 64) + (zq & 7) * 8);
+    // fragment gathers (see wgrad_bf16_kernel): x pixels at stride 64 B, dz pixels of one sub-lattice at stride 128 B
+    const int g4 = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned chan = (unsigned)((16 * (g4 & 1) + 4 * pp) * 2);
+    const unsigned b_lane = lds0 + (unsigned)((2 * wn) * (32 * 64) + (8 * (g4 >> 1) + q4) * 64) + chan;
+    const unsigned a_lane = lds0 + XROW + (unsigned)((MT * wm) * (64 * 64) + (8 * (g4 >> 1) + q4) * 128) + chan;
+
+    f32x16 acc[4][MT][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][m][c][e] = 0.f;
+
+    f32x4 sx[XL], sz[ZL];
+    auto issue = [&](int u) {
+        const int uc = u < p.n_units ? u : split;                    // past the end: a valid unit, never used
+        const int seg = uc % p.tbx, row = uc / p.tbx;                // row = n * H + i
+        const int x0 = 32 * seg;
+        const int img = row / p.H, i = row % p.H;
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int gx = x0 + xp + 8 * j;
+            const unsigned vo = gx < p.W ? (unsigned)((((size_t)row * p.W + gx) * p.ldx) * xes + (p.x16 ? (xq >> 1) * 16 : xq * 16)) : 0x80000000u;
+            sx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, (int)vo, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < ZL; ++j) {
+            const int idx = zi + (256 / ZQ) * j;                      // 0 .. 127 = dz row (0/1) * 64 + pixel
+            const int zr = idx >> 6, zp = idx & 63;
+            const int gx = 2 * x0 + zp;
+            const unsigned vo = gx < 2 * p.W ? (unsigned)((((size_t)(img * 2 * p.H + 2 * i + zr) * (2 * p.W) + gx) * p.lddz) * zes + (p.z16 ? (zq >> 1) * 16 : zq * 16)) : 0x80000000u;
+            sz[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_z, (int)vo, 0, 0));
+        }
+    };
+    auto commit = [&](int stage) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            uint2 v; v.x = cb_pack2_pinned(sx[j].x, sx[j].y); v.y = cb_pack2_pinned(sx[j].z, sx[j].w);
+            if (p.x16) { v.x = __builtin_bit_cast(unsigned, (xq & 1) ? sx[j].z : sx[j].x); v.y = __builtin_bit_cast(unsigned, (xq & 1) ? sx[j].w : sx[j].y); }
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(xw + (unsigned)(stage * STAGE)), "v"(v), "n"(j * 8 * 64) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < ZL; ++j) {
+            const int idx = zi + (256 / ZQ) * j;
+            const unsigned off = (unsigned)((idx >> 6) * ZROW + (idx & 63) * 64);
+            uint2 v; v.x = cb_pack2_pinned(sz[j].x, sz[j].y); v.y = cb_pack2_pinned(sz[j].z, sz[j].w);
+            if (p.z16) { v.x = __builtin_bit_cast(unsigned, (zq & 1) ? sz[j].z : sz[j].x); v.y = __builtin_bit_cast(unsigned, (zq & 1) ? sz[j].w : sz[j].y); }
+            asm volatile("ds_write_b64 %0, %1" :: "v"(zw + off + (unsigned)(stage * STAGE)), "v"(v) : "memory");
+        }
+    };
+    auto compute = [&](int stage) {
+        const unsigned ab = a_lane + (unsigned)(stage * STAGE), bb = b_lane + (unsigned)(stage * STAGE);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            i32x2 fa[4][MT][2], fb[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                WG_RDTR(fb[c][0], bb, c * (32 * 64) + ks * 1024);
+                WG_RDTR(fb[c][1], bb, c * (32 * 64) + ks * 1024 + 256);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    WG_RDTR(fa[t][m][0], ab, (t >> 1) * ZROW + m * (64 * 64) + (32 * ks + (t & 1)) * 64);
+                    WG_RDTR(fa[t][m][1], ab, (t >> 1) * ZROW + m * (64 * 64) + (32 * ks + (t & 1)) * 64 + 512);
+                }
+            // every fragment register is tied to the wait (a copy the compiler makes of one must not be scheduled ahead of it)
+            if constexpr (MT == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]),
+                             "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]),
+                             "+v"(fa[2][0][0]), "+v"(fa[2][0][1]), "+v"(fa[2][1][0]), "+v"(fa[2][1][1]), "+v"(fa[3][0][0]), "+v"(fa[3][0][1]), "+v"(fa[3][1][0]), "+v"(fa[3][1][1]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]),
+                             "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[2][0][0]), "+v"(fa[2][0][1]), "+v"(fa[3][0][0]), "+v"(fa[3][0][1]));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    bf16x8 av;
+                    { i32x4 t4; t4.x = fa[t][m][0].x; t4.y = fa[t][m][0].y; t4.z = fa[t][m][1].x; t4.w = fa[t][m][1].y; av = __builtin_bit_cast(bf16x8, t4); }
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        bf16x8 bv;
+                        { i32x4 t4; t4.x = fb[c][0].x; t4.y = fb[c][0].y; t4.z = fb[c][1].x; t4.w = fb[c][1].y; bv = __builtin_bit_cast(bf16x8, t4); }
+                        // (s_nop: wait states for compiler-made copies in front of an inline-asm MFMA, see wgrad_bf16_kernel)
+                        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[t][m][c]) : "v"(av), "v"(bv) : "memory");
+                    }
+                }
+        }
+    };
+
+    int u = split;
+    issue(u);
+    commit(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int stage = 0;
+    for (; u < p.n_units; u += p.splits) {
+        issue(u + p.splits);
+        compute(stage);
+        commit(stage ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stage ^= 1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // accumulator register e of (tap t, block m, sub-tile c) = (output channel co0 + 32 (MT wm + m) + row(e, lh), input channel ci0 + 32 (2 wn + c) + li)
+    float* o_base = p.out + (size_t)split * 4 * p.Cout * p.Cin;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = co0 + 32 * (MT * wm + m) + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    float v;
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[t][m][c][e]));
+                    o_base[((size_t)t * p.Cout + co) * p.Cin + ci0 + 32 * (2 * wn + c) + li] = v;
+                }
+}
+
+}  // namespace
+
+namespace {
+
+__global__ __launch_bounds__(256, 1) void convt_wgrad_bf16_kernel_128(CtWgBf16Args p) { convt_wgrad_bf16_body<2>(p); }
+__global__ __launch_bounds__(256, 1) void convt_wgrad_bf16_kernel_64(CtWgBf16Args p) { convt_wgrad_bf16_body<1>(p); }
+
+void convt_wgrad_bf16_plan(CtWgBf16Args& a) {
+    const int cot = a.Cout % 128 == 0 ? 128 : 64;
+    a.n_co = a.Cout / cot; a.n_ci = a.Cin / 128;
+    a.tbx = (a.W + 31) / 32; a.n_units = a.N * a.H * a.tbx;
+    const int npairs = a.n_co * a.n_ci;
+    int splits = conv_bf16_cus() / npairs; if (splits < 1) splits = 1; if (splits > a.n_units) splits = a.n_units;
+    a.splits = splits;
+}
+
+}  // namespace
+
+extern "C" int unet_convT2x2_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout) {
+    return (unet_convT2x2_bf16_supported(N, H, W, Cin, Cout) && Cin % 128 == 0) ? 1 : 0;
+}
+extern "C" size_t unet_convT2x2_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout) {
+    if (!unet_convT2x2_wgrad_bf16_supported(N, H, W, Cin, Cout)) return 0;
+    CtWgBf16Args a{}; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    convt_wgrad_bf16_plan(a);
+    return a.splits > 1 ? (size_t)a.splits * 4 * Cout * Cin * sizeof(float) : 16;
+}
+// dw[a,b,co,ci] = sum_{n,i,j} dz[n,2i+a,2j+b,co] * xin[n,i,j,ci], operands rounded to bf16 (or stored as bf16), fp32 accumulation
+extern "C" int unet_convT2x2_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                                           int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(xin && dz && dw && ws && unet_convT2x2_wgrad_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && (!x_bf16 || ldx % 8 == 0) && (!dz_bf16 || lddz % 8 == 0));
+    UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
+    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * 4 * lddz * 4 < ((size_t)1 << 31));
+    if (ws_bytes < unet_convT2x2_wgrad_bf16_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
+    CtWgBf16Args a{};
+    a.x = (const float*)xin; a.dz = (const float*)dz; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.x16 = x_bf16 ? 1 : 0; a.z16 = dz_bf16 ? 1 : 0;
+    convt_wgrad_bf16_plan(a);
+    a.out = a.splits > 1 ? (float*)ws : dw;
+    a.x_bytes = (unsigned)((size_t)N * H * W * ldx * (a.x16 ? 2 : 4)); a.dz_bytes = (unsigned)((size_t)N * H * W * 4 * lddz * (a.z16 ? 2 : 4));
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(a.n_co * a.n_ci * a.splits));
+    if (Cout % 128 == 0) convt_wgrad_bf16_kernel_128<<<grid, 256, 0, st>>>(a);
+    else                 convt_wgrad_bf16_kernel_64<<<grid, 256, 0, st>>>(a);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    if (a.splits > 1) {
+        const long n4 = (long)4 * Cout * Cin / 4;
+        int sl = 1;
+        while (sl < 16 && 2 * sl <= a.splits && n4 * sl < 256 * 1024) sl *= 2;
+        wgrad_bf16_reduce_kernel<<<(unsigned)((n4 * sl + 255) / 256), 256, 0, st>>>((const float*)ws, dw, n4, a.splits, sl);
+        rc = UNET_LAUNCH_STATUS();
+    }
+    return rc;
+}

@@ -209,9 +209,14 @@ class Engine:
     def _ybuf(self, name, shape, consumer):
         """BatchNorm-output buffer of `name`, read only by the 3x3 layer `consumer`: bf16 when that layer contracts in bf16."""
         n, h, w, _ = shape
-        if self.compute_dtype == "bf16" and self.bf16_storage and self._use_bf16(consumer, n, h, w) \
-                and self.L.unet_conv3x3_wgrad_bf16_supported(n, h, w, self.cin[consumer], self.cout[consumer]) == 1:
-            return self._buf("y16_" + name, shape, torch.bfloat16)
+        if self.compute_dtype == "bf16" and self.bf16_storage:
+            ci, co = self.cin[consumer], self.cout[consumer]
+            if self.kind[consumer] == "deconv":
+                ok = self._use_bf16_convt(consumer, n, h, w) and self.L.unet_convT2x2_wgrad_bf16_supported(n, h, w, ci, co) == 1
+            else:
+                ok = self._use_bf16(consumer, n, h, w) and self.L.unet_conv3x3_wgrad_bf16_supported(n, h, w, ci, co) == 1
+            if ok:
+                return self._buf("y16_" + name, shape, torch.bfloat16)
         return self._buf("y_" + name, shape)
 
     def _use_bf16(self, name, n, h, w, dgrad=False):
@@ -508,7 +513,8 @@ class Engine:
             f("up_%d" % lvl, cur, cat[..., ch:], training)
             hh, ww = cat.shape[1], cat.shape[2]
             ya = f("dec_%da" % lvl, cat, self._ybuf("dec_%da" % lvl, (n, hh, ww, ch), "dec_%db" % lvl), training)
-            cur = f("dec_%db" % lvl, ya, self._buf("y_dec_%db" % lvl, (n, hh, ww, ch)), training)
+            yb = self._ybuf("dec_%db" % lvl, (n, hh, ww, ch), "up_%d" % (lvl - 1)) if lvl > 1 else self._buf("y_dec_1b", (n, hh, ww, ch))
+            cur = f("dec_%db" % lvl, ya, yb, training)
         yl = f("logits", cur, self._buf("y_logits", (n, h, w, self.K)), training)
         prob = self._buf("softmax", (n, h, w, self.K))
         P = n * h * w
@@ -537,9 +543,11 @@ class Engine:
         n, ho, wo, _ = r.shape
         P = n * ho * wo
         s = self.stat[name]
-        dz16 = (self.compute_dtype == "bf16" and self.bf16_storage and kind == "conv3" and not eval_mode
-                and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1
-                and (not need_dx or self._use_bf16(name, n, ho, wo, dgrad=True)))
+        dz16 = self.compute_dtype == "bf16" and self.bf16_storage and not eval_mode and (
+            (kind == "conv3" and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1
+             and (not need_dx or self._use_bf16(name, n, ho, wo, dgrad=True)))
+            or (kind == "deconv" and self._use_bf16_convt(name, n, x.shape[1], x.shape[2])
+                and L.unet_convT2x2_wgrad_bf16_supported(n, x.shape[1], x.shape[2], cin, cout) == 1))
         dz = self._buf("dz16_" + name, tuple(r.shape), torch.bfloat16) if dz16 else self._buf("dz_" + name, tuple(r.shape))
         pre = self.bnbwd_part.pop(name, None) if not eval_mode else None
         if dz16:
@@ -553,7 +561,7 @@ class Engine:
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
             L.unet_bn_bwd_any(_p(dy), _ld(dy), _p(pdy), _ld(pdy) if pdy is not None else 0, _p(pidx), n, ho, wo, _p(r), cout,
-                              _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 1, _p(dz), cout, 1,
+                              _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 0 if kind == "deconv" else 1, _p(dz), cout, 1,
                               _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]), _p(self.g[name + "/bias"]), part_ptr, rows,
                               _p(ws), nb, st)
         elif eval_mode:
@@ -588,7 +596,11 @@ class Engine:
         def wgrad():
             sd = self.overlap_wgrad
             st2 = self._stream()
-            if kind == "deconv":
+            if kind == "deconv" and self._use_bf16_convt(name, n, hi, wi) and L.unet_convT2x2_wgrad_bf16_supported(n, hi, wi, cin, cout) == 1:
+                nb2 = L.unet_convT2x2_wgrad_bf16_workspace(n, hi, wi, cin, cout)
+                L.unet_convT2x2_wgrad_bf16_ex(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw),
+                                              n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+            elif kind == "deconv":
                 if self.convt_wgrad_wide and L.unet_convT2x2_wgrad_wide_supported(n, hi, wi, cin, cout) == 1:
                     nb2 = L.unet_convT2x2_wgrad_wide_workspace(n, hi, wi, cin, cout)
                     L.unet_convT2x2_wgrad_wide(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)

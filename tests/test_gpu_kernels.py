@@ -861,3 +861,28 @@ def test_convT2x2_bf16_fwd_dgrad_match_oracle_on_rounded_operands(hip, shape):
     t1 = dx.double().sum((0, 1, 2)); t2 = (dx.double() * r_prev.double()).sum((0, 1, 2))
     assert (pv2[:, 0] - t1).abs().max().item() < 1e-4 * t1.abs().max().item() + 1e-3
     assert (pv2[:, 1] - t2).abs().max().item() < 1e-4 * t2.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 32, 128, 64), (2, 6, 40, 128, 128), (1, 8, 16, 256, 128), (3, 5, 70, 128, 64), (2, 4, 8, 1024, 512)])
+def test_convT2x2_bf16_wgrad_matches_oracle_on_rounded_operands(hip, shape):
+    # bf16 transposed-conv weight gradient (stride-2 sub-lattice gathers through the transposing LDS read): fp64 oracle on the
+    # bf16-rounded operands; ragged / narrow widths, padded leading dimensions, both channel-tile widths, several units per
+    # workgroup (last shape: 32 channel tiles), bf16-stored operands bit-identical, reruns bit-identical
+    n, h, w, ci, co = shape
+    assert hip.unet_convT2x2_wgrad_bf16_supported(n, h, w, ci, co) == 1
+    rng = np.random.default_rng(ci + co + h)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    dz = rng.standard_normal((n, co, 2 * h, 2 * w)).astype(np.float32)
+    _, dw_ref, _ = on.deconv2x2_bwd(bf16_round(x), np.zeros((2, 2, co, ci)), bf16_round(dz))
+    xd = torch.zeros(n, h, w, ci + 8, device=DEV); xd[..., :ci] = to_nhwc(x); xv = xd[..., :ci]
+    dzd = torch.zeros(n, 2 * h, 2 * w, co + 8, device=DEV); dzd[..., :co] = to_nhwc(dz); dzv = dzd[..., :co]
+    nb = hip.unet_convT2x2_wgrad_bf16_workspace(n, h, w, ci, co)
+    ws = ws_bytes(nb)
+    outs = []
+    for xa, lx, xf, za, lz, zf in ((xv, ci + 8, 0, dzv, co + 8, 0), (xv, ci + 8, 0, dzv, co + 8, 0),
+                                   (xv.contiguous().to(torch.bfloat16), ci, 1, dzv.contiguous().to(torch.bfloat16), co, 1)):
+        dw = torch.full((2, 2, co, ci), float("nan"), device=DEV)
+        hip.unet_convT2x2_wgrad_bf16_ex(P(xa), lx, xf, P(za), lz, zf, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+        outs.append(dw)
+    assert relerr(outs[0].cpu().numpy().astype(np.float64), dw_ref) < 2e-5
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
