@@ -316,7 +316,27 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_wgrad_kernel(const float* 
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[e][j] = 0.f;
-            for (long pix = p0 + pl; pix < p1; pix += npl) {
+            long pix = p0 + pl;
+            // four pixels per trip, all their loads issued before the first use (one pixel per trip left the kernel latency-bound
+            // at ~1 TB/s; the summation order per accumulator is unchanged)
+            for (; pix + 3 * (long)npl < p1; pix += 4 * (long)npl) {
+                f32x4 xv[4]; float g[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(pix + u * (long)npl) * ldx + 4 * qq);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[u][j] = (k0 + j < K) ? dz[(size_t)(pix + u * (long)npl) * lddz + k0 + j] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k0 + j < K) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[e][j] += xv[u][e] * g[u][j];
+                        }
+            }
+            for (; pix < p1; pix += npl) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)pix * ldx + 4 * qq);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
