@@ -169,6 +169,10 @@ int unet_convT2x2_wgrad_wide(const float* xin, int ldx, const float* dz, int ldd
  * x_bf16 / dz_bf16: that tensor is stored as bf16.  stat_part nullable: forward -- BatchNorm sums of the output, rows =
  * unet_convT2x2_bf16_stats_rows(..., 0) (one per input-pixel tile and tap); data gradient -- with r_prev, the BatchNorm-backward
  * sums (sum dx, sum dx * r_prev) of the layer that produced x, rows = unet_convT2x2_bf16_stats_rows(..., 1). */
+/* every pack of a step in one launch: jobs[njobs][6] int64 = {fp32 kernel, forward operand, data-gradient operand,
+ * Cin | Cout << 32, kind (0: 3x3 HWIO, 1: transposed conv [2][2][Cout][Cin]), first 256-thread block of the job};
+ * a job needs ceil(taps * Cin * Cout / 8 / 256) blocks (taps = 9 / 4) */
+int unet_bf16_pack_weights_batch(const void* jobs, int njobs, int total_blocks, void* stream);
 int unet_convT2x2_bf16_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_convT2x2_bf16_packed_bytes(int Cin, int Cout);
 int unet_convT2x2_bf16_pack_weights(const float* w, void* packed, int Cin, int Cout, int mode, void* stream);

@@ -1397,3 +1397,65 @@ extern "C" int unet_convT2x2_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16,
     }
     return rc;
 }
+
+// ---- all weight packs of a step in one launch ---------------------------------------------------------------------------------------
+// jobs[njobs][6] int64: {fp32 kernel, forward operand, data-gradient operand, Cin | Cout << 32, kind (0: 3x3, 1: transposed conv),
+// first 256-thread block of this job}; a job covers both operands (the two packs of a layer read the same weights).
+namespace {
+
+__global__ __launch_bounds__(256) void bf16_pack_batch_kernel(const long long* __restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (long long)blockIdx.x >= jobs[(j + 1) * 6 + 5]) ++j;
+    const long long* jb = jobs + j * 6;
+    const float* w = reinterpret_cast<const float*>(jb[0]);
+    uint4* dst0 = reinterpret_cast<uint4*>(jb[1]); uint4* dst1 = reinterpret_cast<uint4*>(jb[2]);
+    const int Cin = (int)(jb[3] & 0xffffffffll), Cout = (int)(jb[3] >> 32), kind = (int)jb[4];
+    const long i = ((long)blockIdx.x - jb[5]) * 256 + threadIdx.x;
+    if (kind == 0) {
+        // 3x3: thread = 8 reduce channels of one (tap, output channel); forward reduces over Cin, the data gradient over Cout
+        const long n = (long)9 * Cin * Cout / 8;
+        if (i >= n) return;
+#pragma unroll
+        for (int mode = 0; mode < 2; ++mode) {
+            const int outc = mode ? Cin : Cout;
+            const int o = (int)(i % outc); long rest = i / outc;
+            const int kh = (int)(rest % 2); rest /= 2;
+            const int tap = (int)(rest % 9); const int chunk = (int)(rest / 9);
+            const int k0 = chunk * 16 + kh * 8;
+            unsigned v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a, b;
+                if (mode == 0) { a = w[((size_t)tap * Cin + k0 + 2 * e) * Cout + o]; b = w[((size_t)tap * Cin + k0 + 2 * e + 1) * Cout + o]; }
+                else           { a = w[((size_t)(8 - tap) * Cin + o) * Cout + k0 + 2 * e]; b = w[((size_t)(8 - tap) * Cin + o) * Cout + k0 + 2 * e + 1]; }
+                v[e] = cb_pack2(a, b);
+            }
+            (mode ? dst1 : dst0)[i] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+        const long n = (long)4 * Cin * Cout / 8;
+        if (i >= n) return;
+#pragma unroll
+        for (int mode = 0; mode < 2; ++mode) {
+            const int K = mode ? 4 * Cout : Cin, Ncol = mode ? Cin : 4 * Cout;
+            const int col = (int)(i % Ncol); const int k0 = (int)(i / Ncol) * 8;
+            unsigned v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + 2 * e;
+                const float a = mode == 0 ? w[(size_t)col * K + k] : w[(size_t)k * Ncol + col];
+                const float b = mode == 0 ? w[(size_t)col * K + k + 1] : w[(size_t)(k + 1) * Ncol + col];
+                v[e] = cb_pack2(a, b);
+            }
+            (mode ? dst1 : dst0)[i] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int unet_bf16_pack_weights_batch(const void* jobs, int njobs, int total_blocks, void* stream) {
+    UNET_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0);
+    bf16_pack_batch_kernel<<<(unsigned)total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)jobs, njobs);
+    return UNET_LAUNCH_STATUS();
+}

@@ -229,22 +229,26 @@ class Engine:
     def _bf16_kernels(self, name):
         """(forward operand, data-gradient operand): the layer's fp32 master kernel packed to bf16, refreshed after every
         parameter change."""
+        if not self._bf16_W:
+            # persistent operand buffers + the job table of the batched pack (one launch per parameter change)
+            rows, blk = [], 0
+            for n, kind, cin, cout in self.layers:
+                if kind not in ("conv3", "deconv") or cin % 64 or cout % 64:
+                    continue
+                taps = 4 if kind == "deconv" else 9
+                nb = taps * cin * cout * 2
+                w = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
+                self._bf16_W[n] = w
+                rows.append([self.p[n + "/kernel"].data_ptr(), w[0].data_ptr(), w[1].data_ptr(), cin | (cout << 32),
+                             1 if kind == "deconv" else 0, blk])
+                blk += (taps * cin * cout // 8 + 255) // 256
+            self._bf16_jobs = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+            self._bf16_blocks = blk
+            self._bf16_dirty = True
         if self._bf16_dirty:
-            self._bf16_fresh = set()
+            self.L.unet_bf16_pack_weights_batch(_p(self._bf16_jobs), self._bf16_jobs.shape[0], self._bf16_blocks, self._stream())
             self._bf16_dirty = False
-        w = self._bf16_W.get(name)
-        if w is None:
-            nbytes = self.L.unet_convT2x2_bf16_packed_bytes if self.kind[name] == "deconv" else self.L.unet_conv3x3_bf16_packed_bytes
-            nb = nbytes(self.cin[name], self.cout[name])
-            w = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
-            self._bf16_W[name] = w
-        if name not in self._bf16_fresh:
-            st = self._stream()
-            pack = self.L.unet_convT2x2_bf16_pack_weights if self.kind[name] == "deconv" else self.L.unet_conv3x3_bf16_pack_weights
-            pack(_p(self.p[name + "/kernel"]), _p(w[0]), self.cin[name], self.cout[name], 0, st)
-            pack(_p(self.p[name + "/kernel"]), _p(w[1]), self.cin[name], self.cout[name], 1, st)
-            self._bf16_fresh.add(name)
-        return w
+        return self._bf16_W[name]
 
     def _use_bf16_convt(self, name, n, h, w):
         return (self.compute_dtype == "bf16" and self.kind[name] == "deconv"

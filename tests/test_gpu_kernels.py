@@ -886,3 +886,24 @@ def test_convT2x2_bf16_wgrad_matches_oracle_on_rounded_operands(hip, shape):
         outs.append(dw)
     assert relerr(outs[0].cpu().numpy().astype(np.float64), dw_ref) < 2e-5
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_bf16_pack_weights_batch_matches_single_packs(hip):
+    # one launch for every layer's operands == the per-layer pack kernels, bit for bit (3x3 and transposed-conv jobs mixed)
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    layers = [(0, 64, 128), (1, 256, 128), (0, 128, 64), (1, 128, 64)]           # (kind, Cin, Cout)
+    rows, blk, keep = [], 0, []
+    for kind, ci, co in layers:
+        taps = 4 if kind else 9
+        w = torch.randn((2, 2, co, ci) if kind else (3, 3, ci, co), device=DEV, generator=g)
+        nb = taps * ci * co * 2
+        a, b = ws_bytes(nb), ws_bytes(nb); a0, b0 = ws_bytes(nb), ws_bytes(nb)
+        pack = hip.unet_convT2x2_bf16_pack_weights if kind else hip.unet_conv3x3_bf16_pack_weights
+        pack(P(w), P(a0), ci, co, 0, ST()); pack(P(w), P(b0), ci, co, 1, ST())
+        rows.append([w.data_ptr(), a.data_ptr(), b.data_ptr(), ci | (co << 32), kind, blk])
+        blk += (taps * ci * co // 8 + 255) // 256
+        keep.append((w, a, b, a0, b0, nb))
+    jobs = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    hip.unet_bf16_pack_weights_batch(P(jobs), len(rows), blk, ST())
+    for w, a, b, a0, b0, nb in keep:
+        assert torch.equal(a[:nb], a0[:nb]) and torch.equal(b[:nb], b0[:nb])
