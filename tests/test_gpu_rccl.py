@@ -25,15 +25,16 @@ from oracle import unet_numpy as on
 img, lab = on.synthetic_batch(2, 1, 2, 64, 64, seed=3)
 rng = np.random.default_rng(0)
 masks = {"drop_4": rng.integers(0, 2, (2, 512, 8, 8)), "drop_b": rng.integers(0, 2, (2, 1024, 4, 4))}
-a = model.UNet(2, 2, 1, seed=5)
-b = model.UNet(2, 2, 1, seed=5)
-b.parallel = par.DataParallel(b.engine, bucket_bytes=8 << 20, force=True)
-assert len(b.parallel.buckets) >= 5
-for _ in range(2):
-    la = a.train_step((img, lab, None, None), dropout_masks=masks).numpy()
-    lb = b.train_step((img, lab, None, None), dropout_masks=masks).numpy()
-    assert la == lb, (la, lb)
-assert torch.equal(a.engine.theta, b.engine.theta)          # bit-identical: SUM over one rank is the identity
+for cd in ("bf16", "fp32"):                                 # the mixed-precision mode goes through the same buckets / hooks
+    a = model.UNet(2, 2, 1, seed=5, compute_dtype=cd)
+    b = model.UNet(2, 2, 1, seed=5, compute_dtype=cd)
+    b.parallel = par.DataParallel(b.engine, bucket_bytes=8 << 20, force=True)
+    assert len(b.parallel.buckets) >= 5
+    for _ in range(2):
+        la = a.train_step((img, lab, None, None), dropout_masks=masks).numpy()
+        lb = b.train_step((img, lab, None, None), dropout_masks=masks).numpy()
+        assert la == lb, (cd, la, lb)
+    assert torch.equal(a.engine.theta, b.engine.theta)      # bit-identical: SUM over one rank is the identity
 red = b._reduce_loss(b.parallel, b.train_step((img, lab, None, None), dropout_masks=masks))
 assert np.isfinite(red.numpy())
 b.parallel.average_moving_stats()
