@@ -19,7 +19,9 @@ def _write_tiles(folder, imgs, masks):
         np.save(os.path.join(folder, "t%02d_mask.npy" % i), mk)
 
 
-def test_learns_real_tiles_with_device_augmentation(tmp_path):
+@pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
+def test_learns_real_tiles_with_device_augmentation(tmp_path, compute_dtype):
+    # (bf16: the mixed-precision mode must train the reference's own tiles to the same held-out quality bar)
     d = np.load(FIX)
     imgs, masks = d["images"], d["masks"]
     _write_tiles(tmp_path / "train", imgs[:12], masks[:12])
@@ -30,7 +32,7 @@ def test_learns_real_tiles_with_device_augmentation(tmp_path):
         feed.DeviceFeed(rd.batches(4, classmap=True, pin=False, raw=True), dev, classmap=True, number_classes=2, onehot=False),
         aug.DeviceAugmenter(rotation_flag=True, reflection_flag=True, jitter_augmentation_severity=0.1, noise_augmentation_severity=0.02,
                             scale_augmentation_severity=0.1, blur_augmentation_max_sigma=2, seed=0, device=dev), 2)
-    net = model.UNet(2, 4, 1, learning_rate=1e-3, seed=0)
+    net = model.UNet(2, 4, 1, learning_rate=1e-3, seed=0, compute_dtype=compute_dtype)
     losses = []
     for _ in range(500):           # BN moving statistics (momentum 0.99) need a few hundred steps before eval mode is meaningful
         x, y = next(pipe)
@@ -45,6 +47,6 @@ def test_learns_real_tiles_with_device_augmentation(tmp_path):
     truth = masks[12:].astype(np.int64)
     acc = (pred == truth).mean()
     inter = ((pred == 1) & (truth == 1)).sum(); union = ((pred == 1) | (truth == 1)).sum()
-    print("held-out pixel accuracy %.4f, IoU %.4f, background fraction %.4f" % (acc, inter / max(union, 1), (truth == 0).mean()))
+    print("%s: held-out pixel accuracy %.4f, IoU %.4f, background fraction %.4f" % (compute_dtype, acc, inter / max(union, 1), (truth == 0).mean()))
     assert acc > max(0.9, (truth == 0).mean() + 0.05), acc
     assert inter / max(union, 1) > 0.6, inter / max(union, 1)
