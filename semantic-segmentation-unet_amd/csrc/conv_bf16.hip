@@ -979,7 +979,6 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // reads still allowed in flight when fa[ks][r] is needed: everything issued after it
-                constexpr int dummy = 0; (void)dummy;
                 const int after = (1 - ks) * (NCO + 4) + (3 - r);
                 if (NCO == 4) {
                     if (after >= 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[ks][r]), "+v"(fb[ks][0]), "+v"(fb[ks][1]), "+v"(fb[ks][2]), "+v"(fb[ks][3]));
