@@ -288,7 +288,33 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_dgrad_kernel(const float* 
     const int nq = Cin >> 2;
     const long total = P * nq;
     const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (K <= 8 && stride % nq == 0 && i < total) {
+        // the grid stride is a multiple of the quads per pixel: a thread keeps its channel quad, so its 4 x K weights live in
+        // registers (the LDS reads of sW, 16 per element at K = 4, were what bounded this kernel, not HBM)
+        const int cq = (int)(i % nq);
+        float wr[4][8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wr[e][k] = k < K ? sW[(4 * cq + e) * K + k] : 0.f;
+        for (; i < total; i += stride) {
+            const long pix = i / nq;
+            float g[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = k < K ? dz[(size_t)pix * lddz + k] : 0.f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < K) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += g[k] * wr[e][k];
+                }
+            *reinterpret_cast<f32x4*>(dx + (size_t)pix * lddx + 4 * cq) = acc;
+        }
+        return;
+    }
+    for (; i < total; i += stride) {
         const long pix = i / nq; const int cq = (int)(i - pix * nq);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < K; ++k) {
