@@ -207,6 +207,64 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const float* 
     }
 }
 
+// the same for 2..4 input channels in ONE pass over dz (the per-channel grid above reads dz once per input channel): a thread keeps
+// 9 x CIN accumulator quads; requires the 4-pixel strip geometry (W % 4 == 0, block ranges multiples of 4)
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_direct_wgrad_multi_kernel(const float* __restrict__ x, int ldx,
+        const float* __restrict__ dz, int lddz, float* __restrict__ part, int N, int H, int W, int Cout, long pix_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sR[];        // [pl][9][Cout]
+    const int tpp = Cout >> 2, npl = 256 / tpp;
+    const int q = threadIdx.x % tpp, pl = threadIdx.x / tpp;
+    const long P = (long)N * H * W;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    long p1 = p0 + pix_per_block; if (p1 > P) p1 = P;
+    f32x4 acc[CIN][9];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long pix = p0 + 4 * pl; pix < p1; pix += 4 * npl) {
+        long t = pix; const int x0 = (int)(t % W); t /= W; const int y = (int)(t % H); const int n = (int)(t / H);
+        f32x4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const f32x4*>(dz + (size_t)(pix + u) * lddz + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int gy = y + r - 1;
+            const bool rok = (unsigned)gy < (unsigned)H;
+            const float* row = x + ((size_t)(n * H + (rok ? gy : y)) * W) * ldx;
+            float v[6][CIN];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int gx = x0 + c - 1;
+                const bool ok = rok && (unsigned)gx < (unsigned)W;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) v[c][ci] = ok ? row[(size_t)gx * ldx + ci] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) acc[ci][3 * r + b] += v[u + b][ci] * g[u];
+        }
+    }
+    // part[blk][tap][ci][co], one input channel at a time through the same LDS tree as the per-channel kernel
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) *reinterpret_cast<f32x4*>(sR + ((size_t)pl * 9 + tap) * Cout + 4 * q) = acc[ci][tap];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 9 * Cout; i += 256) {
+            const int tap = i / Cout, co = i % Cout;
+            float s = 0.f;
+            for (int l = 0; l < npl; ++l) s += sR[((size_t)l * 9 + tap) * Cout + co];
+            part[(((size_t)blockIdx.x * 9 + tap) * CIN + ci) * Cout + co] = s;
+        }
+    }
+}
+
 // one wave per output element: lanes stride over the per-block partials, fixed shuffle tree (deterministic)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nparts) {
     const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -460,7 +518,13 @@ extern "C" int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float*
     const long ppb = ((P + blocks - 1) / blocks + 3) & ~3L;         // multiple of 4: a block's range is whole 4-pixel strips
     const size_t smem = (size_t)(256 / tpp) * 9 * Cout * sizeof(float);
     UNET_CHECK_ARG(smem <= 64 * 1024);
-    conv3x3_direct_wgrad_kernel<<<dim3(blocks, Cin), 256, smem, (hipStream_t)stream>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cin, Cout, ppb);
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin >= 2 && Cin <= 4 && W % 4 == 0) {                       // every block range is whole 4-pixel strips (ppb % 4 == 0, P % 4 == 0)
+        if (Cin == 2)      conv3x3_direct_wgrad_multi_kernel<2><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb);
+        else if (Cin == 3) conv3x3_direct_wgrad_multi_kernel<3><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb);
+        else               conv3x3_direct_wgrad_multi_kernel<4><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb);
+    } else
+        conv3x3_direct_wgrad_kernel<<<dim3(blocks, Cin), 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cin, Cout, ppb);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     const long n = 9L * Cin * Cout;
     sum_partials_kernel<<<unet_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>((const float*)ws, dw, n, blocks);
