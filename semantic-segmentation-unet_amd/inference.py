@@ -84,10 +84,10 @@ def _write(path, mask):
     Image.fromarray(mask).save(path)
 
 
-def inference(checkpoint_filepath, image_folder, output_folder, number_classes, number_channels, image_format):
+def inference(checkpoint_filepath, image_folder, output_folder, number_classes, number_channels, image_format, compute_dtype=None):
     os.makedirs(output_folder, exist_ok=True)
     names = sorted(f for f in os.listdir(image_folder) if f.endswith("." + image_format))
-    unet = unet_model_module.UNet(number_classes, 1, number_channels, 1e-4)
+    unet = unet_model_module.UNet(number_classes, 1, number_channels, 1e-4, compute_dtype=compute_dtype)
     unet.load_checkpoint(checkpoint_filepath)
     for i, name in enumerate(names):
         print("{}/{}".format(i, len(names)))
@@ -111,8 +111,11 @@ def main(argv=None):
     ap.add_argument("--number_classes", dest="number_classes", type=int, required=True)
     ap.add_argument("--number_channels", dest="number_channels", type=int, required=True)
     ap.add_argument("--image_format", dest="image_format", type=str, default="tif")
+    ap.add_argument("--compute_dtype", choices=["fp32", "bf16"], default=None,
+                    help="opt-in extra: bf16 = mixed-precision contractions (fp32 is the reference's arithmetic and the default)")
     a = ap.parse_args(argv)
-    inference(a.checkpoint_filepath, a.image_folder, a.output_folder, a.number_classes, a.number_channels, a.image_format)
+    inference(a.checkpoint_filepath, a.image_folder, a.output_folder, a.number_classes, a.number_channels, a.image_format,
+              compute_dtype=a.compute_dtype)
 
 
 if __name__ == "__main__":
