@@ -106,11 +106,13 @@ int unet_conv3x3_dgrad_bf16_bnstats(const float* dz, int lddz, const void* wpd, 
                                     float* stat_part, size_t stat_bytes, void* stream);
 /* general forms: an operand that only bf16 contractions read may be STORED as bf16 (x_bf16 / dz_bf16 != 0; leading dimension in
  * elements) -- its producer (unet_bn_apply_bf16out, unet_bn_bwd_any) rounds exactly as these kernels' staging would, so the
- * results are bit-identical to fp32 storage; stat_part (and r_prev) nullable */
-int unet_conv3x3_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
+ * results are bit-identical to fp32 storage; stat_part (and r_prev) nullable.  out_bf16 / dx_bf16 / r_bf16: the OUTPUT (resp. the
+ * producer's saved activation) is a bf16 tensor -- the opt-in activation-storage mode (Keras mixed_bfloat16 semantics: activations
+ * bf16, BatchNorm arithmetic fp32), which does change the numbers BatchNorm sees; the fused sums are taken before the rounding */
+int unet_conv3x3_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, void* out, int ldo, int out_bf16,
                              int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
-int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
-                               int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
+                               int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16, int c0, int c1,
                                float* stat_part, size_t stat_bytes, void* stream);
 /* weight gradient in the same arithmetic (both operands rounded to bf16, fp32 accumulation, split partial sums added in a
  * fixed order): dw[a,b,ci,co] = sum xin[n,y+a-1,x+b-1,ci] * dz[n,y,x,co] */

@@ -33,6 +33,7 @@ struct ConvBf16Args {
     int tby, tbx, n_px, n_co;
     unsigned x_bytes;
     int in16;                    // the input tensor is stored as bf16 (ldx in elements): staged without conversion
+    int out16, r16;              // the output / the producer's saved activation (STATS 2) is stored as bf16 (ldo / bn_ldr in elements)
     float* stat_part;            // STATS 1: BatchNorm sums of the output (sum y, sum y^2); STATS 2: BatchNorm-backward sums (sum dx, sum dx * r)
     const float* bn_r; int bn_ldr, bn_c0, bn_c1;     // STATS 2: saved activation of the producer layer, whose dy is dx[..., c0:c1)
 };
@@ -75,15 +76,18 @@ template <> __device__ __forceinline__ void cb_wait_ab<2>(int issued, bf16x8& a,
 // row); group g issues the A fragment of group g + 1 and its share of the next column shift's B fragments, waits for its own
 // (counted: LDS operations retire in order) and runs its MFMAs.
 template <int NCO, int ST, int STAGE_BYTES>
-__device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_base0, unsigned b_base0) {
+__device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_base0, const unsigned (&b_base0)[NCO]) {
     constexpr int CT = 32 * NCO;
     constexpr int AO = 0, BO = 0;                                   // (the stage offset does not fit the 16-bit immediate)
-    const unsigned a_base = a_base0 + ST * STAGE_BYTES, b_base = b_base0 + ST * STAGE_BYTES;
+    const unsigned a_base = a_base0 + ST * STAGE_BYTES;
+    unsigned b_base[NCO];                                           // one base per sub-tile: its columns sit swizzled in the image
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) b_base[c] = b_base0[c] + ST * STAGE_BYTES;
     constexpr int BPG = NCO / 2;                                   // next-shift B reads per group: 3 * NCO over 6 groups
     CbFrags<NCO> fr;
 #pragma unroll
     for (int k = 0; k < 3 * NCO; ++k)
-        CB_RD128(fr.b[0][k / NCO][k % NCO], b_base, BO + (3 * (k / NCO) + 0) * 2 * CT * 16 + (k % NCO) * 512);
+        CB_RD128(fr.b[0][k / NCO][k % NCO], b_base[k % NCO], BO + (3 * (k / NCO) + 0) * 2 * CT * 16);
     CB_RD128(fr.a[0], a_base, AO + 0);
 #pragma unroll
     for (int g = 0; g < 18; ++g) {
@@ -97,7 +101,7 @@ __device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_bas
         if (bs < 2) {
 #pragma unroll
             for (int k = q * BPG; k < (q + 1) * BPG; ++k) {
-                CB_RD128(fr.b[(bs + 1) & 1][k / NCO][k % NCO], b_base, BO + (3 * (k / NCO) + bs + 1) * 2 * CT * 16 + (k % NCO) * 512);
+                CB_RD128(fr.b[(bs + 1) & 1][k / NCO][k % NCO], b_base[k % NCO], BO + (3 * (k / NCO) + bs + 1) * 2 * CT * 16);
                 ++issued;
             }
         }
@@ -158,15 +162,27 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
     const unsigned wr_base = lds0 + (unsigned)((f >> 1) * kPlane + (tid >> 2) * 16 + (f & 1) * 8);
     const unsigned a_base = lds0 + (unsigned)(lh * kPlane + (4 * wv * kPW + li) * 16);
-    const unsigned b_base = lds0 + (unsigned)(kXP + lh * CT * 16 + li * 16);
-
-    // weight pieces wv + 4k of a chunk: piece = 64 channels x 16 B of one (tap, k half); [tap][half][Cout][8] in memory
+    // Sub-tile c of a lane is output channel NCO li + c: a lane's NCO accumulator sub-tiles are NCO consecutive channels and the
+    // epilogue stores them with one instruction per pixel (16 / 8 bytes fp32, 8 / 4 bytes bf16).  The B fragment of sub-tile c
+    // therefore reads column q = NCO j + c in lane j -- a 64- (32-) byte lane stride, 4-way bank conflicts on a linear image --
+    // so column q is kept at slot (q & ~15) + ((q + (q >> 4)) & 15): a rotation inside every aligned group of 16 columns, which
+    // makes the 16 lanes of a ds_read_b128 group hit 16 (NCO = 2: 14) different slots and costs the DMA nothing (its lanes still
+    // read one contiguous 256-byte run).
+    unsigned b_base[NCO];
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+        const int q = NCO * li + c;
+        b_base[c] = lds0 + (unsigned)(kXP + lh * CT * 16 + ((q & ~15) + ((q + (q >> 4)) & 15)) * 16);
+    }
+    // weight pieces wv + 4k of a chunk: piece = 64 columns x 16 B of one (tap, k half); [tap][half][Cout][8] in memory
     unsigned woff[KW];
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         const int id = wv + 4 * k;
         const int row = id / (CT / 64), blk = id % (CT / 64);
-        woff[k] = (unsigned)((row * p.Cout + co0 + 64 * blk) * 16 + lane * 16);
+        const int pos = 64 * blk + lane;                              // slot in the image -> the column stored there
+        const int col = (pos & ~15) + ((pos - (pos >> 4)) & 15);
+        woff[k] = (unsigned)((row * p.Cout + co0 + col) * 16);
     }
     const size_t wchunk = (size_t)18 * p.Cout * 16;
     const char* wsrc = reinterpret_cast<const char*>(p.wp);
@@ -225,69 +241,103 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
-    // epilogue: accumulator register e of (row r, sub-tile c) = pixel (ty0 + 4 wv + r, tx0 + (e&3) + 8 (e>>2) + 4 lh), channel co0 + 32 c + li.
-    // Buffer stores: the 16 per-lane offsets (column, channel lane) are computed once, row / sub-tile go into the scalar offset;
-    // columns past the image edge get an offset the range check drops.
-    float st1[NCO], st2[NCO];
-    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.N * p.H * p.W * p.ldo * 4), 0x00020000);
+    // epilogue: accumulator register e of (row r, sub-tile c) = pixel (ty0 + 4 wv + r, tx0 + (e&3) + 8 (e>>2) + 4 lh), channel
+    // co0 + NCO li + c (see the weight image): one buffer store per pixel and lane.  The 16 per-lane offsets (column, channel
+    // group) are computed once, the row goes into the scalar offset; columns past the image edge get an offset the range check
+    // drops.  out16 / r16: the output / the producer's saved activation is a bf16 tensor (same indexing, 2-byte elements).
+    typedef unsigned ovec_t __attribute__((ext_vector_type(NCO)));
+    typedef unsigned hvec_t __attribute__((ext_vector_type(NCO / 2)));
+    float st1[NCO], st2[NCO], bv[NCO];
+    const int oes = p.out16 ? 2 : 4, res = p.r16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.N * p.H * p.W * p.ldo * oes), 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? p.bn_r : p.out), 0,
-                                                                            STATS == 2 ? (int)((size_t)p.N * p.H * p.W * p.bn_ldr * 4) : 0, 0x00020000);
+                                                                            STATS == 2 ? (int)((size_t)p.N * p.H * p.W * p.bn_ldr * res) : 0, 0x00020000);
+    const int cl = co0 + NCO * li;                                    // this lane's first channel
+    const bool with_r = STATS == 2 && cl >= p.bn_c0 && cl < p.bn_c1;  // (c0, c1 multiples of 64: all NCO channels or none)
     int ovoff[16], rvoff[16];
     bool colok[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
         colok[e] = tx0 + col < p.W;
-        ovoff[e] = colok[e] ? (col * p.ldo + li) * 4 : (int)0x80000000;
-        rvoff[e] = (STATS == 2 && colok[e]) ? (col * p.bn_ldr + li) * 4 : (int)0x80000000;
+        ovoff[e] = colok[e] ? (col * p.ldo + NCO * li) * oes : (int)0x80000000;
+        rvoff[e] = (with_r && colok[e]) ? (col * p.bn_ldr + (cl - p.bn_c0)) * res : (int)0x80000000;
     }
+    const float lo = p.relu ? 0.f : -INFINITY;
 #pragma unroll
-    for (int c = 0; c < NCO; ++c) {
-        const int cb = co0 + 32 * c;
-        const float bv = p.bias ? p.bias[cb + li] : 0.f;
-        const float lo = p.relu ? 0.f : -INFINITY;
-        const bool with_r = STATS == 2 && cb >= p.bn_c0 && cb < p.bn_c1;            // uniform: c0, c1 are multiples of 64
-        st1[c] = 0.f; st2[c] = 0.f;
+    for (int c = 0; c < NCO; ++c) { bv[c] = p.bias ? p.bias[cl + c] : 0.f; st1[c] = 0.f; st2[c] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gy = ty0 + 4 * wv + r;
-            if (gy >= p.H) continue;                                                 // uniform per wave
-            const int pix0 = (img * p.H + gy) * p.W + tx0;
-            const int so = (pix0 * p.ldo + cb) * 4;
-            // STATS 2: the 16 saved-activation values first, all loads in flight together
-            float rv[16];
+    for (int r = 0; r < 4; ++r) {
+        const int gy = ty0 + 4 * wv + r;
+        if (gy >= p.H) continue;                                                     // uniform per wave
+        const int pix0 = (img * p.H + gy) * p.W + tx0;
+        const int so = (pix0 * p.ldo + co0) * oes;
+        // STATS 2: the saved activation in two batches of 8 pixels, each batch's loads in flight together
 #pragma unroll
-            for (int e = 0; e < 16; ++e) rv[e] = 0.f;
-            if (with_r) {
-                const int sr = (pix0 * p.bn_ldr + (cb - p.bn_c0)) * 4;
+        for (int eh = 0; eh < 2; ++eh) {
+            float rv[8][NCO];
+            if (STATS == 2) {
+                const int sr = pix0 * p.bn_ldr * res;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, rvoff[e], sr, 0));
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    if (p.r16) {
+                        hvec_t h;
+                        if constexpr (NCO == 4) h = __builtin_amdgcn_raw_buffer_load_b64(srd_r, rvoff[8 * eh + e8], sr, 0);
+                        else                    h[0] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, rvoff[8 * eh + e8], sr, 0);
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c)
+                            rv[e8][c] = __builtin_bit_cast(float, (c & 1) ? ((unsigned)h[c >> 1] & 0xffff0000u) : ((unsigned)h[c >> 1] << 16));
+                    } else {
+                        ovec_t f;
+                        if constexpr (NCO == 4) f = __builtin_amdgcn_raw_buffer_load_b128(srd_r, rvoff[8 * eh + e8], sr, 0);
+                        else                    f = __builtin_amdgcn_raw_buffer_load_b64(srd_r, rvoff[8 * eh + e8], sr, 0);
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c) rv[e8][c] = __builtin_bit_cast(float, (unsigned)f[c]);
+                    }
+                }
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v;
-                asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[r][c][e]));
-                v = fmaxf(v + bv, lo);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd_o, ovoff[e], so, 0);
-                if (STATS != 0 && colok[e]) { st1[c] += v; st2[c] += STATS == 1 ? v * v : v * rv[e]; }
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int e = 8 * eh + e8;
+                float v[NCO];
+#pragma unroll
+                for (int c = 0; c < NCO; ++c) {
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[r][c][e]));
+                    v[c] = fmaxf(v[c] + bv[c], lo);
+                    if (STATS == 1 && colok[e]) { st1[c] += v[c]; st2[c] += v[c] * v[c]; }
+                    if (STATS == 2 && colok[e]) { st1[c] += v[c]; st2[c] += v[c] * rv[e8][c]; }
+                }
+                if (p.out16) {
+                    hvec_t h;
+#pragma unroll
+                    for (int c = 0; c < NCO; c += 2) h[c >> 1] = cb_pack2(v[c], v[c + 1]);
+                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b64(h, srd_o, ovoff[e], so, 0);
+                    else                    __builtin_amdgcn_raw_buffer_store_b32(h[0], srd_o, ovoff[e], so, 0);
+                } else {
+                    ovec_t ov;
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c) ov[c] = __builtin_bit_cast(unsigned, v[c]);
+                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b128(ov, srd_o, ovoff[e], so, 0);
+                    else                    __builtin_amdgcn_raw_buffer_store_b64(ov, srd_o, ovoff[e], so, 0);
+                }
             }
         }
     }
     if (STATS != 0) {
-        // per-channel sums of this tile: the two half-waves (same channels, different pixels), then the four waves through LDS in a
-        // fixed order -> stat_part[channel / 64][row = pixel tile][channel % 64][2]
+        // per-channel sums of this tile (of the fp32 values, before any rounding of the stored tensor): the two half-waves (same
+        // channels, different pixels), then the four waves through LDS in a fixed order ->
+        // stat_part[channel / 64][row = pixel tile][channel % 64][2]
         float* red = reinterpret_cast<float*>(smem);                  // free: the last chunk ended with a barrier
 #pragma unroll
         for (int c = 0; c < NCO; ++c) {
             st1[c] += __shfl_xor(st1[c], 32); st2[c] += __shfl_xor(st2[c], 32);
-            if (lh == 0) { red[((wv * NCO + c) * 32 + li) * 2] = st1[c]; red[((wv * NCO + c) * 32 + li) * 2 + 1] = st2[c]; }
+            if (lh == 0) { red[((wv * 32 + li) * NCO + c) * 2] = st1[c]; red[((wv * 32 + li) * NCO + c) * 2 + 1] = st2[c]; }
         }
         __syncthreads();
-        if (tid < CT) {
-            const int c = tid >> 5, l = tid & 31;
+        if (tid < CT) {                                               // tid = channel within the tile = NCO * lane + c
             float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) { a += red[((w4 * NCO + c) * 32 + l) * 2]; b += red[((w4 * NCO + c) * 32 + l) * 2 + 1]; }
+            for (int w4 = 0; w4 < 4; ++w4) { a += red[(w4 * CT + tid) * 2]; b += red[(w4 * CT + tid) * 2 + 1]; }
             const int ch = co0 + tid, row = t % p.n_px;
             float* o = p.stat_part + (((size_t)(ch >> 6) * p.n_px + row) * 64 + (ch & 63)) * 2;
             o[0] = a; o[1] = b;
@@ -330,12 +380,13 @@ int conv_bf16_cus() {
     return cus;
 }
 
-struct ConvBf16Stats { int mode; float* part; size_t bytes; const float* r; int ldr, c0, c1; };
+struct ConvBf16Stats { int mode; float* part; size_t bytes; const float* r; int ldr, c0, c1, r16; };
 
 int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
-                  int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st, const ConvBf16Stats* stats = nullptr, int in16 = 0) {
+                  int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st, const ConvBf16Stats* stats = nullptr, int in16 = 0,
+                  int out16 = 0) {
     ConvBf16Args a{};
-    a.in16 = in16;
+    a.in16 = in16; a.out16 = out16; a.r16 = stats ? stats->r16 : 0;
     a.x = x; a.wp = (const uint16_t*)wp; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.tby = (H + 15) / 16; a.tbx = (W + 31) / 32; a.n_px = N * a.tby * a.tbx;
@@ -392,7 +443,7 @@ extern "C" int unet_conv3x3_fwd_bf16_stats(const float* x, int ldx, const void* 
     UNET_CHECK_ARG(x && wp && out && stat_part && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
     UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * ldo * 4 < ((size_t)1 << 31));
-    const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0};
+    const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0, 0};
     return run_conv_bf16(x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream, &s);
 }
 
@@ -405,7 +456,7 @@ extern "C" int unet_conv3x3_dgrad_bf16_bnstats(const float* dz, int lddz, const 
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
     UNET_CHECK_ARG(c0 >= 0 && c0 < c1 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0);
     UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
-    const ConvBf16Stats s{2, stat_part, stat_bytes, r_prev, ldr, c0, c1};
+    const ConvBf16Stats s{2, stat_part, stat_bytes, r_prev, ldr, c0, c1, 0};
     return run_conv_bf16(dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream, &s);
 }
 
@@ -835,19 +886,20 @@ extern "C" int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* d
 }
 
 // forward with every option: x_bf16 (input stored as bf16, ldx in elements), stat_part nullable (BatchNorm sums as in _stats)
-extern "C" int unet_conv3x3_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
+extern "C" int unet_conv3x3_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, void* out, int ldo, int out_bf16,
                                         int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(x && wp && out && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
     UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * ldo * 4 < ((size_t)1 << 31));
     UNET_CHECK_ARG(!x_bf16 || ldx % 8 == 0);
-    const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0};
-    return run_conv_bf16((const float*)x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream, stat_part ? &s : nullptr, x_bf16 ? 1 : 0);
+    const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0, 0};
+    return run_conv_bf16((const float*)x, ldx, wp, bias, (float*)out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream, stat_part ? &s : nullptr,
+                         x_bf16 ? 1 : 0, out_bf16 ? 1 : 0);
 }
 
 // data gradient with every option: dz_bf16 (dz stored as bf16), r_prev / stat_part nullable (producer's BatchNorm-backward sums)
-extern "C" int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
-                                          int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+extern "C" int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
+                                          int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16, int c0, int c1,
                                           float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(dz && wpd && dx && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
@@ -855,8 +907,9 @@ extern "C" int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16,
     UNET_CHECK_ARG(!r_prev || (c0 >= 0 && c0 < c1 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0));
     UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
     UNET_CHECK_ARG(!dz_bf16 || lddz % 8 == 0);
-    const ConvBf16Stats s{2, stat_part, stat_bytes, r_prev, ldr, c0, c1};
-    return run_conv_bf16((const float*)dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream, r_prev ? &s : nullptr, dz_bf16 ? 1 : 0);
+    const ConvBf16Stats s{2, stat_part, stat_bytes, (const float*)r_prev, ldr, c0, c1, r_bf16 ? 1 : 0};
+    return run_conv_bf16((const float*)dz, lddz, wpd, nullptr, (float*)dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream, r_prev ? &s : nullptr,
+                         dz_bf16 ? 1 : 0, dx_bf16 ? 1 : 0);
 }
 
 // ---- 2x2 / stride-2 transposed convolution on the bf16 matrix cores (forward and data gradient) -----------------------------------

@@ -378,7 +378,7 @@ class Engine:
                 stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
                 self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16_ex,
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout,
-                            n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+                            int(r.dtype == torch.bfloat16), n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:
                     fused_stats = (stat_part, rows)
             elif self._use_fused(name, h, w):
@@ -670,13 +670,13 @@ class Engine:
                     r_prev = self.saved[pname][1]
                     part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
                     self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16_ex,
-                                _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
-                                _p(r_prev), r_prev.shape[-1], c0, c1, _p(part), part.numel() * 4, st)
+                                _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx.dtype == torch.bfloat16), n, ho, wo, cin, cout,
+                                _p(r_prev), r_prev.shape[-1], int(r_prev.dtype == torch.bfloat16), c0, c1, _p(part), part.numel() * 4, st)
                     self.bnbwd_part[pname] = (part, rows, c0)
                 else:
                     self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16_ex,
-                                _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
-                                None, 0, 0, 0, None, 0, st)
+                                _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx.dtype == torch.bfloat16), n, ho, wo, cin, cout,
+                                None, 0, 0, 0, 0, None, 0, st)
             elif self._use_fused(name, ho, wo, dgrad=True):
                 prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
                 rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, ho, wo, cout, cin) if prod else 0

@@ -777,12 +777,12 @@ def test_bf16_stored_operands_bit_identical(hip):
     hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wp), ci, co, 0, ST())
     hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wpd), ci, co, 1, ST())
     y0 = torch.empty(n, h, w, co, device=DEV); y1 = torch.empty_like(y0)
-    hip.unet_conv3x3_fwd_bf16_ex(P(x), ci, 0, P(wp), P(b), P(y0), co, n, h, w, ci, co, 1, None, 0, ST())
-    hip.unet_conv3x3_fwd_bf16_ex(P(x16), ci, 1, P(wp), P(b), P(y1), co, n, h, w, ci, co, 1, None, 0, ST())
+    hip.unet_conv3x3_fwd_bf16_ex(P(x), ci, 0, P(wp), P(b), P(y0), co, 0, n, h, w, ci, co, 1, None, 0, ST())
+    hip.unet_conv3x3_fwd_bf16_ex(P(x16), ci, 1, P(wp), P(b), P(y1), co, 0, n, h, w, ci, co, 1, None, 0, ST())
     assert torch.equal(y0, y1)
     d0 = torch.empty(n, h, w, ci, device=DEV); d1 = torch.empty_like(d0)
-    hip.unet_conv3x3_dgrad_bf16_ex(P(dz), co, 0, P(wpd), P(d0), ci, n, h, w, ci, co, None, 0, 0, 0, None, 0, ST())
-    hip.unet_conv3x3_dgrad_bf16_ex(P(dz16), co, 1, P(wpd), P(d1), ci, n, h, w, ci, co, None, 0, 0, 0, None, 0, ST())
+    hip.unet_conv3x3_dgrad_bf16_ex(P(dz), co, 0, P(wpd), P(d0), ci, 0, n, h, w, ci, co, None, 0, 0, 0, 0, None, 0, ST())
+    hip.unet_conv3x3_dgrad_bf16_ex(P(dz16), co, 1, P(wpd), P(d1), ci, 0, n, h, w, ci, co, None, 0, 0, 0, 0, None, 0, ST())
     assert torch.equal(d0, d1)
     nbw = hip.unet_conv3x3_wgrad_bf16_workspace(n, h, w, ci, co)
     ws = ws_bytes(nbw)
@@ -907,3 +907,34 @@ def test_bf16_pack_weights_batch_matches_single_packs(hip):
     hip.unet_bf16_pack_weights_batch(P(jobs), len(rows), blk, ST())
     for w, a, b, a0, b0, nb in keep:
         assert torch.equal(a[:nb], a0[:nb]) and torch.equal(b[:nb], b0[:nb])
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 40, 128, 64), (1, 16, 32, 64, 128)])
+def test_conv3x3_bf16_output_storage_is_the_rounded_fp32_output(hip, shape):
+    # activation-storage mode: the forward / data-gradient kernels can store their OUTPUT as bf16 and read the producer's saved
+    # activation (for the fused BatchNorm-backward sums) as bf16.  The stored tensor must be exactly the rounded fp32 output, and
+    # the sums -- taken before the rounding -- must be bit-equal to those of the fp32-output call.
+    n, h, w, ci, co = shape
+    g = torch.Generator(device=DEV); g.manual_seed(co + h)
+    x = torch.randn(n, h, w, ci, device=DEV, generator=g); dz = torch.randn(n, h, w, co, device=DEV, generator=g)
+    wt = torch.randn(3, 3, ci, co, device=DEV, generator=g) / (3 * ci ** 0.5); b = torch.randn(co, device=DEV, generator=g)
+    nb = hip.unet_conv3x3_bf16_packed_bytes(ci, co)
+    wp, wpd = ws_bytes(nb), ws_bytes(nb)
+    hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wp), ci, co, 0, ST())
+    hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wpd), ci, co, 1, ST())
+    rows = hip.unet_conv3x3_bf16_stats_rows(n, h, w, ci, co)
+    p0 = torch.empty((co // 64) * rows * 128, device=DEV); p1 = torch.empty_like(p0)
+    y32 = torch.empty(n, h, w, co, device=DEV); y16 = torch.full((n, h, w, co + 8), float("nan"), device=DEV, dtype=torch.bfloat16)
+    hip.unet_conv3x3_fwd_bf16_ex(P(x), ci, 0, P(wp), P(b), P(y32), co, 0, n, h, w, ci, co, 1, P(p0), p0.numel() * 4, ST())
+    hip.unet_conv3x3_fwd_bf16_ex(P(x), ci, 0, P(wp), P(b), P(y16), co + 8, 1, n, h, w, ci, co, 1, P(p1), p1.numel() * 4, ST())
+    assert torch.equal(y32.to(torch.bfloat16), y16[..., :co]) and torch.isnan(y16[..., co:].float()).all()
+    assert torch.equal(p0, p1)
+    r32 = torch.randn(n, h, w, ci, device=DEV, generator=g).to(torch.bfloat16).float()      # bf16-representable values
+    r16 = r32.to(torch.bfloat16)
+    rows2 = hip.unet_conv3x3_bf16_stats_rows(n, h, w, co, ci)
+    q0 = torch.empty((ci // 64) * rows2 * 128, device=DEV); q1 = torch.empty_like(q0)
+    d32 = torch.empty(n, h, w, ci, device=DEV); d16 = torch.empty(n, h, w, ci, device=DEV, dtype=torch.bfloat16)
+    hip.unet_conv3x3_dgrad_bf16_ex(P(dz), co, 0, P(wpd), P(d32), ci, 0, n, h, w, ci, co, P(r32), ci, 0, 0, ci, P(q0), q0.numel() * 4, ST())
+    hip.unet_conv3x3_dgrad_bf16_ex(P(dz), co, 0, P(wpd), P(d16), ci, 1, n, h, w, ci, co, P(r16), ci, 1, 0, ci, P(q1), q1.numel() * 4, ST())
+    assert torch.equal(d32.to(torch.bfloat16), d16)
+    assert torch.equal(q0, q1)
