@@ -223,10 +223,14 @@ int unet_bn_bwd_pooled(const float* dy_skip, int lddy, const float* pooled_dy, i
                        const float* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
                        float* dz, int lddz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, void* stream);
 /* all three forms in one call (pooled_dy/idx nullable, part_sums nullable), dz optionally stored as bf16 (dz_bf16 != 0) */
-int unet_bn_bwd_any(const float* dy, int lddy, const float* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
-                    const float* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
+int unet_bn_bwd_any(const void* dy, int lddy, const void* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
+                    const void* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
                     void* dz, int lddz, int dz_bf16, float* dgamma, float* dbeta, float* dbias, const float* part_sums, int rows,
-                    void* ws, size_t ws_bytes, void* stream);
+                    void* ws, size_t ws_bytes, void* stream, int r_bf16, int dy_bf16, int pooled_dy_bf16);
+/* BatchNorm apply (+ the 2x2 max pool when pooled / idx are given) with the conv output it reads (r_bf16) and / or what it writes
+ * (y_bf16: y and pooled) stored as bf16 */
+int unet_bn_apply_any(const void* r, int ldr, int r_bf16, const float* scale, const float* shift, void* y, int ldy, int y_bf16,
+                      void* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int unet_bn_bwd_from_partials(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
                               const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,
                               float* dbias, const float* part_sums, int rows, void* ws, size_t ws_bytes, void* stream);

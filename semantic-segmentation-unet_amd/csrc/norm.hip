@@ -14,6 +14,18 @@ template <int VEC> __device__ __forceinline__ void vload(float (&v)[VEC], const 
     if constexpr (VEC == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
     else v[0] = *p;
 }
+// load from an fp32 tensor or (in16, VEC == 4) from a bf16 tensor of the same logical layout (element index idx)
+template <int VEC> __device__ __forceinline__ void vload_dt(float (&v)[VEC], const float* base, size_t idx, int in16) {
+    if constexpr (VEC == 4) {
+        if (in16) {
+            const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+            v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+            v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+            return;
+        }
+    }
+    vload<VEC>(v, base + idx);
+}
 template <int VEC> __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
     if constexpr (VEC == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
     else *p = v[0];
@@ -40,7 +52,7 @@ template <int VEC> __device__ __forceinline__ Lay make_lay(int C, int tpp) {
 // Optional second gradient source for the BatchNorm-backward kernels: the layer's output also went through MaxPool2D(2)
 // (encoder levels, UNet/model.py:50-53,89-91), so dy(pixel) = dy_skip(pixel) + [pixel is its window's first max] * pooled_dy.
 // Reading it here saves the separate pool-backward pass that would read-modify-write the whole skip gradient.
-struct PoolGrad { const float* pdy; int ldp; const uint8_t* idx; int H, W, C; };
+struct PoolGrad { const float* pdy; int ldp; const uint8_t* idx; int H, W, C; int p16; };
 
 template <int VEC> __device__ __forceinline__ void add_pool_grad(float (&g)[VEC], const PoolGrad& pg, long pix, int c0) {
     if (!pg.pdy) return;
@@ -48,7 +60,7 @@ template <int VEC> __device__ __forceinline__ void add_pool_grad(float (&g)[VEC]
     const long opix = (n * (pg.H >> 1) + (y >> 1)) * (pg.W >> 1) + (x >> 1);
     const int pos = ((y & 1) << 1) | (x & 1);
     float q[VEC];
-    vload<VEC>(q, pg.pdy + (size_t)opix * pg.ldp + c0);
+    vload_dt<VEC>(q, pg.pdy, (size_t)opix * pg.ldp + c0, pg.p16);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) if (pg.idx[(size_t)opix * pg.C + c0 + e] == pos) g[e] += q[e];
 }
@@ -198,10 +210,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const long pix = i / nq; const int c0 = (int)(i - pix * nq) * VEC;
         float v[VEC], a[VEC], b[VEC];
-        vload<VEC>(v, r + (size_t)pix * ldr + c0); vload<VEC>(a, scale + c0); vload<VEC>(b, shift + c0);
+        vload_dt<VEC>(v, r, (size_t)pix * ldr + c0, out16 & 2); vload<VEC>(a, scale + c0); vload<VEC>(b, shift + c0);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[e] = fmaf(a[e], v[e], b[e]);
-        vstore_dt<VEC>(y, (size_t)pix * ldy + c0, v, out16);
+        vstore_dt<VEC>(y, (size_t)pix * ldy + c0, v, out16 & 1);
     }
 }
 
@@ -223,15 +235,15 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
         for (int pos = 0; pos < 4; ++pos) {
             const size_t pix = (size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1);
             float v[4];
-            vload<4>(v, r + pix * ldr + 4 * cq);
+            vload_dt<4>(v, r, pix * ldr + 4 * cq, out16 & 2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[e] = fmaf(a[e], v[e], b[e]);
                 if (pos == 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)pos; }
             }
-            vstore_dt<4>(y, pix * ldy + 4 * cq, v, out16);
+            vstore_dt<4>(y, pix * ldy + 4 * cq, v, out16 & 1);
         }
-        vstore_dt<4>(pooled, (size_t)opix * ldp + 4 * cq, best, out16);
+        vstore_dt<4>(pooled, (size_t)opix * ldp + 4 * cq, best, out16 & 1);
         *reinterpret_cast<uint32_t*>(idx + (size_t)opix * C + 4 * cq) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     }
 }
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
         int ldr, const float* __restrict__ mean, const float* __restrict__ invstd, long P, int C, int tpp, long ppb,
-        double* __restrict__ part, PoolGrad pg) {
+        double* __restrict__ part, PoolGrad pg, int dt) {
     extern __shared__ __attribute__((aligned(16))) double sRd[];
     const Lay l = make_lay<VEC>(C, tpp);
     const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P) p1 = P;
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             float g[4][VEC], v[4][VEC];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                vload<VEC>(g[u], dy + (size_t)(pix + u * st) * lddy + l.c0); vload<VEC>(v[u], r + (size_t)(pix + u * st) * ldr + l.c0);
+                vload_dt<VEC>(g[u], dy, (size_t)(pix + u * st) * lddy + l.c0, dt & 4); vload_dt<VEC>(v[u], r, (size_t)(pix + u * st) * ldr + l.c0, dt & 2);
                 add_pool_grad<VEC>(g[u], pg, pix + u * st, l.c0);
             }
 #pragma unroll
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         }
         for (; pix < p1; pix += st) {
             float g[VEC], v[VEC];
-            vload<VEC>(g, dy + (size_t)pix * lddy + l.c0); vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
+            vload_dt<VEC>(g, dy, (size_t)pix * lddy + l.c0, dt & 4); vload_dt<VEC>(v, r, (size_t)pix * ldr + l.c0, dt & 2);
             add_pool_grad<VEC>(g, pg, pix, l.c0);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -293,7 +305,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
         int ldr, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
         const float* __restrict__ dgamma, const float* __restrict__ dbeta, long P, int C, int tpp, long ppb, int relu,
-        float* __restrict__ dz, int lddz, double* __restrict__ part, PoolGrad pg, int dz16) {
+        float* __restrict__ dz, int lddz, double* __restrict__ part, PoolGrad pg, int dt) {
     extern __shared__ __attribute__((aligned(16))) double sRd[];
     const Lay l = make_lay<VEC>(C, tpp);
     const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P) p1 = P;
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             float g[4][VEC], v[4][VEC];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                vload<VEC>(g[u], dy + (size_t)(pix + u * st) * lddy + l.c0); vload<VEC>(v[u], r + (size_t)(pix + u * st) * ldr + l.c0);
+                vload_dt<VEC>(g[u], dy, (size_t)(pix + u * st) * lddy + l.c0, dt & 4); vload_dt<VEC>(v[u], r, (size_t)(pix + u * st) * ldr + l.c0, dt & 2);
                 add_pool_grad<VEC>(g[u], pg, pix + u * st, l.c0);
             }
 #pragma unroll
@@ -327,12 +339,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                     if (relu && !(v[u][e] > 0.f)) d = 0.f;
                     o[e] = d; acc[0][e] += (double)d;
                 }
-                vstore_dt<VEC>(dz, (size_t)(pix + u * st) * lddz + l.c0, o, dz16);
+                vstore_dt<VEC>(dz, (size_t)(pix + u * st) * lddz + l.c0, o, dt & 1);
             }
         }
         for (; pix < p1; pix += st) {
             float g[VEC], v[VEC], o[VEC];
-            vload<VEC>(g, dy + (size_t)pix * lddy + l.c0); vload<VEC>(v, r + (size_t)pix * ldr + l.c0);
+            vload_dt<VEC>(g, dy, (size_t)pix * lddy + l.c0, dt & 4); vload_dt<VEC>(v, r, (size_t)pix * ldr + l.c0, dt & 2);
             add_pool_grad<VEC>(g, pg, pix, l.c0);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 if (relu && !(v[e] > 0.f)) d = 0.f;
                 o[e] = d; acc[0][e] += (double)d;
             }
-            vstore_dt<VEC>(dz, (size_t)pix * lddz + l.c0, o, dz16);
+            vstore_dt<VEC>(dz, (size_t)pix * lddz + l.c0, o, dt & 1);
         }
     }
     block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
@@ -464,7 +476,8 @@ extern "C" int unet_bn_apply_maxpool_bf16out(const float* r, int ldr, const floa
 
 static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
         const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta, float* dbias,
-        const float* part_sums, int rows, PoolGrad pg, void* ws, size_t ws_bytes, void* stream, int dz16 = 0) {
+        const float* part_sums, int rows, PoolGrad pg, void* ws, size_t ws_bytes, void* stream, int dt = 0) {
+    // dt: bit 0 = dz stored as bf16, bit 1 = r stored as bf16, bit 2 = dy stored as bf16 (leading dimensions in elements)
     UNET_CHECK_ARG(dy && r && gamma && mean && invstd && dz && dgamma && dbeta && dbias && ws && P > 0 && C > 0);
     UNET_CHECK_ARG(lddy >= C && ldr >= C && lddz >= C);
     Plan pl;
@@ -478,15 +491,15 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     if (part_sums) {
         bn_bwd_finalize_partials_kernel<<<C, 256, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
     } else {
-        if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg);
-        else             bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg);
+        if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, dt);
+        else             bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, 0);
         rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
         bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(part, pl.nblk, C, dgamma, dbeta);
     }
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     double* part2 = part + (size_t)2 * pl.nblk * C;
-    if (dz16 && pl.vec != 4) return UNET_EINVAL;
-    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, dz16);
+    if ((dt || pg.p16) && pl.vec != 4) return UNET_EINVAL;
+    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, dt);
     else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, 0);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     colsum_finalize_kernel<<<C, 64, 0, st>>>(part2, pl.nblk, C, dbias);
@@ -497,7 +510,7 @@ extern "C" int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, c
         const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta, float* dbias,
         void* ws, size_t ws_bytes, void* stream) {
     return bn_bwd_launch(dy, lddy, r, ldr, gamma, mean, invstd, P, C, relu, dz, lddz, dgamma, dbeta, dbias, nullptr, 0,
-                         PoolGrad{nullptr, 0, nullptr, 0, 0, 0}, ws, ws_bytes, stream);
+                         PoolGrad{nullptr, 0, nullptr, 0, 0, 0, 0}, ws, ws_bytes, stream);
 }
 
 // unet_bn_bwd for a layer whose output also feeds MaxPool2D(2): the gradient is dy_skip + unpool(pooled_dy) (first-max indices
@@ -507,7 +520,7 @@ extern "C" int unet_bn_bwd_pooled(const float* dy_skip, int lddy, const float* p
         float* dz, int lddz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(pooled_dy && idx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ldp >= C);
     return bn_bwd_launch(dy_skip, lddy, r, ldr, gamma, mean, invstd, (long)N * H * W, C, relu, dz, lddz, dgamma, dbeta, dbias, nullptr, 0,
-                         PoolGrad{pooled_dy, ldp, idx, H, W, C}, ws, ws_bytes, stream);
+                         PoolGrad{pooled_dy, ldp, idx, H, W, C, 0}, ws, ws_bytes, stream);
 }
 
 // unet_bn_bwd with the reduction pass replaced by the partial sums of a fused data-gradient kernel
@@ -517,20 +530,41 @@ extern "C" int unet_bn_bwd_from_partials(const float* dy, int lddy, const float*
         const float* part_sums, int rows, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(part_sums && rows > 0 && C % 64 == 0);
     return bn_bwd_launch(dy, lddy, r, ldr, gamma, mean, invstd, P, C, relu, dz, lddz, dgamma, dbeta, dbias, part_sums, rows,
-                         PoolGrad{nullptr, 0, nullptr, 0, 0, 0}, ws, ws_bytes, stream);
+                         PoolGrad{nullptr, 0, nullptr, 0, 0, 0, 0}, ws, ws_bytes, stream);
 }
 
 // All three forms of the BatchNorm backward in one call, with the choice of storing dz as bf16 (dz_bf16 != 0: `dz` is a bf16
 // tensor [P][lddz]; its consumers are the bf16 data / weight gradient kernels, which would round the fp32 values the same way):
 // pooled_dy / idx nullable (unet_bn_bwd_pooled when given), part_sums nullable (unet_bn_bwd_from_partials when given).
-extern "C" int unet_bn_bwd_any(const float* dy, int lddy, const float* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
-        const float* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
+extern "C" int unet_bn_bwd_any(const void* dy, int lddy, const void* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
+        const void* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
         void* dz, int lddz, int dz_bf16, float* dgamma, float* dbeta, float* dbias, const float* part_sums, int rows,
-        void* ws, size_t ws_bytes, void* stream) {
+        void* ws, size_t ws_bytes, void* stream, int r_bf16, int dy_bf16, int pooled_dy_bf16) {
     UNET_CHECK_ARG(N > 0 && H > 0 && W > 0 && (pooled_dy == nullptr) == (idx == nullptr));
     UNET_CHECK_ARG(!pooled_dy || (H % 2 == 0 && W % 2 == 0 && ldp >= C));
     UNET_CHECK_ARG(!part_sums || (rows > 0 && C % 64 == 0));
-    const PoolGrad pg = pooled_dy ? PoolGrad{pooled_dy, ldp, idx, H, W, C} : PoolGrad{nullptr, 0, nullptr, 0, 0, 0};
-    return bn_bwd_launch(dy, lddy, r, ldr, gamma, mean, invstd, (long)N * H * W, C, relu, (float*)dz, lddz, dgamma, dbeta, dbias,
-                         part_sums, part_sums ? rows : 0, pg, ws, ws_bytes, stream, dz_bf16 ? 1 : 0);
+    const PoolGrad pg = pooled_dy ? PoolGrad{(const float*)pooled_dy, ldp, idx, H, W, C, pooled_dy_bf16 ? 1 : 0} : PoolGrad{nullptr, 0, nullptr, 0, 0, 0, 0};
+    return bn_bwd_launch((const float*)dy, lddy, (const float*)r, ldr, gamma, mean, invstd, (long)N * H * W, C, relu, (float*)dz, lddz, dgamma, dbeta, dbias,
+                         part_sums, part_sums ? rows : 0, pg, ws, ws_bytes, stream, (dz_bf16 ? 1 : 0) | (r_bf16 ? 2 : 0) | (dy_bf16 ? 4 : 0));
+}
+
+// BatchNorm apply (+ optional 2x2 max pool: pooled / idx non-null) with either side stored as bf16: r_bf16 (the conv output it
+// reads), y_bf16 (what it writes, y and pooled alike)
+extern "C" int unet_bn_apply_any(const void* r, int ldr, int r_bf16, const float* scale, const float* shift, void* y, int ldy, int y_bf16,
+                                 void* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    UNET_CHECK_ARG(r && scale && shift && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldr >= C && ldy >= C && ldr % 4 == 0 && ldy % 4 == 0);
+    UNET_CHECK_ARG(unet_aligned16(r) && unet_aligned16(y) && unet_aligned16(scale) && unet_aligned16(shift) && (pooled == nullptr) == (idx == nullptr));
+    const int flags = (y_bf16 ? 1 : 0) | (r_bf16 ? 2 : 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (pooled) {
+        UNET_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && ldp >= C && ldp % 4 == 0 && unet_aligned16(pooled) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0);
+        const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+        long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+        bn_apply_pool_kernel<<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, (float*)pooled, ldp, idx, N, H, W, C, flags);
+    } else {
+        const long P = (long)N * H * W, total = P * (C / 4);
+        long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+        bn_apply_kernel<4><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, P, C, flags);
+    }
+    return UNET_LAUNCH_STATUS();
 }

@@ -161,6 +161,9 @@ class Engine:
         # results are bit-identical to fp32 storage (tests assert that); only the bytes moved change.
         self.bf16_storage = os.environ.get("UNET_BF16_STORAGE", "1") != "0"
         self.bf16_storage_cat = os.environ.get("UNET_BF16_STORAGE_CAT", "1") != "0"    # ... the concat / pooled tensors too (A/B switch)
+        # opt-in: ALSO keep the 3x3 layers' conv outputs r (what BatchNorm reads) as bf16 in training -- the Keras mixed_bfloat16
+        # convention (bf16 activations, fp32 BatchNorm arithmetic).  Unlike the storage above this changes what BatchNorm sees.
+        self.bf16_activations = os.environ.get("UNET_BF16_ACTIVATIONS", "0") == "1"
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -376,6 +379,9 @@ class Engine:
                 self.saved_V[name] = None
                 rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
                 stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
+                # (dec_2b..4b: their saved activation is read by the transposed-conv data gradient's epilogue, which takes fp32)
+                if self.bf16_activations and self.bf16_storage and rows > 0 and name not in ("dec_2b", "dec_3b", "dec_4b"):
+                    r = self._buf("r16_" + name, (n, h, w, cout), torch.bfloat16)
                 self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16_ex,
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout,
                             int(r.dtype == torch.bfloat16), n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
@@ -430,7 +436,11 @@ class Engine:
                                   _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(ws), nb, st)
         else:
             L.unet_bn_eval_coeffs(_p(gm), _p(bt), _p(mm), _p(mv), BN_EPS, cout, _p(s[2]), _p(s[3]), st)
-        if pool is not None and y_out.dtype == torch.bfloat16:
+        if r.dtype == torch.bfloat16:
+            L.unet_bn_apply_any(_p(r), cout, 1, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), int(y_out.dtype == torch.bfloat16),
+                                _p(pool[0]) if pool is not None else None, cout, _p(pool[1]) if pool is not None else None,
+                                r.shape[0], r.shape[1], r.shape[2], cout, st)
+        elif pool is not None and y_out.dtype == torch.bfloat16:
             L.unet_bn_apply_maxpool_bf16out(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
                                             r.shape[0], r.shape[1], r.shape[2], cout, st)
         elif pool is not None:         # (pooled, idx): BN apply and the level's max pool in one pass
@@ -567,7 +577,8 @@ class Engine:
             L.unet_bn_bwd_any(_p(dy), _ld(dy), _p(pdy), _ld(pdy) if pdy is not None else 0, _p(pidx), n, ho, wo, _p(r), cout,
                               _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 0 if kind == "deconv" else 1, _p(dz), cout, 1,
                               _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]), _p(self.g[name + "/bias"]), part_ptr, rows,
-                              _p(ws), nb, st)
+                              _p(ws), nb, st, int(r.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16),
+                              int(pdy is not None and pdy.dtype == torch.bfloat16))
         elif eval_mode:
             L.unet_bn_eval_bwd(_p(dy), _ld(dy), _p(r), cout, _p(s[2]), _p(dz), cout, P, cout, 0 if kind == "deconv" else 1, st)
         elif pre is not None:

@@ -808,7 +808,7 @@ def test_bf16_stored_operands_bit_identical(hip):
     gr = [torch.empty(co, device=DEV) for _ in range(6)]
     hip.unet_bn_bwd(P(dy), co, P(r), co, P(gm), P(mean), P(invstd), n * h * w, co, 1, P(zf_), co, P(gr[0]), P(gr[1]), P(gr[2]), P(wsb), nbb, ST())
     hip.unet_bn_bwd_any(P(dy), co, None, 0, None, n, h, w, P(r), co, P(gm), P(mean), P(invstd), co, 1, P(zh), co, 1,
-                        P(gr[3]), P(gr[4]), P(gr[5]), None, 0, P(wsb), nbb, ST())
+                        P(gr[3]), P(gr[4]), P(gr[5]), None, 0, P(wsb), nbb, ST(), 0, 0, 0)
     assert torch.equal(zf_.to(torch.bfloat16), zh)
     assert all(torch.equal(gr[i], gr[i + 3]) for i in range(3))
 
