@@ -186,11 +186,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs p) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
-        for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
+// fixed-order sum of the split partials; SL slices of the split range per output so that few outputs x many splits still fill
+// the chip (see wino_partial_reduce_kernel)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits, int sl) {
+    __shared__ f32x4 part[256];
+    const int per = 256 / sl;
+    const int o = threadIdx.x % per, sj = threadIdx.x / per;
+    const long i = (long)blockIdx.x * per + o;
+    const int k0 = (int)((long)splits * sj / sl), k1 = (int)((long)splits * (sj + 1) / sl);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int k = k0; k < k1; ++k) s += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
+    if (sl == 1) { if (i < n4) reinterpret_cast<f32x4*>(dw)[i] = s; return; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (sj == 0 && i < n4) {
+        for (int j = 1; j < sl; ++j) s += part[j * per + o];
         reinterpret_cast<f32x4*>(dw)[i] = s;
     }
 }
@@ -220,9 +231,9 @@ int run_wgrad(const float* a, int lda, int Ha, int Wa, const float* b, int ldb, 
     int rc = UNET_LAUNCH_STATUS();
     if (rc) return rc;
     const long n4 = (long)(E / 4);
-    int blocks = unet_cdiv(n4, 256);
-    if (blocks > 2048) blocks = 2048;
-    wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(ws, dw, n4, p.splits);
+    int sl = 1;
+    while (sl < 16 && 2 * sl <= p.splits && n4 * sl < 256 * 1024) sl *= 2;
+    wgrad_reduce_kernel<<<(unsigned)((n4 * sl + 255) / 256), 256, 0, st>>>(ws, dw, n4, p.splits, sl);
     return UNET_LAUNCH_STATUS();
 }
 

@@ -1148,12 +1148,25 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
     }
 }
 
-__global__ void wino_partial_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4 sacc = reinterpret_cast<const f32x4*>(ws)[i];
-        for (int k = 1; k < splits; ++k) sacc += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
-        reinterpret_cast<f32x4*>(dw)[i] = sacc;
+// dw = sum over the split partials in a fixed order: a block covers 256/SL consecutive float4 outputs x SL slices of the split
+// range (SL a power of two <= 16, chosen on the host so that a small weight tensor with many splits -- 64 x 64 channels, 256
+// splits: 36 blocks of serial 256-term sums before -- still fills the chip); each thread sums its slice front to back, the
+// first thread of an output adds the slice sums front to back.
+__global__ __launch_bounds__(256) void wino_partial_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits, int sl) {
+    __shared__ f32x4 part[256];
+    const int per = 256 / sl;
+    const int o = threadIdx.x % per, sj = threadIdx.x / per;
+    const long i = (long)blockIdx.x * per + o;
+    const int k0 = (int)((long)splits * sj / sl), k1 = (int)((long)splits * (sj + 1) / sl);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int k = k0; k < k1; ++k) s += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
+    if (sl == 1) { if (i < n4) reinterpret_cast<f32x4*>(dw)[i] = s; return; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (sj == 0 && i < n4) {
+        for (int j = 1; j < sl; ++j) s += part[j * per + o];
+        reinterpret_cast<f32x4*>(dw)[i] = s;
     }
 }
 
@@ -1310,7 +1323,9 @@ extern "C" int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, cons
     wino_wgrad_fused_kernel<<<dim3((unsigned)(a.mt * a.nt * a.splits)), 256, 0, st>>>(a);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     const long n4 = 9L * Cin * Cout / 4;
-    wino_partial_reduce_kernel<<<grid_for(n4, 2048), 256, 0, st>>>((const float*)ws, dw, n4, a.splits);
+    int sl = 1;
+    while (sl < 16 && 2 * sl <= a.splits && n4 * sl < 256 * 1024) sl *= 2;
+    wino_partial_reduce_kernel<<<(unsigned)((n4 * sl + 255) / 256), 256, 0, st>>>((const float*)ws, dw, n4, a.splits, sl);
     return UNET_LAUNCH_STATUS();
 }
 
