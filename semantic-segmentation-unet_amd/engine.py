@@ -227,9 +227,9 @@ class Engine:
             return False
         cin, cout = self.cin[name], self.cout[name]
         k, nn = (cout, cin) if dgrad else (cin, cout)
-        # the bf16 kernels address their tensors with 32-bit buffer offsets: every operand (concat buffers have twice the
-        # channels) must stay below 2 GiB, larger problems fall back to the fp32 kernels
-        if n * h * w * 2 * max(cin, cout) * 4 >= 2 ** 31:
+        # the bf16 kernels address their tensors with 32-bit buffer offsets: every operand (leading dimension <= max(Cin, Cout):
+        # a concat input IS the layer's Cin) must stay below 2 GiB, larger problems fall back to the fp32 kernels
+        if n * h * w * max(cin, cout) * 4 >= 2 ** 31:
             return False
         return self.L.unet_conv3x3_bf16_supported(n, h, w, k, nn) == 1
 
@@ -259,7 +259,7 @@ class Engine:
 
     def _use_bf16_convt(self, name, n, h, w):
         return (self.compute_dtype == "bf16" and self.kind[name] == "deconv"
-                and n * h * w * 4 * 2 * self.cout[name] * 4 < 2 ** 31 and n * h * w * self.cin[name] * 4 < 2 ** 31
+                and n * h * w * 4 * self.cout[name] * 4 < 2 ** 31 and n * h * w * self.cin[name] * 4 < 2 ** 31
                 and self.L.unet_convT2x2_bf16_supported(n, h, w, self.cin[name], self.cout[name]) == 1)
 
     def _fused_kernels(self, name):
@@ -563,7 +563,7 @@ class Engine:
         P = n * ho * wo
         s = self.stat[name]
         dz16 = self.compute_dtype == "bf16" and self.bf16_storage and not eval_mode and (
-            (kind == "conv3" and n * ho * wo * 2 * max(cin, cout) * 4 < 2 ** 31 and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1
+            (kind == "conv3" and n * ho * wo * max(cin, cout) * 4 < 2 ** 31 and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1
              and (not need_dx or self._use_bf16(name, n, ho, wo, dgrad=True)))
             or (kind == "deconv" and self._use_bf16_convt(name, n, x.shape[1], x.shape[2])
                 and L.unet_convT2x2_wgrad_bf16_supported(n, x.shape[1], x.shape[2], cin, cout) == 1))
@@ -630,7 +630,7 @@ class Engine:
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
                 L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
-            elif (self.compute_dtype == "bf16" and n * ho * wo * 2 * max(cin, cout) * 4 < 2 ** 31
+            elif (self.compute_dtype == "bf16" and n * ho * wo * max(cin, cout) * 4 < 2 ** 31
                   and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1):
                 nb2 = L.unet_conv3x3_wgrad_bf16_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16_ex,
