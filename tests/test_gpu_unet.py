@@ -286,6 +286,14 @@ def test_bf16_full_size_config4_step_properties():
     losses = runs[0][0]
     assert all(np.isfinite(losses)) and min(losses[-2:]) < losses[0]
     e = net.engine
+    # at this size every wide 3x3 layer must actually take the bf16 kernels (a too-cautious size guard once sent the largest layer
+    # back to fp32 without any test noticing): 17 forward, 17 data-gradient, 17 weight-gradient launches in one step
+    e.profile = {}
+    net.train_step((img.cuda(), lab.cuda(), None, None))
+    counts = {k: len(v) for k, v in e.profile.items()}
+    e.profile = None
+    assert counts.get("conv3x3_fwd_bf16") == 17 and counts.get("conv3x3_dgrad_bf16") == 17 and counts.get("conv3x3_wgrad_bf16") == 17, counts
+    assert any(k.startswith("cat16_") for k in e.bufs) and any(k.startswith("dz16_up_") for k in e.bufs)
     prob = e.forward(img.cuda(), training=False, labels=lab.cuda(), global_batch_size=n)
     assert (prob.sum(-1) - 1).abs().max().item() < 1e-5 and prob.min().item() >= 0
     ce = -(torch.log(prob.double().clamp_min(1e-30)) * lab.cuda().double()).sum(-1).mean().item()
