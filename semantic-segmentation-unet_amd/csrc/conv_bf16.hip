@@ -345,12 +345,15 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     }
 }
 
+// (the 64-channel-tile kernels are built for TWO workgroups per CU -- 128 + 128 registers, 76 KB of LDS each: they serve the
+// full-resolution layers, which run on HBM, and a second workgroup's loads and stores fill the first one's epilogue: 64->64 @512^2
+// 0.32 -> 0.27 ms in a same-box A/B)
 __global__ __launch_bounds__(256, 1) void conv_bf16_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 0>(p); }
-__global__ __launch_bounds__(256, 1) void conv_bf16_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 0>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 0>(p); }
 __global__ __launch_bounds__(256, 1) void conv_bf16_stats_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 1>(p); }
-__global__ __launch_bounds__(256, 1) void conv_bf16_stats_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 1>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_stats_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 1>(p); }
 __global__ __launch_bounds__(256, 1) void conv_bf16_bnbwd_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 2>(p); }
-__global__ __launch_bounds__(256, 1) void conv_bf16_bnbwd_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 2>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_bnbwd_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 2>(p); }
 
 // fp32 HWIO weights -> bf16 [chunk][tap][k half][out channel][8]: mode 0 forward (reduce over Cin), mode 1 data gradient
 // (reduce over Cout, taps flipped, output channel = the layer's input channel)
