@@ -531,7 +531,7 @@ __device__ __forceinline__ void wg_wait_tied2(int n, bf16x8& a, bf16x8& b0, bf16
                  default: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b0), "+v"(b1)); }
 }
 
-__global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgBf16Args p) {
     __shared__ __attribute__((aligned(1024))) char smem[kWgXRing + 4 * kWgDzRow];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -573,10 +573,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
     // Staging passes.  Pass j of a strip chunk carries input rows y0-1+2j, y0+2j (ring slots 2j, 2j+1 mod 6) and, for j >= 1, dz
-    // rows y0+2(j-1), +1 (dz slots 2((j-1)&1), +1); compute step s needs passes <= s+1.  HBM latency under load is several
-    // thousand cycles against 1152 MFMA cycles per step, so the loads run THREE passes ahead in a register ring
-    // (pass j -> stg[j % 3]): iteration s issues pass s+4, computes step s and commits pass s+2.
-    f32x4 stg[3][9];
+    // rows y0+2(j-1), +1 (dz slots 2((j-1)&1), +1); compute step s needs passes <= s+1: iteration s issues pass s+2, computes
+    // step s and commits pass s+2.  The kernel is built for TWO workgroups per CU (8 taps in 128 AGPRs, the ninth in VGPRs, 112
+    // VGPRs, 46 KB of LDS): a second workgroup -- or another stream's kernel: the BatchNorm passes and the 64-channel-tile data
+    // gradient co-reside with it -- fills the load-latency and barrier gaps.  (The one-workgroup form ran its loads three passes
+    // ahead in a register ring instead; alone it was as fast, inside the step 0.8 ms slower because nothing could share a CU.)
+    f32x4 stg[1][9];
     unsigned voff[9];
     int y0 = 0, y_end = 0;
     // (both roles run the SAME instruction sequence -- 9 loads, 9 conversions and writes per pass, the dz role's ninth column is
@@ -614,165 +616,165 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
         for (int r = 0; r < 4; ++r) xb[r] = a_lane + (unsigned)(((2 * s + r) % 6) * kWgXRow);
         zb[0] = b_lane + (unsigned)(((s & 1) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
         // One asm block per step (generated: 80 transposing reads, 36 MFMAs, counted waits; LDS operations retire in order).  The
-        // fragments live in fixed registers v[232:255] -- A buffers four deep, B two -- because a 128-bit MFMA operand has to be
+        // fragments live in fixed registers v[88:111] -- A buffers four deep, B two -- because a 128-bit MFMA operand has to be
         // assembled from two 64-bit reads: as separate asm statements that took compiler copies plus s_nop padding in front of
         // every MFMA (57 cycles per MFMA measured); inside one block nothing can be scheduled between a read and its use.
         asm volatile(
-            "ds_read_b64_tr_b16 v[248:249], %13 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[250:251], %13 offset:256\n\t"
-            "ds_read_b64_tr_b16 v[232:233], %9 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[234:235], %9 offset:256\n\t"
-            "ds_read_b64_tr_b16 v[236:237], %9 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[238:239], %9 offset:320\n\t"
-            "ds_read_b64_tr_b16 v[240:241], %9 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[242:243], %9 offset:384\n\t"
-            "ds_read_b64_tr_b16 v[252:253], %13 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[254:255], %13 offset:1280\n\t"
-            "ds_read_b64_tr_b16 v[244:245], %10 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[246:247], %10 offset:256\n\t"
+            "ds_read_b64_tr_b16 v[104:105], %13 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[106:107], %13 offset:256\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %9 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %9 offset:256\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %9 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %9 offset:320\n\t"
+            "ds_read_b64_tr_b16 v[96:97], %9 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %9 offset:384\n\t"
+            "ds_read_b64_tr_b16 v[108:109], %13 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[110:111], %13 offset:1280\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %10 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %10 offset:256\n\t"
             "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %0, v[232:235], v[248:251], %0\n\t"
-            "ds_read_b64_tr_b16 v[232:233], %10 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[234:235], %10 offset:320\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[88:91], v[104:107], %0\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %10 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %10 offset:320\n\t"
             "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %1, v[236:239], v[248:251], %1\n\t"
-            "ds_read_b64_tr_b16 v[236:237], %10 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[238:239], %10 offset:384\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, v[92:95], v[104:107], %1\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %10 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %10 offset:384\n\t"
             "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %2, v[240:243], v[248:251], %2\n\t"
-            "ds_read_b64_tr_b16 v[240:241], %11 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[242:243], %11 offset:256\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, v[96:99], v[104:107], %2\n\t"
+            "ds_read_b64_tr_b16 v[96:97], %11 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %11 offset:256\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %3, v[244:247], v[248:251], %3\n\t"
-            "ds_read_b64_tr_b16 v[244:245], %11 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[246:247], %11 offset:320\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, v[100:103], v[104:107], %3\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %11 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %11 offset:320\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %4, v[232:235], v[248:251], %4\n\t"
-            "ds_read_b64_tr_b16 v[232:233], %11 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[234:235], %11 offset:384\n\t"
+            "v_mfma_f32_32x32x16_bf16 %4, v[88:91], v[104:107], %4\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %11 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %11 offset:384\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %5, v[236:239], v[248:251], %5\n\t"
-            "ds_read_b64_tr_b16 v[236:237], %9 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[238:239], %9 offset:1280\n\t"
+            "v_mfma_f32_32x32x16_bf16 %5, v[92:95], v[104:107], %5\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %9 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %9 offset:1280\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %6, v[240:243], v[248:251], %6\n\t"
-            "ds_read_b64_tr_b16 v[240:241], %9 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[242:243], %9 offset:1344\n\t"
+            "v_mfma_f32_32x32x16_bf16 %6, v[96:99], v[104:107], %6\n\t"
+            "ds_read_b64_tr_b16 v[96:97], %9 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %9 offset:1344\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %7, v[244:247], v[248:251], %7\n\t"
-            "ds_read_b64_tr_b16 v[244:245], %9 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[246:247], %9 offset:1408\n\t"
+            "v_mfma_f32_32x32x16_bf16 %7, v[100:103], v[104:107], %7\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %9 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %9 offset:1408\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %8, v[232:235], v[248:251], %8\n\t"
-            "ds_read_b64_tr_b16 v[248:249], %14 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[250:251], %14 offset:256\n\t"
-            "ds_read_b64_tr_b16 v[232:233], %10 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[234:235], %10 offset:1280\n\t"
+            "v_mfma_f32_32x32x16_bf16 %8, v[88:91], v[104:107], %8\n\t"
+            "ds_read_b64_tr_b16 v[104:105], %14 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[106:107], %14 offset:256\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %10 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %10 offset:1280\n\t"
             "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %0, v[236:239], v[252:255], %0\n\t"
-            "ds_read_b64_tr_b16 v[236:237], %10 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[238:239], %10 offset:1344\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[92:95], v[108:111], %0\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %10 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %10 offset:1344\n\t"
             "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %1, v[240:243], v[252:255], %1\n\t"
-            "ds_read_b64_tr_b16 v[240:241], %10 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[242:243], %10 offset:1408\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, v[96:99], v[108:111], %1\n\t"
+            "ds_read_b64_tr_b16 v[96:97], %10 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %10 offset:1408\n\t"
             "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %2, v[244:247], v[252:255], %2\n\t"
-            "ds_read_b64_tr_b16 v[244:245], %11 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[246:247], %11 offset:1280\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, v[100:103], v[108:111], %2\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %11 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %11 offset:1280\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %3, v[232:235], v[252:255], %3\n\t"
-            "ds_read_b64_tr_b16 v[232:233], %11 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[234:235], %11 offset:1344\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, v[88:91], v[108:111], %3\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %11 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %11 offset:1344\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %4, v[236:239], v[252:255], %4\n\t"
-            "ds_read_b64_tr_b16 v[236:237], %11 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[238:239], %11 offset:1408\n\t"
+            "v_mfma_f32_32x32x16_bf16 %4, v[92:95], v[108:111], %4\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %11 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %11 offset:1408\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %5, v[240:243], v[252:255], %5\n\t"
-            "ds_read_b64_tr_b16 v[240:241], %10 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[242:243], %10 offset:256\n\t"
+            "v_mfma_f32_32x32x16_bf16 %5, v[96:99], v[108:111], %5\n\t"
+            "ds_read_b64_tr_b16 v[96:97], %10 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %10 offset:256\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %6, v[244:247], v[252:255], %6\n\t"
-            "ds_read_b64_tr_b16 v[244:245], %10 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[246:247], %10 offset:320\n\t"
+            "v_mfma_f32_32x32x16_bf16 %6, v[100:103], v[108:111], %6\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %10 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %10 offset:320\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %7, v[232:235], v[252:255], %7\n\t"
-            "ds_read_b64_tr_b16 v[232:233], %10 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[234:235], %10 offset:384\n\t"
+            "v_mfma_f32_32x32x16_bf16 %7, v[88:91], v[108:111], %7\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %10 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %10 offset:384\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %8, v[236:239], v[252:255], %8\n\t"
-            "ds_read_b64_tr_b16 v[252:253], %14 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[254:255], %14 offset:1280\n\t"
-            "ds_read_b64_tr_b16 v[236:237], %11 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[238:239], %11 offset:256\n\t"
+            "v_mfma_f32_32x32x16_bf16 %8, v[92:95], v[108:111], %8\n\t"
+            "ds_read_b64_tr_b16 v[108:109], %14 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[110:111], %14 offset:1280\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %11 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %11 offset:256\n\t"
             "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %0, v[240:243], v[248:251], %0\n\t"
-            "ds_read_b64_tr_b16 v[240:241], %11 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[242:243], %11 offset:320\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[96:99], v[104:107], %0\n\t"
+            "ds_read_b64_tr_b16 v[96:97], %11 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %11 offset:320\n\t"
             "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %1, v[244:247], v[248:251], %1\n\t"
-            "ds_read_b64_tr_b16 v[244:245], %11 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[246:247], %11 offset:384\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, v[100:103], v[104:107], %1\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %11 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %11 offset:384\n\t"
             "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %2, v[232:235], v[248:251], %2\n\t"
-            "ds_read_b64_tr_b16 v[232:233], %12 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[234:235], %12 offset:256\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, v[88:91], v[104:107], %2\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %12 offset:0\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %12 offset:256\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %3, v[236:239], v[248:251], %3\n\t"
-            "ds_read_b64_tr_b16 v[236:237], %12 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[238:239], %12 offset:320\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, v[92:95], v[104:107], %3\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %12 offset:64\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %12 offset:320\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %4, v[240:243], v[248:251], %4\n\t"
-            "ds_read_b64_tr_b16 v[240:241], %12 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[242:243], %12 offset:384\n\t"
+            "v_mfma_f32_32x32x16_bf16 %4, v[96:99], v[104:107], %4\n\t"
+            "ds_read_b64_tr_b16 v[96:97], %12 offset:128\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %12 offset:384\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %5, v[244:247], v[248:251], %5\n\t"
-            "ds_read_b64_tr_b16 v[244:245], %10 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[246:247], %10 offset:1280\n\t"
+            "v_mfma_f32_32x32x16_bf16 %5, v[100:103], v[104:107], %5\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %10 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %10 offset:1280\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %6, v[232:235], v[248:251], %6\n\t"
-            "ds_read_b64_tr_b16 v[232:233], %10 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[234:235], %10 offset:1344\n\t"
+            "v_mfma_f32_32x32x16_bf16 %6, v[88:91], v[104:107], %6\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %10 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %10 offset:1344\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %7, v[236:239], v[248:251], %7\n\t"
-            "ds_read_b64_tr_b16 v[236:237], %10 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[238:239], %10 offset:1408\n\t"
+            "v_mfma_f32_32x32x16_bf16 %7, v[92:95], v[104:107], %7\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %10 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %10 offset:1408\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %8, v[240:243], v[248:251], %8\n\t"
-            "ds_read_b64_tr_b16 v[240:241], %11 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[242:243], %11 offset:1280\n\t"
+            "v_mfma_f32_32x32x16_bf16 %8, v[96:99], v[104:107], %8\n\t"
+            "ds_read_b64_tr_b16 v[96:97], %11 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %11 offset:1280\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %0, v[244:247], v[252:255], %0\n\t"
-            "ds_read_b64_tr_b16 v[244:245], %11 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[246:247], %11 offset:1344\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, v[100:103], v[108:111], %0\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %11 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %11 offset:1344\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %1, v[232:235], v[252:255], %1\n\t"
-            "ds_read_b64_tr_b16 v[232:233], %11 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[234:235], %11 offset:1408\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, v[88:91], v[108:111], %1\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %11 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %11 offset:1408\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %2, v[236:239], v[252:255], %2\n\t"
-            "ds_read_b64_tr_b16 v[236:237], %12 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[238:239], %12 offset:1280\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, v[92:95], v[108:111], %2\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %12 offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %12 offset:1280\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %3, v[240:243], v[252:255], %3\n\t"
-            "ds_read_b64_tr_b16 v[240:241], %12 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[242:243], %12 offset:1344\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, v[96:99], v[108:111], %3\n\t"
+            "ds_read_b64_tr_b16 v[96:97], %12 offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %12 offset:1344\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %4, v[244:247], v[252:255], %4\n\t"
-            "ds_read_b64_tr_b16 v[244:245], %12 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[246:247], %12 offset:1408\n\t"
+            "v_mfma_f32_32x32x16_bf16 %4, v[100:103], v[108:111], %4\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %12 offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %12 offset:1408\n\t"
             "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %5, v[232:235], v[252:255], %5\n\t"
+            "v_mfma_f32_32x32x16_bf16 %5, v[88:91], v[108:111], %5\n\t"
             "s_waitcnt lgkmcnt(4)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %6, v[236:239], v[252:255], %6\n\t"
+            "v_mfma_f32_32x32x16_bf16 %6, v[92:95], v[108:111], %6\n\t"
             "s_waitcnt lgkmcnt(2)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %7, v[240:243], v[252:255], %7\n\t"
+            "v_mfma_f32_32x32x16_bf16 %7, v[96:99], v[108:111], %7\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %8, v[244:247], v[252:255], %8\n\t"
-            : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8])
+            "v_mfma_f32_32x32x16_bf16 %8, v[100:103], v[108:111], %8\n\t"
+            : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+v"(acc[8])
             : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(zb[0]), "v"(zb[1])
-            : "memory", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+            : "memory", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111");
     };
 
     for (int sc = split; sc < p.n_sc; sc += p.splits) {
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
         const int img = strip / p.tbx, x0 = 32 * (strip % p.tbx);
         y0 = chunk * p.rpc;
         y_end = y0 + p.rpc < p.H ? y0 + p.rpc : p.H;
-        const int steps = ((y_end - y0 + 1) / 2 + 2) / 3 * 3;         // rounded up to the ring depth: the extra steps see zero dz rows
+        const int steps = (y_end - y0 + 1) / 2;
         // per-thread offsets inside a row (the row goes into the scalar offset); columns outside the image / the patch: rejected
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -791,20 +793,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
         }
         // fill: passes 0 and 1 committed, 2 and 3 in flight.  (The previous strip's last step ended with a barrier: every wave is
         // done reading the rings.)
-        issue(stg[0], 0); issue(stg[1], 1);
-        commit(stg[0], 0); commit(stg[1], 1);
-        issue(stg[2], 2); issue(stg[0], 3);
+        issue(stg[0], 0); commit(stg[0], 0);
+        issue(stg[0], 1); commit(stg[0], 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        for (int s = 0; s < steps; s += 3) {
-            if (!(p.ablate & 2)) issue(stg[1], s + 4);
+        for (int s = 0; s < steps; ++s) {
+            if (!(p.ablate & 2)) issue(stg[0], s + 2);
             if (!(p.ablate & 1)) compute(s);
-            commit(stg[2], s + 2); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!(p.ablate & 2)) issue(stg[2], s + 5);
-            if (!(p.ablate & 1)) compute(s + 1);
-            commit(stg[0], s + 3); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!(p.ablate & 2)) issue(stg[0], s + 6);
-            if (!(p.ablate & 1)) compute(s + 2);
-            commit(stg[1], s + 4); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            commit(stg[0], s + 2); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // passes still in flight belong to nobody
     }
@@ -818,7 +813,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(WgBf16Args p) {
         for (int e = 0; e < 16; ++e) {
             const int ci = ci0 + 32 * cisub + (e & 3) + 8 * (e >> 2) + 4 * lh;
             float v;
-            asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[t][e]));
+            if (t < 8) asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[t][e]));
+            else v = acc[t][e];                       // the ninth tap accumulates in VGPRs: 8 x 16 AGPRs + 128 VGPRs = two workgroups per CU
             o_base[((size_t)t * p.Cin + ci) * p.Cout + co0 + 32 * cosub + li] = v;
         }
 }
