@@ -1414,7 +1414,10 @@ __global__ __launch_bounds__(256, 1) void convt_wgrad_bf16_kernel_128(CtWgBf16Ar
 __global__ __launch_bounds__(256, 1) void convt_wgrad_bf16_kernel_64(CtWgBf16Args p) { convt_wgrad_bf16_body<1>(p); }
 
 void convt_wgrad_bf16_plan(CtWgBf16Args& a) {
-    const int cot = a.Cout % 128 == 0 ? 128 : 64;
+    // 64-output-channel tiles by default: 128 AGPRs + 103 VGPRs, so the kernel shares a CU with the other stream's kernels (the
+    // 128-channel tile takes all 256 AGPRs; alone it is as fast, in the step 0.13 ms slower).  UNET_CONVT_WGRAD_NARROW=0: A/B switch
+    static const int narrow = [] { const char* e = getenv("UNET_CONVT_WGRAD_NARROW"); return e ? atoi(e) : 1; }();
+    const int cot = (a.Cout % 128 == 0 && !narrow) ? 128 : 64;
     a.n_co = a.Cout / cot; a.n_ci = a.Cin / 128;
     a.tbx = (a.W + 31) / 32; a.n_units = a.N * a.H * a.tbx;
     const int npairs = a.n_co * a.n_ci;
@@ -1449,8 +1452,8 @@ extern "C" int unet_convT2x2_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16,
     a.x_bytes = (unsigned)((size_t)N * H * W * ldx * (a.x16 ? 2 : 4)); a.dz_bytes = (unsigned)((size_t)N * H * W * 4 * lddz * (a.z16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(a.n_co * a.n_ci * a.splits));
-    if (Cout % 128 == 0) convt_wgrad_bf16_kernel_128<<<grid, 256, 0, st>>>(a);
-    else                 convt_wgrad_bf16_kernel_64<<<grid, 256, 0, st>>>(a);
+    if (a.n_co * 128 == Cout) convt_wgrad_bf16_kernel_128<<<grid, 256, 0, st>>>(a);
+    else                      convt_wgrad_bf16_kernel_64<<<grid, 256, 0, st>>>(a);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     if (a.splits > 1) {
         const long n4 = (long)4 * Cout * Cin / 4;
