@@ -3,14 +3,29 @@
 (BASELINE.json configs[1]; configs[2] when launched on 8 GPUs).  One "step" = one full optimizer step of the hot path:
 forward + per-pixel softmax-CE + backward + (gradient all-reduce) + Keras-Adam, dropout active, inputs resident in HBM.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA 3x3 implicit-GEMM conv): algorithmic
-FLOPs of its forward launches / their HIP-event durations measured live in the timed steps, against the dense fp32
-matrix peak (backward launches overlap on two streams and are listed under `kernels`).  `cpu_baseline` times the oracle's torch-CPU restatement of the same train
-step on the host cores over a bounded sample (rank 0, N=1 only) -- a reported baseline, not the target.
+Rank 0 prints ONE JSON line.
+
+`roofline` is for the dominant kernel = the 3x3-conv kernel family with the most ms per step (forward, data gradient or
+weight gradient).  Durations are HIP events recorded on the launch stream, live inside the timed region, on every 8th
+timed step; those sampled steps run the backward on ONE stream (the `--no-overlap` schedule) so that every family's
+events are exclusive durations -- on the other steps the weight gradients overlap the data-gradient chain on a side
+stream and a bracketed launch would include shared time.
+  * `achieved`/`frac`: EXECUTED matrix-core FLOP/s and its fraction of the dense MFMA peak for the dtype.  The fp32
+    kernels are Winograd F(2x2,3x3): they execute 16 multiplies per 2x2 output tile and channel pair where the direct
+    algorithm needs 36, so executed = algorithmic / 2.25; the bf16 kernels are implicit GEMMs (executed = algorithmic);
+  * `effective`: the algorithmic (direct-convolution, 2*9*N*H*W*Cin*Cout per launch) rate -- it may exceed the
+    peak for a Winograd kernel and is NOT a roofline fraction;
+  * `traffic`: HBM bytes per launch from separate rocprofv3 --pmc passes committed under profiles/ (`traffic_source`:
+    "offline PMC" -- it is read from that file, not measured by this run), null when no pass exists for the family.
+`step_executed_frac` = executed FLOPs of the whole step (3x3 Winograd layers / 2.25 + everything else) / step time / peak.
+`cpu_baseline` times the oracle's torch-CPU fp32 restatement of the same train step on the host cores (rank 0, N=1 only):
+config 2 at batch 8, 1 warm-up + 3 timed steps -- a reported baseline, not the target.
+`extra_configs` (N=1 only): short driver-visible runs of BASELINE configs 4 and 5's per-GPU workloads (bf16 512x512x3 / 4
+classes / batch 8, and fp32 1024x1024x3 / 6 classes / batch 2), each with its own roofline block.
 """
 import argparse
 import importlib
@@ -22,10 +37,39 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "semantic-segmentation-unet_amd"
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything initialises HIP (RCCL needs dmabuf IPC here)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, chip table (dense, spec)
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table: ~2.5 PF dense bf16 (spec)
-TRAIN_GFLOP_PER_IMG = {(512, 1, 2): 1154.00}
+WINOGRAD_MULT_RATIO = 2.25           # F(2x2,3x3): 36 direct multiplies per tile and channel pair -> 16
+
+FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16?, offline PMC traffic file)
+    "conv3x3_fwd_winograd_fused": ("wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "r02_wino_fwd_pmc_traffic.json"),
+    "conv3x3_dgrad_winograd_fused": ("wino_fused_stream_kernel / _bnstats (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "r02_wino_dgrad_pmc_traffic.json"),
+    "conv3x3_wgrad_winograd_fused": ("wino_wgrad_fused_kernel (3x3 conv weight gradient, Winograd F(2x2,3x3), reduce over tiles on v_mfma_f32_32x32x2_f32)", True, False, "r02_wino_wgrad_pmc_traffic.json"),
+    "conv3x3_fwd_bf16": ("conv_bf16_kernel_{128,64} (3x3 conv forward, implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02_bf16_fwd_pmc_traffic.json"),
+    "conv3x3_dgrad_bf16": ("conv_bf16_kernel_{128,64} (3x3 conv data gradient, implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02_bf16_dgrad_pmc_traffic.json"),
+    "conv3x3_wgrad_bf16": ("wgrad_bf16_kernel (3x3 conv weight gradient, pixel contraction on v_mfma_f32_32x32x16_bf16)", False, True, "r02_bf16_wgrad_pmc_traffic.json"),
+}
+
+
+def train_flops_per_image(hw, channels, classes):
+    """(total, part executed by Winograd kernels in fp32 mode, part executed by bf16 MFMA kernels in bf16 mode): algorithmic
+    FLOPs of one training image, 2 flops/MAC over conv + transposed conv; backward = dgrad + wgrad, no dgrad for conv_1a
+    (512x512x1, 2 classes -> 1154.00 G)."""
+    eng = importlib.import_module(PKG + ".engine")
+    res = {"conv_1": hw, "conv_2": hw // 2, "conv_3": hw // 4, "conv_4": hw // 8, "bott_": hw // 16,
+           "up_4": hw // 16, "dec_4": hw // 8, "up_3": hw // 8, "dec_3": hw // 4, "up_2": hw // 4, "dec_2": hw // 2,
+           "up_1": hw // 2, "dec_1": hw, "logits": hw}
+    total = wide = 0.0
+    for name, kind, cin, cout in eng.layer_table(channels, classes):
+        s = next(v for k, v in res.items() if name.startswith(k))
+        taps = {"conv3": 9, "deconv": 4, "conv1": 1}[kind]
+        f = 2.0 * taps * s * s * cin * cout * (2 if name == "conv_1a" else 3)
+        total += f
+        if kind == "conv3" and cin % 64 == 0 and cout % 64 == 0:
+            wide += f
+    return total, wide
 
 
 def synthetic(batch, channels, classes, hw, seed, device):
@@ -58,7 +102,9 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("UNET_CPU_BASELINE_THREADS", "32"))))
 
 
-def cpu_baseline(hw, channels, classes, batch=2, steps=2):
+def cpu_baseline(hw, channels, classes, batch=8, steps=3):
+    """config 2 at B=8, 1 warm-up + 3 timed steps of the oracle's torch-CPU fp32 restatement.  Prints a
+    partial result after every timed step so that the parent still has a number if its time budget runs out."""
     import numpy as np
     import torch
     from oracle import unet_numpy as on
@@ -70,40 +116,121 @@ def cpu_baseline(hw, channels, classes, batch=2, steps=2):
     masks = {"drop_4": rng.integers(0, 2, (batch, 512, hw // 8, hw // 8)),
              "drop_b": rng.integers(0, 2, (batch, 1024, hw // 16, hw // 16))}
     net = ot.TorchUNet(classes, batch, channels, dtype=torch.float32)
-    net.train_step(img[:1], lab[:1], {k: v[:1] for k, v in masks.items()})        # warm-up (threads, allocator)
+    net.train_step(img, lab, masks)                                               # the 1 warm-up step (threads, allocator)
     t0 = time.time()
-    for _ in range(steps):
+    for i in range(steps):
         net.train_step(img, lab, masks)
-    dt = time.time() - t0
-    return {"value": round(batch * steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d train steps of batch %d (%dx%dx%d, %d classes), torch-CPU fp32 restatement, %.1f s"
-                      % (steps, batch, hw, hw, channels, classes, dt)}
+        dt = time.time() - t0
+        print(json.dumps({"value": round(batch * (i + 1) / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+                          "sample": "1 warm-up + %d timed train steps of batch %d (%dx%dx%d, %d classes), oracle torch-CPU fp32 "
+                                    "restatement, %.1f s timed" % (i + 1, batch, hw, hw, channels, classes, dt)}), flush=True)
 
 
-def cpu_baseline_bounded(args, budget_s=240):
+def cpu_baseline_bounded(args, budget_s=420):
     """Run the CPU leg in a child process (never touches the GPU) with a hard time budget, so a slow or oversubscribed
-    host cannot hold back the benchmark's JSON line."""
+    host cannot hold back the benchmark's JSON line; the child's last per-step line is the result."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(args.size),
-           "--channels", str(args.channels), "--classes", str(args.classes)]
+           "--channels", str(args.channels), "--classes", str(args.classes), "--batch", str(args.batch)]
+    out, note = "", ""
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                return json.loads(line)
-        return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
-                "sample": "cpu baseline child failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
-                "sample": "cpu baseline exceeded its %d s budget on this host" % budget_s}
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            out, err = p.communicate(timeout=budget_s)
+            if p.returncode != 0:
+                note = "child failed: " + (err.strip().splitlines() or ["?"])[-1][:160]
+        except subprocess.TimeoutExpired:
+            p.kill()                                   # exactly the child this function started
+            out, err = p.communicate()
+            note = "stopped at the %d s budget" % budget_s
+    except Exception as e:                              # noqa: BLE001
+        note = "could not start: %r" % (e,)
+    for line in reversed((out or "").strip().splitlines()):
+        if line.startswith("{"):
+            r = json.loads(line)
+            if note:
+                r["sample"] += " (" + note + ")"
+            return r
+    return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port", "sample": "cpu baseline: " + (note or "no output")}
+
+
+def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype, steps, warmup, no_overlap, kernel_events,
+                 sample_every, barrier):
+    """W warm-up + K timed optimizer steps of one workload -> dict with dt, per-family kernel figures, final loss."""
+    import torch
+    G = batch * world
+    net = model.UNet(classes, G, channels, learning_rate=3e-4, device=dev, seed=0,
+                     compute_dtype={"f32": "fp32", "bf16": "bf16"}[dtype])
+    net.engine.overlap_wgrad = not no_overlap
+    if world > 1:
+        par = importlib.import_module(PKG + ".parallel")
+        net.parallel = par.DataParallel(net.engine)
+    img, lab = synthetic(batch, channels, classes, size, 1234 + rank, dev)
+    inputs = (img, lab, None, None)          # no metric objects -> no per-step host sync inside the timed loop
+    for _ in range(warmup):
+        net.train_step(inputs)
+    prof = {} if kernel_events else None
+    sampled = 0
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        s = prof is not None and i % sample_every == sample_every // 2
+        net.engine.profile = prof if s else None
+        net.engine.overlap_wgrad = (not no_overlap) and not s      # sampled steps: one stream -> exclusive event durations
+        sampled += int(s)
+        net.train_step(inputs)
+    barrier()
+    dt = time.perf_counter() - t0
+    net.engine.profile = None
+    final_loss = float(net.engine.loss_buf[0].item())
+    kernels = {}
+    if prof:
+        for key, evs in prof.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            desc, wino, bf16, _ = FAMILY.get(key, (key, False, False, None))
+            eff = fl / (ms * 1e-3) / 1e12
+            ex = eff / WINOGRAD_MULT_RATIO if wino else eff
+            peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+            kernels[key] = {"launches_per_step": len(evs) // sampled, "ms_per_step": round(ms / sampled, 3),
+                            "avg_launch_ms": round(ms / len(evs), 4), "effective_tflops": round(eff, 2),
+                            "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4), "exclusive": True}
+    del net
+    torch.cuda.empty_cache()
+    return {"dt": dt, "kernels": kernels, "final_loss": final_loss, "sampled_steps": sampled, "G": G}
+
+
+def roofline_of(kernels, workload_key):
+    """The 3x3 family with the most exclusive ms per step."""
+    cands = {k: v for k, v in kernels.items() if k in FAMILY}
+    if not cands:
+        return None
+    key = max(cands, key=lambda k: cands[k]["ms_per_step"])
+    v = cands[key]
+    desc, wino, bf16, tfile = FAMILY[key]
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    r = {"bound": "mfma", "kernel": desc, "family": key, "achieved": v["executed_tflops"], "peak": peak, "unit": "TFLOP/s",
+         "frac": v["executed_frac"], "effective": v["effective_tflops"],
+         "flop_accounting": ("executed = algorithmic / 2.25 (Winograd F(2x2,3x3))" if wino else "executed = algorithmic (implicit GEMM)"),
+         "launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"], "ms_per_step": v["ms_per_step"],
+         "timing": "HIP events on the launch stream, sampled timed steps, single-stream backward (exclusive)",
+         "traffic": None, "traffic_source": None}
+    tf = os.path.join(ROOT, "profiles", tfile)
+    if os.path.exists(tf):
+        t = json.load(open(tf))
+        if t.get("workload") == workload_key and t.get("launches_per_step") == v["launches_per_step"]:
+            r["traffic"] = round(t["hbm_bytes_per_launch"])
+            r["traffic_source"] = "offline PMC (profiles/%s; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)" % tfile
+            r["algorithmic_bytes_per_launch"] = round(t["algorithmic_bytes_per_launch"])
+    return r
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--channels", type=int, default=1)
@@ -112,10 +239,12 @@ def main():
                     help="contraction precision of the 3x3 layers; bf16 = BASELINE config 4 (fp32 master weights, fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream (A/B switch)")
+    ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream in every step (A/B switch)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short config-4 / config-5 runs")
+    ap.add_argument("--sample-every", type=int, default=8, help="kernel events on one timed step in this many")
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.size, args.channels, args.classes)), flush=True)
+        cpu_baseline(args.size, args.channels, args.classes, batch=args.batch)
         return
 
     import torch
@@ -129,112 +258,69 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-
-    model = importlib.import_module(PKG + ".model")
-    G = args.batch * world
-    net = model.UNet(args.classes, G, args.channels, learning_rate=3e-4, device=dev, seed=0,
-                     compute_dtype={"f32": "fp32", "bf16": "bf16"}[args.dtype])
-    net.engine.overlap_wgrad = not args.no_overlap
-    if world > 1:
-        par = importlib.import_module(PKG + ".parallel")
-        net.parallel = par.DataParallel(net.engine)
-    img, lab = synthetic(args.batch, args.channels, args.classes, args.size, 1234 + rank, dev)
-    inputs = (img, lab, None, None)          # no metric objects -> no per-step host sync inside the timed loop
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        net.train_step(inputs)
-    # HIP events around the conv launches on every 4th timed step (the roofline kernel's duration is measured live, inside the
-    # timed region; bracketing every launch of every step costs ~0.7 % of the step in event traffic)
-    prof = None if args.no_kernel_events else {}
-    sampled = 0
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        net.engine.profile = prof if (prof is not None and i % 4 == 0) else None
-        sampled += int(net.engine.profile is not None)
-        net.train_step(inputs)
-    net.engine.profile = prof
-    barrier()
-    dt = time.perf_counter() - t0
+    model = importlib.import_module(PKG + ".model")
+    sample_every = max(2, min(args.sample_every, args.steps)) if args.steps > 1 else 1
+    res = run_workload(model, dev, world, rank, args.size, args.channels, args.classes, args.batch, args.dtype, args.steps,
+                       args.warmup, args.no_overlap, not args.no_kernel_events, sample_every, barrier)
+    dt = res["dt"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(net.engine.loss_buf[0].item())
 
-    roofline = None
-    extra = {}
-    if net.engine.profile:
-        for key, evs in net.engine.profile.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
-            fl = sum(f for _, _, f in evs)
-            extra[key] = {"launches_per_step": len(evs) // sampled, "ms_per_step": round(ms / sampled, 3),
-                          "avg_launch_ms": round(ms / len(evs), 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
-        # Dominant kernel = the 3x3 conv forward kernel of the active route: wino_fused_stream_stats_kernel (fully fused, persistent
-        # Winograd F(2x2,3x3), default) or igemm_kernel<0,*,*,false> (UNET_CONV_ROUTE=direct).  Forward launches run alone on the
-        # GPU, so their event durations are the kernel's own; backward launches (dgrad / wgrad on two streams) overlap and
-        # are listed under `kernels` with shared time included.  `achieved` is ALGORITHMIC (direct-convolution) FLOP/s as
-        # SURVEY.md 8(d) defines the work; Winograd executes 2.25x fewer multiplies, so `executed` = achieved / 2.25 is
-        # the rate the matrix cores actually run at and `achieved` may exceed the MFMA peak.
-        kf, kd, kb = extra.get("conv3x3_fwd_winograd_fused"), extra.get("conv3x3_fwd"), extra.get("conv3x3_fwd_bf16")
-        tfile = None
-        if kb:
-            roofline = {"bound": "mfma", "kernel": "conv_bf16_kernel_{128,64} (3x3 conv forward, implicit GEMM on v_mfma_f32_32x32x16_bf16)",
-                        "achieved": kb["tflops"], "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(kb["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
-                        "launches_per_step": kb["launches_per_step"], "avg_launch_ms": kb["avg_launch_ms"]}
-            tfile = "r01f_conv_bf16_fwd_pmc_traffic.json"
-        elif kf:
-            roofline = {"bound": "mfma", "kernel": "wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
-                        "achieved": kf["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(kf["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "executed": round(kf["tflops"] / 2.25, 2), "executed_frac": round(kf["tflops"] / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "traffic": None, "launches_per_step": kf["launches_per_step"], "avg_launch_ms": kf["avg_launch_ms"]}
-            tfile = "r01e_wino_stream_fwd_pmc_traffic.json"
-        elif kd:
-            roofline = {"bound": "mfma", "kernel": "igemm_kernel<0,*,*,false> (3x3 conv forward, v_mfma_f32_32x32x2_f32)",
-                        "achieved": kd["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(kd["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                        "launches_per_step": kd["launches_per_step"], "avg_launch_ms": kd["avg_launch_ms"]}
-            tfile = "r01_igemm_fwd_pmc_traffic.json"
-        if roofline:
-            # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction,
-            # WRITE_SIZE) of this same workload, committed under profiles/; only valid for the default workload.
-            tf = os.path.join(ROOT, "profiles", tfile or "none")
-            if os.path.exists(tf) and (args.size, args.channels, args.classes, args.batch) == ((512, 3, 4, 8) if kb else (512, 1, 2, 8)):
-                t = json.load(open(tf))
-                if t.get("launches_per_step") == roofline["launches_per_step"]:
-                    roofline["traffic"] = round(t["hbm_bytes_per_launch"])
-                    roofline["traffic_unit"] = "bytes/launch (PMC, profiles/%s)" % tfile
-                    roofline["algorithmic_bytes_per_launch"] = round(t["algorithmic_bytes_per_launch"])
+    def summarize(r, dt_, size, channels, classes, batch, dtype, steps, warmup, nworld):
+        ips = r["G"] * steps / dt_
+        total, wide = train_flops_per_image(size, channels, classes)
+        peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+        executed = (total - wide) + (wide / WINOGRAD_MULT_RATIO if dtype == "f32" else wide)
+        wk = "%dx%dx%d/%d classes/batch %d/%s" % (size, size, channels, classes, batch, dtype)
+        return ips, {
+            "ms_per_step": round(dt_ / steps * 1e3, 3),
+            "roofline": roofline_of(r["kernels"], wk), "kernels": r["kernels"],
+            "step_effective_tflops_per_gpu": round(ips / nworld * total / 1e12, 2),
+            "step_executed_tflops_per_gpu": round(ips / nworld * executed / 1e12, 2),
+            "step_executed_frac": round(ips / nworld * executed / 1e12 / peak, 4),
+            "train_gflop_per_image": round(total / 1e9, 2), "final_loss": round(r["final_loss"], 6),
+            "sampled_steps": r["sampled_steps"],
+        }
+
+    extras = []
+    if world == 1 and not args.no_extra and (args.size, args.channels, args.classes, args.batch, args.dtype) == (512, 1, 2, 8, "f32"):
+        for (size, ch, kc, b, dty, label) in ((512, 3, 4, 8, "bf16", "BASELINE config 4 per-GPU workload"),
+                                              (1024, 3, 6, 2, "f32", "BASELINE config 5 per-GPU workload")):
+            st, wu = 16, 4
+            try:
+                r2 = run_workload(model, dev, 1, 0, size, ch, kc, b, dty, st, wu, False, True, 8, barrier)
+                ips2, s2 = summarize(r2, r2["dt"], size, ch, kc, b, dty, st, wu, 1)
+                s2.pop("kernels")
+                extras.append(dict({"workload": "%s: synthetic %dx%dx%d, %d classes, batch %d, %s" % (label, size, size, ch, kc, b, dty),
+                                    "value": round(ips2, 3), "unit": "images/sec", "steps": st, "warmup": wu, "dtype": dty}, **s2))
+            except Exception as e:                      # noqa: BLE001 -- never lose the headline line to an extra run
+                extras.append({"workload": label, "error": repr(e)[:300]})
+
     if rank == 0:
-        ips = G * args.steps / dt
+        ips, s = summarize(res, dt, args.size, args.channels, args.classes, args.batch, args.dtype, args.steps, args.warmup, world)
         out = {
             "metric": "training images/sec", "value": round(ips, 3), "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": s.pop("ms_per_step"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "U-Net train step (fwd + softmax-CE + bwd + Keras-Adam%s), synthetic %dx%dx%d tiles, "
                                    "%d classes, batch %d per GPU, random-init weights, dropout on"
                                    % (" + RCCL gradient all-reduce" if world > 1 else "", args.size, args.size,
                                       args.channels, args.classes, args.batch),
-                       "global_batch": G, "parallelism": "dp%d" % world},
-            "roofline": roofline, "kernels": extra, "final_loss": round(final_loss, 6),
+                       "global_batch": res["G"], "parallelism": "dp%d" % world},
         }
-        gf = TRAIN_GFLOP_PER_IMG.get((args.size, args.channels, args.classes))
-        if gf:
-            out["step_tflops_per_gpu"] = round(ips / world * gf / 1e3, 2)
-            out["step_frac_of_fp32_mfma_peak"] = round(ips / world * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_bounded(args)
-        else:
-            out["cpu_baseline"] = None
+        out.update(s)
+        out["cpu_baseline"] = cpu_baseline_bounded(args) if (world == 1 and not args.no_cpu_baseline) else None
+        if extras:
+            out["extra_configs"] = extras
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

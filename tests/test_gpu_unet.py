@@ -356,3 +356,61 @@ def test_bf16_activation_storage_tracks_the_default_bf16_mode():
     net = runs[0][2]
     losses = [runs[0][0]] + [float(net.train_step(batch).numpy()) for _ in range(25)]
     assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0]
+
+
+def _full_size_properties(n, c, k, hw, dtype, steps=4):
+    """size-independent properties of the train step at a BASELINE shape (the oracle never sees tiles this large):
+    bit-reproducible steps from the same seed, finite and falling loss on a fixed batch, proper softmax in eval mode, device
+    argmax == torch argmax of the same probabilities, reported loss == mean pixel cross-entropy recomputed from the softmax."""
+    model = pkg("model")
+    g = torch.Generator().manual_seed(19)
+    img = torch.randn(n, c, hw, hw, generator=g)
+    cls = torch.randint(0, k, (n, hw // 8, hw // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    lab = torch.nn.functional.one_hot(cls, k).to(torch.int32)
+    img, lab = img.cuda(), lab.cuda()
+    runs = []
+    for _ in range(2):
+        net = model.UNet(k, n, c, learning_rate=1e-3, seed=0, compute_dtype=dtype)
+        losses = [float(net.train_step((img, lab, None, None)).numpy()) for _ in range(steps)]
+        runs.append((losses, net.engine.theta.clone()))
+        if len(runs) == 1:
+            del net
+            torch.cuda.empty_cache()
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    losses = runs[0][0]
+    assert all(np.isfinite(losses)) and min(losses[-2:]) < losses[0], losses
+    e = net.engine
+    e.profile = {}
+    net.train_step((img, lab, None, None))
+    counts = {key: len(v) for key, v in e.profile.items()}
+    e.profile = None
+    prob = e.forward(img, training=False, labels=lab, global_batch_size=n)
+    assert tuple(prob.shape) == (n, hw, hw, k)
+    assert (prob.sum(-1) - 1).abs().max().item() < 1e-5 and prob.min().item() >= 0
+    assert torch.equal(e.argmax(prob).long(), prob.argmax(-1))
+    ce = -(torch.log(prob.double().clamp_min(1e-30)) * lab.double()).sum(-1).mean().item()
+    assert abs(float(e.loss_buf[0].item()) - ce) < 1e-5 * max(1.0, abs(ce))
+    del net, e
+    torch.cuda.empty_cache()
+    return counts
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_full_size_config5_step_properties(dtype):
+    # BASELINE config 5's per-GPU workload: 1024x1024x3 tiles, 6 classes, batch 2 (the deep-encoder / large-tile regime)
+    counts = _full_size_properties(2, 3, 6, 1024, dtype)
+    if dtype == "fp32":
+        assert counts.get("conv3x3_fwd_winograd_fused") == 17 and counts.get("conv3x3_dgrad_winograd_fused") == 17 \
+            and counts.get("conv3x3_wgrad_winograd_fused") == 17, counts
+    else:
+        assert counts.get("conv3x3_fwd_bf16") == 17 and counts.get("conv3x3_dgrad_bf16") == 17 \
+            and counts.get("conv3x3_wgrad_bf16") == 17, counts
+
+
+def test_bf16_operand_beyond_2gib_falls_back_to_fp32_kernels():
+    # the bf16 kernels address their operands with 32-bit buffer offsets (engine._use_bf16): at 1024x1024, batch 4 the concat
+    # input of dec_1a is exactly 2 GiB, so that ONE layer must take the fp32 Winograd kernels and the step must stay sound
+    counts = _full_size_properties(4, 3, 6, 1024, "bf16", steps=3)
+    assert counts.get("conv3x3_fwd_bf16") == 16 and counts.get("conv3x3_fwd_winograd_fused") == 1, counts
+    assert counts.get("conv3x3_wgrad_bf16", 0) + counts.get("conv3x3_wgrad_winograd_fused", 0) == 17, counts
+    assert counts.get("conv3x3_dgrad_bf16", 0) + counts.get("conv3x3_dgrad_winograd_fused", 0) == 17, counts
