@@ -167,8 +167,9 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
         net.parallel = par.DataParallel(net.engine)
     img, lab = synthetic(batch, channels, classes, size, 1234 + rank, dev)
     inputs = (img, lab, None, None)          # no metric objects -> no per-step host sync inside the timed loop
+    step = net.train_step if world == 1 else (lambda inp: net.dist_train_step(net.parallel, inp))   # N>1: + the loss SUM (X2)
     for _ in range(warmup):
-        net.train_step(inputs)
+        step(inputs)
     prof = {} if kernel_events else None
     sampled = 0
     barrier()
@@ -178,7 +179,7 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
         net.engine.profile = prof if s else None
         net.engine.overlap_wgrad = (not no_overlap) and not s      # sampled steps: one stream -> exclusive event durations
         sampled += int(s)
-        net.train_step(inputs)
+        step(inputs)
     barrier()
     dt = time.perf_counter() - t0
     net.engine.profile = None

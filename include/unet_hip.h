@@ -244,9 +244,11 @@ int unet_dropout(const float* x, int ldx, float* out, int ldo, long P, int C, co
                  uint32_t seed, float rate, void* stream);
 
 /* ---- Softmax(axis=-1) + CategoricalCrossentropy + loss reduction + accuracy, UNet/model.py:142,77,211-215,226 ----- */
+/* ce_clip_eps = 0: cross-entropy from the softmax's logits; > 0 (Keras: 1e-7): the probability path of
+ * keras.backend.categorical_crossentropy (clip to [eps, 1-eps], no gradient outside the range) -- SURVEY.md 8(a) a8 (K) */
 size_t unet_softmax_ce_workspace(long P);
 int unet_softmax_ce(const float* logits, int ldz, const int* labels_onehot, float* prob, float* dlogits, int lddz,
-                    long P, int K, float label_smoothing, float loss_scale, float grad_scale,
+                    long P, int K, float label_smoothing, float loss_scale, float grad_scale, float ce_clip_eps,
                     float* loss_out, float* correct_out, void* ws, size_t ws_bytes, void* stream);
 /* np.argmax(softmax, axis=-1), UNet/inference.py:107,166 (first maximum wins) */
 int unet_argmax(const float* p, int ldp, int* out, long P, int K, void* stream);

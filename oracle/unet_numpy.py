@@ -211,10 +211,18 @@ def ce_loss_fwd(logits_nhwc, labels_onehot, global_batch_size, label_smoothing, 
     return loss, p, y
 
 
-def ce_loss_bwd(p, y, global_batch_size):
-    """d loss / d logits for the from-logits path: (p * sum(y) - y) / (G*H*W)."""
+def ce_loss_bwd(p, y, global_batch_size, contract=None):
+    """d loss / d logits.  From-logits path: (p * sum(y) - y) / (G*H*W).  Clipped-probability path
+    (keras.backend.categorical_crossentropy, from_logits=False): q = p / sum(p) (= p), clip to [eps, 1-eps] -- TF's
+    clip_by_value passes the gradient only where eps <= q <= 1-eps -- so g_k = dl/dp_k = -y_k/p_k inside the range and 0
+    outside; through the softmax Jacobian dl/dz_i = p_i (g_i - sum_j g_j p_j)."""
     n, h, w, _ = p.shape
-    return (p * y.sum(axis=-1, keepdims=True) - y) / (global_batch_size * h * w)
+    if contract is None or contract.ce_from_softmax_logits:
+        return (p * y.sum(axis=-1, keepdims=True) - y) / (global_batch_size * h * w)
+    eps = contract.ce_clip_eps
+    inside = (p >= eps) & (p <= 1.0 - eps)
+    gp = np.where(inside, -y, 0.0)                      # g_k * p_k
+    return (gp - p * gp.sum(axis=-1, keepdims=True)) / (global_batch_size * h * w)
 
 
 def adam_keras_step(theta, g, m, v, t, lr, contract):
@@ -307,7 +315,7 @@ class OracleUNet:
             keep.update(loc)
         return softmax, c
 
-    def _block_bwd(self, name, kind, dy, cache, grads):
+    def _block_bwd(self, name, kind, dy, cache, grads, relu_masks=None):
         P = self.params
         x, r, bnc = cache[name]
         dr, dg, dbt = bn_train_bwd(dy, P[name + "/gamma"], bnc)
@@ -315,22 +323,25 @@ class OracleUNet:
         if kind == "deconv":
             dx, dw, db = deconv2x2_bwd(x, P[name + "/kernel"], dr)
         else:
-            dz = dr * (r > 0)
+            dz = dr * (relu_masks[name] if relu_masks is not None else (r > 0))
             dx, dw, db = conv_same_bwd(x, P[name + "/kernel"], dz)
         grads[name + "/kernel"], grads[name + "/bias"] = dw, db
         return dx
 
-    def loss_and_grads(self, images, labels, dropout_masks):
-        """Forward (training=True) + loss + gradients of every trainable tensor.  UNet/model.py:208-219."""
+    def loss_and_grads(self, images, labels, dropout_masks, relu_masks=None, pool_idx=None):
+        """Forward (training=True) + loss + gradients of every trainable tensor.  UNet/model.py:208-219.
+        relu_masks {layer: 0/1 [N,C,H,W]} / pool_idx {"pool_l": first-max index [N,C,H/2,W/2]} replace the oracle's own
+        ReLU masks / pool winners IN THE BACKWARD PASS: the network is piecewise linear, and with the branch decisions of
+        another evaluation (the HIP run's) imposed, the gradient is a smooth function of the inputs -- tests use this to
+        compare gradients at 1e-4 instead of the 5e-2 that mask flips of near-zero pre-activations otherwise force."""
         softmax, c = self.forward(images, training=True, dropout_masks=dropout_masks)
+        if pool_idx is not None:
+            c.update(pool_idx)
         loss, p, y = ce_loss_fwd(c["logits_nhwc"], labels, self.global_batch_size, self.label_smoothing, self.contract)
-        if self.contract.ce_from_softmax_logits:
-            dl = ce_loss_bwd(p, y, self.global_batch_size)
-        else:
-            raise NotImplementedError("backward for the clip path is not restated")
+        dl = ce_loss_bwd(p, y, self.global_batch_size, self.contract)
         L = {n: k for n, k, _, _ in self.layers}
         g = {}
-        b = lambda name, d: self._block_bwd(name, L[name], d, c, g)
+        b = lambda name, d: self._block_bwd(name, L[name], d, c, g, relu_masks)
         scale = 1.0 / (1.0 - self.contract.dropout_rate)
         d = np.ascontiguousarray(dl.transpose(0, 3, 1, 2))
         d = b("logits", d)

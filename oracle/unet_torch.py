@@ -82,7 +82,15 @@ class TorchUNet:
         y = torch.as_tensor(np.asarray(labels) if not torch.is_tensor(labels) else labels).to(self.dtype)
         if self.label_smoothing:
             y = y * (1.0 - self.label_smoothing) + self.label_smoothing / y.shape[-1]
-        ell = -(y * torch.log_softmax(logits, dim=-1)).sum(-1)
+        if self.contract.ce_from_softmax_logits:
+            ell = -(y * torch.log_softmax(logits, dim=-1)).sum(-1)
+        else:
+            # keras.backend.categorical_crossentropy(from_logits=False) as written: renormalise, clip, -sum y log q
+            # (torch.clamp, like tf.clip_by_value, passes the gradient where min <= x <= max)
+            q = torch.softmax(logits, dim=-1)
+            q = q / q.sum(-1, keepdim=True)
+            q = torch.clamp(q, self.contract.ce_clip_eps, 1.0 - self.contract.ce_clip_eps)
+            ell = -(y * torch.log(q)).sum(-1)
         return (ell.sum(0) / self.global_batch_size).mean()
 
     def loss_and_grads(self, images, labels, dropout_masks):

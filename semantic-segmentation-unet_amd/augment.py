@@ -153,8 +153,14 @@ class AugmentingFeed:
         self.L.unet_zscore_nhwc_to_nchw(_p(x), _p(out), b, h, w, c, _p(ws), nb, st)
         cm = m.to(torch.uint8)
         onehot = torch.empty(b, h, w, self.k, dtype=torch.int32, device=dev)
-        self.L.unet_labels_onehot(_p(cm), _p(onehot), b * h * w, self.k, None, st)
+        # class ids >= number_classes are counted on the device (the reference's reader raises IndexError for them,
+        # UNet/imagereader.py:302-312); train.py reads the counter at its per-epoch sync point
+        bad = getattr(self.feed, "_bad", None)
+        self.L.unet_labels_onehot(_p(cm), _p(onehot), b * h * w, self.k, _p(bad) if bad is not None else None, st)
         return out, onehot
+
+    def out_of_range_labels(self):
+        return self.feed.out_of_range_labels() if hasattr(self.feed, "out_of_range_labels") else 0
 
     def close(self):
         self.feed.close()

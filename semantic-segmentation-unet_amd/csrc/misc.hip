@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 // ---- softmax + CE (from logits) + accuracy + dlogits ------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ z, int ldz, const int* __restrict__ labels,
         float* __restrict__ prob, float* __restrict__ dz, int lddz, long P, int K, float label_smoothing, float grad_scale,
-        double* __restrict__ part_loss, unsigned long long* __restrict__ part_correct) {
+        float clip_eps, double* __restrict__ part_loss, unsigned long long* __restrict__ part_correct) {
     __shared__ double sL[256];
     __shared__ unsigned int sC[256];
     double lsum = 0.0; unsigned int csum = 0;
@@ -113,7 +113,24 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
                 if (li > lbest) { lbest = li; al = k; }
                 float y = (float)li;
                 if (label_smoothing > 0.f) y = y * (1.f - label_smoothing) + label_smoothing / (float)K;
-                ysum += y; ell -= y * ((zp[k] - m) - lse);
+                ysum += y;
+                if (clip_eps > 0.f) {
+                    // Keras backend categorical_crossentropy on probabilities: renormalise (sum p = 1 here), clip to
+                    // [eps, 1-eps], -sum y log q; the clip passes no gradient outside its range
+                    const float q = expf(zp[k] - m) * inv;
+                    ell -= y * logf(fminf(fmaxf(q, clip_eps), 1.f - clip_eps));
+                } else {
+                    ell -= y * ((zp[k] - m) - lse);
+                }
+            }
+        }
+        float gdot = 0.f;                        // clip path: sum_j g_j p_j with g_j = -y_j / q_j inside the clip range
+        if (dz && clip_eps > 0.f) {
+            for (int k = 0; k < K; ++k) {
+                const float pk = expf(zp[k] - m) * inv;
+                float y = (float)labels[(size_t)pix * K + k];
+                if (label_smoothing > 0.f) y = y * (1.f - label_smoothing) + label_smoothing / (float)K;
+                if (pk >= clip_eps && pk <= 1.f - clip_eps) gdot -= y;          // g_j p_j = -y_j
             }
         }
         for (int k = 0; k < K; ++k) {
@@ -122,7 +139,12 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
             if (dz) {
                 float y = (float)labels[(size_t)pix * K + k];
                 if (label_smoothing > 0.f) y = y * (1.f - label_smoothing) + label_smoothing / (float)K;
-                dz[(size_t)pix * lddz + k] = (pk * ysum - y) * grad_scale;
+                if (clip_eps > 0.f) {
+                    const float gp = (pk >= clip_eps && pk <= 1.f - clip_eps) ? -y : 0.f;     // p_k g_k
+                    dz[(size_t)pix * lddz + k] = (gp - pk * gdot) * grad_scale;
+                } else {
+                    dz[(size_t)pix * lddz + k] = (pk * ysum - y) * grad_scale;
+                }
             }
         }
         lsum += (double)ell; csum += (labels && al == am) ? 1u : 0u;
@@ -270,17 +292,21 @@ extern "C" int unet_dropout(const float* x, int ldx, float* out, int ldo, long P
 extern "C" size_t unet_softmax_ce_workspace(long P) { return (size_t)grid_for(P, 1024) * 16; }
 
 // prob, dlogits, labels, loss_out, correct_out may each be null (inference: prob only).
+// ce_clip_eps == 0: cross-entropy from the softmax's logits (graph-mode Keras sees the Softmax op and calls
+// softmax_cross_entropy_with_logits); ce_clip_eps > 0 (Keras epsilon 1e-7): the probability path of
+// keras.backend.categorical_crossentropy -- clip to [eps, 1-eps], -sum y log q, no gradient outside the clip range.
 extern "C" int unet_softmax_ce(const float* logits, int ldz, const int* labels_onehot, float* prob, float* dlogits, int lddz,
-        long P, int K, float label_smoothing, float loss_scale, float grad_scale, float* loss_out, float* correct_out,
-        void* ws, size_t ws_bytes, void* stream) {
+        long P, int K, float label_smoothing, float loss_scale, float grad_scale, float ce_clip_eps, float* loss_out,
+        float* correct_out, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(logits && ws && P > 0 && K > 0 && ldz >= K && (!dlogits || (labels_onehot && lddz >= K)));
+    UNET_CHECK_ARG(ce_clip_eps >= 0.f && ce_clip_eps < 0.5f);
     UNET_CHECK_ARG((!loss_out && !correct_out) || labels_onehot);
     const int nblk = grid_for(P, 1024);
     if (ws_bytes < unet_softmax_ce_workspace(P)) return UNET_ENOSPC;
     double* pl = (double*)ws;
     unsigned long long* pc = (unsigned long long*)((char*)ws + (size_t)nblk * 8);
     softmax_ce_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(logits, ldz, labels_onehot, prob, dlogits, lddz, P, K,
-                                                             label_smoothing, grad_scale, pl, pc);
+                                                             label_smoothing, grad_scale, ce_clip_eps, pl, pc);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     if (loss_out || correct_out) {
         softmax_ce_finalize_kernel<<<1, 64, 0, (hipStream_t)stream>>>(pl, pc, nblk, loss_scale, loss_out, correct_out);

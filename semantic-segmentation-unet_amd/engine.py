@@ -32,6 +32,7 @@ BN_MOMENTUM = 0.99
 BN_MOVING_VAR_UNBIASED = 1
 DROPOUT_RATE = 0.5
 ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-7
+CE_CLIP_EPS = 0.0              # 0: CE from the softmax's logits (graph-mode Keras); 1e-7: Keras' clipped-probability path
 
 
 def layer_table(number_channels, number_classes):
@@ -71,6 +72,25 @@ for _l in (1, 2, 3):
     PRODUCER["up_%d" % _l] = ("dec_%db" % (_l + 1), 0, 1, 1)   # (up_4's input went through the dropout: no direct producer)
 
 
+def flat_layout(number_channels, number_classes):
+    """-> (slices {name/suffix: (offset, count, shape)}, layer_range {layer: (start, end)}, total): the flat parameter /
+    gradient / Adam-moment buffers, layers in backward-completion order (logits first, conv_1a last), every tensor padded to
+    4 floats.  Data-parallel buckets are contiguous ranges of this order (parallel.py)."""
+    kind = {n: k for n, k, _, _ in layer_table(number_channels, number_classes)}
+    cin = {n: ci for n, _, ci, _ in layer_table(number_channels, number_classes)}
+    cout = {n: co for n, _, _, co in layer_table(number_channels, number_classes)}
+    slices, layer_range, off = {}, {}, 0
+    for name in BACKWARD_ORDER:
+        start = off
+        for suffix, shape in (("kernel", kernel_shape(kind[name], cin[name], cout[name])),
+                              ("bias", (cout[name],)), ("gamma", (cout[name],)), ("beta", (cout[name],))):
+            n = int(np.prod(shape))
+            slices[name + "/" + suffix] = (off, n, shape)
+            off += (n + 3) // 4 * 4
+        layer_range[name] = (start, off)
+    return slices, layer_range, off
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -95,17 +115,7 @@ class Engine:
         self.cin = {n: ci for n, _, ci, _ in self.layers}
         self.cout = {n: co for n, _, _, co in self.layers}
         # ---- flat parameter / gradient / moment buffers, backward-completion order, every tensor padded to 4 floats
-        self.slices = {}
-        off = 0
-        self.layer_range = {}
-        for name in BACKWARD_ORDER:
-            start = off
-            for suffix, shape in (("kernel", kernel_shape(self.kind[name], self.cin[name], self.cout[name])),
-                                  ("bias", (self.cout[name],)), ("gamma", (self.cout[name],)), ("beta", (self.cout[name],))):
-                n = int(np.prod(shape))
-                self.slices[name + "/" + suffix] = (off, n, shape)
-                off += (n + 3) // 4 * 4
-            self.layer_range[name] = (start, off)
+        self.slices, self.layer_range, off = flat_layout(number_channels, number_classes)
         self.n_flat = off
         self.theta = torch.zeros(off, dtype=torch.float32, device=self.dev)
         self.grad = torch.zeros_like(self.theta)
@@ -125,6 +135,7 @@ class Engine:
         self._ws = None
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.dev)             # [loss, correct]
         self.dropout_seed = seed
+        self.ce_clip_eps = CE_CLIP_EPS
         self.init_parameters(seed)
         self.on_layer_grads_ready = None        # hook(name) for data-parallel bucketing (parallel.py)
         self.profile = None                     # bench.py: {"conv3x3_fwd": [(ev0, ev1, flops)], ...} when enabled
@@ -540,7 +551,7 @@ class Engine:
         nb = L.unet_softmax_ce_workspace(P)
         ws = self._workspace(nb)
         if labels is None:
-            L.unet_softmax_ce(_p(yl), self.K, None, _p(prob), None, 0, P, self.K, 0.0, 0.0, 0.0, None, None, _p(ws), nb, st)
+            L.unet_softmax_ce(_p(yl), self.K, None, _p(prob), None, 0, P, self.K, 0.0, 0.0, 0.0, 0.0, None, None, _p(ws), nb, st)
         else:
             lab = labels.to(self.dev).contiguous()
             assert lab.dtype == torch.int32 and tuple(lab.shape) == (n, h, w, self.K), "labels must be int32 one-hot [N,H,W,K]"
@@ -548,7 +559,7 @@ class Engine:
             scale = 1.0 / (float(G) * h * w)                       # sum_n / G then mean over H,W  (UNet/model.py:213-215)
             dl = self._buf("dy_logits", (n, h, w, self.K)) if want_grad else None
             L.unet_softmax_ce(_p(yl), self.K, _p(lab), _p(prob), _p(dl), self.K, P, self.K, float(label_smoothing), scale,
-                              scale, _p(self.loss_buf[0:1]), _p(self.loss_buf[1:2]), _p(ws), nb, st)
+                              scale, float(self.ce_clip_eps), _p(self.loss_buf[0:1]), _p(self.loss_buf[1:2]), _p(ws), nb, st)
             self._labels_keepalive = lab
         return prob
 

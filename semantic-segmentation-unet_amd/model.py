@@ -27,6 +27,12 @@ class Mean:
         self.total += float(value)
         self.count += 1.0
 
+    def add(self, total, count):
+        """(total, count) pair summed over replicas -- tf.keras metrics under MirroredStrategy aggregate their `total` and
+        `count` variables with SUM on read."""
+        self.total += float(total)
+        self.count += float(count)
+
     def result(self):
         return np.float32(self.total / self.count) if self.count else np.float32(0.0)
 
@@ -71,10 +77,14 @@ class _KerasLikeModel:
         self._o = owner
 
     def __call__(self, x, training=False, dropout_masks=None):
+        """numpy in -> numpy out (the reference's callers run np.squeeze / np.argmax(...).astype on the result,
+        UNet/inference.py:105-107,164-166); torch tensor in -> device tensor out (no host copy)."""
         o = self._o
         xt = torch.as_tensor(np.asarray(x, dtype=np.float32)) if not torch.is_tensor(x) else x.float()
         prob = o.engine.forward(xt, training=bool(training), dropout_masks=dropout_masks)
-        return prob.clone()          # engine buffers are reused by the next call
+        if torch.is_tensor(x):
+            return prob.clone()      # engine buffers are reused by the next call
+        return prob.cpu().numpy()
 
     @property
     def trainable_weights(self):
@@ -200,15 +210,21 @@ class UNet:
 
     def _update_metrics(self, images, loss_metric, accuracy_metric):
         e = self.engine
-        loss = e.loss_buf[0:1].clone()
+        vals = e.loss_buf.clone()                                        # [per-replica loss, correctly classified pixels]
+        self._reduced = None
         if loss_metric is not None or accuracy_metric is not None:       # forces the per-step host sync the reference has
-            lb = e.loss_buf.tolist()
+            world = 1
+            if self.parallel is not None and self.parallel.world_size > 1:
+                # metric variables are summed over the replicas (X3); the same 8-byte all-reduce serves the loss SUM (X2)
+                self._reduced = self.parallel.reduce_sum(vals.clone())
+                world = self.parallel.world_size
+            lb = (self._reduced if self._reduced is not None else vals).tolist()
             n, _, h, w = images.shape
             if loss_metric is not None:
-                loss_metric.update_state(lb[0])
+                loss_metric.add(lb[0], world) if hasattr(loss_metric, "add") else loss_metric.update_state(lb[0] / world)
             if accuracy_metric is not None:
-                accuracy_metric.update_state(lb[1], n * h * w)
-        return _Loss(loss)
+                accuracy_metric.update_state(lb[1], n * h * w * world)
+        return _Loss(vals[0:1])
 
     # -- reference UNet/model.py:230-235,252-256: one replica per process here; the cross-replica SUM of the per-replica
     #    losses is an RCCL all-reduce in parallel.DataParallel (reference: dist_strategy.reduce(SUM, ...)).
@@ -223,5 +239,7 @@ class UNet:
     def _reduce_loss(self, dist_strategy, loss):
         strat = dist_strategy if dist_strategy is not None else self.parallel
         if strat is not None and getattr(strat, "world_size", 1) > 1:
+            if getattr(self, "_reduced", None) is not None:              # already summed together with the metric pairs
+                return _Loss(self._reduced[0:1])
             return _Loss(strat.reduce_sum(loss._t))
         return loss

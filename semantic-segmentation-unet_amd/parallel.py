@@ -41,6 +41,10 @@ class DataParallel:
         self._pending = []
         self.force = force            # tests: issue the collectives even with a single rank
         engine.on_layer_grads_ready = self._on_layer
+        # every replica draws its OWN dropout masks (MirroredStrategy replicas do); the init seed stays common -- parameters are
+        # broadcast from rank 0 anyway
+        if hasattr(engine, "dropout_seed"):
+            engine.dropout_seed = engine.dropout_seed * self.world_size + self.rank
         if broadcast and (self.world_size > 1 or force):
             self.broadcast_state()
 

@@ -56,8 +56,9 @@ class SyntheticReader(_Base):
     def get_image_size(self):
         return (self.h, self.w, self.c)
 
-    def batches(self, batch_size, classmap=False, pin=True, raw=False):       # (raw: the synthetic tiles are N(0,1) either way)
-        g = torch.Generator().manual_seed(self.seed)
+    def batches(self, batch_size, classmap=False, pin=True, raw=False, worker=0, num_workers=1):
+        # (raw: the synthetic tiles are N(0,1) either way; every worker draws its own stream)
+        g = torch.Generator().manual_seed(self.seed * 1000003 + worker)
         pin_ = _pin if pin else (lambda t: t)
         while True:
             img = torch.randn(batch_size, self.c, self.h, self.w, generator=g)
@@ -70,8 +71,17 @@ class SyntheticReader(_Base):
 
 
 class TileFolderReader(_Base):
-    def __init__(self, folder, number_classes, shuffle=False, seed=0):
+    """Key selection follows the reference reader (UNet/imagereader.py:209-243):
+      * shuffle=True: every sample is an independent uniform draw WITH replacement from the key list; with
+        balance_classes a class is drawn uniformly from range(number_classes) (re-drawn while it has no example), then a
+        uniform example among the tiles whose mask contains that class (:211-233; the reference reads the class list from the
+        LMDB key suffix written by build_lmdb.py:123,178 -- here it is computed from the mask file);
+      * shuffle=False: worker `w` of `num_workers` walks keys w, w+num_workers, ... modulo the key count (:239-241) and
+        class balancing is ignored ("without shuffle you cannot balance classes", :238)."""
+
+    def __init__(self, folder, number_classes, shuffle=False, seed=0, balance_classes=False):
         self.folder, self.k, self.shuffle, self.seed = folder, number_classes, shuffle, seed
+        self.balance_classes = bool(balance_classes)
         self.names = sorted(f[:-4] for f in os.listdir(folder) if f.endswith(".npy") and not f.endswith("_mask.npy"))
         if not self.names:
             raise IOError("no <name>.npy tiles in " + folder)
@@ -80,6 +90,13 @@ class TileFolderReader(_Base):
         self.c = 1 if first.ndim == 2 else first.shape[2]
         if self.h % 16 or self.w % 16:
             raise IOError("Input Image tile size must be a multiple of 16")     # cf. UNet/imagereader.py:136-139
+        self.keys = [[]]                                                         # per class: indices of the tiles containing it
+        if self.balance_classes:
+            for i, name in enumerate(self.names):
+                for cls in np.unique(np.load(os.path.join(folder, name + "_mask.npy"))):
+                    while len(self.keys) <= int(cls):
+                        self.keys.append([])
+                    self.keys[int(cls)].append(i)
 
     def get_image_count(self):
         return len(self.names)
@@ -98,18 +115,39 @@ class TileFolderReader(_Base):
             return (np.ascontiguousarray(chw, dtype=np.float32) if raw else zscore_normalize(chw)), mk.astype(np.uint8)
         return zscore_normalize(im.transpose(2, 0, 1)), one_hot(mk, self.k)
 
-    def batches(self, batch_size, classmap=False, pin=True, raw=False):
+    def key_sequence(self, worker=0, num_workers=1):
+        """Infinite iterator of tile indices for one reader worker."""
+        rng = np.random.default_rng([self.seed, worker])
+        pos = worker % len(self.names)
+        while True:
+            if self.shuffle and self.balance_classes:
+                while True:
+                    label = int(rng.integers(0, self.k))
+                    if label >= len(self.keys):
+                        raise IndexError("Number of classes specified differs from number of observed classes in data")
+                    if self.keys[label]:
+                        break
+                yield self.keys[label][int(rng.integers(0, len(self.keys[label])))]
+            elif self.shuffle:
+                yield int(rng.integers(0, len(self.names)))
+            else:
+                yield pos
+                pos = (pos + num_workers) % len(self.names)
+
+    def batches(self, batch_size, classmap=False, pin=True, raw=False, worker=0, num_workers=1):
         """raw=True (with classmap=True): un-normalised pixel values, for the device pipeline that augments before z-scoring"""
         pin_ = _pin if pin else (lambda t: t)
-        rng = np.random.default_rng(self.seed)
-        pos = 0
-        order = np.arange(len(self.names))
+        keys = self.key_sequence(worker, num_workers)
         while True:
             imgs, labs = [], []
             for _ in range(batch_size):
-                if pos == 0 and self.shuffle:
-                    rng.shuffle(order)
-                i, l = self._load(self.names[order[pos]], classmap, raw)
+                i, l = self._load(self.names[next(keys)], classmap, raw)
                 imgs.append(i); labs.append(l)
-                pos = (pos + 1) % len(order)
             yield pin_(torch.as_tensor(np.stack(imgs))), pin_(torch.as_tensor(np.stack(labs)))
+
+
+def round_robin(iterators):
+    """One stream from several worker iterators (the synchronous hand-over's stand-in for the reference's shared queue)."""
+    while True:
+        for it in iterators:
+            yield next(it)

@@ -16,6 +16,8 @@ import json
 import os
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before HIP initialises: RCCL needs dmabuf IPC on this platform
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -53,7 +55,10 @@ def best_epoch_index(test_loss):
 
 def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, test_lmdb_filepath, use_augmentation,
                 number_classes, balance_classes, learning_rate, test_every_n_steps, early_stopping_count,
-                train_reader=None, test_reader=None, max_epochs=None, quiet=False, compute_dtype=None):
+                train_reader=None, test_reader=None, max_epochs=None, quiet=False, compute_dtype=None, unet_factory=None):
+    """unet_factory (tests): callable(number_classes, global_batch_size, number_channels, learning_rate, device=..., compute_dtype=...)
+    standing in for model.UNet, so the loop semantics can be checked without a GPU; the default is the HIP-backed class, which
+    refuses to run anywhere but on an MI355X."""
     say = (lambda *a: None) if quiet else print
     for k, v in (("batch_size", batch_size), ("number_classes", number_classes), ("learning_rate", learning_rate),
                  ("test_every_n_steps", test_every_n_steps), ("balance_classes", balance_classes),
@@ -66,15 +71,37 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    have_gpu = torch.cuda.is_available()
+    dev_ = torch.device("cuda", local) if have_gpu else torch.device("cpu")
+    if have_gpu:
+        torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=dev_) if have_gpu else dist.init_process_group("gloo")
     global_batch_size = batch_size * world
 
+    # reader workers: `reader_count` per replica (the reference scales it by the replica count, UNet/train.py:63); worker ids
+    # are global, so the non-shuffled test readers of different ranks walk DISJOINT strides of the key list -- each global
+    # test batch is split over the replicas like experimental_distribute_dataset does (UNet/train.py:85-90) -- and every
+    # training worker draws its own random key stream (UNet/imagereader.py:209-233)
+    reader_count = max(1, int(reader_count))
+    total_workers = reader_count * world
+    worker_ids = [rank * reader_count + w for w in range(reader_count)]
     if train_reader is None:
-        train_reader = readers.TileFolderReader(train_lmdb_filepath, number_classes, shuffle=True, seed=rank)
+        train_reader = readers.TileFolderReader(train_lmdb_filepath, number_classes, shuffle=True, seed=0,
+                                                balance_classes=bool(balance_classes))
+    elif balance_classes and not getattr(train_reader, "balance_classes", False):
+        raise ValueError("--balance_classes 1 needs a reader that implements class-balanced sampling (readers.TileFolderReader); "
+                         "the reader passed in does not")
     if test_reader is None:
         test_reader = readers.TileFolderReader(test_lmdb_filepath, number_classes, shuffle=False)
+
+    def worker_batches(reader, **kw):
+        import inspect
+        if "worker" not in inspect.signature(reader.batches).parameters:       # a caller-supplied reader without worker streams
+            if total_workers > 1:
+                raise ValueError("reader_count x replicas > 1 needs a reader whose batches() takes worker/num_workers")
+            return [reader.batches(batch_size, **kw)]
+        return [reader.batches(batch_size, worker=w, num_workers=total_workers, **kw) for w in worker_ids]
     say("Test Reader has {} images".format(test_reader.get_image_count()))
     say("Train Reader has {} images".format(train_reader.get_image_count()))
     feeds = []
@@ -86,29 +113,28 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
         use_feed = os.environ.get("UNET_FEED", "1") != "0"
         if use_feed:
             from .feed import DeviceFeed
-            dev_ = torch.device("cuda", local)
             if use_augmentation:
                 # the reference augments inside its reader processes (UNet/imagereader.py:283-301, settings :79-85), ~31 images/s
                 # per host core; here the raw tiles go to the device and the same sequence runs as HIP kernels (augment.py)
                 from .augment import AugmentingFeed, DeviceAugmenter
-                raw_feed = DeviceFeed(train_reader.batches(batch_size, classmap=True, pin=False, raw=True), dev_, classmap=True,
+                raw_feed = DeviceFeed(worker_batches(train_reader, classmap=True, pin=False, raw=True), dev_, classmap=True,
                                       number_classes=number_classes, onehot=False)
                 train_batches = AugmentingFeed(raw_feed, DeviceAugmenter(
                     rotation_flag=True, reflection_flag=True, jitter_augmentation_severity=0.1, noise_augmentation_severity=0.02,
                     scale_augmentation_severity=0.1, blur_augmentation_max_sigma=2, intensity_augmentation_severity=None,
                     seed=rank, device=dev_), number_classes)
             else:
-                train_batches = DeviceFeed(train_reader.batches(batch_size, classmap=True, pin=False), dev_, classmap=True, number_classes=number_classes)
-            test_batches = DeviceFeed(test_reader.batches(batch_size, classmap=True, pin=False), dev_, classmap=True, number_classes=number_classes)
+                train_batches = DeviceFeed(worker_batches(train_reader, classmap=True, pin=False), dev_, classmap=True, number_classes=number_classes)
+            test_batches = DeviceFeed(worker_batches(test_reader, classmap=True, pin=False), dev_, classmap=True, number_classes=number_classes)
             feeds = [train_batches, test_batches]
         else:
-            train_batches = train_reader.batches(batch_size)
-            test_batches = test_reader.batches(batch_size)
+            train_batches = readers.round_robin(worker_batches(train_reader))
+            test_batches = readers.round_robin(worker_batches(test_reader))
         number_channels = train_reader.get_image_size()[2]
-        net = unet_model_module.UNet(number_classes, global_batch_size, number_channels, learning_rate,
-                                     device=torch.device("cuda", local), compute_dtype=compute_dtype)
+        net = (unet_factory or unet_model_module.UNet)(number_classes, global_batch_size, number_channels, learning_rate,
+                                                       device=dev_, compute_dtype=compute_dtype)
         strategy = None
-        if world > 1:
+        if world > 1 and unet_factory is None:
             from .parallel import DataParallel
             strategy = net.parallel = DataParallel(net.engine)
 
@@ -136,7 +162,7 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
             step = 0
             while step <= steps_this_epoch:                      # N+1 steps, as the reference's `step > N: break`
                 images, labels = next(train_batches)
-                net.dist_train_step(strategy, (images.cuda(non_blocking=True), labels.cuda(non_blocking=True),
+                net.dist_train_step(strategy, (images.to(dev_, non_blocking=True), labels.to(dev_, non_blocking=True),
                                                train_loss_metric, train_acc_metric))
                 say("Train Epoch {}: Batch {}/{}: Loss {} Accuracy = {}".format(
                     epoch, step, train_epoch_size, train_loss_metric.result(), train_acc_metric.result()))
@@ -149,11 +175,14 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
             step = 0
             while step <= test_epoch_size:
                 images, labels = next(test_batches)
-                loss_value = net.dist_test_step(strategy, (images.cuda(non_blocking=True), labels.cuda(non_blocking=True),
+                loss_value = net.dist_test_step(strategy, (images.to(dev_, non_blocking=True), labels.to(dev_, non_blocking=True),
                                                            test_loss_metric, test_acc_metric))
                 epoch_test_loss.append(loss_value.numpy())
                 step += 1
             test_loss.append(float(np.mean(epoch_test_loss)))
+            for f in feeds:                                       # the reference's reader raises IndexError for a class id >= number_classes
+                if hasattr(f, "out_of_range_labels") and f.out_of_range_labels() > 0:          # (UNet/imagereader.py:302-312)
+                    raise IndexError("Number of classes specified differs from number of observed classes in data")
             say("Test Epoch: {}: Loss = {} Accuracy = {}".format(epoch, test_loss_metric.result(), test_acc_metric.result()))
             if writers:
                 writers[1].scalar("loss", test_loss_metric.result(), (epoch + 1) * train_epoch_size)

@@ -393,16 +393,24 @@ def test_dropout_mask_and_rng(hip):
     assert torch.equal(o1[kept], (x * 2.0)[kept])
 
 
-@pytest.mark.parametrize("k,ls", [(2, 0.0), (4, 0.0), (6, 0.1)])
-def test_softmax_ce_accuracy_argmax(hip, k, ls):
+@pytest.mark.parametrize("k,ls,clip", [(2, 0.0, 0.0), (4, 0.0, 0.0), (6, 0.1, 0.0), (2, 0.0, 1e-7), (4, 0.1, 1e-7), (3, 0.0, 1e-3)])
+def test_softmax_ce_accuracy_argmax(hip, k, ls, clip):
+    # clip = 0: cross-entropy from the softmax's logits; clip > 0: Keras' clipped-probability path (Contract.ce_from_softmax_logits
+    # False) -- logits scaled so that some probabilities really fall outside [eps, 1-eps] and take the zero-gradient branch
     n, h, w = 2, 16, 24
     rng = np.random.default_rng(k)
-    z = rng.standard_normal((n, h, w, k)) * 3
+    z = rng.standard_normal((n, h, w, k)) * (3 if clip == 0.0 else 9)
     cls = rng.integers(0, k, (n, h, w))
     lab = (cls[..., None] == np.arange(k)).astype(np.int32)
     G = 4
-    loss_ref, p_ref, y = on.ce_loss_fwd(z, lab, G, ls, on.Contract())
-    dl_ref = on.ce_loss_bwd(p_ref, y, G)
+    contract = on.Contract(ce_from_softmax_logits=(clip == 0.0), ce_clip_eps=clip if clip else 1e-7)
+    loss_ref, p_ref, y = on.ce_loss_fwd(z, lab, G, ls, contract)
+    dl_ref = on.ce_loss_bwd(p_ref, y, G, contract)
+    if clip:
+        # a probability within fp32 rounding of a clip edge may legitimately fall on the other side: keep the test decisive
+        edge = np.minimum(np.abs(p_ref - clip), np.abs(p_ref - (1 - clip))) < 1e-6 * np.maximum(clip, 1e-6) + 1e-9
+        assert not edge.any()
+        assert ((p_ref < clip) | (p_ref > 1 - clip)).any()
     zd, labd = dev(z), dev(lab, np.int32)
     pix = n * h * w
     prob = torch.empty(n, h, w, k, device=DEV); dl = torch.empty(n, h, w, k, device=DEV)
@@ -410,10 +418,10 @@ def test_softmax_ce_accuracy_argmax(hip, k, ls):
     nb = hip.unet_softmax_ce_workspace(pix)
     ws = ws_bytes(nb)
     s = 1.0 / (G * h * w)
-    hip.unet_softmax_ce(P(zd), k, P(labd), P(prob), P(dl), k, pix, k, ls, s, s, P(res[0:1]), P(res[1:2]), P(ws), nb, ST())
+    hip.unet_softmax_ce(P(zd), k, P(labd), P(prob), P(dl), k, pix, k, ls, s, s, clip, P(res[0:1]), P(res[1:2]), P(ws), nb, ST())
     assert relerr(prob.cpu().numpy(), p_ref) < 2e-6
     assert relerr(dl.cpu().numpy(), dl_ref) < 5e-6
-    assert abs(res[0].item() - loss_ref) < 2e-6 * abs(loss_ref)
+    assert abs(res[0].item() - loss_ref) < (2e-6 if clip == 0.0 else 2e-5) * abs(loss_ref)   # (log(1 - 1e-7) carries fp32's 6e-8 ulp of 1)
     assert res[1].item() == float((np.argmax(p_ref, -1) == cls).sum())
     am = torch.empty(n, h, w, dtype=torch.int32, device=DEV)
     hip.unet_argmax(P(prob), k, P(am), pix, k, ST())

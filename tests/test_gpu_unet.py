@@ -68,9 +68,14 @@ def test_unet_matches_numpy_oracle(cfg):
     ref = on.OracleUNet(k, G, c, learning_rate=3e-4, params=prm, dtype=np.float64)
 
     # --- inference path: eval-mode forward + argmax mask (reference UNet/inference.py:159-166)
-    sm = net.get_keras_model()(img).cpu().numpy()
+    sm = net.get_keras_model()(img)
     sm_ref, _ = ref.forward(img, training=False)
-    assert sm.shape == (n, hw, hw, k)
+    assert isinstance(sm, np.ndarray) and sm.shape == (n, hw, hw, k)         # numpy in -> numpy out
+    # the reference's own post-processing lines run unchanged on the return value (UNet/inference.py:104-107)
+    one = net.get_keras_model()(img[:1])
+    one = np.squeeze(one)
+    pred = np.squeeze(np.argmax(one, axis=-1).astype(np.int32))
+    assert pred.shape == (hw, hw) and pred.dtype == np.int32 and np.array_equal(pred, np.argmax(ref.forward(img[:1], training=False)[0][0], -1))
     assert np.abs(sm - sm_ref).max() < 2e-5
     ok, undecided, differ = argmax_agreement(sm, sm_ref)
     assert ok and differ == 0, (undecided, differ)
@@ -132,7 +137,7 @@ def test_unet_matches_torch_restatement_at_128():
     net = model.UNet(k, n, c)
     net.engine.load_parameters(prm)
     ref = ot.TorchUNet(k, n, c, params=prm, dtype=torch.float64)
-    sm = net.get_keras_model()(img).cpu().numpy()
+    sm = net.get_keras_model()(img)
     with torch.no_grad():
         sm_ref = ref.forward(img, False)[0].numpy()
     assert np.abs(sm - sm_ref).max() < 5e-5
@@ -414,3 +419,55 @@ def test_bf16_operand_beyond_2gib_falls_back_to_fp32_kernels():
     assert counts.get("conv3x3_fwd_bf16") == 16 and counts.get("conv3x3_fwd_winograd_fused") == 1, counts
     assert counts.get("conv3x3_wgrad_bf16", 0) + counts.get("conv3x3_wgrad_winograd_fused", 0) == 17, counts
     assert counts.get("conv3x3_dgrad_bf16", 0) + counts.get("conv3x3_dgrad_winograd_fused", 0) == 17, counts
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, 2, 32, "fp32"), (2, 3, 4, 64, "fp32"), (1, 1, 2, 128, "fp32")])
+def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
+    # End-to-end gradients at 1e-4 instead of 5e-2.  The network is piecewise linear: its gradient is discontinuous only in the
+    # branch decisions (ReLU masks, max-pool winners), and fp32 rounding flips a few of those for pre-activations within ~1e-7
+    # of zero -- which is all the 5e-2 bound of test_unet_matches_numpy_oracle has to absorb.  Here the fp64 oracle's BACKWARD
+    # pass is given the HIP run's own decisions (r > 0 of every layer, the pool's first-max indices); what remains is a smooth
+    # function evaluated in fp32 vs fp64, so a 2-3 % systematic error in any weight-gradient kernel cannot hide.
+    n, c, k, hw, _ = cfg
+    img, lab, prm, masks = make_case(41, n, c, k, hw)
+    model = pkg("model")
+    net = model.UNet(k, n, c)
+    net.engine.load_parameters(prm)
+    e = net.engine
+    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+    e.backward()
+    torch.cuda.synchronize()
+    relu = {name: (e.saved[name][1].float().permute(0, 3, 1, 2) > 0).cpu().numpy() for name, kind, _, _ in e.layers if kind != "deconv"}
+    pidx = {"pool_%d" % l: e.idx[l].permute(0, 3, 1, 2).cpu().numpy().astype(np.int64) for l in (1, 2, 3, 4)}
+    ref = on.OracleUNet(k, n, c, params=prm, dtype=np.float64)
+    # the imposed decisions must be ones the oracle could have taken itself: they may differ from its own only where its
+    # pre-activation / window spread is at rounding level
+    _, cache = ref.forward(img, training=True, dropout_masks=masks)
+    for name, m in relu.items():
+        r64 = cache[name][1]
+        assert np.abs(r64[m != (r64 > 0)]).max(initial=0.0) < 1e-4 * np.abs(r64).max(), name
+    loss_ref, _, g_ref, _, _ = ref.loss_and_grads(img, lab, masks, relu_masks=relu, pool_idx=pidx)
+    assert abs(e.loss_buf[0].item() - loss_ref) < 1e-5 * abs(loss_ref)
+    errs = grad_errors(e.export_gradients(), g_ref)
+    worst = max((v, key) for key, v in errs.items())
+    assert worst[0] < 1e-4, sorted(errs.items(), key=lambda t: -t[1])[:6]
+
+
+def test_clipped_probability_cross_entropy_mode_matches_oracle():
+    # Contract.ce_from_softmax_logits = False (the other (K) reading of Keras' CategoricalCrossentropy(from_logits=False)):
+    # engine.ce_clip_eps = 1e-7 against the oracle with the same switch -- loss and gradients, same tolerances as the default
+    n, c, k, hw = 2, 1, 2, 32
+    img, lab, prm, masks = make_case(43, n, c, k, hw)
+    model = pkg("model")
+    net = model.UNet(k, n, c)
+    net.engine.load_parameters(prm)
+    net.engine.ce_clip_eps = 1e-7
+    contract = on.Contract(ce_from_softmax_logits=False, ce_clip_eps=1e-7)
+    ref = on.OracleUNet(k, n, c, params=prm, dtype=np.float64, contract=contract)
+    e = net.engine
+    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+    e.backward()
+    loss_ref, _, g_ref, _, _ = ref.loss_and_grads(img, lab, masks)
+    assert abs(e.loss_buf[0].item() - loss_ref) < 1e-5 * abs(loss_ref)
+    errs = grad_errors(e.export_gradients(), g_ref)
+    assert max(errs.values()) < 5e-2 and errs["logits/kernel"] < 5e-5, errs

@@ -131,3 +131,26 @@ def test_train_step_and_eval_match_between_restatements():
     lt, st = t.test_step(img, lab)
     assert abs(le - float(lt)) < 1e-10 and np.abs(se - st.numpy()).max() < 1e-10
     assert (o.predict_mask(img) == t.predict_mask(img)).all()
+
+
+def test_ce_clip_path_numpy_backward_matches_torch_autograd():
+    """Contract.ce_from_softmax_logits=False (Keras' clipped-probability cross-entropy): the hand-written numpy backward equals
+    torch autograd through the literal formula (renormalise, clamp, -sum y log q), including pixels outside the clip range."""
+    import torch
+    from oracle import unet_torch as ot
+    rng = np.random.default_rng(3)
+    n, h, w, k, G = 2, 6, 5, 4, 4
+    z = rng.standard_normal((n, h, w, k)) * 8
+    lab = (rng.integers(0, k, (n, h, w))[..., None] == np.arange(k)).astype(np.int32)
+    for eps, ls in ((1e-7, 0.0), (1e-3, 0.1)):
+        c = on.Contract(ce_from_softmax_logits=False, ce_clip_eps=eps)
+        loss, p, y = on.ce_loss_fwd(z, lab, G, ls, c)
+        dl = on.ce_loss_bwd(p, y, G, c)
+        assert ((p < eps) | (p > 1 - eps)).any()
+        net = ot.TorchUNet.__new__(ot.TorchUNet)
+        net.contract, net.dtype, net.label_smoothing, net.global_batch_size = c, torch.float64, ls, G
+        zt = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+        lt = net.loss(zt, lab)
+        lt.backward()
+        assert abs(float(lt) - loss) < 1e-12 * abs(loss)
+        assert np.abs(zt.grad.numpy() - dl).max() < 1e-12 * np.abs(dl).max() + 1e-18

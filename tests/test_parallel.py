@@ -1,7 +1,8 @@
 """Data-parallel path on CPU: world_size-2 gloo processes drive parallel.DataParallel with a stub engine (the class only
 touches grad/theta/adam/moving/layer_range/on_layer_grads_ready), checking bucket construction, that every bucket is
 all-reduced with SUM exactly once per step in gradient-readiness order, the rank-0 broadcast, the loss reduce and the
-moving-stat average."""
+moving-stat average; and an oracle-backed engine (fp64 train step behind the same flat layout and hook
+protocol) showing that an R = 2 run through DataParallel equals the reference's global-batch semantics exactly."""
 import os
 import socket
 
@@ -95,26 +96,131 @@ def test_data_parallel_buckets_gloo_world2():
     assert res == {0: "ok", 1: "ok"}, res
 
 
-def test_split_batch_gradient_equals_sum_of_replica_gradients():
-    """Why SUM is the right collective: with the loss divided by the GLOBAL batch (reference UNet/model.py:213) and
-    per-replica BatchNorm, the R-replica gradient is the sum of the per-chunk gradients (oracle, fp64)."""
+class OracleEngine:
+    """CPU stand-in for engine.Engine behind parallel.DataParallel: the SAME flat layout (engine.flat_layout) and hook
+    protocol, with the oracle's fp64 train step as the arithmetic -- per-replica BatchNorm, loss divided by the GLOBAL batch
+    (reference UNet/model.py:213), gradients written layer by layer in backward-completion order with
+    on_layer_grads_ready(name) after each, then one Keras-Adam step on the flat buffers."""
+
+    def __init__(self, k, G, c, prm, lr):
+        from oracle import unet_numpy as on
+        eng = pkg("engine")
+        self.on, self.eng, self.lr, self.G = on, eng, lr, G
+        self.slices, self.layer_range, self.n_flat = eng.flat_layout(c, k)
+        self.net = on.OracleUNet(k, G, c, learning_rate=lr, params=prm, dtype=np.float64)
+        self.theta = torch.zeros(self.n_flat, dtype=torch.float64)
+        self.grad = torch.full((self.n_flat,), float("nan"), dtype=torch.float64)
+        self.adam_m = torch.zeros(self.n_flat, dtype=torch.float64)
+        self.adam_v = torch.zeros(self.n_flat, dtype=torch.float64)
+        for key, (o, n, shape) in self.slices.items():
+            self.theta[o:o + n] = torch.as_tensor(np.asarray(prm[key], np.float64).reshape(-1))
+        self.moving = {key: torch.as_tensor(np.asarray(v, np.float64)) for key, v in prm.items() if "moving" in key}
+        self.on_layer_grads_ready = None
+        self.dropout_seed = 0
+        self.iterations = 0
+
+    def parameters_changed(self):
+        pass
+
+    def backward(self, img, lab, masks):
+        for key, (o, n, shape) in self.slices.items():               # theta may have been broadcast: the oracle reads it back
+            self.net.params[key] = self.theta[o:o + n].numpy().reshape(shape).copy()
+        loss, _, g, cache, _ = self.net.loss_and_grads(img, lab, masks)
+        self.grad.zero_()
+        for name in self.eng.BACKWARD_ORDER:
+            for sfx in ("kernel", "bias", "gamma", "beta"):
+                o, n, _ = self.slices[name + "/" + sfx]
+                self.grad[o:o + n] = torch.as_tensor(np.ascontiguousarray(g[name + "/" + sfx]).reshape(-1))
+            self.on_layer_grads_ready(name)
+        return loss
+
+    def adam_step(self):
+        self.iterations += 1
+        th, m, v = self.on.adam_keras_step(self.theta.numpy(), self.grad.numpy(), self.adam_m.numpy(), self.adam_v.numpy(),
+                                           self.iterations, self.lr, self.net.contract)
+        self.theta, self.adam_m, self.adam_v = torch.as_tensor(th), torch.as_tensor(m), torch.as_tensor(v)
+
+
+def _case(n=2, c=1, k=2, hw=16, seed=2):
     from oracle import unet_numpy as on
-    n, c, k, hw = 2, 1, 2, 16
-    img, lab = on.synthetic_batch(n, c, k, hw, hw, seed=2)
-    prm = on.init_params(c, k, seed=2)
-    rng = np.random.default_rng(2)
-    masks = {"drop_4": rng.integers(0, 2, (n, 512, 2, 2)), "drop_b": rng.integers(0, 2, (n, 1024, 1, 1))}
-    total, loss_total = None, 0.0
+    img, lab = on.synthetic_batch(n, c, k, hw, hw, seed=seed)
+    prm = on.init_params(c, k, seed=seed)
+    rng = np.random.default_rng(seed)
+    for key in prm:                                                    # non-trivial bias / gamma / beta so their gradients matter
+        if key.endswith(("bias", "beta")):
+            prm[key] = rng.normal(0, 0.1, prm[key].shape).astype(np.float32)
+        if key.endswith("gamma"):
+            prm[key] = rng.uniform(0.5, 1.5, prm[key].shape).astype(np.float32)
+    masks = {"drop_4": rng.integers(0, 2, (n, 512, hw // 8, hw // 8)), "drop_b": rng.integers(0, 2, (n, 1024, hw // 16, hw // 16))}
+    return img, lab, prm, masks
+
+
+def _dp_worker(rank, world, port, bucket_bytes, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        par = pkg("parallel")
+        img, lab, prm, masks = _case()
+        if rank != 0:                                    # replicas start from DIFFERENT weights: the rank-0 broadcast must fix that
+            prm = {key: v + 1.0 for key, v in prm.items()}
+        e = OracleEngine(2, world, 1, prm, 3e-4)
+        dp = par.DataParallel(e, bucket_bytes=bucket_bytes)
+        assert e.dropout_seed == rank                                  # every replica draws its own dropout stream
+        sl = slice(rank, rank + 1)                                     # this replica's image of the global batch of 2
+        dp.begin_step()
+        loss = e.backward(img[sl], lab[sl], {key: v[sl] for key, v in masks.items()})
+        dp.finish_step()
+        e.adam_step()
+        total = dp.reduce_sum(torch.tensor([loss], dtype=torch.float64))
+        out.put((rank, dict(grad=e.grad.numpy().copy(), theta=e.theta.numpy().copy(), loss=float(total), nb=len(dp.buckets))))
+    except Exception:
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [25 * 1024 * 1024, 512])
+def test_two_rank_step_equals_the_reference_global_batch_semantics(bucket_bytes):
+    """R = 2 replicas of one image each through parallel.DataParallel over gloo == what the reference's MirroredStrategy step
+    computes for the global batch of 2 (UNet/model.py:204-235): per-replica BatchNorm statistics, per-replica loss = sum of the
+    replica's pixel losses / GLOBAL batch, gradients combined with SUM, ONE Keras-Adam step on the summed gradient; the
+    returned loss is the SUM of the per-replica losses.  With 512-byte buckets every layer closes its own bucket, so the bucket
+    edges sit directly behind each layer's bias / gamma / beta (and the 16-byte padding of the flat layout): every element,
+    padding included, must be reduced exactly once.  fp64 and a commutative two-term sum: the comparison is exact."""
+    from oracle import unet_numpy as on
+    eng = pkg("engine")
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, bucket_bytes, out)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(out.get(timeout=600) for _ in procs)
+    [p.join(60) for p in procs]
+    assert all(isinstance(v, dict) for v in res.values()), res
+    # single-process statement of the same semantics
+    img, lab, prm, masks = _case()
+    slices, _, n_flat = eng.flat_layout(1, 2)
+    gsum, lsum = None, 0.0
     for r in range(2):
-        o = on.OracleUNet(k, n, c, params=prm, dtype=np.float64)            # global batch n, this replica holds 1 image
-        loss, _, g, _, _ = o.loss_and_grads(img[r:r + 1], lab[r:r + 1], {kk: v[r:r + 1] for kk, v in masks.items()})
-        loss_total += loss
-        total = g if total is None else {kk: total[kk] + g[kk] for kk in g}
-    # a single replica holding both images but normalising each image separately is the same function:
-    o = on.OracleUNet(k, n, c, params=prm, dtype=np.float64)
-    la, _, ga, _, _ = o.loss_and_grads(img[0:1], lab[0:1], {kk: v[0:1] for kk, v in masks.items()})
-    lb, _, gb, _, _ = o.loss_and_grads(img[1:2], lab[1:2], {kk: v[1:2] for kk, v in masks.items()})
-    assert loss_total == pytest.approx(la + lb, rel=1e-12)
-    for kk in total:
-        assert np.allclose(total[kk], ga[kk] + gb[kk], rtol=1e-12, atol=1e-15)
-    assert loss_total > 0
+        o = on.OracleUNet(2, 2, 1, params=prm, dtype=np.float64)               # global batch 2, this replica holds image r
+        loss, _, g, _, _ = o.loss_and_grads(img[r:r + 1], lab[r:r + 1], {key: v[r:r + 1] for key, v in masks.items()})
+        lsum += loss
+        gsum = g if gsum is None else {key: gsum[key] + g[key] for key in g}
+    ref = on.OracleUNet(2, 2, 1, learning_rate=3e-4, params=prm, dtype=np.float64)
+    ref.apply_gradients(gsum)
+    for r in range(2):
+        got = res[r]
+        assert got["nb"] == (23 if bucket_bytes == 512 else got["nb"]) and got["nb"] >= 3
+        assert got["loss"] == pytest.approx(lsum, rel=1e-14)
+        covered = np.zeros(n_flat, bool)
+        for key, (o_, n_, shape) in slices.items():
+            assert np.array_equal(got["grad"][o_:o_ + n_].reshape(shape), gsum[key]), key
+            assert np.allclose(got["theta"][o_:o_ + n_].reshape(shape), ref.params[key], rtol=0, atol=1e-15), key
+            covered[o_:o_ + n_] = True
+        assert np.all(got["grad"][~covered] == 0.0)                       # padding: reduced (0 + 0), never left as garbage
+    assert np.array_equal(res[0]["theta"], res[1]["theta"])                # replicas stay in lock-step
+    # and it is NOT the single-replica batch-of-2 step (BatchNorm couples the images there): the distinction is real
+    o = on.OracleUNet(2, 2, 1, params=prm, dtype=np.float64)
+    _, _, gj, _, _ = o.loss_and_grads(img, lab, masks)
+    assert not np.allclose(gj["conv_1a/kernel"], gsum["conv_1a/kernel"], rtol=1e-3)
