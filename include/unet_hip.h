@@ -292,6 +292,11 @@ int unet_zscore_nhwc_to_nchw(const float* img, float* out, int N, int H, int W, 
  * the condition the reference raises IndexError for */
 int unet_labels_onehot(const uint8_t* classmap, int* onehot, long P, int K, unsigned* out_of_range, void* stream);
 
+/* ---- host-side helper of the checkpoint format (tf.train.Checkpoint = TensorBundle, UNet/train.py:96,184; UNet/model.py:81-83):
+ * CRC-32C as TensorFlow's crc32c::Extend(init, data, n) -- the block trailers of `ckpt.index` and the per-tensor checksums of
+ * BundleEntryProto.  Pure host code, no device work, no stream. */
+uint32_t unet_crc32c_extend(uint32_t init, const void* data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,10 @@
-"""Builds csrc/*.hip into the in-tree C-ABI library `libunet_hip.so` for gfx950 (hipcc cross-compiles without a GPU)."""
+"""Builds csrc/*.hip into the in-tree C-ABI library `libunet_hip.so` for gfx950 (hipcc cross-compiles without a GPU).
+
+Staleness is decided by CONTENT, not by mtimes: every object file and the library carry a stamp = sha256 over the compiler
+flags, the source text and the text of the headers it includes (`<name>.o.stamp`, `libunet_hip.so.stamp`).  A change of FLAGS,
+a touched-but-identical file, or a pushed `.so` that is newer than edited sources can therefore neither force nor hide a
+rebuild; `library_is_current()` lets a loader check that the binary it maps corresponds to the sources next to it."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -6,35 +12,62 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libunet_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_direct.hip", "winograd.hip", "convt_stream.hip", "conv_bf16.hip", "augment.hip", "norm.hip", "misc.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_direct.hip", "winograd.hip", "convt_stream.hip", "conv_bf16.hip", "augment.hip",
+           "norm.hip", "misc.hip", "crc32c.hip"]
+HEADERS = ["common.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared"]
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _sha(*chunks):
+    h = hashlib.sha256()
+    for c in chunks:
+        h.update(c if isinstance(c, bytes) else c.encode())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def source_stamp(src):
+    hdr = [open(os.path.join(CSRC, h), "rb").read() for h in HEADERS]
+    return _sha(" ".join(FLAGS), open(os.path.join(CSRC, src), "rb").read(), *hdr)
+
+
+def library_stamp():
+    return _sha(" ".join(LINK_FLAGS), *[source_stamp(s) for s in SOURCES])
+
+
+def _read(path):
+    try:
+        return open(path).read().strip()
+    except OSError:
+        return None
+
+
+def library_is_current():
+    """True when libunet_hip.so exists and was built from exactly the sources + flags in this tree."""
+    return os.path.exists(LIB_PATH) and _read(LIB_PATH + ".stamp") == library_stamp()
 
 
 def build_library(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdrs = [os.path.join(CSRC, "common.h")]
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + hdrs):
+        stamp = source_stamp(s)
+        if force or not os.path.exists(obj) or _read(obj + ".stamp") != stamp:
             cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+            open(obj + ".stamp", "w").write(stamp)
         objs.append(obj)
-    if force or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB_PATH] + objs
+    if force or not library_is_current():
+        cmd = [hipcc] + LINK_FLAGS + ["-o", LIB_PATH] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        open(LIB_PATH + ".stamp", "w").write(library_stamp())
     return LIB_PATH
 
 

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "unet_hip.h")
 LIB_PATH = os.environ.get("UNET_HIP_LIB") or os.path.join(HERE, "csrc", "libunet_hip.so")     # override: diagnostics only
 
-_DECL = re.compile(r"\b(int|size_t)\s+(unet_\w+)\s*\(([^)]*)\)\s*;", re.S)
+_DECL = re.compile(r"\b(int|size_t|uint32_t)\s+(unet_\w+)\s*\(([^)]*)\)\s*;", re.S)
 
 
 def _ctype(decl):
@@ -29,7 +29,7 @@ def parse_header(path=HEADER):
     out = {}
     for ret, name, args in _DECL.findall(text):
         at = [t for t in (_ctype(a) for a in args.split(",")) if t is not None]
-        out[name] = (ctypes.c_int if ret == "int" else ctypes.c_size_t, at)
+        out[name] = ({"int": ctypes.c_int, "size_t": ctypes.c_size_t, "uint32_t": ctypes.c_uint32}[ret], at)
     return out
 
 
@@ -41,6 +41,11 @@ class _Lib:
     def __init__(self):
         if not os.path.exists(LIB_PATH):
             raise UnetHipError("HIP extension %s is missing; run build() -- there is no CPU fallback" % LIB_PATH)
+        if "UNET_HIP_LIB" not in os.environ:
+            from . import _build
+            if not _build.library_is_current():     # a binary that does not correspond to the sources next to it: refuse, loudly
+                raise UnetHipError("%s was not built from the sources/flags in this tree (content stamp mismatch); "
+                                   "run build() (python __graft_entry__.py)" % LIB_PATH)
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         for name, (res, args) in self.protos.items():

@@ -399,17 +399,20 @@ def test_softmax_ce_accuracy_argmax(hip, k, ls, clip):
     # False) -- logits scaled so that some probabilities really fall outside [eps, 1-eps] and take the zero-gradient branch
     n, h, w = 2, 16, 24
     rng = np.random.default_rng(k)
-    z = rng.standard_normal((n, h, w, k)) * (3 if clip == 0.0 else 9)
+    z = rng.standard_normal((n, h, w, k)) * (3 if clip == 0.0 else 14)
     cls = rng.integers(0, k, (n, h, w))
     lab = (cls[..., None] == np.arange(k)).astype(np.int32)
     G = 4
     contract = on.Contract(ce_from_softmax_logits=(clip == 0.0), ce_clip_eps=clip if clip else 1e-7)
+    if clip:
+        # fp32 cannot resolve the clip edges exactly (1 - 1e-7 is 0.99999988 in fp32, as it is for TF's own fp32 constants), so a
+        # probability within rounding of an edge may legitimately land on the other side: move such pixels to uniform logits
+        p0 = on.softmax_lastaxis(z)
+        near = (np.abs(p0 - clip) < 1e-3 * clip) | (np.abs((1 - p0) - clip) < 0.75 * clip + 2e-7)
+        z[near.any(-1)] = 0.0
     loss_ref, p_ref, y = on.ce_loss_fwd(z, lab, G, ls, contract)
     dl_ref = on.ce_loss_bwd(p_ref, y, G, contract)
     if clip:
-        # a probability within fp32 rounding of a clip edge may legitimately fall on the other side: keep the test decisive
-        edge = np.minimum(np.abs(p_ref - clip), np.abs(p_ref - (1 - clip))) < 1e-6 * np.maximum(clip, 1e-6) + 1e-9
-        assert not edge.any()
         assert ((p_ref < clip) | (p_ref > 1 - clip)).any()
     zd, labd = dev(z), dev(lab, np.int32)
     pix = n * h * w
