@@ -1,17 +1,28 @@
 """HBM traffic of one kernel family from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE are KiB per dispatch; they do not fit
-one pass).  usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <kernel substring> <launches per step>
-Takes the LAST `launches per step` dispatches of the matching kernels (one whole step) and prints a JSON fragment.
-FETCH_SIZE is doubled: the gfx950 correction of MI355X_MICROARCH.md (wide coalesced reads are tallied at half their bytes)."""
+one pass).  usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <kernel substrings, comma separated>
+<launches per step> [workload key] [algorithmic bytes per step]
+Takes the LAST `launches per step` dispatches of the matching kernels (one whole step) and prints the JSON that bench.py reads as
+`roofline.traffic`.  FETCH_SIZE is doubled: the gfx950 correction of MI355X_MICROARCH.md (wide coalesced reads are tallied at
+half their bytes)."""
 import csv, json, sys
-def per_dispatch(path, counter, sub):
+def per_dispatch(path, counter, subs):
     rows = {}
     for r in csv.DictReader(open(path)):
-        if r.get("Counter_Name") == counter and sub in r.get("Kernel_Name", ""):
+        if r.get("Counter_Name") == counter and any(s in r.get("Kernel_Name", "") for s in subs):
             rows[int(r["Dispatch_Id"])] = rows.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     return [rows[k] for k in sorted(rows)]
-fetch = per_dispatch(sys.argv[1], "FETCH_SIZE", sys.argv[3]); write = per_dispatch(sys.argv[2], "WRITE_SIZE", sys.argv[3])
+subs = sys.argv[3].split(",")
+fetch = per_dispatch(sys.argv[1], "FETCH_SIZE", subs); write = per_dispatch(sys.argv[2], "WRITE_SIZE", subs)
 n = int(sys.argv[4])
 assert len(fetch) >= n and len(write) >= n, (len(fetch), len(write))
 rd = 2.0 * 1024.0 * sum(fetch[-n:]); wr = 1024.0 * sum(write[-n:])
-print(json.dumps({"launches_per_step": n, "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr,
-                  "hbm_bytes_per_launch": (rd + wr) / n}, indent=1))
+out = {"kernels": subs, "launches_per_step": n, "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr,
+       "hbm_bytes_per_launch": (rd + wr) / n}
+if len(sys.argv) > 5:
+    out["workload"] = sys.argv[5]
+if len(sys.argv) > 6:
+    alg = float(sys.argv[6])
+    out.update({"algorithmic_bytes_per_step": alg, "algorithmic_bytes_per_launch": alg / n, "traffic_over_algorithmic": (rd + wr) / alg})
+out["note"] = ("FETCH_SIZE (KiB) doubled per the gfx950 correction in MI355X_MICROARCH.md (wide coalesced reads are tallied at half their "
+               "bytes); WRITE_SIZE (KiB) as read; two separate --pmc passes of `bench.py --steps 2 --warmup 1 --no-overlap`, last step")
+print(json.dumps(out, indent=1))

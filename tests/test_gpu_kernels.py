@@ -408,7 +408,8 @@ def test_softmax_ce_accuracy_argmax(hip, k, ls, clip):
         # fp32 cannot resolve the clip edges exactly (1 - 1e-7 is 0.99999988 in fp32, as it is for TF's own fp32 constants), so a
         # probability within rounding of an edge may legitimately land on the other side: move such pixels to uniform logits
         p0 = on.softmax_lastaxis(z)
-        near = (np.abs(p0 - clip) < 1e-3 * clip) | (np.abs((1 - p0) - clip) < 0.75 * clip + 2e-7)
+        q0 = 1 - p0
+        near = (np.abs(p0 - clip) < 1e-3 * clip) | ((q0 > 0.4 * clip) & (q0 < 3 * clip) if clip < 1e-5 else (np.abs(q0 - clip) < 1e-3 * clip))
         z[near.any(-1)] = 0.0
     loss_ref, p_ref, y = on.ce_loss_fwd(z, lab, G, ls, contract)
     dl_ref = on.ce_loss_bwd(p_ref, y, G, contract)
