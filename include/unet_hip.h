@@ -105,7 +105,7 @@ int unet_conv3x3_dgrad_bf16_bnstats(const float* dz, int lddz, const void* wpd, 
                                     int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
                                     float* stat_part, size_t stat_bytes, void* stream);
 /* general forms: an operand that only bf16 contractions read may be STORED as bf16 (x_bf16 / dz_bf16 != 0; leading dimension in
- * elements) -- its producer (unet_bn_apply_bf16out, unet_bn_bwd_any) rounds exactly as these kernels' staging would, so the
+ * elements) -- its producer (unet_bn_apply_any, unet_bn_bwd_any) rounds exactly as these kernels' staging would, so the
  * results are bit-identical to fp32 storage; stat_part (and r_prev) nullable.  out_bf16 / dx_bf16 / r_bf16: the OUTPUT (resp. the
  * producer's saved activation) is a bf16 tensor -- the opt-in activation-storage mode (Keras mixed_bfloat16 semantics: activations
  * bf16, BatchNorm arithmetic fp32), which does change the numbers BatchNorm sees; the fused sums are taken before the rounding */
@@ -205,14 +205,9 @@ int unet_bn_train_finalize_partials(const float* part, int rows, long P, int C, 
 int unet_bn_eval_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
                         float eps, int C, float* scale, float* shift, void* stream);
 int unet_bn_apply(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy, long P, int C, void* stream);
-/* the same, y stored as bf16 (ldy in elements): for an output read only by bf16 contractions */
-int unet_bn_apply_bf16out(const float* r, int ldr, const float* scale, const float* shift, void* y16, int ldy,
-                          long P, int C, void* stream);
 /* the same plus the MaxPool2D(2) that follows (UNet/model.py:50-53) in one pass: pooled [N,H/2,W/2,C] and first-max indices */
 int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy,
                           float* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream);
-int unet_bn_apply_maxpool_bf16out(const float* r, int ldr, const float* scale, const float* shift, void* y16, int ldy,
-                                  void* pooled16, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream);
 /* backward of [ReLU ->] BN: dz = relu'(r) * d r, plus dgamma, dbeta and dbias = column sums of dz */
 int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
                 const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,

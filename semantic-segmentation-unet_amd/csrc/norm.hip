@@ -11,31 +11,54 @@
 namespace {
 
 template <int VEC> __device__ __forceinline__ void vload(float (&v)[VEC], const float* p) {
-    if constexpr (VEC == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    if constexpr (VEC == 8) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p), u = *reinterpret_cast<const f32x4*>(p + 4);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; v[4] = u[0]; v[5] = u[1]; v[6] = u[2]; v[7] = u[3];
+    } else if constexpr (VEC == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
     else v[0] = *p;
 }
-// load from an fp32 tensor or (in16, VEC == 4) from a bf16 tensor of the same logical layout (element index idx)
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// load from an fp32 tensor or (in16, VEC >= 4) from a bf16 tensor of the same logical layout (element index idx).  VEC == 8 is the
+// 16-byte-per-lane form for bf16 tensors (8 channels per lane; an fp32 tensor is then two 16-byte loads): 8-byte accesses run at
+// 0.54-0.70 of the 16-byte rate on this memory system, which is what held the bf16-storage mode back in round 1
 template <int VEC> __device__ __forceinline__ void vload_dt(float (&v)[VEC], const float* base, size_t idx, int in16) {
+    if constexpr (VEC == 8) {
+        if (in16) {
+            const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + idx);
+            v[0] = bf_lo(t.x); v[1] = bf_hi(t.x); v[2] = bf_lo(t.y); v[3] = bf_hi(t.y);
+            v[4] = bf_lo(t.z); v[5] = bf_hi(t.z); v[6] = bf_lo(t.w); v[7] = bf_hi(t.w);
+            return;
+        }
+    }
     if constexpr (VEC == 4) {
         if (in16) {
             const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
-            v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
-            v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+            v[0] = bf_lo(t.x); v[1] = bf_hi(t.x); v[2] = bf_lo(t.y); v[3] = bf_hi(t.y);
             return;
         }
     }
     vload<VEC>(v, base + idx);
 }
 template <int VEC> __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
-    if constexpr (VEC == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
+    if constexpr (VEC == 8) {
+        f32x4 t = {v[0], v[1], v[2], v[3]}, u = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(p) = t; *reinterpret_cast<f32x4*>(p + 4) = u;
+    } else if constexpr (VEC == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
     else *p = v[0];
 }
 
-// store to an fp32 tensor or (out16, VEC == 4) to a bf16 tensor of the same logical layout: element index idx, nearest-even
+// store to an fp32 tensor or (out16, VEC >= 4) to a bf16 tensor of the same logical layout: element index idx, nearest-even
 // rounding by the instruction the bf16 conv kernels use when they stage fp32 operands, so a bf16-stored tensor is bit-for-bit
 // what those kernels would have made of the fp32 one
 __device__ __forceinline__ unsigned bn_pack2(float lo, float hi) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
 template <int VEC> __device__ __forceinline__ void vstore_dt(float* base, size_t idx, const float (&v)[VEC], int out16) {
+    if constexpr (VEC == 8) {
+        if (out16) {
+            uint4 t; t.x = bn_pack2(v[0], v[1]); t.y = bn_pack2(v[2], v[3]); t.z = bn_pack2(v[4], v[5]); t.w = bn_pack2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + idx) = t; return;
+        }
+    }
     if constexpr (VEC == 4) {
         if (out16) { uint2 t; t.x = bn_pack2(v[0], v[1]); t.y = bn_pack2(v[2], v[3]); *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + idx) = t; return; }
     }
@@ -220,31 +243,42 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // BN apply fused with the 2x2 max pool that follows the encoder's second conv of a level (UNet/model.py:36,50-53): one thread =
 // one pooled pixel x channel quad: reads the 4 r values, writes the 4 normalised values (the skip tensor) and their first-max
 // (row-major window order, the reference's tie rule) + its index -- the skip tensor is not read back for pooling.
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
         const float* __restrict__ shift, float* __restrict__ y, int ldy, float* __restrict__ pooled, int ldp, uint8_t* __restrict__ idx,
         int N, int H, int W, int C, int out16) {
-    const int H2 = H / 2, W2 = W / 2, nq = C / 4;
+    const int H2 = H / 2, W2 = W / 2, nq = C / VEC;
     const long total = (long)N * H2 * W2 * nq, stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         long t = i; const int cq = (int)(t % nq); t /= nq;
         const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const int n = (int)(t / H2);
         const long opix = ((long)n * H2 + oy) * W2 + ox;
-        float a[4], b[4], best[4]; uint8_t bi[4];
-        vload<4>(a, scale + 4 * cq); vload<4>(b, shift + 4 * cq);
+        float a[VEC], b[VEC], best[VEC]; uint8_t bi[VEC];
+        vload<VEC>(a, scale + VEC * cq); vload<VEC>(b, shift + VEC * cq);
+        float v[4][VEC];
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
             const size_t pix = (size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1);
-            float v[4];
-            vload_dt<4>(v, r, pix * ldr + 4 * cq, out16 & 2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = fmaf(a[e], v[e], b[e]);
-                if (pos == 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)pos; }
-            }
-            vstore_dt<4>(y, pix * ldy + 4 * cq, v, out16 & 1);
+            vload_dt<VEC>(v[pos], r, pix * ldr + VEC * cq, out16 & 2);
         }
-        vstore_dt<4>(pooled, (size_t)opix * ldp + 4 * cq, best, out16 & 1);
-        *reinterpret_cast<uint32_t*>(idx + (size_t)opix * C + 4 * cq) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            const size_t pix = (size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                v[pos][e] = fmaf(a[e], v[pos][e], b[e]);
+                if (pos == 0 || v[pos][e] > best[e]) { best[e] = v[pos][e]; bi[e] = (uint8_t)pos; }
+            }
+            vstore_dt<VEC>(y, pix * ldy + VEC * cq, v[pos], out16 & 1);
+        }
+        vstore_dt<VEC>(pooled, (size_t)opix * ldp + VEC * cq, best, out16 & 1);
+        uint32_t w0 = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+        if constexpr (VEC == 8) {
+            const uint32_t w1 = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+            *reinterpret_cast<uint2*>(idx + (size_t)opix * C + VEC * cq) = make_uint2(w0, w1);
+        } else {
+            *reinterpret_cast<uint32_t*>(idx + (size_t)opix * C + VEC * cq) = w0;
+        }
     }
 }
 
@@ -370,9 +404,11 @@ __global__ __launch_bounds__(64) void colsum_finalize_kernel(const double* __res
 constexpr long MAX_BLOCKS = 2048;
 struct Plan { int vec, tpp, nblk; long ppb; size_t smem2, smem1; };
 
-bool make_plan(long P, int C, int ld_a, int ld_b, int ld_c, bool aligned, Plan* pl) {
+bool make_plan(long P, int C, int ld_a, int ld_b, int ld_c, bool aligned, Plan* pl, bool wide = false) {
     int vec = 0, tpp = 0;
-    if (C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && ld_c % 4 == 0 && aligned) { vec = 4; tpp = C / 4; }
+    // wide: 8 channels (16 bytes of a bf16 tensor) per lane -- chosen whenever one of the tensors is stored as bf16
+    if (wide && C % 8 == 0 && (C / 8) <= 256 && 256 % (C / 8) == 0 && ld_a % 8 == 0 && ld_b % 8 == 0 && ld_c % 8 == 0 && aligned) { vec = 8; tpp = C / 8; }
+    else if (C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && ld_c % 4 == 0 && aligned) { vec = 4; tpp = C / 4; }
     else if (C <= 256) { vec = 1; tpp = 1; while (tpp < C) tpp <<= 1; }
     else return false;
     // a block covers 256/tpp pixels per pass; give every lane ~8 passes, up to 2048 blocks (8 per CU)
@@ -436,17 +472,6 @@ extern "C" int unet_bn_apply(const float* r, int ldr, const float* scale, const 
     return UNET_LAUNCH_STATUS();
 }
 
-// the same with the result stored as bf16 (y16: [P][ldy] bf16 elements) for a consumer that contracts in bf16 anyway
-extern "C" int unet_bn_apply_bf16out(const float* r, int ldr, const float* scale, const float* shift, void* y16, int ldy,
-                                     long P, int C, void* stream) {
-    UNET_CHECK_ARG(r && scale && shift && y16 && P > 0 && C > 0 && ldr >= C && ldy >= C);
-    UNET_CHECK_ARG(C % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0 && unet_aligned16(r) && unet_aligned16(y16) && unet_aligned16(scale) && unet_aligned16(shift));
-    const long total = P * (C / 4);
-    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    bn_apply_kernel<4><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, (float*)y16, ldy, P, C, 1);
-    return UNET_LAUNCH_STATUS();
-}
-
 // y = scale * r + shift (as unet_bn_apply) and, in the same pass, pooled = MaxPool2D(2)(y) with the first-max index
 extern "C" int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy,
                                      float* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream) {
@@ -456,21 +481,7 @@ extern "C" int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale
                    (reinterpret_cast<uintptr_t>(idx) & 3u) == 0);
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    bn_apply_pool_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, 0);
-    return UNET_LAUNCH_STATUS();
-}
-
-// the same with y and pooled stored as bf16 (both read only by bf16 contractions; max commutes with the rounding, the index is
-// taken on the fp32 values)
-extern "C" int unet_bn_apply_maxpool_bf16out(const float* r, int ldr, const float* scale, const float* shift, void* y16, int ldy,
-                                             void* pooled16, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream) {
-    UNET_CHECK_ARG(r && scale && shift && y16 && pooled16 && idx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0);
-    UNET_CHECK_ARG(ldr >= C && ldy >= C && ldp >= C && ldr % 4 == 0 && ldy % 4 == 0 && ldp % 4 == 0);
-    UNET_CHECK_ARG(unet_aligned16(r) && unet_aligned16(y16) && unet_aligned16(pooled16) && unet_aligned16(scale) && unet_aligned16(shift) &&
-                   (reinterpret_cast<uintptr_t>(idx) & 3u) == 0);
-    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    bn_apply_pool_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, (float*)y16, ldy, (float*)pooled16, ldp, idx, N, H, W, C, 1);
+    bn_apply_pool_kernel<4><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, 0);
     return UNET_LAUNCH_STATUS();
 }
 
@@ -483,7 +494,7 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     Plan pl;
     const bool al = unet_aligned16(dy) && unet_aligned16(r) && unet_aligned16(dz) && unet_aligned16(gamma) && unet_aligned16(mean) &&
                     unet_aligned16(invstd) && unet_aligned16(dgamma) && unet_aligned16(dbeta) && (!pg.pdy || (unet_aligned16(pg.pdy) && pg.ldp % 4 == 0));
-    UNET_CHECK_ARG(make_plan(P, C, lddy, ldr, lddz, al, &pl));
+    UNET_CHECK_ARG(make_plan(P, C, lddy, ldr, lddz, al && (!pg.pdy || pg.ldp % 8 == 0 || !(dt || pg.p16)), &pl, dt != 0 || pg.p16 != 0));
     if (ws_bytes < unet_bn_workspace(P, C)) return UNET_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)ws;
@@ -491,15 +502,17 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     if (part_sums) {
         bn_bwd_finalize_partials_kernel<<<C, 256, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
     } else {
-        if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, dt);
-        else             bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, 0);
+        if (pl.vec == 8)      bn_bwd_reduce_kernel<8><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, dt);
+        else if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, dt);
+        else                  bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, 0);
         rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
         bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(part, pl.nblk, C, dgamma, dbeta);
     }
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     double* part2 = part + (size_t)2 * pl.nblk * C;
-    if ((dt || pg.p16) && pl.vec != 4) return UNET_EINVAL;
-    if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, dt);
+    if ((dt || pg.p16) && pl.vec < 4) return UNET_EINVAL;
+    if (pl.vec == 8) bn_bwd_apply_kernel<8><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, dt);
+    else if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, dt);
     else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, 0);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     colsum_finalize_kernel<<<C, 64, 0, st>>>(part2, pl.nblk, C, dbias);
@@ -556,15 +569,20 @@ extern "C" int unet_bn_apply_any(const void* r, int ldr, int r_bf16, const float
     UNET_CHECK_ARG(unet_aligned16(r) && unet_aligned16(y) && unet_aligned16(scale) && unet_aligned16(shift) && (pooled == nullptr) == (idx == nullptr));
     const int flags = (y_bf16 ? 1 : 0) | (r_bf16 ? 2 : 0);
     hipStream_t st = (hipStream_t)stream;
+    // 8 channels (16 bytes of a bf16 tensor) per lane whenever a bf16 tensor is involved and the shapes allow it
+    const bool wide = flags != 0 && C % 8 == 0 && ldr % 8 == 0 && ldy % 8 == 0 && (!pooled || ldp % 8 == 0);
+    const int vec = wide ? 8 : 4;
     if (pooled) {
-        UNET_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && ldp >= C && ldp % 4 == 0 && unet_aligned16(pooled) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0);
-        const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+        UNET_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && ldp >= C && ldp % 4 == 0 && unet_aligned16(pooled) && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0);
+        const long total = (long)N * (H / 2) * (W / 2) * (C / vec);
         long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-        bn_apply_pool_kernel<<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, (float*)pooled, ldp, idx, N, H, W, C, flags);
+        if (wide) bn_apply_pool_kernel<8><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, (float*)pooled, ldp, idx, N, H, W, C, flags);
+        else      bn_apply_pool_kernel<4><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, (float*)pooled, ldp, idx, N, H, W, C, flags);
     } else {
-        const long P = (long)N * H * W, total = P * (C / 4);
+        const long P = (long)N * H * W, total = P * (C / vec);
         long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-        bn_apply_kernel<4><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, P, C, flags);
+        if (wide) bn_apply_kernel<8><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, P, C, flags);
+        else      bn_apply_kernel<4><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, P, C, flags);
     }
     return UNET_LAUNCH_STATUS();
 }

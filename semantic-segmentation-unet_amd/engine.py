@@ -172,9 +172,11 @@ class Engine:
         # results are bit-identical to fp32 storage (tests assert that); only the bytes moved change.
         self.bf16_storage = os.environ.get("UNET_BF16_STORAGE", "1") != "0"
         self.bf16_storage_cat = os.environ.get("UNET_BF16_STORAGE_CAT", "1") != "0"    # ... the concat / pooled tensors too (A/B switch)
-        # opt-in: ALSO keep the 3x3 layers' conv outputs r (what BatchNorm reads) as bf16 in training -- the Keras mixed_bfloat16
-        # convention (bf16 activations, fp32 BatchNorm arithmetic).  Unlike the storage above this changes what BatchNorm sees.
-        self.bf16_activations = os.environ.get("UNET_BF16_ACTIVATIONS", "0") == "1"
+        # stage 3 (default on; UNET_BF16_ACTIVATIONS=0 restores stage 2): in training ALSO keep the wide layers' conv outputs r (what
+        # BatchNorm reads) and the activation gradients dy the data-gradient kernels write as bf16 -- the Keras mixed_bfloat16
+        # convention (bf16 activations and activation gradients, fp32 BatchNorm arithmetic: the fused sums are taken from the fp32
+        # accumulators before the rounding).  Unlike the storage above this changes what BatchNorm sees (by one bf16 rounding).
+        self.bf16_activations = os.environ.get("UNET_BF16_ACTIVATIONS", "1") != "0"
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -452,18 +454,13 @@ class Engine:
                                   _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(ws), nb, st)
         else:
             L.unet_bn_eval_coeffs(_p(gm), _p(bt), _p(mm), _p(mv), BN_EPS, cout, _p(s[2]), _p(s[3]), st)
-        if r.dtype == torch.bfloat16:
-            L.unet_bn_apply_any(_p(r), cout, 1, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), int(y_out.dtype == torch.bfloat16),
+        if r.dtype == torch.bfloat16 or y_out.dtype == torch.bfloat16:
+            L.unet_bn_apply_any(_p(r), cout, int(r.dtype == torch.bfloat16), _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), int(y_out.dtype == torch.bfloat16),
                                 _p(pool[0]) if pool is not None else None, cout, _p(pool[1]) if pool is not None else None,
                                 r.shape[0], r.shape[1], r.shape[2], cout, st)
-        elif pool is not None and y_out.dtype == torch.bfloat16:
-            L.unet_bn_apply_maxpool_bf16out(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
-                                            r.shape[0], r.shape[1], r.shape[2], cout, st)
         elif pool is not None:         # (pooled, idx): BN apply and the level's max pool in one pass
             L.unet_bn_apply_maxpool(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
                                     r.shape[0], r.shape[1], r.shape[2], cout, st)
-        elif y_out.dtype == torch.bfloat16:
-            L.unet_bn_apply_bf16out(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), P, cout, st)
         else:
             L.unet_bn_apply(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), P, cout, st)
         self.saved[name] = (x, r)
@@ -573,11 +570,7 @@ class Engine:
         n, ho, wo, _ = r.shape
         P = n * ho * wo
         s = self.stat[name]
-        dz16 = self.compute_dtype == "bf16" and self.bf16_storage and not eval_mode and (
-            (kind == "conv3" and n * ho * wo * max(cin, cout) * 4 < 2 ** 31 and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1
-             and (not need_dx or self._use_bf16(name, n, ho, wo, dgrad=True)))
-            or (kind == "deconv" and self._use_bf16_convt(name, n, x.shape[1], x.shape[2])
-                and L.unet_convT2x2_wgrad_bf16_supported(n, x.shape[1], x.shape[2], cin, cout) == 1))
+        dz16 = self._dz16(name, need_dx, eval_mode)
         dz = self._buf("dz16_" + name, tuple(r.shape), torch.bfloat16) if dz16 else self._buf("dz_" + name, tuple(r.shape))
         pre = self.bnbwd_part.pop(name, None) if not eval_mode else None
         if dz16:
@@ -674,7 +667,10 @@ class Engine:
             with torch.cuda.stream(self.side):
                 wgrad()
         if need_dx:
-            dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
+            if self._dx16(name, eval_mode):
+                dx = self._buf("dy16_in_" + name, (n, hi, wi, cin), torch.bfloat16)
+            else:
+                dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
             if kind == "deconv" and self._use_bf16_convt(name, n, hi, wi):
                 prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
                 rows = L.unet_convT2x2_bf16_stats_rows(n, hi, wi, cin, cout, 1) if prod else 0
@@ -733,6 +729,38 @@ class Engine:
         if not self.overlap_wgrad and not eval_mode:
             wgrad()
         return dx
+
+    def _dz16(self, name, need_dx=True, eval_mode=False):
+        """the layer's BatchNorm backward takes the unified bf16-capable entry point (dz stored as bf16; dy / r may be bf16)"""
+        if self.compute_dtype != "bf16" or not self.bf16_storage or eval_mode or name not in self.saved:
+            return False
+        L = self.L
+        kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
+        x, r = self.saved[name]
+        n, ho, wo, _ = r.shape
+        if kind == "conv3":
+            return (n * ho * wo * max(cin, cout) * 4 < 2 ** 31 and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1
+                    and (not need_dx or self._use_bf16(name, n, ho, wo, dgrad=True)))
+        if kind == "deconv":
+            return (self._use_bf16_convt(name, n, x.shape[1], x.shape[2])
+                    and L.unet_convT2x2_wgrad_bf16_supported(n, x.shape[1], x.shape[2], cin, cout) == 1)
+        return False
+
+    def _dx16(self, name, eval_mode):
+        """the 3x3 layer's data gradient may be WRITTEN as bf16: every reader of it is a BatchNorm backward that takes bf16 dy"""
+        if self.compute_dtype != "bf16" or not (self.bf16_storage and self.bf16_activations) or eval_mode or self.kind[name] != "conv3":
+            return False
+        need1 = lambda nm: self._dz16(nm, nm != "conv_1a", eval_mode)
+        if name.startswith("dec_") and name.endswith("a"):             # [skip, upsampled]: conv_Nb (through the fused pool path) and up_N
+            lvl = int(name[4])
+            return lvl != 4 and self.fuse_pool and need1("conv_%db" % lvl) and need1("up_%d" % lvl)
+        if name.startswith("conv_") and name.endswith("a"):            # pooled gradient of the level above, formed inside its BatchNorm backward
+            lvl = int(name[5])
+            return lvl >= 2 and self.fuse_pool and need1("conv_%db" % (lvl - 1))
+        if name == "bott_a":                                           # goes through the separate pool-backward + dropout kernels (fp32)
+            return False
+        prod = PRODUCER.get(name)
+        return prod is not None and prod[3] == 1 and need1(prod[0])
 
     def input_gradient_eval(self, dprob):
         """After forward(training=False): gradient of sum(dprob * softmax) w.r.t. the input image, fp32 [N,C,H,W].

@@ -809,7 +809,7 @@ def test_bf16_stored_operands_bit_identical(hip):
     sc = torch.rand(co, device=DEV, generator=g) + 0.5; sh = torch.randn(co, device=DEV, generator=g)
     yf = torch.empty(n, h, w, co, device=DEV); yh = torch.empty(n, h, w, co, device=DEV, dtype=torch.bfloat16)
     hip.unet_bn_apply(P(r), co, P(sc), P(sh), P(yf), co, n * h * w, co, ST())
-    hip.unet_bn_apply_bf16out(P(r), co, P(sc), P(sh), P(yh), co, n * h * w, co, ST())
+    hip.unet_bn_apply_any(P(r), co, 0, P(sc), P(sh), P(yh), co, 1, None, 0, None, n, h, w, co, ST())
     assert torch.equal(yf.to(torch.bfloat16), yh)
     gm = torch.rand(co, device=DEV, generator=g) + 0.5
     mean = r.mean((0, 1, 2)); invstd = 1.0 / torch.sqrt(r.var((0, 1, 2), unbiased=False) + 1e-3)
@@ -950,3 +950,56 @@ def test_conv3x3_bf16_output_storage_is_the_rounded_fp32_output(hip, shape):
     hip.unet_conv3x3_dgrad_bf16_ex(P(dz), co, 0, P(wpd), P(d16), ci, 1, n, h, w, ci, co, P(r16), ci, 1, 0, ci, P(q1), q1.numel() * 4, ST())
     assert torch.equal(d32.to(torch.bfloat16), d16)
     assert torch.equal(q0, q1)
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 10, 64, 64), (1, 8, 12, 128, 192), (2, 4, 6, 1024, 1024), (1, 6, 8, 256, 264)])
+@pytest.mark.parametrize("mix", ["all16", "r16", "dy16", "out16"])
+def test_batchnorm_kernels_on_bf16_stored_tensors(hip, shape, mix):
+    # The BatchNorm passes with any of their tensors stored as bf16 (8 channels = 16 bytes per lane): results must equal the fp32
+    # kernels run on the same (bf16-representable) values -- elementwise outputs bit for bit after the same rounding, the per-channel
+    # sums to fp64-summation-order noise.  Shapes include padded leading dimensions (ld > C).
+    n, h, w, c, ld = shape
+    g = torch.Generator(device=DEV).manual_seed(c + h)
+    r16f = mix in ("all16", "r16"); dy16f = mix in ("all16", "dy16"); o16f = mix in ("all16", "out16")
+    def mk(scale=1.0):
+        t = (torch.randn(n, h, w, ld, device=DEV, generator=g) * scale).to(torch.bfloat16)
+        return t
+    r16 = mk().clamp_min(0) ; dy16 = mk(0.1); pdy16 = (torch.randn(n, h // 2, w // 2, ld, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    r32, dy32, pdy32 = r16.float(), dy16.float(), pdy16.float()
+    sc = torch.rand(c, device=DEV, generator=g) + 0.5; sh = torch.randn(c, device=DEV, generator=g)
+    rr, dd, pp = (r16 if r16f else r32), (dy16 if dy16f else dy32), (pdy16 if dy16f else pdy32)
+    odt = torch.bfloat16 if o16f else torch.float32
+    # ---- apply (+ pool)
+    y_ref = torch.empty(n, h, w, ld, device=DEV); y = torch.zeros(n, h, w, ld, device=DEV, dtype=odt)
+    hip.unet_bn_apply(P(r32), ld, P(sc), P(sh), P(y_ref), ld, n * h * w, c, ST())
+    hip.unet_bn_apply_any(P(rr), ld, int(r16f), P(sc), P(sh), P(y), ld, int(o16f), None, 0, None, n, h, w, c, ST())
+    assert torch.equal(y_ref[..., :c].to(odt), y[..., :c])
+    pl_ref = torch.empty(n, h // 2, w // 2, ld, device=DEV); ix_ref = torch.empty(n, h // 2, w // 2, c, device=DEV, dtype=torch.uint8)
+    pl = torch.zeros(n, h // 2, w // 2, ld, device=DEV, dtype=odt); ix = torch.empty_like(ix_ref)
+    hip.unet_bn_apply_maxpool(P(r32), ld, P(sc), P(sh), P(y_ref), ld, P(pl_ref), ld, P(ix_ref), n, h, w, c, ST())
+    hip.unet_bn_apply_any(P(rr), ld, int(r16f), P(sc), P(sh), P(y), ld, int(o16f), P(pl), ld, P(ix), n, h, w, c, ST())
+    assert torch.equal(y_ref[..., :c].to(odt), y[..., :c]) and torch.equal(pl_ref[..., :c].to(odt), pl[..., :c]) and torch.equal(ix_ref, ix)
+    # ---- backward: plain, pooled, from partial sums
+    gm = torch.rand(c, device=DEV, generator=g) + 0.5
+    rv = r32[..., :c]
+    mean = rv.mean((0, 1, 2)).contiguous(); invstd = (1.0 / torch.sqrt(rv.var((0, 1, 2), unbiased=False) + 1e-3)).contiguous()
+    nbb = hip.unet_bn_workspace(n * h * w, c); wsb = ws_bytes(nbb)
+    for pooled in (False, True):
+        z_ref = torch.empty(n, h, w, ld, device=DEV); z = torch.zeros(n, h, w, ld, device=DEV, dtype=odt)
+        gr = [torch.empty(c, device=DEV) for _ in range(6)]
+        if pooled:
+            hip.unet_bn_bwd_pooled(P(dy32), ld, P(pdy32), ld, P(ix_ref), n, h, w, P(r32), ld, P(gm), P(mean), P(invstd), c, 1, P(z_ref), ld,
+                                   P(gr[0]), P(gr[1]), P(gr[2]), P(wsb), nbb, ST())
+        else:
+            hip.unet_bn_bwd(P(dy32), ld, P(r32), ld, P(gm), P(mean), P(invstd), n * h * w, c, 1, P(z_ref), ld, P(gr[0]), P(gr[1]), P(gr[2]), P(wsb), nbb, ST())
+        hip.unet_bn_bwd_any(P(dd), ld, P(pp) if pooled else None, ld if pooled else 0, P(ix_ref) if pooled else None, n, h, w, P(rr), ld,
+                            P(gm), P(mean), P(invstd), c, 1, P(z), ld, int(o16f), P(gr[3]), P(gr[4]), P(gr[5]), None, 0, P(wsb), nbb, ST(),
+                            int(r16f), int(dy16f), int(dy16f))
+        for i in range(3):
+            assert (gr[i] - gr[i + 3]).abs().max().item() <= 2e-6 * gr[i].abs().max().item() + 1e-7, (pooled, i)
+        zr = z_ref[..., :c]
+        if o16f:     # one bf16 ulp where the sums' last bits move a value across a rounding boundary
+            assert ((zr.to(torch.bfloat16).float() - z[..., :c].float()).abs() <= 2.0 ** -7 * zr.abs() + 1e-9).all()
+            assert (zr.to(torch.bfloat16) != z[..., :c]).float().mean().item() < 1e-3
+        else:
+            assert (zr - z[..., :c]).abs().max().item() <= 2e-6 * zr.abs().max().item()
