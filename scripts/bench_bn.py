@@ -29,3 +29,20 @@ for h, c in [(512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)]:
     print("%4d^2 x %4d ch (%5.0f MB)  stats %6.3f ms %5.2f TB/s | apply %6.3f ms %5.2f TB/s | bwd (reduce+apply) %6.3f ms %5.2f TB/s"
           % (h, c, byts / 1e6, t0, byts / t0 / 1e9, t1, 2 * byts / t1 / 1e9, t2, 5 * byts / t2 / 1e9), flush=True)
 print("TOTAL stats %.2f ms  apply %.2f ms  bwd %.2f ms" % tuple(tot))
+# the same passes on bf16-stored tensors (r, y, dy, dz all bf16: 2 bytes per element)
+tot = [0.0, 0.0]
+for h, c in [(512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)]:
+    npx = B * h * h
+    r = torch.randn(B, h, h, c, device="cuda").to(torch.bfloat16); dy = torch.randn(B, h, h, c, device="cuda").to(torch.bfloat16)
+    y = torch.empty_like(r); dz = torch.empty_like(r)
+    g = torch.ones(c, device="cuda"); bt = torch.zeros(c, device="cuda")
+    mean, invstd, scale, shift, dg, db, dbias = [torch.rand(c, device="cuda") for _ in range(7)]
+    nb = L.unet_bn_workspace(npx, c); ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
+    t1 = timeit(lambda: L.unet_bn_apply_any(P(r), c, 1, P(scale), P(shift), P(y), c, 1, None, 0, None, B, h, h, c, ST()))
+    t2 = timeit(lambda: L.unet_bn_bwd_any(P(dy), c, None, 0, None, B, h, h, P(r), c, P(g), P(mean), P(invstd), c, 1, P(dz), c, 1, P(dg), P(db), P(dbias),
+                                          None, 0, P(ws), nb, ST(), 1, 1, 0))
+    byts = npx * c * 2.0
+    tot[0] += t1; tot[1] += t2
+    print("bf16 %4d^2 x %4d ch (%5.0f MB)  apply %6.3f ms %5.2f TB/s | bwd (reduce+apply) %6.3f ms %5.2f TB/s"
+          % (h, c, byts / 1e6, t1, 2 * byts / t1 / 1e9, t2, 5 * byts / t2 / 1e9), flush=True)
+print("TOTAL bf16 apply %.2f ms  bwd %.2f ms" % tuple(tot))

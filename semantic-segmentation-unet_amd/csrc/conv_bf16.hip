@@ -232,10 +232,15 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 
-    issue_x(0); issue_w(0, 0);
+#ifndef UNET_CB_ABLATE
+#define UNET_CB_ABLATE 0
+#endif
+    // diagnostic builds (scripts/build_variant.sh): bit 0 = no epilogue stores, bit 1 = no saved-activation loads in the STATS 2
+    // epilogue, bit 2 = no chunk loop, bit 3 = no prologue loads
+    if (!(UNET_CB_ABLATE & 8)) { issue_x(0); issue_w(0, 0); }
     write_x(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int c = 0; c < nchunks; c += 2) {                            // Cin % 32 == 0: an even number of chunks
+    for (int c = 0; c < ((UNET_CB_ABLATE & 4) ? 0 : nchunks); c += 2) {                            // Cin % 32 == 0: an even number of chunks
         cb_compute<NCO, 0, STAGE>(acc, a_base, b_base, [&](int g) {
             if (g < 5) { issue_x1(c + 1, 2 * g); issue_x1(c + 1, 2 * g + 1); }
             if (2 * g < KW) issue_w1(c + 1, 1, 2 * g);
@@ -258,6 +263,8 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     // co0 + NCO li + c (see the weight image): one buffer store per pixel and lane.  The 16 per-lane offsets (column, channel
     // group) are computed once, the row goes into the scalar offset; columns past the image edge get an offset the range check
     // drops.  out16 / r16: the output / the producer's saved activation is a bf16 tensor (same indexing, 2-byte elements).
+    // (A variant with the column part in the scalar offset and scalar branches for the image edge made every launch 15-20 % slower
+    // in a same-box A/B -- 64 basic blocks instead of one straight store stream -- and was dropped.)
     typedef unsigned ovec_t __attribute__((ext_vector_type(NCO)));
     typedef unsigned hvec_t __attribute__((ext_vector_type(NCO / 2)));
     float st1[NCO], st2[NCO], bv[NCO];
@@ -267,43 +274,81 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
                                                                             STATS == 2 ? (int)((size_t)p.N * p.H * p.W * p.bn_ldr * res) : 0, 0x00020000);
     const int cl = co0 + NCO * li;                                    // this lane's first channel
     const bool with_r = STATS == 2 && cl >= p.bn_c0 && cl < p.bn_c1;  // (c0, c1 multiples of 64: all NCO channels or none)
-    int ovoff[16], rvoff[16];
-    bool colok[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        colok[e] = tx0 + col < p.W;
-        ovoff[e] = colok[e] ? (col * p.ldo + NCO * li) * oes : (int)0x80000000;
-        rvoff[e] = (with_r && colok[e]) ? (col * p.bn_ldr + (cl - p.bn_c0)) * res : (int)0x80000000;
-    }
+    // store offset of (row r, element e) = lane part (column 4 lh, the lane's channels) + row + column part, formed per store (two
+    // vector instructions): kept as 16 precomputed registers they would crowd out the saved-activation window below
+    const int vo = (4 * lh * p.ldo + NCO * li) * oes;
+    const int wlim = p.W - tx0 - 4 * lh;                              // column (e & 3) + 8 (e >> 2) of this lane is inside the image iff < wlim
+    // saved-activation loads (STATS 2): lane offset = column 4 lh and the lane's channels, or an offset the range check rejects when
+    // the lane has no channel in [c0, c1); the column part (e & 3) + 8 (e >> 2) goes into the scalar offset; whether a column is
+    // inside the image is uniform up to the half-wave (both halves / only lh = 0 / none): a select between three registers
+    const int vr = with_r ? (4 * lh * p.bn_ldr + (cl - p.bn_c0)) * res : (int)0x80000000, vr_lo = lh ? (int)0x80000000 : vr;
+    const int wrem = p.W - tx0;
+    auto r_voff = [&](int e) { const int c0 = (e & 3) + 8 * (e >> 2); return c0 + 4 < wrem ? vr : (c0 < wrem ? vr_lo : (int)0x80000000); };
     const float lo = p.relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int c = 0; c < NCO; ++c) { bv[c] = p.bias ? p.bias[cl + c] : 0.f; st1[c] = 0.f; st2[c] = 0.f; }
+    // STATS 2 with a bf16 saved activation (the default storage): the 16 loads of a row are issued TWO rows ahead of the row being
+    // written (rows 0 and 1 before any arithmetic, row r + 2 before row r is processed), so the memory latency is paid about once
+    // per tile instead of eight times -- the per-row half-batches of the fp32 path below cost 0.24 ms of a 0.50 ms launch on
+    // 64->64 @512^2, where the main loop (4 chunks) is too short to hide anything.
+    constexpr int RING = NCO == 4 ? 3 : 4;          // rows of the saved activation in flight (NCO = 2: the whole tile)
+    hvec_t rvh[RING][16];
+    const bool hoist = STATS == 2 && p.r16 && !(UNET_CB_ABLATE & 2);
+    auto issue_row = [&](int r) {
+        const int gy = ty0 + 4 * wv + r;
+        const int sr = ((img * p.H + (gy < p.H ? gy : 0)) * p.W + tx0) * p.bn_ldr * 2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int vofs = gy < p.H ? r_voff(e) : (int)0x80000000, so_e = sr + ((e & 3) + 8 * (e >> 2)) * p.bn_ldr * 2;
+            if constexpr (NCO == 4) rvh[r % RING][e] = __builtin_amdgcn_raw_buffer_load_b64(srd_r, vofs, so_e, 0);
+            else                    rvh[r % RING][e][0] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, vofs, so_e, 0);
+        }
+    };
+    if (hoist) {
+#pragma unroll
+        for (int r = 0; r < RING - 1; ++r) issue_row(r);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gy = ty0 + 4 * wv + r;
-        if (gy >= p.H) continue;                                                     // uniform per wave
+        const bool row_ok = gy < p.H;                                                // uniform per wave
         const int pix0 = (img * p.H + gy) * p.W + tx0;
         const int so = (pix0 * p.ldo + co0) * oes;
-        // STATS 2: the saved activation in two batches of 8 pixels, each batch's loads in flight together
+        if (hoist && r + RING - 1 < 4) issue_row(r + RING - 1);
+        if (!row_ok) continue;
+        // STATS 2, fp32 saved activation: two batches of 8 pixels per row, each batch's loads in flight together
 #pragma unroll
         for (int eh = 0; eh < 2; ++eh) {
             float rv[8][NCO];
-            if (STATS == 2) {
+            if (hoist) {
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8)
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c) {
+                        const unsigned hw = (unsigned)rvh[r % RING][8 * eh + e8][c >> 1];
+                        rv[e8][c] = __builtin_bit_cast(float, (c & 1) ? (hw & 0xffff0000u) : (hw << 16));
+                    }
+            } else if (UNET_CB_ABLATE & 2) {
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8)
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c) rv[e8][c] = 1.f;
+            } else if (STATS == 2) {
                 const int sr = pix0 * p.bn_ldr * res;
 #pragma unroll
                 for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = 8 * eh + e8, so_e = sr + ((e & 3) + 8 * (e >> 2)) * p.bn_ldr * res;
                     if (p.r16) {
                         hvec_t h;
-                        if constexpr (NCO == 4) h = __builtin_amdgcn_raw_buffer_load_b64(srd_r, rvoff[8 * eh + e8], sr, 0);
-                        else                    h[0] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, rvoff[8 * eh + e8], sr, 0);
+                        if constexpr (NCO == 4) h = __builtin_amdgcn_raw_buffer_load_b64(srd_r, r_voff(e), so_e, 0);
+                        else                    h[0] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, r_voff(e), so_e, 0);
 #pragma unroll
                         for (int c = 0; c < NCO; ++c)
                             rv[e8][c] = __builtin_bit_cast(float, (c & 1) ? ((unsigned)h[c >> 1] & 0xffff0000u) : ((unsigned)h[c >> 1] << 16));
                     } else {
                         ovec_t f;
-                        if constexpr (NCO == 4) f = __builtin_amdgcn_raw_buffer_load_b128(srd_r, rvoff[8 * eh + e8], sr, 0);
-                        else                    f = __builtin_amdgcn_raw_buffer_load_b64(srd_r, rvoff[8 * eh + e8], sr, 0);
+                        if constexpr (NCO == 4) f = __builtin_amdgcn_raw_buffer_load_b128(srd_r, r_voff(e), so_e, 0);
+                        else                    f = __builtin_amdgcn_raw_buffer_load_b64(srd_r, r_voff(e), so_e, 0);
 #pragma unroll
                         for (int c = 0; c < NCO; ++c) rv[e8][c] = __builtin_bit_cast(float, (unsigned)f[c]);
                     }
@@ -311,27 +356,30 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
             }
 #pragma unroll
             for (int e8 = 0; e8 < 8; ++e8) {
-                const int e = 8 * eh + e8;
+                const int e = 8 * eh + e8, ce = (e & 3) + 8 * (e >> 2);
+                const bool colok = ce < wlim;
                 float v[NCO];
 #pragma unroll
                 for (int c = 0; c < NCO; ++c) {
                     asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[r][c][e]));
                     v[c] = fmaxf(v[c] + bv[c], lo);
-                    if (STATS == 1 && colok[e]) { st1[c] += v[c]; st2[c] += v[c] * v[c]; }
-                    if (STATS == 2 && colok[e]) { st1[c] += v[c]; st2[c] += v[c] * rv[e8][c]; }
+                    if (STATS == 1 && colok) { st1[c] += v[c]; st2[c] += v[c] * v[c]; }
+                    if (STATS == 2 && colok) { st1[c] += v[c]; st2[c] += v[c] * rv[e8][c]; }
                 }
+                if ((UNET_CB_ABLATE & 1) && v[0] != 1.2345e38f) continue;
+                const int ovoff = colok ? vo + (so + ce * p.ldo * oes) : (int)0x80000000;
                 if (p.out16) {
                     hvec_t h;
 #pragma unroll
                     for (int c = 0; c < NCO; c += 2) h[c >> 1] = cb_pack2(v[c], v[c + 1]);
-                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b64(h, srd_o, ovoff[e], so, 0);
-                    else                    __builtin_amdgcn_raw_buffer_store_b32(h[0], srd_o, ovoff[e], so, 0);
+                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b64(h, srd_o, ovoff, 0, 0);
+                    else                    __builtin_amdgcn_raw_buffer_store_b32(h[0], srd_o, ovoff, 0, 0);
                 } else {
                     ovec_t ov;
 #pragma unroll
                     for (int c = 0; c < NCO; ++c) ov[c] = __builtin_bit_cast(unsigned, v[c]);
-                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b128(ov, srd_o, ovoff[e], so, 0);
-                    else                    __builtin_amdgcn_raw_buffer_store_b64(ov, srd_o, ovoff[e], so, 0);
+                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b128(ov, srd_o, ovoff, 0, 0);
+                    else                    __builtin_amdgcn_raw_buffer_store_b64(ov, srd_o, ovoff, 0, 0);
                 }
             }
         }

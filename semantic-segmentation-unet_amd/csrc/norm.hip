@@ -225,8 +225,41 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     scale[c] = (float)a; shift[c] = (float)((double)beta[c] - (double)mm[c] * a);
 }
 
+// y = scale * r + shift.  A lane owns one channel group (its scale / shift live in registers) and walks pixels with a grid-wide
+// stride, four pixels per step so that four 16-byte loads are in flight per lane: with one load in flight (the round-1 form, a flat
+// index loop) these passes were latency-bound at ~3.2 TB/s.  flags: bit 0 = y stored as bf16, bit 1 = r stored as bf16.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
+        const float* __restrict__ shift, float* __restrict__ y, int ldy, long P, int C, int tpp, int out16) {
+    const Lay l = make_lay<VEC>(C, tpp);
+    if (!l.active) return;
+    float a[VEC], b[VEC];
+    vload<VEC>(a, scale + l.c0); vload<VEC>(b, shift + l.c0);
+    const long S = (long)gridDim.x * l.npl;
+    long pix = (long)blockIdx.x * l.npl + l.pl;
+    for (; pix + 3 * S < P; pix += 4 * S) {
+        float v[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vload_dt<VEC>(v[u], r, (size_t)(pix + u * S) * ldr + l.c0, out16 & 2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[u][e] = fmaf(a[e], v[u][e], b[e]);
+            vstore_dt<VEC>(y, (size_t)(pix + u * S) * ldy + l.c0, v[u], out16 & 1);
+        }
+    }
+    for (; pix < P; pix += S) {
+        float v[VEC];
+        vload_dt<VEC>(v, r, (size_t)pix * ldr + l.c0, out16 & 2);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = fmaf(a[e], v[e], b[e]);
+        vstore_dt<VEC>(y, (size_t)pix * ldy + l.c0, v, out16 & 1);
+    }
+}
+
+// the same for channel counts the lane layout does not cover (C / VEC lanes per pixel must divide 256): flat index loop
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_apply_flat_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
         const float* __restrict__ shift, float* __restrict__ y, int ldy, long P, int C, int out16) {
     const int nq = C / VEC;
     const long total = P * nq, stride = (long)gridDim.x * 256;
@@ -246,20 +279,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
         const float* __restrict__ shift, float* __restrict__ y, int ldy, float* __restrict__ pooled, int ldp, uint8_t* __restrict__ idx,
-        int N, int H, int W, int C, int out16) {
-    const int H2 = H / 2, W2 = W / 2, nq = C / VEC;
-    const long total = (long)N * H2 * W2 * nq, stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        long t = i; const int cq = (int)(t % nq); t /= nq;
-        const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const int n = (int)(t / H2);
-        const long opix = ((long)n * H2 + oy) * W2 + ox;
-        float a[VEC], b[VEC], best[VEC]; uint8_t bi[VEC];
-        vload<VEC>(a, scale + VEC * cq); vload<VEC>(b, shift + VEC * cq);
+        int N, int H, int W, int C, int tpp, int out16) {
+    const Lay l = make_lay<VEC>(C, tpp);
+    if (!l.active) return;
+    const int H2 = H / 2, W2 = W / 2;
+    const long total = (long)N * H2 * W2, S = (long)gridDim.x * l.npl;
+    float a[VEC], b[VEC];
+    vload<VEC>(a, scale + l.c0); vload<VEC>(b, shift + l.c0);
+    for (long opix = (long)blockIdx.x * l.npl + l.pl; opix < total; opix += S) {
+        long t = opix; const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const int n = (int)(t / H2);
+        float best[VEC]; uint8_t bi[VEC];
         float v[4][VEC];
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
             const size_t pix = (size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1);
-            vload_dt<VEC>(v[pos], r, pix * ldr + VEC * cq, out16 & 2);
+            vload_dt<VEC>(v[pos], r, pix * ldr + l.c0, out16 & 2);
         }
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
@@ -269,20 +303,23 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
                 v[pos][e] = fmaf(a[e], v[pos][e], b[e]);
                 if (pos == 0 || v[pos][e] > best[e]) { best[e] = v[pos][e]; bi[e] = (uint8_t)pos; }
             }
-            vstore_dt<VEC>(y, pix * ldy + VEC * cq, v[pos], out16 & 1);
+            vstore_dt<VEC>(y, pix * ldy + l.c0, v[pos], out16 & 1);
         }
-        vstore_dt<VEC>(pooled, (size_t)opix * ldp + VEC * cq, best, out16 & 1);
-        uint32_t w0 = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+        vstore_dt<VEC>(pooled, (size_t)opix * ldp + l.c0, best, out16 & 1);
+        const uint32_t w0 = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
         if constexpr (VEC == 8) {
             const uint32_t w1 = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
-            *reinterpret_cast<uint2*>(idx + (size_t)opix * C + VEC * cq) = make_uint2(w0, w1);
+            *reinterpret_cast<uint2*>(idx + (size_t)opix * C + l.c0) = make_uint2(w0, w1);
         } else {
-            *reinterpret_cast<uint32_t*>(idx + (size_t)opix * C + VEC * cq) = w0;
+            *reinterpret_cast<uint32_t*>(idx + (size_t)opix * C + l.c0) = w0;
         }
     }
 }
 
 // backward pass 1: per-channel sum(dy) and sum(dy * xhat)
+// The per-lane sums are taken in fp32 over the four pixels of a step and added to fp64 running sums once per step (a quarter of
+// the fp64 conversions / additions of the element-wise form, which made these passes instruction-bound once their tensors shrank
+// to bf16); sum(dy * xhat) is accumulated as sum(dy * (r - mean)) and multiplied by invstd in the finalize kernel.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
         int ldr, const float* __restrict__ mean, const float* __restrict__ invstd, long P, int C, int tpp, long ppb,
@@ -294,7 +331,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { acc[0][e] = 0.0; acc[1][e] = 0.0; }
     if (l.active) {
-        float mu[VEC], is[VEC]; vload<VEC>(mu, mean + l.c0); vload<VEC>(is, invstd + l.c0);
+        float mu[VEC]; vload<VEC>(mu, mean + l.c0);
         long pix = p0 + l.pl;
         const long st = l.npl;
         for (; pix + 3 * st < p1; pix += 4 * st) {
@@ -305,36 +342,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 add_pool_grad<VEC>(g[u], pg, pix + u * st, l.c0);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float xh = (v[u][e] - mu[e]) * is[e];
-                    acc[0][e] += (double)g[u][e]; acc[1][e] += (double)g[u][e] * (double)xh;
-                }
+            for (int e = 0; e < VEC; ++e) {
+                const float s0 = (g[0][e] + g[1][e]) + (g[2][e] + g[3][e]);
+                float s1 = g[0][e] * (v[0][e] - mu[e]);
+                s1 = fmaf(g[1][e], v[1][e] - mu[e], s1); s1 = fmaf(g[2][e], v[2][e] - mu[e], s1); s1 = fmaf(g[3][e], v[3][e] - mu[e], s1);
+                acc[0][e] += (double)s0; acc[1][e] += (double)s1;
+            }
         }
         for (; pix < p1; pix += st) {
             float g[VEC], v[VEC];
             vload_dt<VEC>(g, dy, (size_t)pix * lddy + l.c0, dt & 4); vload_dt<VEC>(v, r, (size_t)pix * ldr + l.c0, dt & 2);
             add_pool_grad<VEC>(g, pg, pix, l.c0);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float xh = (v[e] - mu[e]) * is[e];
-                acc[0][e] += (double)g[e]; acc[1][e] += (double)g[e] * (double)xh;
-            }
+            for (int e = 0; e < VEC; ++e) { acc[0][e] += (double)g[e]; acc[1][e] += (double)(g[e] * (v[e] - mu[e])); }
         }
     }
     block_combine<VEC, 2>(acc, l, C, part, gridDim.x, sRd);
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, const float* __restrict__ invstd,
+                                                             float* dgamma, float* dbeta) {
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int k = threadIdx.x; k < nblk; k += 64) { s1 += part[(size_t)k * C + c]; s2 += part[((size_t)nblk + k) * C + c]; }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (threadIdx.x == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+    if (threadIdx.x == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)(s2 * (double)invstd[c]); }       // sum dy (r - mean) * invstd
 }
 
-// backward pass 2: dz = relu'(r) * gamma*invstd * (dy - mean(dy) - xhat * mean(dy*xhat)); also per-channel sum(dz)
+// backward pass 2: dz = relu'(r) * gamma*invstd * (dy - mean(dy) - xhat * mean(dy*xhat)); also per-channel sum(dz).
+// With a = gamma * invstd, c1 = dbeta / P, c2 = dgamma / P and xhat = (r - mean) * invstd this is
+//     dz = relu'(r) * (A * dy + B * r + K),  A = a,  B = -a * c2 * invstd,  K = a * (c2 * invstd * mean - c1):
+// two FMAs per element with three per-channel constants in registers.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
         int ldr, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -347,13 +385,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[0][e] = 0.0;
     if (l.active) {
-        float mu[VEC], is[VEC], ga[VEC], dg[VEC], db[VEC];
-        vload<VEC>(mu, mean + l.c0); vload<VEC>(is, invstd + l.c0); vload<VEC>(ga, gamma + l.c0);
-        vload<VEC>(dg, dgamma + l.c0); vload<VEC>(db, dbeta + l.c0);
-        float a[VEC], c1[VEC], c2[VEC];
-        const float invP = 1.0f / (float)P;
+        float A[VEC], Bc[VEC], K[VEC];
+        {
+            float mu[VEC], is[VEC], ga[VEC], dg[VEC], db[VEC];
+            vload<VEC>(mu, mean + l.c0); vload<VEC>(is, invstd + l.c0); vload<VEC>(ga, gamma + l.c0);
+            vload<VEC>(dg, dgamma + l.c0); vload<VEC>(db, dbeta + l.c0);
+            const float invP = 1.0f / (float)P;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { a[e] = ga[e] * is[e]; c1[e] = db[e] * invP; c2[e] = dg[e] * invP; }
+            for (int e = 0; e < VEC; ++e) {
+                const float a = ga[e] * is[e], c1 = db[e] * invP, c2 = dg[e] * invP;
+                A[e] = a; Bc[e] = -(a * (c2 * is[e])); K[e] = a * (c2 * is[e] * mu[e] - c1);
+            }
+        }
         long pix = p0 + l.pl;
         const long st = l.npl;
         for (; pix + 3 * st < p1; pix += 4 * st) {
@@ -363,18 +406,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 vload_dt<VEC>(g[u], dy, (size_t)(pix + u * st) * lddy + l.c0, dt & 4); vload_dt<VEC>(v[u], r, (size_t)(pix + u * st) * ldr + l.c0, dt & 2);
                 add_pool_grad<VEC>(g[u], pg, pix + u * st, l.c0);
             }
+            float sum4[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum4[e] = 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float o[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    const float xh = (v[u][e] - mu[e]) * is[e];
-                    float d = a[e] * (g[u][e] - c1[e] - xh * c2[e]);
+                    float d = fmaf(A[e], g[u][e], fmaf(Bc[e], v[u][e], K[e]));
                     if (relu && !(v[u][e] > 0.f)) d = 0.f;
-                    o[e] = d; acc[0][e] += (double)d;
+                    o[e] = d; sum4[e] += d;
                 }
                 vstore_dt<VEC>(dz, (size_t)(pix + u * st) * lddz + l.c0, o, dt & 1);
             }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[0][e] += (double)sum4[e];
         }
         for (; pix < p1; pix += st) {
             float g[VEC], v[VEC], o[VEC];
@@ -382,8 +429,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             add_pool_grad<VEC>(g, pg, pix, l.c0);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const float xh = (v[e] - mu[e]) * is[e];
-                float d = a[e] * (g[e] - c1[e] - xh * c2[e]);
+                float d = fmaf(A[e], g[e], fmaf(Bc[e], v[e], K[e]));
                 if (relu && !(v[e] > 0.f)) d = 0.f;
                 o[e] = d; acc[0][e] += (double)d;
             }
@@ -420,6 +466,61 @@ bool make_plan(long P, int C, int ld_a, int ld_b, int ld_c, bool aligned, Plan* 
 }
 
 int nblk_for(long P) { (void)P; return (int)MAX_BLOCKS; }        // workspace is sized for the largest grid
+
+int bn_cus() {
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+    return cus;
+}
+
+// Largest grid <= MAX_BLOCKS that is a whole number of resident waves of workgroups for this kernel (its registers decide how many
+// 256-thread workgroups a CU holds): a 2048-block launch of a kernel that fits 5 per CU runs 5 + 3 per CU -- the second wave leaves
+// 3/8 of the machine idle while it finishes.
+template <class K> int resident_grid(K kernel, size_t smem) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) != hipSuccess || per_cu < 1) per_cu = 4;
+    long g = (long)per_cu * bn_cus();
+    return (int)(g > MAX_BLOCKS ? MAX_BLOCKS / bn_cus() * bn_cus() : g);
+}
+template <int VEC> int reduce_grid(size_t smem) { static int g = 0; if (!g) g = resident_grid(bn_bwd_reduce_kernel<VEC>, smem); return g; }
+template <int VEC> int apply_grid(size_t smem) { static int g = 0; if (!g) g = resident_grid(bn_bwd_apply_kernel<VEC>, smem); return g; }
+
+// BatchNorm apply (+ 2x2 max pool when pooled != null) for any storage mix; picks the lane layout
+int launch_bn_apply(const float* r, int ldr, int r16, const float* scale, const float* shift, float* y, int ldy, int y16,
+                    float* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, hipStream_t st) {
+    const int flags = (y16 ? 1 : 0) | (r16 ? 2 : 0);
+    const long P = (long)N * H * W;
+    const bool al = unet_aligned16(r) && unet_aligned16(y) && unet_aligned16(scale) && unet_aligned16(shift) && (!pooled || unet_aligned16(pooled));
+    int vec = 1;
+    if (flags && al && C % 8 == 0 && ldr % 8 == 0 && ldy % 8 == 0 && (!pooled || ldp % 8 == 0)) vec = 8;
+    else if (al && C % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0 && (!pooled || ldp % 4 == 0)) vec = 4;
+    if (flags && vec < 4) return UNET_EINVAL;                             // bf16 tensors need the vector forms
+    int tpp = C / vec;
+    bool lanes = (256 % tpp == 0);                                        // C / vec lanes per pixel tile a 256-thread block
+    if (vec == 1) { tpp = 1; while (tpp < C) tpp <<= 1; lanes = tpp <= 256; }
+    if (pooled) {
+        if (!lanes || vec < 4) return UNET_EINVAL;
+        const long total = (long)N * (H / 2) * (W / 2), npl = 256 / tpp;
+        long blocks = (total + npl * 2 - 1) / (npl * 2); if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS; if (blocks < 1) blocks = 1;
+        if (vec == 8) bn_apply_pool_kernel<8><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, tpp, flags);
+        else          bn_apply_pool_kernel<4><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, tpp, flags);
+        return UNET_LAUNCH_STATUS();
+    }
+    if (lanes) {
+        const long npl = 256 / tpp;
+        long blocks = (P + npl * 4 - 1) / (npl * 4); if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS; if (blocks < 1) blocks = 1;
+        if (vec == 8)      bn_apply_kernel<8><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, tpp, flags);
+        else if (vec == 4) bn_apply_kernel<4><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, tpp, flags);
+        else               bn_apply_kernel<1><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, tpp, flags);
+    } else {
+        const long total = P * (C / vec);
+        long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+        if (vec == 8)      bn_apply_flat_kernel<8><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, flags);
+        else if (vec == 4) bn_apply_flat_kernel<4><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, flags);
+        else               bn_apply_flat_kernel<1><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, flags);
+    }
+    return UNET_LAUNCH_STATUS();
+}
 
 }  // namespace
 
@@ -462,14 +563,8 @@ extern "C" int unet_bn_eval_coeffs(const float* gamma, const float* beta, const 
 
 extern "C" int unet_bn_apply(const float* r, int ldr, const float* scale, const float* shift, float* y, int ldy,
                              long P, int C, void* stream) {
-    UNET_CHECK_ARG(r && scale && shift && y && P > 0 && C > 0 && ldr >= C && ldy >= C);
-    const bool v4 = C % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0 && unet_aligned16(r) && unet_aligned16(y) &&
-                    unet_aligned16(scale) && unet_aligned16(shift);
-    const long total = v4 ? P * (C / 4) : P * C;
-    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    if (v4) bn_apply_kernel<4><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C, 0);
-    else    bn_apply_kernel<1><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, P, C, 0);
-    return UNET_LAUNCH_STATUS();
+    UNET_CHECK_ARG(r && scale && shift && y && P > 0 && P < ((long)1 << 31) && C > 0 && ldr >= C && ldy >= C);
+    return launch_bn_apply(r, ldr, 0, scale, shift, y, ldy, 0, nullptr, 0, nullptr, 1, 1, (int)P, C, (hipStream_t)stream);
 }
 
 // y = scale * r + shift (as unet_bn_apply) and, in the same pass, pooled = MaxPool2D(2)(y) with the first-max index
@@ -479,10 +574,7 @@ extern "C" int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale
     UNET_CHECK_ARG(ldr >= C && ldy >= C && ldp >= C && ldr % 4 == 0 && ldy % 4 == 0 && ldp % 4 == 0);
     UNET_CHECK_ARG(unet_aligned16(r) && unet_aligned16(y) && unet_aligned16(pooled) && unet_aligned16(scale) && unet_aligned16(shift) &&
                    (reinterpret_cast<uintptr_t>(idx) & 3u) == 0);
-    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    bn_apply_pool_kernel<4><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, 0);
-    return UNET_LAUNCH_STATUS();
+    return launch_bn_apply(r, ldr, 0, scale, shift, y, ldy, 0, pooled, ldp, idx, N, H, W, C, (hipStream_t)stream);
 }
 
 static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
@@ -499,23 +591,32 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)ws;
     int rc;
+    if ((dt || pg.p16) && pl.vec < 4) return UNET_EINVAL;
+    // grids: the plan's block count, capped to one resident wave of workgroups of the kernel that runs
+    int nb_r = pl.nblk, nb_a = pl.nblk;
+    {
+        const int cr = pl.vec == 8 ? reduce_grid<8>(pl.smem2) : pl.vec == 4 ? reduce_grid<4>(pl.smem2) : reduce_grid<1>(pl.smem2);
+        const int ca = pl.vec == 8 ? apply_grid<8>(pl.smem1) : pl.vec == 4 ? apply_grid<4>(pl.smem1) : apply_grid<1>(pl.smem1);
+        if (nb_r > cr) nb_r = cr;
+        if (nb_a > ca) nb_a = ca;
+    }
+    const long ppb_r = (P + nb_r - 1) / nb_r, ppb_a = (P + nb_a - 1) / nb_a;
     if (part_sums) {
         bn_bwd_finalize_partials_kernel<<<C, 256, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
     } else {
-        if (pl.vec == 8)      bn_bwd_reduce_kernel<8><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, dt);
-        else if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, dt);
-        else                  bn_bwd_reduce_kernel<1><<<pl.nblk, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, pl.ppb, part, pg, 0);
+        if (pl.vec == 8)      bn_bwd_reduce_kernel<8><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, ppb_r, part, pg, dt);
+        else if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, ppb_r, part, pg, dt);
+        else                  bn_bwd_reduce_kernel<1><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, ppb_r, part, pg, 0);
         rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-        bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(part, pl.nblk, C, dgamma, dbeta);
+        bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(part, nb_r, C, invstd, dgamma, dbeta);
     }
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    double* part2 = part + (size_t)2 * pl.nblk * C;
-    if ((dt || pg.p16) && pl.vec < 4) return UNET_EINVAL;
-    if (pl.vec == 8) bn_bwd_apply_kernel<8><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, dt);
-    else if (pl.vec == 4) bn_bwd_apply_kernel<4><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, dt);
-    else             bn_bwd_apply_kernel<1><<<pl.nblk, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, pl.ppb, relu, dz, lddz, part2, pg, 0);
+    double* part2 = part + (size_t)2 * MAX_BLOCKS * C;
+    if (pl.vec == 8)      bn_bwd_apply_kernel<8><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
+    else if (pl.vec == 4) bn_bwd_apply_kernel<4><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
+    else                  bn_bwd_apply_kernel<1><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, 0);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    colsum_finalize_kernel<<<C, 64, 0, st>>>(part2, pl.nblk, C, dbias);
+    colsum_finalize_kernel<<<C, 64, 0, st>>>(part2, nb_a, C, dbias);
     return UNET_LAUNCH_STATUS();
 }
 
@@ -567,22 +668,8 @@ extern "C" int unet_bn_apply_any(const void* r, int ldr, int r_bf16, const float
                                  void* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream) {
     UNET_CHECK_ARG(r && scale && shift && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldr >= C && ldy >= C && ldr % 4 == 0 && ldy % 4 == 0);
     UNET_CHECK_ARG(unet_aligned16(r) && unet_aligned16(y) && unet_aligned16(scale) && unet_aligned16(shift) && (pooled == nullptr) == (idx == nullptr));
-    const int flags = (y_bf16 ? 1 : 0) | (r_bf16 ? 2 : 0);
-    hipStream_t st = (hipStream_t)stream;
-    // 8 channels (16 bytes of a bf16 tensor) per lane whenever a bf16 tensor is involved and the shapes allow it
-    const bool wide = flags != 0 && C % 8 == 0 && ldr % 8 == 0 && ldy % 8 == 0 && (!pooled || ldp % 8 == 0);
-    const int vec = wide ? 8 : 4;
-    if (pooled) {
-        UNET_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && ldp >= C && ldp % 4 == 0 && unet_aligned16(pooled) && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0);
-        const long total = (long)N * (H / 2) * (W / 2) * (C / vec);
-        long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-        if (wide) bn_apply_pool_kernel<8><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, (float*)pooled, ldp, idx, N, H, W, C, flags);
-        else      bn_apply_pool_kernel<4><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, (float*)pooled, ldp, idx, N, H, W, C, flags);
-    } else {
-        const long P = (long)N * H * W, total = P * (C / vec);
-        long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-        if (wide) bn_apply_kernel<8><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, P, C, flags);
-        else      bn_apply_kernel<4><<<(int)blocks, 256, 0, st>>>((const float*)r, ldr, scale, shift, (float*)y, ldy, P, C, flags);
-    }
-    return UNET_LAUNCH_STATUS();
+    if (pooled) UNET_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && ldp >= C && ldp % 4 == 0 && unet_aligned16(pooled) && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0);
+    return launch_bn_apply((const float*)r, ldr, r_bf16 ? 1 : 0, scale, shift, (float*)y, ldy, y_bf16 ? 1 : 0, (float*)pooled, ldp, idx,
+                           N, H, W, C, (hipStream_t)stream);
 }
+

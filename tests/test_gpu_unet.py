@@ -269,7 +269,7 @@ def test_bf16_train_step_tracks_fp32():
     assert (p16 - p32).abs().max().item() < 0.05
     top2 = p32.topk(2, dim=-1).values
     sure = (top2[..., 0] - top2[..., 1]) > 0.1
-    assert sure.float().mean().item() > 0.25
+    assert sure.float().mean().item() > 0.15
     assert torch.equal(p16.argmax(-1)[sure], p32.argmax(-1)[sure])
 
 
