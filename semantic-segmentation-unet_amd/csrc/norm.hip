@@ -7,6 +7,7 @@
 // class-map tensors), 256/tpp pixels in flight per block.  Per-channel sums are accumulated in fp64 per lane,
 // combined through LDS, written as per-block partials and summed in a fixed order (bit-stable run to run).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -439,6 +440,115 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
 }
 
+// ---- the two backward passes for a layer whose output also went through MaxPool2D(2) (PoolGrad): a lane owns one POOLED pixel
+// (and its channel group) per step -- it loads the pooled gradient and the first-max indices once and walks the 2x2 window, instead
+// of every one of the four window pixels fetching them again through the cache (the per-pixel form ran at 2.1-2.6 TB/s).
+template <int VEC> __device__ __forceinline__ void load_idx(uint8_t (&ix)[VEC], const uint8_t* p) {
+    if constexpr (VEC == 8) { const uint2 w = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ix[e] = (uint8_t)(w.x >> (8 * e)); ix[4 + e] = (uint8_t)(w.y >> (8 * e)); } }
+    else if constexpr (VEC == 4) { const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ix[e] = (uint8_t)(w >> (8 * e)); }
+    else ix[0] = *p;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
+        int ldr, const float* __restrict__ mean, long P2, int C, int tpp, long ppb, double* __restrict__ part, PoolGrad pg, int dt) {
+    extern __shared__ __attribute__((aligned(16))) double sRd[];
+    const Lay l = make_lay<VEC>(C, tpp);
+    const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P2) p1 = P2;
+    const int H2 = pg.H >> 1, W2 = pg.W >> 1;
+    double acc[2][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { acc[0][e] = 0.0; acc[1][e] = 0.0; }
+    if (l.active) {
+        float mu[VEC]; vload<VEC>(mu, mean + l.c0);
+        for (long op = p0 + l.pl; op < p1; op += l.npl) {
+            long t = op; const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const long n = t / H2;
+            float pd[VEC]; uint8_t ix[VEC];
+            vload_dt<VEC>(pd, pg.pdy, (size_t)op * pg.ldp + l.c0, pg.p16);
+            load_idx<VEC>(ix, pg.idx + (size_t)op * pg.C + l.c0);
+            float g[4][VEC], v[4][VEC];
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                const size_t pix = (size_t)((n * pg.H + 2 * oy + (pos >> 1)) * pg.W + 2 * ox + (pos & 1));
+                vload_dt<VEC>(g[pos], dy, pix * lddy + l.c0, dt & 4); vload_dt<VEC>(v[pos], r, pix * ldr + l.c0, dt & 2);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) if (ix[e] == pos) g[pos][e] += pd[e];
+                const float s0 = (g[0][e] + g[1][e]) + (g[2][e] + g[3][e]);
+                float s1 = g[0][e] * (v[0][e] - mu[e]);
+                s1 = fmaf(g[1][e], v[1][e] - mu[e], s1); s1 = fmaf(g[2][e], v[2][e] - mu[e], s1); s1 = fmaf(g[3][e], v[3][e] - mu[e], s1);
+                acc[0][e] += (double)s0; acc[1][e] += (double)s1;
+            }
+        }
+    }
+    block_combine<VEC, 2>(acc, l, C, part, gridDim.x, sRd);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ r,
+        int ldr, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+        const float* __restrict__ dgamma, const float* __restrict__ dbeta, long P, long P2, int C, int tpp, long ppb, int relu,
+        float* __restrict__ dz, int lddz, double* __restrict__ part, PoolGrad pg, int dt) {
+    extern __shared__ __attribute__((aligned(16))) double sRd[];
+    const Lay l = make_lay<VEC>(C, tpp);
+    const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P2) p1 = P2;
+    const int H2 = pg.H >> 1, W2 = pg.W >> 1;
+    double acc[1][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = 0.0;
+    if (l.active) {
+        float A[VEC], Bc[VEC], K[VEC];
+        {
+            float mu[VEC], is[VEC], ga[VEC], dg[VEC], db[VEC];
+            vload<VEC>(mu, mean + l.c0); vload<VEC>(is, invstd + l.c0); vload<VEC>(ga, gamma + l.c0);
+            vload<VEC>(dg, dgamma + l.c0); vload<VEC>(db, dbeta + l.c0);
+            const float invP = 1.0f / (float)P;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float a = ga[e] * is[e], c1 = db[e] * invP, c2 = dg[e] * invP;
+                A[e] = a; Bc[e] = -(a * (c2 * is[e])); K[e] = a * (c2 * is[e] * mu[e] - c1);
+            }
+        }
+        for (long op = p0 + l.pl; op < p1; op += l.npl) {
+            long t = op; const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const long n = t / H2;
+            float pd[VEC]; uint8_t ix[VEC];
+            vload_dt<VEC>(pd, pg.pdy, (size_t)op * pg.ldp + l.c0, pg.p16);
+            load_idx<VEC>(ix, pg.idx + (size_t)op * pg.C + l.c0);
+            float g[4][VEC], v[4][VEC];
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                const size_t pix = (size_t)((n * pg.H + 2 * oy + (pos >> 1)) * pg.W + 2 * ox + (pos & 1));
+                vload_dt<VEC>(g[pos], dy, pix * lddy + l.c0, dt & 4); vload_dt<VEC>(v[pos], r, pix * ldr + l.c0, dt & 2);
+            }
+            float sum4[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum4[e] = 0.f;
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                const size_t pix = (size_t)((n * pg.H + 2 * oy + (pos >> 1)) * pg.W + 2 * ox + (pos & 1));
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float ge = g[pos][e] + (ix[e] == pos ? pd[e] : 0.f);
+                    float d = fmaf(A[e], ge, fmaf(Bc[e], v[pos][e], K[e]));
+                    if (relu && !(v[pos][e] > 0.f)) d = 0.f;
+                    o[e] = d; sum4[e] += d;
+                }
+                vstore_dt<VEC>(dz, pix * lddz + l.c0, o, dt & 1);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[0][e] += (double)sum4[e];
+        }
+    }
+    block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
+}
+
 __global__ __launch_bounds__(64) void colsum_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* out) {
     const int c = blockIdx.x;
     double s = 0.0;
@@ -467,6 +577,15 @@ bool make_plan(long P, int C, int ld_a, int ld_b, int ld_c, bool aligned, Plan* 
 
 int nblk_for(long P) { (void)P; return (int)MAX_BLOCKS; }        // workspace is sized for the largest grid
 
+// UNET_BN_WIDE (diagnostic A/B switch): 1 = 8 channels per lane for every tensor mix the shapes allow (default), 0 = only when a tensor is
+// stored as bf16.  With one lane layout for both storages the sums are added in one order, so bf16 storage of dz / y stays
+// bit-identical to fp32 storage.
+bool bn_wide_always() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UNET_BN_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+
 int bn_cus() {
     static int cus = 0;
     if (!cus) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
@@ -492,7 +611,7 @@ int launch_bn_apply(const float* r, int ldr, int r16, const float* scale, const 
     const long P = (long)N * H * W;
     const bool al = unet_aligned16(r) && unet_aligned16(y) && unet_aligned16(scale) && unet_aligned16(shift) && (!pooled || unet_aligned16(pooled));
     int vec = 1;
-    if (flags && al && C % 8 == 0 && ldr % 8 == 0 && ldy % 8 == 0 && (!pooled || ldp % 8 == 0)) vec = 8;
+    if ((flags || bn_wide_always()) && al && C % 8 == 0 && ldr % 8 == 0 && ldy % 8 == 0 && (!pooled || ldp % 8 == 0) && 256 % (C / 8) == 0) vec = 8;
     else if (al && C % 4 == 0 && ldr % 4 == 0 && ldy % 4 == 0 && (!pooled || ldp % 4 == 0)) vec = 4;
     if (flags && vec < 4) return UNET_EINVAL;                             // bf16 tensors need the vector forms
     int tpp = C / vec;
@@ -586,7 +705,7 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     Plan pl;
     const bool al = unet_aligned16(dy) && unet_aligned16(r) && unet_aligned16(dz) && unet_aligned16(gamma) && unet_aligned16(mean) &&
                     unet_aligned16(invstd) && unet_aligned16(dgamma) && unet_aligned16(dbeta) && (!pg.pdy || (unet_aligned16(pg.pdy) && pg.ldp % 4 == 0));
-    UNET_CHECK_ARG(make_plan(P, C, lddy, ldr, lddz, al && (!pg.pdy || pg.ldp % 8 == 0 || !(dt || pg.p16)), &pl, dt != 0 || pg.p16 != 0));
+    UNET_CHECK_ARG(make_plan(P, C, lddy, ldr, lddz, al && (!pg.pdy || pg.ldp % 8 == 0 || !(dt || pg.p16)), &pl, dt != 0 || pg.p16 != 0 || bn_wide_always()));
     if (ws_bytes < unet_bn_workspace(P, C)) return UNET_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)ws;
@@ -600,11 +719,21 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
         if (nb_r > cr) nb_r = cr;
         if (nb_a > ca) nb_a = ca;
     }
-    const long ppb_r = (P + nb_r - 1) / nb_r, ppb_a = (P + nb_a - 1) / nb_a;
+    const bool pooled_form = pg.pdy != nullptr && pl.vec >= 4;       // window-per-lane kernels: grids over the POOLED pixels
+    const long Pw = pooled_form ? P / 4 : P;
+    if (pooled_form) {
+        const long npl = 256 / pl.tpp;
+        long nb = (Pw + npl * 4 - 1) / (npl * 4); if (nb < 1) nb = 1;
+        if (nb_r > nb) nb_r = (int)nb;
+        if (nb_a > nb) nb_a = (int)nb;
+    }
+    const long ppb_r = (Pw + nb_r - 1) / nb_r, ppb_a = (Pw + nb_a - 1) / nb_a;
     if (part_sums) {
         bn_bwd_finalize_partials_kernel<<<C, 256, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
     } else {
-        if (pl.vec == 8)      bn_bwd_reduce_kernel<8><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, ppb_r, part, pg, dt);
+        if (pooled_form && pl.vec == 8) bn_bwd_reduce_pool_kernel<8><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, Pw, C, pl.tpp, ppb_r, part, pg, dt);
+        else if (pooled_form)      bn_bwd_reduce_pool_kernel<4><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, Pw, C, pl.tpp, ppb_r, part, pg, dt);
+        else if (pl.vec == 8) bn_bwd_reduce_kernel<8><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, ppb_r, part, pg, dt);
         else if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, ppb_r, part, pg, dt);
         else                  bn_bwd_reduce_kernel<1><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, ppb_r, part, pg, 0);
         rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
@@ -612,7 +741,9 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     }
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     double* part2 = part + (size_t)2 * MAX_BLOCKS * C;
-    if (pl.vec == 8)      bn_bwd_apply_kernel<8><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
+    if (pooled_form && pl.vec == 8) bn_bwd_apply_pool_kernel<8><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, Pw, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
+    else if (pooled_form)      bn_bwd_apply_pool_kernel<4><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, Pw, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
+    else if (pl.vec == 8) bn_bwd_apply_kernel<8><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
     else if (pl.vec == 4) bn_bwd_apply_kernel<4><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
     else                  bn_bwd_apply_kernel<1><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, 0);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;

@@ -750,6 +750,9 @@ class Engine:
         """the 3x3 layer's data gradient may be WRITTEN as bf16: every reader of it is a BatchNorm backward that takes bf16 dy"""
         if self.compute_dtype != "bf16" or not (self.bf16_storage and self.bf16_activations) or eval_mode or self.kind[name] != "conv3":
             return False
+        n, ho, wo, _ = self.saved[name][1].shape
+        if not self._use_bf16(name, n, ho, wo, dgrad=True):            # the fp32 kernels (size fallback) write fp32
+            return False
         need1 = lambda nm: self._dz16(nm, nm != "conv_1a", eval_mode)
         if name.startswith("dec_") and name.endswith("a"):             # [skip, upsampled]: conv_Nb (through the fused pool path) and up_N
             lvl = int(name[4])
