@@ -86,42 +86,36 @@ int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* V_saved,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* ---- bf16 matrix-core 3x3 convolution (BASELINE config 4: bf16 forward/backward, fp32 master weights; the reference keeps
  * its mixed-precision policy commented out, UNet/train.py:52-54) ------------------------------------------------------
- * Operands rounded to bf16 (nearest-even), exact products, fp32 accumulation; activations / gradients stay fp32 in memory.
+ * Operands rounded to bf16 (nearest-even), exact products, fp32 accumulation.
  * Cin % 64 == 0, Cout % 64 == 0, tensors < 2 GiB.  Weights are packed on the device once per step from the fp32 master copy
  * (HWIO, UNet/model.py:31): mode 0 for the forward, mode 1 for the data gradient. */
 int unet_conv3x3_bf16_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_conv3x3_bf16_packed_bytes(int Cin, int Cout);
 int unet_conv3x3_bf16_pack_weights(const float* w, void* packed, int Cin, int Cout, int mode, void* stream);
-int unet_conv3x3_fwd_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
-                          int N, int H, int W, int Cin, int Cout, int relu, void* stream);
-int unet_conv3x3_dgrad_bf16(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
-                            int N, int H, int W, int Cin, int Cout, void* stream);
-/* the same two kernels leaving BatchNorm sums behind (one row of partials per 16x32-pixel tile, layout and finalize as for
- * unet_conv3x3_fwd_winograd_fused_stats / unet_conv3x3_dgrad_winograd_fused_bnstats) */
+/* One entry point per direction, every option a parameter:
+ *  - x_bf16 / dz_bf16: that operand is STORED as bf16 (leading dimension in elements).  A producer (unet_bn_apply_any,
+ *    unet_bn_bwd_any) rounds exactly as these kernels' staging would, so bf16 storage of an operand is bit-identical to fp32 storage;
+ *  - in_scale / in_shift (forward, nullable): BatchNorm-apply on load -- x is the producer layer's conv output r and the operand is
+ *    bf16(in_scale[c] * r + in_shift[c]) inside the image, exactly 0 at the padding: bit-identical to applying the BatchNorm in a pass
+ *    of its own (UNet/model.py:36 then :30), without that pass;
+ *  - out_bf16 / dx_bf16 / r_bf16: the OUTPUT (resp. the producer's saved activation) is a bf16 tensor -- Keras mixed_bfloat16
+ *    semantics (activations and their gradients bf16, BatchNorm arithmetic fp32; the fused sums are taken before the rounding);
+ *  - stat_part (nullable): one row of partial sums per 16 x 32 pixel tile, [C/64][rows][64][2]: forward (sum y, sum y^2) of the output
+ *    for unet_bn_train_finalize_partials; data gradient, with r_prev = the saved activation of the layer whose dy is dx[..., c0:c1):
+ *    (sum dx, sum dx * r_prev) for unet_bn_bwd_any / unet_bn_bwd_from_partials. */
 int unet_conv3x3_bf16_stats_rows(int N, int H, int W, int Cin, int Cout);
-int unet_conv3x3_fwd_bf16_stats(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
-                                int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
-int unet_conv3x3_dgrad_bf16_bnstats(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
-                                    int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
-                                    float* stat_part, size_t stat_bytes, void* stream);
-/* general forms: an operand that only bf16 contractions read may be STORED as bf16 (x_bf16 / dz_bf16 != 0; leading dimension in
- * elements) -- its producer (unet_bn_apply_any, unet_bn_bwd_any) rounds exactly as these kernels' staging would, so the
- * results are bit-identical to fp32 storage; stat_part (and r_prev) nullable.  out_bf16 / dx_bf16 / r_bf16: the OUTPUT (resp. the
- * producer's saved activation) is a bf16 tensor -- the opt-in activation-storage mode (Keras mixed_bfloat16 semantics: activations
- * bf16, BatchNorm arithmetic fp32), which does change the numbers BatchNorm sees; the fused sums are taken before the rounding */
-int unet_conv3x3_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, void* out, int ldo, int out_bf16,
-                             int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
-int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
-                               int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16, int c0, int c1,
-                               float* stat_part, size_t stat_bytes, void* stream);
+int unet_conv3x3_fwd_bf16(const void* x, int ldx, int x_bf16, const float* in_scale, const float* in_shift, const void* wp,
+                          const float* bias, void* out, int ldo, int out_bf16,
+                          int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
+int unet_conv3x3_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
+                            int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16, int c0, int c1,
+                            float* stat_part, size_t stat_bytes, void* stream);
 /* weight gradient in the same arithmetic (both operands rounded to bf16, fp32 accumulation, split partial sums added in a
  * fixed order): dw[a,b,ci,co] = sum xin[n,y+a-1,x+b-1,ci] * dz[n,y,x,co] */
 int unet_conv3x3_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_conv3x3_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout);
-int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+int unet_conv3x3_wgrad_bf16(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
                             int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-int unet_conv3x3_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
-                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
 int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                             int N, int H, int W, int Cin, int Cout, int relu, void* stream);

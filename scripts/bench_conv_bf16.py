@@ -22,11 +22,11 @@ for name, h, ci, co in [("1b", 512, 64, 64), ("2a", 256, 64, 128), ("2b", 256, 1
     out = torch.empty(B, h, h, co, device="cuda")
     wp = torch.empty(L.unet_conv3x3_bf16_packed_bytes(ci, co), dtype=torch.uint8, device="cuda")
     tp = timeit(lambda: L.unet_conv3x3_bf16_pack_weights(P(w), P(wp), ci, co, 0, ST()))
-    t = timeit(lambda: L.unet_conv3x3_fwd_bf16(P(x), ci, P(wp), P(b), P(out), co, B, h, h, ci, co, 1, ST()))
+    t = timeit(lambda: L.unet_conv3x3_fwd_bf16(P(x), ci, 0, None, None, P(wp), P(b), P(out), co, 0, B, h, h, ci, co, 1, None, 0, ST()))
     fl = 2.0 * 9 * B * h * h * ci * co
     dz = torch.randn(B, h, h, co, device="cuda"); dw = torch.empty_like(w)
     nbw = L.unet_conv3x3_wgrad_bf16_workspace(B, h, h, ci, co); wsw = torch.empty(nbw + 256, dtype=torch.uint8, device="cuda")
-    tw = timeit(lambda: L.unet_conv3x3_wgrad_bf16(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(wsw), nbw, ST()))
+    tw = timeit(lambda: L.unet_conv3x3_wgrad_bf16(P(x), ci, 0, P(dz), co, 0, P(dw), B, h, h, ci, co, P(wsw), nbw, ST()))
     print("        wgrad %7.3f ms %7.1f TF" % (tw, fl / tw / 1e9))
     by = 4.0 * B * h * h * (ci + co)
     tot += t

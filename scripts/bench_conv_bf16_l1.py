@@ -24,14 +24,18 @@ for name, h, ci, co in [("1b", 512, 64, 64), ("dec1a", 512, 128, 64), ("2b", 256
     L.unet_conv3x3_bf16_pack_weights(P(w), P(wp), ci, co, 0, ST()); L.unet_conv3x3_bf16_pack_weights(P(w), P(wpd), ci, co, 1, ST())
     rows = L.unet_conv3x3_bf16_stats_rows(B, h, h, ci, co)
     part = torch.empty((co // 64) * rows * 128, device="cuda")
-    tf = timeit(lambda: L.unet_conv3x3_fwd_bf16_ex(P(x), ci, 1, P(wp), P(b), P(out), co, 1, B, h, h, ci, co, 1, P(part), part.numel() * 4, ST()))
-    tf0 = timeit(lambda: L.unet_conv3x3_fwd_bf16_ex(P(x), ci, 1, P(wp), P(b), P(out), co, 1, B, h, h, ci, co, 1, None, 0, ST()))
+    tf = timeit(lambda: L.unet_conv3x3_fwd_bf16(P(x), ci, 1, None, None, P(wp), P(b), P(out), co, 1, B, h, h, ci, co, 1, P(part), part.numel() * 4, ST()))
+    tf0 = timeit(lambda: L.unet_conv3x3_fwd_bf16(P(x), ci, 1, None, None, P(wp), P(b), P(out), co, 1, B, h, h, ci, co, 1, None, 0, ST()))
+    sc = torch.rand(ci, device="cuda") + 0.5; sh = torch.randn(ci, device="cuda"); y16 = torch.empty_like(x)
+    tn = timeit(lambda: L.unet_conv3x3_fwd_bf16(P(x), ci, 1, P(sc), P(sh), P(wp), P(b), P(out), co, 1, B, h, h, ci, co, 1, P(part), part.numel() * 4, ST()))
+    ta = timeit(lambda: L.unet_bn_apply_any(P(x), ci, 1, P(sc), P(sh), P(y16), ci, 1, None, 0, None, B, h, h, ci, ST()))
+    print("        BatchNorm apply on load: fwd+stats %6.3f ms  vs  separate apply %6.3f + fwd %6.3f = %6.3f ms" % (tn, ta, tf, ta + tf))
     dz = torch.randn(B, h, h, co, device="cuda").to(bf); dx = torch.empty(B, h, h, ci, device="cuda", dtype=bf)
     rp = torch.randn(B, h, h, ci, device="cuda").to(bf)
     rows2 = L.unet_conv3x3_bf16_stats_rows(B, h, h, co, ci)
     part2 = torch.empty((ci // 64) * rows2 * 128, device="cuda")
-    td = timeit(lambda: L.unet_conv3x3_dgrad_bf16_ex(P(dz), co, 1, P(wpd), P(dx), ci, 1, B, h, h, ci, co, P(rp), ci, 1, 0, ci, P(part2), part2.numel() * 4, ST()))
-    td0 = timeit(lambda: L.unet_conv3x3_dgrad_bf16_ex(P(dz), co, 1, P(wpd), P(dx), ci, 1, B, h, h, ci, co, None, 0, 0, 0, 0, None, 0, ST()))
+    td = timeit(lambda: L.unet_conv3x3_dgrad_bf16(P(dz), co, 1, P(wpd), P(dx), ci, 1, B, h, h, ci, co, P(rp), ci, 1, 0, ci, P(part2), part2.numel() * 4, ST()))
+    td0 = timeit(lambda: L.unet_conv3x3_dgrad_bf16(P(dz), co, 1, P(wpd), P(dx), ci, 1, B, h, h, ci, co, None, 0, 0, 0, 0, None, 0, ST()))
     fl = 2.0 * 9 * B * h * h * ci * co
     byf = 2.0 * B * h * h * (ci + co)
     print("%-6s h%4d %4d->%4d | fwd+stats %6.3f ms (%5.0f TF, %4.2f TB/s) plain %6.3f | dgrad+bnbwd %6.3f ms (%5.0f TF, %4.2f TB/s) plain %6.3f"

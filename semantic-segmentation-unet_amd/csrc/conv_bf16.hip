@@ -36,6 +36,7 @@ struct ConvBf16Args {
     int out16, r16;              // the output / the producer's saved activation (STATS 2) is stored as bf16 (ldo / bn_ldr in elements)
     float* stat_part;            // STATS 1: BatchNorm sums of the output (sum y, sum y^2); STATS 2: BatchNorm-backward sums (sum dx, sum dx * r)
     const float* bn_r; int bn_ldr, bn_c0, bn_c1;     // STATS 2: saved activation of the producer layer, whose dy is dx[..., c0:c1)
+    const float* in_scale; const float* in_shift;    // NORM: the input is a producer's conv output r; the operand is bf16(scale * r + shift)
 };
 
 constexpr int kPW = 34, kPlane = 640 * 16, kXP = 2 * kPlane;        // patch row length (pixels), bytes of one k-half plane, of the patch
@@ -124,7 +125,11 @@ __device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_bas
     }
 }
 
-template <int NCO, int STATS>
+// NORM: BatchNorm-apply on load.  The input tensor is the producer layer's conv output r (pre-BatchNorm), and the staging path forms
+// the operand bf16(fma(scale[c], r, shift[c])) -- the very instructions unet_bn_apply_any (norm.hip) + this kernel's own staging
+// conversion would have executed on a materialised BatchNorm output, so the result is bit-identical to that two-pass form while
+// the y tensor is never written or read; positions outside the image stay exact zeros (the padding applies to the BatchNorm OUTPUT).
+template <int NCO, int STATS, int NORM = 0>
 __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     constexpr int CT = 32 * NCO;
     constexpr int WB = 18 * CT * 16;                                // bytes of a chunk's weights for this tile
@@ -149,6 +154,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     // staging duty: float4 quad f of patch pixels (tid >> 2) + 64 j; out-of-image (and past-the-patch) lanes get an offset the
     // buffer's range check rejects, so they load zeros
     unsigned voff[10];
+    int okmask = 0;                                                   // NORM: bit j = staged pixel j of this thread is inside the image
     const int f = tid & 3;
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
@@ -156,6 +162,7 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
         const int gy = ty0 - 1 + pp / kPW, gx = tx0 - 1 + pp % kPW;
         const bool ok = pp < 18 * kPW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         voff[j] = ok ? (unsigned)((((size_t)(img * p.H + gy) * p.W + gx) * p.ldx) * (p.in16 ? 2 : 4) + (p.in16 ? (f >> 1) * 16 : f * 16)) : 0x80000000u;
+        okmask |= ok ? (1 << j) : 0;
     }
     // (compiler-visible buffer loads: it places the vmcnt wait in front of the first use; with inline-asm loads a register copy
     // of a destination can be scheduled ahead of a hand-written wait)
@@ -194,8 +201,13 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     // block around the stream they cost 23 % of a deep layer (ablation: 512->512 @64^2 compute alone 0.092 ms, data movement
     // alone 0.068 ms, together 0.122 ms).
     f32x4 stg[10];
+    f32x4 nsc = {1.f, 1.f, 1.f, 1.f}, nsh = {0.f, 0.f, 0.f, 0.f};       // NORM: scale / shift of this thread's 4 channels of the chunk in flight
     auto issue_x1 = [&](int chunk, int j) {
         stg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff[j], chunk * (p.in16 ? 32 : 64), 0));
+        if (NORM && j == 9) {        // (the thread's channels of a chunk: 16 chunk + 4 f .. + 3, for either storage)
+            nsc = *reinterpret_cast<const f32x4*>(p.in_scale + chunk * 16 + 4 * f);
+            nsh = *reinterpret_cast<const f32x4*>(p.in_shift + chunk * 16 + 4 * f);
+        }
     };
     auto issue_w1 = [&](int chunk, int stage, int k) {
         if (NPIECE % 4 == 0 || wv + 4 * k < NPIECE)
@@ -205,9 +217,24 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     auto write_x1 = [&](int stage, int j) {
         const unsigned wb = wr_base + (unsigned)(stage * STAGE + j * 1024);
         asm volatile("" : "+v"(stg[j]));          // pins every use of the loaded registers (the bf16 selects too) at this point of the stream
-        uint2 v; v.x = cb_pack2_pinned(stg[j].x, stg[j].y); v.y = cb_pack2_pinned(stg[j].z, stg[j].w);
-        if (p.in16) {
-            v.x = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].z : stg[j].x); v.y = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].w : stg[j].y);
+        uint2 v;
+        if (NORM) {
+            float r0, r1, r2, r3;
+            if (p.in16) {
+                const unsigned lo = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].z : stg[j].x), hi = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].w : stg[j].y);
+                r0 = __builtin_bit_cast(float, lo << 16); r1 = __builtin_bit_cast(float, lo & 0xffff0000u);
+                r2 = __builtin_bit_cast(float, hi << 16); r3 = __builtin_bit_cast(float, hi & 0xffff0000u);
+            } else { r0 = stg[j].x; r1 = stg[j].y; r2 = stg[j].z; r3 = stg[j].w; }
+            asm volatile("" : "+v"(nsc), "+v"(nsh));
+            v.x = cb_pack2_pinned(fmaf(nsc.x, r0, nsh.x), fmaf(nsc.y, r1, nsh.y));
+            v.y = cb_pack2_pinned(fmaf(nsc.z, r2, nsh.z), fmaf(nsc.w, r3, nsh.w));
+            const unsigned m = (unsigned)(-((okmask >> j) & 1));          // zero padding of the BatchNorm OUTPUT
+            v.x &= m; v.y &= m;
+        } else {
+            v.x = cb_pack2_pinned(stg[j].x, stg[j].y); v.y = cb_pack2_pinned(stg[j].z, stg[j].w);
+            if (p.in16) {
+                v.x = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].z : stg[j].x); v.y = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].w : stg[j].y);
+            }
         }
         asm volatile("ds_write_b64 %0, %1" :: "v"(wb), "v"(v) : "memory");
     };
@@ -415,6 +442,11 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_stats_kernel_128(ConvBf16Arg
 __global__ __launch_bounds__(256, 2) void conv_bf16_stats_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 1>(p); }
 __global__ __launch_bounds__(256, 1) void conv_bf16_bnbwd_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 2>(p); }
 __global__ __launch_bounds__(256, 2) void conv_bf16_bnbwd_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 2>(p); }
+// forward with BatchNorm-apply on load (NORM)
+__global__ __launch_bounds__(256, 1) void conv_bf16_norm_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 0, 1>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_norm_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 0, 1>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_norm_stats_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 1, 1>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_norm_stats_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 1, 1>(p); }
 
 // fp32 HWIO weights -> bf16 [chunk][tap][k half][out channel][8]: mode 0 forward (reduce over Cin), mode 1 data gradient
 // (reduce over Cout, taps flipped, output channel = the layer's input channel)
@@ -448,8 +480,9 @@ struct ConvBf16Stats { int mode; float* part; size_t bytes; const float* r; int 
 
 int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
                   int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st, const ConvBf16Stats* stats = nullptr, int in16 = 0,
-                  int out16 = 0) {
+                  int out16 = 0, const float* in_scale = nullptr, const float* in_shift = nullptr) {
     ConvBf16Args a{};
+    a.in_scale = in_scale; a.in_shift = in_shift;
     a.in16 = in16; a.out16 = out16; a.r16 = stats ? stats->r16 : 0;
     a.x = x; a.wp = (const uint16_t*)wp; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
@@ -464,7 +497,10 @@ int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, fl
         a.stat_part = stats->part; a.bn_r = stats->r; a.bn_ldr = stats->ldr; a.bn_c0 = stats->c0; a.bn_c1 = stats->c1;
     }
     const dim3 grid((unsigned)(a.n_px * a.n_co));
-    if (mode == 0) { if (wide) conv_bf16_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_kernel_64<<<grid, 256, 0, st>>>(a); }
+    if (in_scale && mode == 0) { if (wide) conv_bf16_norm_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_norm_kernel_64<<<grid, 256, 0, st>>>(a); }
+    else if (in_scale && mode == 1) { if (wide) conv_bf16_norm_stats_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_norm_stats_kernel_64<<<grid, 256, 0, st>>>(a); }
+    else if (in_scale) return UNET_EINVAL;
+    else if (mode == 0) { if (wide) conv_bf16_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_kernel_64<<<grid, 256, 0, st>>>(a); }
     else if (mode == 1) { if (wide) conv_bf16_stats_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_stats_kernel_64<<<grid, 256, 0, st>>>(a); }
     else { if (wide) conv_bf16_bnbwd_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_bnbwd_kernel_64<<<grid, 256, 0, st>>>(a); }
     return UNET_LAUNCH_STATUS();
@@ -486,51 +522,10 @@ extern "C" int unet_conv3x3_bf16_pack_weights(const float* w, void* packed, int 
     return UNET_LAUNCH_STATUS();
 }
 
-// out[n,i,j,co] = relu?(bias[co] + sum_{a,b,ci} bf16(x[n,i+a-1,j+b-1,ci]) * bf16(W[a,b,ci,co])), fp32 accumulation
-extern "C" int unet_conv3x3_fwd_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
-                                     int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
-    UNET_CHECK_ARG(x && wp && out && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
-    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
-    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * ldo * 4 < ((size_t)1 << 31));
-    return run_conv_bf16(x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
-}
-
-// rows of the statistics partials of the two calls below (one per 16 x 32 pixel tile)
+// rows of the statistics partials of unet_conv3x3_fwd_bf16 / unet_conv3x3_dgrad_bf16 (one per 16 x 32 pixel tile)
 extern "C" int unet_conv3x3_bf16_stats_rows(int N, int H, int W, int Cin, int Cout) {
     if (!unet_conv3x3_bf16_supported(N, H, W, Cin, Cout)) return 0;
     return N * ((H + 15) / 16) * ((W + 31) / 32);
-}
-
-// forward + BatchNorm sums of the output: stat_part[Cout/64][rows][64][2] = (sum y, sum y^2) per tile, for unet_bn_train_finalize_partials
-extern "C" int unet_conv3x3_fwd_bf16_stats(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
-                                           int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
-    UNET_CHECK_ARG(x && wp && out && stat_part && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
-    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
-    UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * ldo * 4 < ((size_t)1 << 31));
-    const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0, 0};
-    return run_conv_bf16(x, ldx, wp, bias, out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream, &s);
-}
-
-// data gradient + BatchNorm-backward sums of the producer layer (same contract as unet_conv3x3_dgrad_winograd_fused_bnstats):
-// stat_part[Cin/64][rows][64][2] = (sum dx, sum dx * r_prev) with r_prev channel = dx channel - c0, for channels [c0, c1)
-extern "C" int unet_conv3x3_dgrad_bf16_bnstats(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
-                                               int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
-                                               float* stat_part, size_t stat_bytes, void* stream) {
-    UNET_CHECK_ARG(dz && wpd && dx && r_prev && stat_part && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));
-    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
-    UNET_CHECK_ARG(c0 >= 0 && c0 < c1 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0);
-    UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
-    const ConvBf16Stats s{2, stat_part, stat_bytes, r_prev, ldr, c0, c1, 0};
-    return run_conv_bf16(dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream, &s);
-}
-
-// dx[n,i,j,ci] = sum_{a,b,co} bf16(dz[n,i+1-a,j+1-b,co]) * bf16(W[a,b,ci,co]);  wpd from pack_weights(mode 1)
-extern "C" int unet_conv3x3_dgrad_bf16(const float* dz, int lddz, const void* wpd, float* dx, int lddx,
-                                       int N, int H, int W, int Cin, int Cout, void* stream) {
-    UNET_CHECK_ARG(dz && wpd && dx && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));
-    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
-    UNET_CHECK_ARG((size_t)N * H * W * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
-    return run_conv_bf16(dz, lddz, wpd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream);
 }
 
 // ---- weight gradient on the bf16 matrix cores ------------------------------------------------------------------------------
@@ -913,7 +908,7 @@ extern "C" size_t unet_conv3x3_wgrad_bf16_workspace(int N, int H, int W, int Cin
 
 // dw[a,b,ci,co] (HWIO, UNet/model.py:31) = sum_{n,y,x} bf16(xin[n,y+a-1,x+b-1,ci]) * bf16(dz[n,y,x,co]); x_bf16 / dz_bf16: that
 // operand is already stored as bf16 (leading dimension in elements)
-extern "C" int unet_conv3x3_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+extern "C" int unet_conv3x3_wgrad_bf16(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
                                           int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(xin && dz && dw && ws && unet_conv3x3_wgrad_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG((!x_bf16 || ldx % 8 == 0) && (!dz_bf16 || lddz % 8 == 0));        // 16-byte aligned pixels
@@ -940,25 +935,26 @@ extern "C" int unet_conv3x3_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16, 
     return rc;
 }
 
-extern "C" int unet_conv3x3_wgrad_bf16(const float* xin, int ldx, const float* dz, int lddz, float* dw,
-                                       int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
-    return unet_conv3x3_wgrad_bf16_ex(xin, ldx, 0, dz, lddz, 0, dw, N, H, W, Cin, Cout, ws, ws_bytes, stream);
-}
-
-// forward with every option: x_bf16 (input stored as bf16, ldx in elements), stat_part nullable (BatchNorm sums as in _stats)
-extern "C" int unet_conv3x3_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, void* out, int ldo, int out_bf16,
-                                        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+// out[n,i,j,co] = relu?(bias[co] + sum_{a,b,ci} bf16(x[n,i+a-1,j+b-1,ci]) * bf16(W[a,b,ci,co])), fp32 accumulation.
+// x_bf16: the input is stored as bf16 (ldx in elements); in_scale / in_shift (nullable, Cin floats each, 16-byte aligned): BatchNorm
+// apply on load -- x is the producer's conv output r and the operand is bf16(scale * r + shift) inside the image, 0 outside;
+// out_bf16: the output is stored as bf16; stat_part nullable: BatchNorm sums of the output, [Cout/64][rows][64][2] = (sum y, sum y^2)
+// per 16 x 32 pixel tile, for unet_bn_train_finalize_partials
+extern "C" int unet_conv3x3_fwd_bf16(const void* x, int ldx, int x_bf16, const float* in_scale, const float* in_shift, const void* wp,
+                                     const float* bias, void* out, int ldo, int out_bf16,
+                                     int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr) && (!in_scale || (unet_aligned16(in_scale) && unet_aligned16(in_shift))));
     UNET_CHECK_ARG(x && wp && out && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
     UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * ldo * 4 < ((size_t)1 << 31));
     UNET_CHECK_ARG(!x_bf16 || ldx % 8 == 0);
     const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0, 0};
     return run_conv_bf16((const float*)x, ldx, wp, bias, (float*)out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream, stat_part ? &s : nullptr,
-                         x_bf16 ? 1 : 0, out_bf16 ? 1 : 0);
+                         x_bf16 ? 1 : 0, out_bf16 ? 1 : 0, in_scale, in_shift);
 }
 
 // data gradient with every option: dz_bf16 (dz stored as bf16), r_prev / stat_part nullable (producer's BatchNorm-backward sums)
-extern "C" int unet_conv3x3_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
+extern "C" int unet_conv3x3_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
                                           int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16, int c0, int c1,
                                           float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(dz && wpd && dx && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));

@@ -400,8 +400,8 @@ class Engine:
                 # (dec_2b..4b: their saved activation is read by the transposed-conv data gradient's epilogue, which takes fp32)
                 if self.bf16_activations and self.bf16_storage and rows > 0 and name not in ("dec_2b", "dec_3b", "dec_4b"):
                     r = self._buf("r16_" + name, (n, h, w, cout), torch.bfloat16)
-                self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16_ex,
-                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout,
+                self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
+                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), None, None, _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout,
                             int(r.dtype == torch.bfloat16), n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:
                     fused_stats = (stat_part, rows)
@@ -637,7 +637,7 @@ class Engine:
             elif (self.compute_dtype == "bf16" and n * ho * wo * max(cin, cout) * 4 < 2 ** 31
                   and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1):
                 nb2 = L.unet_conv3x3_wgrad_bf16_workspace(n, ho, wo, cin, cout)
-                self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16_ex,
+                self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16,
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw),
                             n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif (self.wgrad_route in ("fused", "hybrid") and L.unet_winograd_wgrad_fused_supported(n, ho, wo, cin, cout) == 1
@@ -693,12 +693,12 @@ class Engine:
                     pname, c0, c1 = prod[0], prod[1] * (cin // prod[3]), prod[2] * (cin // prod[3])
                     r_prev = self.saved[pname][1]
                     part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
-                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16_ex,
+                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
                                 _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx.dtype == torch.bfloat16), n, ho, wo, cin, cout,
                                 _p(r_prev), r_prev.shape[-1], int(r_prev.dtype == torch.bfloat16), c0, c1, _p(part), part.numel() * 4, st)
                     self.bnbwd_part[pname] = (part, rows, c0)
                 else:
-                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16_ex,
+                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
                                 _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx.dtype == torch.bfloat16), n, ho, wo, cin, cout,
                                 None, 0, 0, 0, 0, None, 0, st)
             elif self._use_fused(name, ho, wo, dgrad=True):
