@@ -39,50 +39,43 @@ int unet_conv3x3_dgrad_mfma(const float* dz, int lddz, const float* w, float* dx
 size_t unet_conv3x3_wgrad_mfma_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_conv3x3_wgrad_mfma(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                             int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-/* Winograd F(2x2,3x3) route for the same layer when channels are wide (exact fp32, 2.25x fewer matrix multiplies):
- * U = weight transform (16*Cin*Cout floats; mode 0 forward, mode 1 data gradient), refreshed whenever w changes. */
-int unet_winograd_supported(int N, int H, int W, int Cin, int Cout);
+/* ---- Winograd F(2x2,3x3) for the wide 3x3 layers: exact fp32, 2.25x fewer matrix multiplies -------------------------------------
+ * Fully fused kernels (raw patch -> LDS, transforms in-kernel, 16-point MFMA, output transform in the epilogue).
+ * Weight operands: unet_winograd_weight_transform(w, mode 2 forward / 3 data gradient) -> Uc (16*Cin*Cout floats), or every
+ * layer's pair in one launch with _batch.  jobs: device array of njobs x 6 int64 = { w, Uc_fwd, Uc_dgrad, Cin | Cout << 32,
+ * first_block, 0 }, first_block = running sum of ceil(Cin*Cout / 2048); total_blocks = that sum.  Cin, Cout multiples of 8. */
 int unet_winograd_weight_transform(const float* w, float* U, int Cin, int Cout, int mode, void* stream);
-/* every fused-route layer's forward (mode 2) and data-gradient (mode 3) transform in one launch.  jobs: device array of
- * njobs x 6 int64 = { w, Uc_fwd, Uc_dgrad, Cin | Cout << 32, first_block, 0 }, first_block = running sum of
- * ceil(Cin*Cout / 2048); total_blocks = that sum over all jobs.  Cin, Cout multiples of 8. */
 int unet_winograd_weight_transform_batch(const void* jobs, int njobs, int total_blocks, void* stream);
-size_t unet_conv3x3_winograd_workspace(int N, int H, int W, int Cin, int Cout);
-/* V_keep (nullable, 16*T*Cin floats, T = N*H/2*W/2): where to leave the transformed input for the weight gradient */
-int unet_conv3x3_fwd_winograd(const float* x, int ldx, const float* U, const float* bias, float* out, int ldo,
-                              int N, int H, int W, int Cin, int Cout, int relu, float* V_keep,
-                              void* ws, size_t ws_bytes, void* stream);
-int unet_conv3x3_dgrad_winograd(const float* dz, int lddz, const float* Ud, float* dx, int lddx,
-                                int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-/* fully fused Winograd for the narrow layers (raw patch -> LDS, transform in-kernel, 16-point MFMA, output transform in the
- * epilogue); Uc from unet_winograd_weight_transform mode 2 (forward) / 3 (data gradient); H, W even, reduce channels % 8,
- * output channels % 64 */
-int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
-                                    int N, int H, int W, int Cin, int Cout, int relu, void* stream);
-/* forward + BatchNorm statistics of its output in one kernel (saves one full read of the activation per layer): rows > 0 when the
- * persistent kernel takes the shape; stat_part holds (Cout/64) * rows * 128 floats; finish with unet_bn_train_finalize_partials */
+/* BatchNorm-apply on load for the forward kernel (UNet/model.py:36 feeding :30 without materialising the BatchNorm output): from the
+ * layer's kernel w, its bias and the PRODUCER's BatchNorm scale / shift (Cin floats each) make Uc = scale . transform(w), bias_out =
+ * bias + sum_taps shift . w and pad[c] = -shift[c] / scale[c] (Cin + 8 floats): the forward kernel then reads the producer's conv
+ * output r directly, with pad as the value of positions outside the image, and computes conv(zero-padded BatchNorm output). */
+size_t unet_winograd_weight_fold_workspace(int Cin, int Cout);
+int unet_winograd_weight_fold(const float* w, const float* bias, const float* scale, const float* shift, float* Uc, float* bias_out,
+                              float* pad, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* forward: H, W even, Cin % 8 == 0, Cout % 64 == 0.  pad nullable (zero padding).  stat_part nullable: BatchNorm statistics of the
+ * output in the same kernel (rows > 0 when the persistent kernel takes the shape; (Cout/64) * rows * 128 floats; finish with
+ * unet_bn_train_finalize_partials) */
 int unet_conv3x3_fwd_winograd_fused_stats_rows(int N, int H, int W, int Cin, int Cout);
-int unet_conv3x3_fwd_winograd_fused_stats(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
-                                          int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes,
-                                          void* stream);
+int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* pad, const float* Uc, const float* bias, float* out, int ldo,
+                                    int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
+/* data gradient; with r_prev / stat_part (both or neither) also the BatchNorm-backward sums (sum dy, sum dy*r) of the layer that
+ * produced this layer's input: dx channels [c0, c1) are that layer's dy, r_prev its saved activation; rows =
+ * unet_conv3x3_fwd_winograd_fused_stats_rows(N,H,W,Cout,Cin); the sums replace the reduction pass of unet_bn_bwd
+ * (unet_bn_bwd_from_partials, part = stat_part + (c0/64)*rows*128) */
 int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
-                                      int N, int H, int W, int Cin, int Cout, void* stream);
+                                      int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+                                      float* stat_part, size_t stat_bytes, void* stream);
 /* fused Winograd weight gradient: raw rows through LDS, per-lane transforms in registers, G^T dU G in the epilogue;
  * needs H, W even and Cin, Cout multiples of 64 */
 int unet_winograd_wgrad_fused_supported(int N, int H, int W, int Cin, int Cout);
-/* data gradient + the BatchNorm-backward sums (sum dy, sum dy*r) of the layer that produced this layer's input: dx channels
- * [c0, c1) are that layer's dy, r_prev its saved activation; rows = unet_conv3x3_fwd_winograd_fused_stats_rows(N,H,W,Cout,Cin);
- * the sums replace the reduction pass of unet_bn_bwd (unet_bn_bwd_from_partials, part = stat_part + (c0/64)*rows*128) */
-int unet_conv3x3_dgrad_winograd_fused_bnstats(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
-                                              int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
-                                              float* stat_part, size_t stat_bytes, void* stream);
 size_t unet_conv3x3_wgrad_winograd_fused_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                                       int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-int unet_winograd_wgrad_supported(int N, int H, int W, int Cin, int Cout);
-size_t unet_conv3x3_wgrad_winograd_workspace(int N, int H, int W, int Cin, int Cout);
-/* V_saved (nullable): the V_keep of the forward call on the same xin; when given, xin is not read */
-int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* V_saved, const float* dz, int lddz, float* dw,
+/* weight gradient of a layer whose input was read through BatchNorm-apply on load (x = scale . r + shift inside the image): dw holds
+ * any wgrad kernel's result on the RAW r; in place dw = scale[ci] * dw + shift[ci] * S[tap][co], S = sum of dz over the pixels whose
+ * tap lies inside the image (border sums of dz; total = column sums of dz = the bias gradient).  ws: 8 * Cout floats. */
+int unet_conv3x3_wgrad_fold_fix(float* dw, const float* scale, const float* shift, const float* dz, int lddz, const float* total,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* ---- bf16 matrix-core 3x3 convolution (BASELINE config 4: bf16 forward/backward, fp32 master weights; the reference keeps
  * its mixed-precision policy commented out, UNet/train.py:52-54) ------------------------------------------------------

@@ -25,23 +25,13 @@ for name, h, ci, co in shapes:
     out = torch.empty(B, h, h, co, device="cuda"); dx = torch.empty(B, h, h, ci, device="cuda"); dw = torch.empty_like(w)
     nb = L.unet_conv3x3_wgrad_mfma_workspace(B, h, h, ci, co); ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
     fl = 2.0 * 9 * B * h * h * ci * co
-    U = torch.empty(16, ci, co, device="cuda"); Ud = torch.empty(16, co, ci, device="cuda")
-    wok = L.unet_winograd_supported(B, h, h, ci, co)
-    if wok:
-        L.unet_winograd_weight_transform(P(w), P(U), ci, co, 0, ST()); L.unet_winograd_weight_transform(P(w), P(Ud), ci, co, 1, ST())
-        nbw = L.unet_conv3x3_winograd_workspace(B, h, h, ci, co); wsw = torch.empty(nbw + 256, dtype=torch.uint8, device="cuda")
-    wwok = L.unet_winograd_wgrad_supported(B, h, h, ci, co)
-    if wwok:
-        nbg = L.unet_conv3x3_wgrad_winograd_workspace(B, h, h, ci, co); wsg = torch.empty(nbg + 256, dtype=torch.uint8, device="cuda")
+    wok = wwok = False          # (the unfused Winograd pipeline left the default library: UNET_EXPERIMENTAL builds only)
     Uc = torch.empty(16 * ci * co, device="cuda"); Ucd = torch.empty(16 * ci * co, device="cuda")
     L.unet_winograd_weight_transform(P(w), P(Uc), ci, co, 2, ST()); L.unet_winograd_weight_transform(P(w), P(Ucd), ci, co, 3, ST())
     nbq = L.unet_conv3x3_wgrad_winograd_fused_workspace(B, h, h, ci, co); wsq = torch.empty(nbq + 256, dtype=torch.uint8, device="cuda")
     fns = {"fwgrad": lambda: L.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(wsq), nbq, ST()),
-           "ffwd": lambda: L.unet_conv3x3_fwd_winograd_fused(P(x), ci, P(Uc), P(b), P(out), co, B, h, h, ci, co, 1, ST()),
-           "fdgrad": lambda: L.unet_conv3x3_dgrad_winograd_fused(P(dz), co, P(Ucd), P(dx), ci, B, h, h, ci, co, ST()),
-           "wwgrad": lambda: L.unet_conv3x3_wgrad_winograd(P(x), ci, None, P(dz), co, P(dw), B, h, h, ci, co, P(wsg), nbg, ST()),
-           "wfwd": lambda: L.unet_conv3x3_fwd_winograd(P(x), ci, P(U), P(b), P(out), co, B, h, h, ci, co, 1, None, P(wsw), nbw, ST()),
-           "wdgrad": lambda: L.unet_conv3x3_dgrad_winograd(P(dz), co, P(Ud), P(dx), ci, B, h, h, ci, co, P(wsw), nbw, ST()),
+           "ffwd": lambda: L.unet_conv3x3_fwd_winograd_fused(P(x), ci, None, P(Uc), P(b), P(out), co, B, h, h, ci, co, 1, None, 0, ST()),
+           "fdgrad": lambda: L.unet_conv3x3_dgrad_winograd_fused(P(dz), co, P(Ucd), P(dx), ci, B, h, h, ci, co, None, 0, 0, 0, None, 0, ST()),
            "fwd": lambda: L.unet_conv3x3_fwd_mfma(P(x), ci, P(w), P(b), P(out), co, B, h, h, ci, co, 1, ST()),
            "dgrad": lambda: L.unet_conv3x3_dgrad_mfma(P(dz), co, P(w), P(dx), ci, B, h, h, ci, co, ST()),
            "wgrad": lambda: L.unet_conv3x3_wgrad_mfma(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(ws), nb, ST())}

@@ -14,7 +14,7 @@ for name, h, ci, co in [("1b", 512, 64, 64), ("2b", 256, 128, 128), ("4b", 64, 5
     out = torch.empty(B, h, h, co, device="cuda"); Uc = torch.empty(16 * ci * co, device="cuda")
     L.unet_winograd_weight_transform(P(w), P(Uc), ci, co, 2, ST())
     for _ in range(3):
-        L.unet_conv3x3_fwd_winograd_fused(P(x), ci, P(Uc), P(b), P(out), co, B, h, h, ci, co, 1, ST())
+        L.unet_conv3x3_fwd_winograd_fused(P(x), ci, None, P(Uc), P(b), P(out), co, B, h, h, ci, co, 1, None, 0, ST())
     torch.cuda.synchronize()
     t = (ctypes.c_longlong * 8)()
     raw.unet_debug_wf_timeline(t)

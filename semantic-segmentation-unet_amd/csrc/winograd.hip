@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void wino_weight_batch_kernel(const long long*
     }
 }
 
+#ifdef UNET_EXPERIMENTAL      /* the unfused pipeline (planes + batched GEMMs): superseded on every layer shape measured, kept for A/B builds */
 // V[xi][tile][c] = (B^T d B)[xi]; thread = (tile, channel quad); patch rows 2ty-1..2ty+2, zero outside the image
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V,
                                                          int N, int H, int W, int C) {
@@ -343,6 +344,8 @@ int wgrad_splits(long T, int Ci, int Co) {
     return (int)s;
 }
 
+#endif  // UNET_EXPERIMENTAL
+
 // ---- fully fused Winograd F(2x2,3x3) forward / data-gradient convolution ------------------------------------------------
 // One workgroup = 8x8 Winograd tiles (16x16 output pixels) x 64 output channels; wave (mi, ni) owns [32 tiles x 32 channels]
 // for ALL 16 Winograd points (16 x f32x16 = 256 AGPRs, one wave per SIMD).  K is streamed in chunks of 8 input channels:
@@ -371,6 +374,7 @@ struct WinoFusedArgs {
     int tbx, tby, nt;            // tile-block grid
     float* stat_part;            // BatchNorm statistics of the output (persistent kernel only), see wf_write_stats; or null
     const float* bn_r; int bn_ldr, bn_c0, bn_c1;      // STATS == 2 (data gradient): saved activation of the producer layer, channels [c0, c1)
+    const float* pad;            // per-input-channel value of the positions outside the image (K floats + 8), or null = zeros: see unet_winograd_weight_fold
 };
 typedef __attribute__((address_space(3))) void lds_void_f;
 constexpr int kWinoFusedMaxK = 4096;
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(WinoFusedArgs p) {
         const int py = pix / 18, px = pix - py * 18;
         const int gy = gy0 + py, gx = gx0 + px;
         const bool ok = pix < DPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        dptr[k] = ok ? p.x + ((size_t)(img * p.H + gy) * p.W + gx) * p.ldx + 4 * dh : g_zero_page_f + 4 * dh;
+        dptr[k] = ok ? p.x + ((size_t)(img * p.H + gy) * p.W + gx) * p.ldx + 4 * dh : (p.pad ? p.pad : g_zero_page_f) + 4 * dh;
     }
     const int urow = 32 * (wv & 1) + drow;
     const unsigned uoff = (unsigned)((urow * 8 + 4 * (dh ^ ((urow >> 3) & 1))) * 4);        // bytes, same for all 8 pieces
@@ -778,13 +782,14 @@ __device__ __forceinline__ void wino_fused_stream_body(const WinoFusedArgs& p, i
         c.img += dstep.img + cy;
         return c;
     };
+    const float* const padsrc = p.pad ? p.pad : g_zero_page_f;
     auto tile_sources = [&](const TileCoord& c, const float* (&dp)[3], const char*& ub0) {
         const int gy0 = 16 * c.by - 1, gx0 = 16 * c.bx - 1;
         const float* xb = p.x + ((long long)(c.img * p.H + gy0) * p.W + gx0) * p.ldx;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const bool ok = (unsigned)(gy0 + ppy[k]) < (unsigned)p.H && (unsigned)(gx0 + ppx[k]) < (unsigned)p.W;
-            dp[k] = ok ? xb + poff[k] : g_zero_page_f + 4 * dh;
+            dp[k] = ok ? xb + poff[k] : padsrc + 4 * dh;
         }
         ub0 = reinterpret_cast<const char*>(p.Uc) + (size_t)c.tn * 64 * 32 + (size_t)(wv >> 1) * ustride_xi;
     };
@@ -1179,6 +1184,7 @@ int wgrad_fused_splits(int N, int H, int W, int Ci, int Co) {
 
 int grid_for(long total, int cap) { long b = (total + 255) / 256; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b; }
 
+#ifdef UNET_EXPERIMENTAL
 bool wino_ok(int N, int H, int W, int Ci, int Co) {
     const long T = (long)N * (H / 2) * (W / 2);
     return H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && T % 32 == 0 && Ci % 32 == 0 && Co % 64 == 0 && Ci % 4 == 0;
@@ -1192,6 +1198,142 @@ int run_wino(const float* x, int ldx, const float* U, const float* bias, float* 
     rc = unet_igemm_batched_planes(V, U, M, T, Kc, Nc, 16, st); if (rc) return rc;
     wino_output_kernel<<<grid_for(T * (Nc / 4), 16384), 256, 0, st>>>(M, bias, out, ldo, N, H, W, Nc, relu);
     return UNET_LAUNCH_STATUS();
+}
+
+#endif  // UNET_EXPERIMENTAL
+
+// ---- BatchNorm-apply on load for the fused forward kernel (SURVEY.md 7 "hard parts": the consumer applies the producer's
+// BatchNorm on load and padded positions must contribute exactly 0) ---------------------------------------------------------------
+// The producer's BatchNorm output y = s[c] * r + t[c] feeds this layer's convolution (UNet/model.py:36 -> :30), zero padded.  Per
+// input channel the scale commutes with the Winograd transforms and the shift is a constant image, so
+//     conv(y; W) = conv(r; s . W)  +  sum_taps t . W           at every pixel whose 3x3 window lies inside the image,
+// and at the border the taps that fall outside must not see the shift.  Reading r with the per-channel padding value
+// pad[c] = -t[c] / s[c] instead of 0 makes a padded tap contribute s W pad = -t W, which cancels the uniform shift term
+// exactly where the zero padding of y would have contributed nothing.  So the unchanged kernel, given
+//     Uc' = s . transform(W),   bias' = bias + sum_{taps, c} t[c] W[tap][c][:],   pad,
+// computes the convolution of the BatchNorm OUTPUT without that tensor ever being written or read.  (s[c] = 0 has no padding
+// value: the fold writes pad = 0 there; such a channel's border pixels would be off by its shift term, so the engine keeps the
+// two-pass form whenever a gamma is exactly 0 -- checked when parameters are loaded.)
+//
+// one thread = 8 consecutive input channels x one output channel (the batch kernel's work item): forward layout only
+__global__ __launch_bounds__(256) void wino_weight_fold_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+        const float* __restrict__ shift, float* __restrict__ uf, float* __restrict__ part, float* __restrict__ pad, int Ci, int Co) {
+    const size_t plane = (size_t)Ci * Co;
+    const long items = (long)(Ci >> 3) * Co;
+    const long it = (long)blockIdx.x * 256 + threadIdx.x;
+    if (it >= items) return;
+    const int c8 = (int)(it / Co), co = (int)(it % Co);
+    float t[16][8];
+    float tsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = 8 * c8 + e;
+        const float sc = scale[ci], sh = shift[ci];
+        float g[3][3], gs = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) { const float v = w[((size_t)(a * 3 + b) * Ci + ci) * Co + co]; gs += v; g[a][b] = sc * v; }
+        tsum = fmaf(sh, gs, tsum);
+        float s[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            s[0][b] = g[0][b];
+            s[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            s[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            s[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t[4 * r + 0][e] = s[r][0]; t[4 * r + 1][e] = 0.5f * (s[r][0] + s[r][1] + s[r][2]);
+            t[4 * r + 2][e] = 0.5f * (s[r][0] - s[r][1] + s[r][2]); t[4 * r + 3][e] = s[r][2];
+        }
+        if (co == 0) pad[ci] = sc != 0.f ? -sh / sc : 0.f;
+    }
+    const size_t offf = ((size_t)c8 * Co + co) * 8;                                   // [k/8][n=co][k%8]
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+        float* o = uf + (size_t)xi * plane + offf;
+        *reinterpret_cast<f32x4*>(o) = f32x4{t[xi][0], t[xi][1], t[xi][2], t[xi][3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{t[xi][4], t[xi][5], t[xi][6], t[xi][7]};
+    }
+    part[(size_t)c8 * Co + co] = tsum;                                  // shift term of this 8-channel group, summed in fixed order below
+}
+
+__global__ __launch_bounds__(256) void wino_fold_bias_kernel(const float* __restrict__ part, int rows, const float* __restrict__ bias,
+                                                             float* __restrict__ bias_out, float* __restrict__ pad, int Ci, int Co) {
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co < Co) {
+        double s = 0.0;
+        for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * Co + co];
+        bias_out[co] = (float)((double)(bias ? bias[co] : 0.f) + s);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) pad[Ci + threadIdx.x] = 0.f;             // the 8 floats the halo pointers may walk past the end
+}
+
+// ---- weight gradient of a layer whose input was read through BatchNorm-apply on load ----------------------------------------------
+// With x = s . r + t inside the image (0 outside), dW[a][b][ci][co] = sum_p x[p + (a,b) - 1][ci] dz[p][co]
+//     = s[ci] * (the kernel's result on the raw r)  +  t[ci] * S[a][b][co],   S = sum of dz over the pixels p whose tap (a, b) lies
+// inside the image = total - (row excluded by a) - (column excluded by b) + (their corner): a = 0 excludes dz row 0, a = 2 row H-1,
+// b = 0 column 0, b = 2 column W-1.  dz_border_sums_kernel leaves the 4 line sums and 4 corner sums per channel (fp64 accumulation,
+// fixed order); wgrad_fold_fix_kernel applies the two terms to dW in place.
+__global__ __launch_bounds__(256) void dz_border_sums_kernel(const float* __restrict__ dz, int lddz, int N, int H, int W, int Co,
+                                                             float* __restrict__ sums /* [8][Co]: row0, rowH-1, col0, colW-1, 4 corners */) {
+    // block = (line id 0..3, 64-channel group); thread = (channel quad q, pixel lane pl); lines are walked by 16 pixel lanes
+    const int line = blockIdx.x & 3, c0 = (blockIdx.x >> 2) * 64;
+    const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int len = line < 2 ? W : H;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int c = c0 + 4 * q;
+    if (c < Co) {
+        for (int n = 0; n < N; ++n)
+            for (int i = pl; i < len; i += 16) {
+                const int y = line == 0 ? 0 : (line == 1 ? H - 1 : i), x = line == 2 ? 0 : (line == 3 ? W - 1 : i);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(dz + ((size_t)(n * H + y) * W + x) * lddz + c);
+                acc[0] += (double)v[0]; acc[1] += (double)v[1]; acc[2] += (double)v[2]; acc[3] += (double)v[3];
+            }
+    }
+    __shared__ double red[16][64];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[pl][4 * q + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && c0 + threadIdx.x < Co) {
+        double s = 0.0;
+        for (int k = 0; k < 16; ++k) s += red[k][threadIdx.x];
+        sums[(size_t)line * Co + c0 + threadIdx.x] = (float)s;
+        if (line == 0) {                                                   // the four corners: tiny, one thread per channel
+            const int ch = c0 + threadIdx.x;
+            double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
+            for (int n = 0; n < N; ++n) {
+                k00 += (double)dz[((size_t)(n * H + 0) * W + 0) * lddz + ch];         k01 += (double)dz[((size_t)(n * H + 0) * W + W - 1) * lddz + ch];
+                k10 += (double)dz[((size_t)(n * H + H - 1) * W + 0) * lddz + ch];     k11 += (double)dz[((size_t)(n * H + H - 1) * W + W - 1) * lddz + ch];
+            }
+            sums[(size_t)4 * Co + ch] = (float)k00; sums[(size_t)5 * Co + ch] = (float)k01;
+            sums[(size_t)6 * Co + ch] = (float)k10; sums[(size_t)7 * Co + ch] = (float)k11;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_fold_fix_kernel(float* __restrict__ dw, const float* __restrict__ scale, const float* __restrict__ shift,
+        const float* __restrict__ sums, const float* __restrict__ total, int Ci, int Co) {
+    const long n4 = (long)9 * Ci * Co / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const long e0 = 4 * i;
+    const int co = (int)(e0 % Co); const long rest = e0 / Co; const int ci = (int)(rest % Ci), tap = (int)(rest / Ci);
+    const int a = tap / 3, b = tap % 3;
+    const float sc = scale[ci], sh = shift[ci];
+    f32x4 v = *reinterpret_cast<f32x4*>(dw + e0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = co + e;
+        float S = total[c];
+        if (a != 1) S -= sums[(size_t)(a == 0 ? 0 : 1) * Co + c];
+        if (b != 1) S -= sums[(size_t)(b == 0 ? 2 : 3) * Co + c];
+        if (a != 1 && b != 1) S += sums[(size_t)(4 + (a == 0 ? 0 : 2) + (b == 0 ? 0 : 1)) * Co + c];
+        v[e] = fmaf(sc, v[e], sh * S);
+    }
+    *reinterpret_cast<f32x4*>(dw + e0) = v;
 }
 
 int wino_stream_cus() {
@@ -1215,8 +1357,9 @@ int wino_stats_rows(int N, int H, int W, int K, int Nout) {
 struct WinoBnBwd { const float* r; int ldr, c0, c1; };
 
 int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo, int N, int H, int W,
-                   int K, int Nout, int relu, float* stat_part, hipStream_t st, const WinoBnBwd* bb = nullptr) {
+                   int K, int Nout, int relu, float* stat_part, hipStream_t st, const WinoBnBwd* bb = nullptr, const float* pad = nullptr) {
     WinoFusedArgs a{};
+    a.pad = pad;
     a.x = x; a.Uc = Uc; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo; a.N = N; a.H = H; a.W = W; a.K = K; a.Nout = Nout; a.relu = relu;
     a.tby = (H / 2 + 7) / 8; a.tbx = (W / 2 + 7) / 8; a.nt = Nout / 64; a.stat_part = stat_part;
     const long blocks = (long)N * a.tby * a.tbx * a.nt;
@@ -1239,42 +1382,31 @@ int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, 
 
 }  // namespace
 
-// Fully fused Winograd (narrow layers): Uc = unet_winograd_weight_transform(w, mode 2 forward / mode 3 data gradient).
-extern "C" int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
-        int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
-    UNET_CHECK_ARG(x && Uc && out && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 8 == 0 && Cout % 64 == 0);
-    UNET_CHECK_ARG(Cin <= kWinoFusedMaxK);
-    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(Uc) && unet_aligned16(out));
-    UNET_CHECK_ARG(!bias || unet_aligned16(bias));
-    return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, nullptr, (hipStream_t)stream);
-}
-
-// Same, plus the BatchNorm statistics of the output: stat_part[Cout/64][rows][64][2] floats (sum, sum of squares per channel
-// over the pixels each row's workgroup-half produced), rows = unet_conv3x3_fwd_winograd_fused_stats_rows(...) > 0;
-// consumed by unet_bn_train_finalize_partials.
+// Fully fused Winograd forward.  Uc = unet_winograd_weight_transform(w, mode 2) / _batch / unet_winograd_weight_fold.
+// pad (nullable): per-input-channel value the kernel reads for positions OUTSIDE the image (Cin + 8 floats); null = zero padding.
+// With unet_winograd_weight_fold it carries BatchNorm-apply on load: x is the producer's conv output r, the weights are scaled by
+// the BatchNorm scale per input channel, the bias takes the shift's contribution and pad = -shift / scale makes every padded
+// position contribute exactly what the zero padding of the BatchNorm OUTPUT would.
+// stat_part (nullable): BatchNorm statistics of the output, stat_part[Cout/64][rows][64][2] floats (sum, sum of squares per channel
+// over the pixels each row's workgroup-half produced), rows = unet_conv3x3_fwd_winograd_fused_stats_rows(...) > 0; consumed by
+// unet_bn_train_finalize_partials.
 extern "C" int unet_conv3x3_fwd_winograd_fused_stats_rows(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || Cout % 64 != 0 || Cin > kWinoFusedMaxK) return 0;
     return wino_stats_rows(N, H, W, Cin, Cout);
 }
 
-extern "C" int unet_conv3x3_fwd_winograd_fused_stats(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo,
+extern "C" int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* pad, const float* Uc, const float* bias, float* out, int ldo,
         int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
-    UNET_CHECK_ARG(x && Uc && out && stat_part && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 8 == 0 && Cout % 64 == 0);
+    UNET_CHECK_ARG(x && Uc && out && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 8 == 0 && Cout % 64 == 0);
     UNET_CHECK_ARG(Cin <= kWinoFusedMaxK);
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(Uc) && unet_aligned16(out));
-    UNET_CHECK_ARG(!bias || unet_aligned16(bias));
-    const int rows = wino_stats_rows(N, H, W, Cin, Cout);
-    UNET_CHECK_ARG(rows > 0);
-    if (stat_bytes < (size_t)(Cout / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
-    return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, (hipStream_t)stream);
-}
-
-extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
-        int N, int H, int W, int Cin, int Cout, void* stream) {
-    UNET_CHECK_ARG(dz && Ucd && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
-    UNET_CHECK_ARG(Cout <= kWinoFusedMaxK);
-    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && lddx % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd) && unet_aligned16(dx));
-    return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, nullptr, (hipStream_t)stream);
+    UNET_CHECK_ARG((!bias || unet_aligned16(bias)) && (!pad || unet_aligned16(pad)));
+    if (stat_part) {
+        const int rows = wino_stats_rows(N, H, W, Cin, Cout);
+        UNET_CHECK_ARG(rows > 0);
+        if (stat_bytes < (size_t)(Cout / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
+    }
+    return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, (hipStream_t)stream, nullptr, pad);
 }
 
 #if UNET_ABLATE == 8
@@ -1283,16 +1415,18 @@ extern "C" int unet_debug_wf_timeline(long long* out4) {
 }
 #endif
 
-// Data gradient + the BatchNorm-backward sums of the layer that PRODUCED this layer's input: dx channels [c0, c1) (multiples of
-// 64) are that layer's dy, r_prev its saved activation (c1 - c0 channels, pixel stride ldr).  stat_part = (Cin/64) * rows * 128
-// floats, rows = unet_conv3x3_fwd_winograd_fused_stats_rows(N, H, W, Cout, Cin); blocks c0/64 .. c1/64 - 1 hold sum(dy) and
-// sum(dy * r) per channel, consumed by unet_bn_bwd_from_partials.
-extern "C" int unet_conv3x3_dgrad_winograd_fused_bnstats(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
+// Data gradient (Ucd = weight transform mode 3) and, with r_prev / stat_part (both or neither), the BatchNorm-backward sums of the
+// layer that PRODUCED this layer's input: dx channels [c0, c1) (multiples of 64) are that layer's dy, r_prev its saved activation
+// (c1 - c0 channels, pixel stride ldr).  stat_part = (Cin/64) * rows * 128 floats, rows = unet_conv3x3_fwd_winograd_fused_stats_rows(
+// N, H, W, Cout, Cin); blocks c0/64 .. c1/64 - 1 hold sum(dy) and sum(dy * r) per channel, consumed by unet_bn_bwd_from_partials.
+extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
         int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
         float* stat_part, size_t stat_bytes, void* stream) {
-    UNET_CHECK_ARG(dz && Ucd && dx && r_prev && stat_part && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
-    UNET_CHECK_ARG(Cout <= kWinoFusedMaxK && c0 >= 0 && c1 > c0 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0 && ldr % 4 == 0);
-    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && lddx % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd) && unet_aligned16(dx) && unet_aligned16(r_prev));
+    UNET_CHECK_ARG(dz && Ucd && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
+    UNET_CHECK_ARG(Cout <= kWinoFusedMaxK && (r_prev == nullptr) == (stat_part == nullptr));
+    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && lddx % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd) && unet_aligned16(dx));
+    if (!r_prev) return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, nullptr, (hipStream_t)stream);
+    UNET_CHECK_ARG(c0 >= 0 && c1 > c0 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0 && ldr % 4 == 0 && unet_aligned16(r_prev));
     const int rows = wino_stats_rows(N, H, W, Cout, Cin);
     UNET_CHECK_ARG(rows > 0);
     if (stat_bytes < (size_t)(Cin / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
@@ -1329,14 +1463,48 @@ extern "C" int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, cons
     return UNET_LAUNCH_STATUS();
 }
 
+#ifdef UNET_EXPERIMENTAL
 extern "C" int unet_winograd_supported(int N, int H, int W, int Cin, int Cout) {
     return (wino_ok(N, H, W, Cin, Cout) && Cin % 64 == 0) ? 1 : 0;
 }
+
+#endif
 
 // U must hold 16*Cin*Cout floats.  mode 0: forward kernel transform; mode 1: data-gradient kernel transform.
 extern "C" int unet_winograd_weight_transform(const float* w, float* U, int Cin, int Cout, int mode, void* stream) {
     UNET_CHECK_ARG(w && U && Cin > 0 && Cout > 0 && mode >= 0 && mode <= 3 && (mode < 2 || (Cin % 8 == 0 && Cout % 8 == 0)));
     wino_weight_kernel<<<grid_for((long)Cin * Cout, 4096), 256, 0, (hipStream_t)stream>>>(w, U, Cin, Cout, mode);
+    return UNET_LAUNCH_STATUS();
+}
+
+// BatchNorm-apply on load (see wino_weight_fold_kernel): from the layer's HWIO kernel w, its bias and the PRODUCER layer's BatchNorm
+// scale / shift (Cin floats each) make Uc (forward operand of unet_conv3x3_fwd_winograd_fused), bias_out (Cout) and pad (Cin + 8).
+extern "C" size_t unet_winograd_weight_fold_workspace(int Cin, int Cout) { return (size_t)(Cin / 8) * Cout * sizeof(float); }
+extern "C" int unet_winograd_weight_fold(const float* w, const float* bias, const float* scale, const float* shift, float* Uc, float* bias_out,
+                                         float* pad, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(w && scale && shift && Uc && bias_out && pad && ws && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 4 == 0 && unet_aligned16(Uc));
+    if (ws_bytes < unet_winograd_weight_fold_workspace(Cin, Cout)) return UNET_ENOSPC;
+    const long items = (long)(Cin / 8) * Cout;
+    hipStream_t st = (hipStream_t)stream;
+    wino_weight_fold_kernel<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(w, scale, shift, Uc, (float*)ws, pad, Cin, Cout);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    wino_fold_bias_kernel<<<(unsigned)((Cout + 255) / 256), 256, 0, st>>>((const float*)ws, Cin / 8, bias, bias_out, pad, Cin, Cout);
+    return UNET_LAUNCH_STATUS();
+}
+
+// Weight gradient of a layer whose input x was read as scale . r + shift (BatchNorm-apply on load): dw holds the kernel's result on the
+// RAW r (any wgrad kernel, HWIO layout); in place dw = scale[ci] * dw + shift[ci] * S[tap][co], S from the border sums of dz and
+// total = the column sums of dz (the bias gradient).  ws: 8 * Cout floats.
+extern "C" int unet_conv3x3_wgrad_fold_fix(float* dw, const float* scale, const float* shift, const float* dz, int lddz, const float* total,
+                                           int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(dw && scale && shift && dz && total && ws && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout % 4 == 0 && lddz >= Cout && lddz % 4 == 0);
+    UNET_CHECK_ARG(unet_aligned16(dw) && unet_aligned16(dz));
+    if (ws_bytes < (size_t)8 * Cout * sizeof(float)) return UNET_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    dz_border_sums_kernel<<<(unsigned)(4 * ((Cout + 63) / 64)), 256, 0, st>>>(dz, lddz, N, H, W, Cout, (float*)ws);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    const long n4 = (long)9 * Cin * Cout / 4;
+    wgrad_fold_fix_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(dw, scale, shift, (const float*)ws, total, Cin, Cout);
     return UNET_LAUNCH_STATUS();
 }
 
@@ -1346,6 +1514,7 @@ extern "C" int unet_winograd_weight_transform_batch(const void* jobs, int njobs,
     return UNET_LAUNCH_STATUS();
 }
 
+#ifdef UNET_EXPERIMENTAL      /* entry points of the unfused pipeline: not part of include/unet_hip.h */
 extern "C" size_t unet_conv3x3_winograd_workspace(int N, int H, int W, int Cin, int Cout) {
     const size_t T = (size_t)N * (H / 2) * (W / 2);
     return 16 * T * ((size_t)Cin + Cout) * sizeof(float);
@@ -1413,3 +1582,4 @@ extern "C" int unet_conv3x3_dgrad_winograd(const float* dz, int lddz, const floa
     float* V = (float*)ws; float* M = V + 16 * T * Cout;
     return run_wino(dz, lddz, Ud, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, V, M, (hipStream_t)stream);
 }
+#endif  // UNET_EXPERIMENTAL

@@ -143,21 +143,16 @@ class Engine:
         # stream, every weight gradient on `side` (it is needed only by the all-reduce / Adam).  The persistent wgrad
         # workgroups (106 KB LDS) co-reside with igemm workgroups and with the HBM-bound BN streams.
         self.overlap_wgrad = True
-        # Winograd F(2x2,3x3) route for the wide 3x3 layers: transformed kernels (forward, dgrad) cached per layer and
-        # refreshed after every parameter update.  Thresholds from same-box A/B runs of bench.py: forward/dgrad win from
-        # 256 channels on both sides (break-even at 128: the unfused transforms move ~14x the activation bytes); the
-        # weight gradient already wins at 128 (121.8 -> 123.1 images/s).
-        # route for forward / dgrad: "fused" = fully fused Winograd kernel wherever it applies (default, fastest on every
-        # layer shape measured); "unfused" = planes + batched GEMM for >= winograd_min_channels, direct below; "direct"
+        # 3x3 route: "fused" = fully fused Winograd F(2x2,3x3) kernels wherever they apply (default, fastest on every layer shape
+        # measured), "direct" = the implicit-GEMM MFMA kernels (also the fallback for odd tile sizes)
         self.conv_route = os.environ.get("UNET_CONV_ROUTE", "fused")
-        self.winograd_min_channels = int(os.environ.get("UNET_WINOGRAD_MIN_C", "256"))
-        self.winograd_wgrad_min_channels = int(os.environ.get("UNET_WINOGRAD_WGRAD_MIN_C", "128"))
-        # weight-gradient route: "fused" = fused Winograd wgrad wherever it applies; "hybrid" = unfused planes + TN GEMM from
-        # `wgrad_unfused_from` channels up, fused below; "unfused" = the previous policy (unfused >= 128, direct below)
         self.wgrad_route = os.environ.get("UNET_WGRAD_ROUTE", "fused")
-        self.wgrad_unfused_from = int(os.environ.get("UNET_WGRAD_UNFUSED_FROM", "512"))
-        self.wino_U = {}
-        self._wino_dirty = True
+        # BatchNorm-apply on load (fp32 fused route): a layer whose only consumer is a fused Winograd conv does not materialise its
+        # BatchNorm output; the consumer reads the conv output r through scaled weights, a folded bias and a per-channel padding
+        # value (unet_winograd_weight_fold), its weight gradient is corrected by unet_conv3x3_wgrad_fold_fix.  UNET_BN_ON_LOAD=0: two passes.
+        self.bn_on_load = os.environ.get("UNET_BN_ON_LOAD", "1") != "0"
+        self._gamma_zero = None
+        self.view = {}
         self._fused_U, self._fused_dirty = None, True
         self.fuse_bn_stats = os.environ.get("UNET_FUSE_BN_STATS", "1") != "0"      # BN sums from the conv epilogue (A/B switch)
         self.bnbwd_part = {}
@@ -209,11 +204,6 @@ class Engine:
             vals[name + "/moving_mean"] = np.zeros(cout, np.float32)
             vals[name + "/moving_var"] = np.ones(cout, np.float32)
         self.load_parameters(vals)
-
-    def _use_winograd(self, name, n, h, w):
-        cin, cout = self.cin[name], self.cout[name]
-        return (self.conv_route == "unfused" and self.kind[name] == "conv3" and min(cin, cout) >= self.winograd_min_channels
-                and self.L.unet_winograd_supported(n, h, w, cin, cout) == 1)
 
     def _use_fused(self, name, h, w, dgrad=False):
         """fully fused Winograd kernel: H, W even, reduce channels % 8 == 0, output channels % 64 == 0"""
@@ -296,27 +286,11 @@ class Engine:
             self._fused_dirty = False
         return self._fused_U[name]
 
-    def _winograd_kernels(self, name):
-        """(U forward, U dgrad) for a layer; all cached transforms are recomputed lazily after a parameter change."""
-        if self._wino_dirty:
-            self.wino_U.clear()
-            self._wino_dirty = False
-        u = self.wino_U.get(name)
-        if u is None:
-            cin, cout = self.cin[name], self.cout[name]
-            u = (torch.empty(16, cin, cout, dtype=torch.float32, device=self.dev),
-                 torch.empty(16, cout, cin, dtype=torch.float32, device=self.dev))
-            st = self._stream()
-            self.L.unet_winograd_weight_transform(_p(self.p[name + "/kernel"]), _p(u[0]), cin, cout, 0, st)
-            self.L.unet_winograd_weight_transform(_p(self.p[name + "/kernel"]), _p(u[1]), cin, cout, 1, st)
-            self.wino_U[name] = u
-        return u
-
     def parameters_changed(self):
         """theta was written from outside (broadcast, checkpoint): every cached transform of the kernels is stale."""
-        self._wino_dirty = True
         self._fused_dirty = True
         self._bf16_dirty = True
+        self._gamma_zero = None                 # re-checked lazily (BatchNorm-apply on load needs every gamma != 0)
 
     def load_parameters(self, values):
         """values: {keras-style name: array in the Keras layout}.  Resets nothing else."""
@@ -361,19 +335,42 @@ class Engine:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def _block_fwd(self, name, x, y_out, training, pool=None):
-        """x: NHWC view (input of the layer), y_out: NHWC view the BN output is written to."""
+    def _gamma_nonzero(self):
+        """BatchNorm-apply on load divides by the BatchNorm scale (pad = -shift / scale): usable while no gamma is exactly 0.
+        Checked (one host sync) after parameters were written from outside, not after optimizer steps."""
+        if self._gamma_zero is None:
+            self._gamma_zero = any(bool((self.p[n + "/gamma"] == 0).any().item()) for n, _, _, _ in self.layers)
+        return not self._gamma_zero
+
+    def _can_defer(self, name, consumer, n, h, w):
+        """`name`'s BatchNorm output feeds only the 3x3 layer `consumer` (spatial size h x w), which runs the fp32 fused Winograd
+        forward and weight-gradient kernels: the output need not be materialised (BatchNorm-apply on load)."""
+        return (self.bn_on_load and self.compute_dtype == "fp32" and self.wgrad_route == "fused" and self._use_fused(consumer, h, w)
+                and self.L.unet_winograd_wgrad_fused_supported(n, h, w, self.cin[consumer], self.cout[consumer]) == 1
+                and self._gamma_nonzero())
+
+    def _fold_buffers(self, name):
+        cin, cout = self.cin[name], self.cout[name]
+        return (self._buf("Ufold_" + name, (16 * cin * cout,)), self._buf("bfold_" + name, (cout,)), self._buf("pad_" + name, (cin + 8,)))
+
+    def _block_fwd(self, name, x, y_out, training, pool=None, in_view=None, r_out=None, stat_out=None):
+        """x: NHWC view (input of the layer), y_out: NHWC view the BN output is written to, or None: the BatchNorm output is NOT
+        materialised (its consumer applies it on load) and the conv output r is returned instead.
+        in_view = (scale, shift) per input channel: x is a producer's conv output (BatchNorm-apply on load, fused Winograd route);
+        r_out: where the conv output goes (default: the layer's own buffer); stat_out = (scale, shift) destinations of the BatchNorm
+        coefficients (default: self.stat[name][2:4])."""
         L, st = self.L, self._stream()
         kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
         n, h, w, _ = x.shape
         w_, b_ = self.p[name + "/kernel"], self.p[name + "/bias"]
         fused_stats = None
+        assert in_view is None or (kind == "conv3" and self._use_fused(name, h, w) and not self._use_bf16(name, n, h, w))
         if kind == "deconv":
-            r = self._buf("r_" + name, (n, 2 * h, 2 * w, cout))
+            r = r_out if r_out is not None else self._buf("r_" + name, (n, 2 * h, 2 * w, cout))
             if self._use_bf16_convt(name, n, h, w):
                 rows = L.unet_convT2x2_bf16_stats_rows(n, h, w, cin, cout, 0) if (training and self.fuse_bn_stats) else 0
                 stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
-                L.unet_convT2x2_fwd_bf16_ex(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout,
+                L.unet_convT2x2_fwd_bf16_ex(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
                                             n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:
                     fused_stats = (stat_part, rows)
@@ -381,89 +378,87 @@ class Engine:
                 rows = L.unet_convT2x2_fwd_stream_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
                 if rows > 0:
                     stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
-                    L.unet_convT2x2_fwd_stream_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout,
+                    L.unet_convT2x2_fwd_stream_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
                                                      _p(stat_part), stat_part.numel() * 4, st)
                     fused_stats = (stat_part, rows)
                 else:
-                    L.unet_convT2x2_fwd_stream(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, st)
+                    L.unet_convT2x2_fwd_stream(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
             else:
-                L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, st)
+                L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
         elif kind == "conv1":
             r = self._buf("r_" + name, (n, h, w, cout))
             L.unet_conv1x1_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
         else:
-            r = self._buf("r_" + name, (n, h, w, cout))
+            r = r_out if r_out is not None else self._buf("r_" + name, (n, h, w, cout))
             if self._use_bf16(name, n, h, w):
-                self.saved_V[name] = None
                 rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
                 stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
                 # (dec_2b..4b: their saved activation is read by the transposed-conv data gradient's epilogue, which takes fp32)
-                if self.bf16_activations and self.bf16_storage and rows > 0 and name not in ("dec_2b", "dec_3b", "dec_4b"):
+                if self.bf16_activations and self.bf16_storage and rows > 0 and name not in ("dec_2b", "dec_3b", "dec_4b") and r_out is None:
                     r = self._buf("r16_" + name, (n, h, w, cout), torch.bfloat16)
                 self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
-                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), None, None, _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), cout,
+                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), None, None, _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
                             int(r.dtype == torch.bfloat16), n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:
                     fused_stats = (stat_part, rows)
             elif self._use_fused(name, h, w):
-                self.saved_V[name] = None
                 rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
-                if rows > 0:
-                    # the conv kernel also leaves the BatchNorm sums of its output (one activation read less per layer)
-                    stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
-                    self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused_stats,
-                                _p(x), _ld(x), _p(self._fused_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1,
-                                _p(stat_part), stat_part.numel() * 4, st)
-                    fused_stats = (stat_part, rows)
+                stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
+                if in_view is not None:
+                    # BatchNorm-apply on load: scaled weight transform, folded bias, per-channel padding value (this step's coefficients)
+                    uc, bias_eff, pad = self._fold_buffers(name)
+                    nbf = L.unet_winograd_weight_fold_workspace(cin, cout)
+                    L.unet_winograd_weight_fold(_p(w_), _p(b_), _p(in_view[0]), _p(in_view[1]), _p(uc), _p(bias_eff), _p(pad), cin, cout,
+                                                _p(self._workspace(nbf)), nbf, st)
                 else:
-                    self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused,
-                                _p(x), _ld(x), _p(self._fused_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
-            elif self._use_winograd(name, n, h, w):
-                nbw = L.unet_conv3x3_winograd_workspace(n, h, w, cin, cout)
-                vk = None
-                if training and min(cin, cout) >= self.winograd_wgrad_min_channels and \
-                        L.unet_winograd_wgrad_supported(n, h, w, cin, cout) == 1:
-                    vk = self._buf("V_" + name, (16, n * (h // 2) * (w // 2), cin))     # kept for the weight gradient
-                self.saved_V[name] = vk
-                self._timed("conv3x3_fwd_winograd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd,
-                            _p(x), _ld(x), _p(self._winograd_kernels(name)[0]), _p(b_), _p(r), cout, n, h, w, cin, cout, 1,
-                            _p(vk), _p(self._workspace(nbw)), nbw, st)
+                    uc, bias_eff, pad = self._fused_kernels(name)[0], b_, None
+                # (with stat_part the conv kernel also leaves the BatchNorm sums of its output: one activation read less per layer)
+                self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused,
+                            _p(x), _ld(x), _p(pad), _p(uc), _p(bias_eff), _p(r), _ld(r), n, h, w, cin, cout, 1,
+                            _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+                if rows > 0:
+                    fused_stats = (stat_part, rows)
             elif L.unet_conv3x3_mfma_supported(cin, cout):
                 self._timed("conv3x3_fwd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
-                            _p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+                            _p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, 1, st)
             else:
                 rows = L.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
                 if rows > 0:
                     stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
-                    L.unet_conv3x3_fwd_direct_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1,
+                    L.unet_conv3x3_fwd_direct_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, 1,
                                                     _p(stat_part), stat_part.numel() * 4, st)
                     fused_stats = (stat_part, rows)
                 else:
-                    L.unet_conv3x3_fwd_direct(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n, h, w, cin, cout, 1, st)
+                    L.unet_conv3x3_fwd_direct(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, 1, st)
         P = r.shape[0] * r.shape[1] * r.shape[2]
         s = self.stat[name]
+        sc_out, sh_out = stat_out if stat_out is not None else (s[2], s[3])
         gm, bt = self.p[name + "/gamma"], self.p[name + "/beta"]
         mm, mv = self.moving[name + "/moving_mean"], self.moving[name + "/moving_var"]
         if training and fused_stats is not None:
             L.unet_bn_train_finalize_partials(_p(fused_stats[0]), fused_stats[1], P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM,
-                                              BN_MOVING_VAR_UNBIASED, _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), st)
+                                              BN_MOVING_VAR_UNBIASED, _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(sc_out), _p(sh_out), st)
         elif training:
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_train_stats(_p(r), cout, P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM, BN_MOVING_VAR_UNBIASED,
-                                  _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(ws), nb, st)
+            L.unet_bn_train_stats(_p(r), _ld(r), P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM, BN_MOVING_VAR_UNBIASED,
+                                  _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(sc_out), _p(sh_out), _p(ws), nb, st)
         else:
-            L.unet_bn_eval_coeffs(_p(gm), _p(bt), _p(mm), _p(mv), BN_EPS, cout, _p(s[2]), _p(s[3]), st)
+            L.unet_bn_eval_coeffs(_p(gm), _p(bt), _p(mm), _p(mv), BN_EPS, cout, _p(sc_out), _p(sh_out), st)
+        self.saved[name] = (x, r)
+        self.view[name] = in_view
+        self.coef[name] = (sc_out, sh_out)
+        if y_out is None:                       # deferred: the consumer applies (sc_out, sh_out) on load
+            return r
         if r.dtype == torch.bfloat16 or y_out.dtype == torch.bfloat16:
-            L.unet_bn_apply_any(_p(r), cout, int(r.dtype == torch.bfloat16), _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), int(y_out.dtype == torch.bfloat16),
+            L.unet_bn_apply_any(_p(r), _ld(r), int(r.dtype == torch.bfloat16), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), int(y_out.dtype == torch.bfloat16),
                                 _p(pool[0]) if pool is not None else None, cout, _p(pool[1]) if pool is not None else None,
                                 r.shape[0], r.shape[1], r.shape[2], cout, st)
         elif pool is not None:         # (pooled, idx): BN apply and the level's max pool in one pass
-            L.unet_bn_apply_maxpool(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
+            L.unet_bn_apply_maxpool(_p(r), _ld(r), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
                                     r.shape[0], r.shape[1], r.shape[2], cout, st)
         else:
-            L.unet_bn_apply(_p(r), cout, _p(s[2]), _p(s[3]), _p(y_out), _ld(y_out), P, cout, st)
-        self.saved[name] = (x, r)
+            L.unet_bn_apply(_p(r), _ld(r), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), P, cout, st)
         return y_out
 
     def _dropout(self, t, key, masks, backward=False):
@@ -502,16 +497,28 @@ class Engine:
             x0 = self._buf("x_nhwc", (n, h, w, c))
             L.unet_nchw_to_nhwc(_p(x), _p(x0), n, c, h, w, st)
         self.saved = {}
-        self.saved_V = {}
+        self.view = {}
+        self.coef = {}
         self.masks = self._prep_masks(dropout_masks) if training else None
         B = BASE
         f = self._block_fwd
-        cur = x0
+        cur, cur_view = x0, None
         self.idx = {}
         self.cat = {}
+        self.catstat = {}
+
+        def pair(a_name, b_name, xin, xin_view, hh, ww, ch, b_out, **kw):
+            """the two convs of a block: a -> b.  a's BatchNorm output feeds only b, so with BatchNorm-apply on load it is never
+            materialised: b reads a's conv output through (scale, shift)."""
+            if self._can_defer(a_name, b_name, n, hh, ww):
+                ra = f(a_name, xin, None, training, in_view=xin_view)
+                sa = self.stat[a_name]
+                return f(b_name, ra, b_out, training, in_view=(sa[2], sa[3]), **kw)
+            ya = f(a_name, xin, self._ybuf(a_name, (n, hh, ww, ch), b_name), training, in_view=xin_view)
+            return f(b_name, ya, b_out, training, **kw)
+
         for lvl, ch in ((1, B), (2, 2 * B), (3, 4 * B), (4, 8 * B)):
             hh, ww = cur.shape[1], cur.shape[2]
-            ya = f("conv_%da" % lvl, cur, self._ybuf("conv_%da" % lvl, (n, hh, ww, ch), "conv_%db" % lvl), training)
             # the concat buffer [skip, upsampled] and the pooled tensor feed 3x3 layers only (dec_Na / the next level's first conv):
             # bf16 storage applies to them as well (levels 1-3; level 4 goes through the dropout and the unfused pool kernels)
             nxt = "conv_%da" % (lvl + 1) if lvl < 4 else "bott_a"
@@ -523,25 +530,35 @@ class Engine:
             pooled = self._buf(("pool16_%d" if c16 else "pool_%d") % lvl, (n, hh // 2, ww // 2, ch), torch.bfloat16 if c16 else torch.float32)
             idx = self._buf("idx_%d" % lvl, (n, hh // 2, ww // 2, ch), torch.uint8)
             fuse_pool = self.fuse_pool and not (lvl == 4 and training)   # level 4 drops out between BN and pool (UNet/model.py:105-107)
-            skip = f("conv_%db" % lvl, ya, cat[..., :ch], training, pool=(pooled, idx) if fuse_pool else None)
+            skip = pair("conv_%da" % lvl, "conv_%db" % lvl, cur, cur_view, hh, ww, ch, cat[..., :ch], pool=(pooled, idx) if fuse_pool else None)
             if not fuse_pool:
                 if lvl == 4 and training:
                     self._dropout(skip, "drop_4", self.masks)
                 L.unet_maxpool2x2_fwd(_p(skip), _ld(skip), _p(pooled), ch, _p(idx), n, hh, ww, ch, st)
             self.idx[lvl] = idx
-            cur = pooled
+            cur, cur_view = pooled, None
         hh, ww = cur.shape[1], cur.shape[2]
-        ya = f("bott_a", cur, self._ybuf("bott_a", (n, hh, ww, 16 * B), "bott_b"), training)
-        cur = f("bott_b", ya, self._buf("y_bott_b", (n, hh, ww, 16 * B)), training)
+        cur = pair("bott_a", "bott_b", cur, None, hh, ww, 16 * B, self._buf("y_bott_b", (n, hh, ww, 16 * B)))
         if training:
             self._dropout(cur, "drop_b", self.masks)
         for lvl, ch in ((4, 8 * B), (3, 4 * B), (2, 2 * B), (1, B)):
             cat = self.cat[lvl]
-            f("up_%d" % lvl, cur, cat[..., ch:], training)
             hh, ww = cat.shape[1], cat.shape[2]
-            ya = f("dec_%da" % lvl, cat, self._ybuf("dec_%da" % lvl, (n, hh, ww, ch), "dec_%db" % lvl), training)
+            cat_view = None
+            if self._can_defer("up_%d" % lvl, "dec_%da" % lvl, n, hh, ww):
+                # the transposed conv writes its output r straight into the upper half of the concat buffer; dec_Na reads the whole
+                # buffer through per-channel coefficients: (1, 0) for the materialised skip half, up_N's BatchNorm for the upper half
+                cs = self.bufs.get("catstat_%d" % lvl)
+                if cs is None:
+                    cs = self._buf("catstat_%d" % lvl, (2, 2 * ch))
+                    cs[0, :ch].fill_(1.0); cs[1, :ch].zero_()
+                self.catstat[lvl] = cs
+                f("up_%d" % lvl, cur, None, training, r_out=cat[..., ch:], stat_out=(cs[0, ch:], cs[1, ch:]))
+                cat_view = (cs[0], cs[1])
+            else:
+                f("up_%d" % lvl, cur, cat[..., ch:], training)
             yb = self._ybuf("dec_%db" % lvl, (n, hh, ww, ch), "up_%d" % (lvl - 1)) if lvl > 1 else self._buf("y_dec_1b", (n, hh, ww, ch))
-            cur = f("dec_%db" % lvl, ya, yb, training)
+            cur = pair("dec_%da" % lvl, "dec_%db" % lvl, cat, cat_view, hh, ww, ch, yb)
         yl = f("logits", cur, self._buf("y_logits", (n, h, w, self.K)), training)
         prob = self._buf("softmax", (n, h, w, self.K))
         P = n * h * w
@@ -583,19 +600,19 @@ class Engine:
             assert not (pool_grad is not None and pre is not None)
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_bwd_any(_p(dy), _ld(dy), _p(pdy), _ld(pdy) if pdy is not None else 0, _p(pidx), n, ho, wo, _p(r), cout,
+            L.unet_bn_bwd_any(_p(dy), _ld(dy), _p(pdy), _ld(pdy) if pdy is not None else 0, _p(pidx), n, ho, wo, _p(r), _ld(r),
                               _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 0 if kind == "deconv" else 1, _p(dz), cout, 1,
                               _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]), _p(self.g[name + "/bias"]), part_ptr, rows,
                               _p(ws), nb, st, int(r.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16),
                               int(pdy is not None and pdy.dtype == torch.bfloat16))
         elif eval_mode:
-            L.unet_bn_eval_bwd(_p(dy), _ld(dy), _p(r), cout, _p(s[2]), _p(dz), cout, P, cout, 0 if kind == "deconv" else 1, st)
+            L.unet_bn_eval_bwd(_p(dy), _ld(dy), _p(r), _ld(r), _p(self.coef[name][0]), _p(dz), cout, P, cout, 0 if kind == "deconv" else 1, st)
         elif pre is not None:
             # sum(dy), sum(dy*r) already came out of the consumer layer's data-gradient kernel: no reduction pass
             part, rows, c0 = pre
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_bwd_from_partials(_p(dy), _ld(dy), _p(r), cout, _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
+            L.unet_bn_bwd_from_partials(_p(dy), _ld(dy), _p(r), _ld(r), _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
                                         0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
                                         _p(self.g[name + "/bias"]), ctypes.c_void_p(part.data_ptr() + (c0 // 64) * rows * 128 * 4), rows,
                                         _p(ws), nb, st)
@@ -604,13 +621,13 @@ class Engine:
             pdy, pidx = pool_grad
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_bwd_pooled(_p(dy), _ld(dy), _p(pdy), _ld(pdy), _p(pidx), n, ho, wo, _p(r), cout, _p(self.p[name + "/gamma"]),
+            L.unet_bn_bwd_pooled(_p(dy), _ld(dy), _p(pdy), _ld(pdy), _p(pidx), n, ho, wo, _p(r), _ld(r), _p(self.p[name + "/gamma"]),
                                  _p(s[0]), _p(s[1]), cout, 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
                                  _p(self.g[name + "/bias"]), _p(ws), nb, st)
         else:
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_bwd(_p(dy), _ld(dy), _p(r), cout, _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
+            L.unet_bn_bwd(_p(dy), _ld(dy), _p(r), _ld(r), _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
                           0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
                           _p(self.g[name + "/bias"]), _p(ws), nb, st)
         w_, dw = self.p[name + "/kernel"], self.g[name + "/kernel"]
@@ -640,18 +657,16 @@ class Engine:
                 self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16,
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw),
                             n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
-            elif (self.wgrad_route in ("fused", "hybrid") and L.unet_winograd_wgrad_fused_supported(n, ho, wo, cin, cout) == 1
-                  and not (self.wgrad_route == "hybrid" and min(cin, cout) >= self.wgrad_unfused_from
-                           and L.unet_winograd_wgrad_supported(n, ho, wo, cin, cout) == 1)):
+            elif self.wgrad_route == "fused" and L.unet_winograd_wgrad_fused_supported(n, ho, wo, cin, cout) == 1:
                 nb2 = L.unet_conv3x3_wgrad_winograd_fused_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_winograd_fused,
                             _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
-            elif (min(cin, cout) >= self.winograd_wgrad_min_channels
-                  and L.unet_winograd_wgrad_supported(n, ho, wo, cin, cout) == 1):
-                nb2 = L.unet_conv3x3_wgrad_winograd_workspace(n, ho, wo, cin, cout)
-                self._timed("conv3x3_wgrad_winograd", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_winograd,
-                            _p(x), _ld(x), _p(self.saved_V.get(name)), _p(dz), cout, _p(dw), n, ho, wo, cin, cout,
-                            _p(self._workspace(nb2, sd)), nb2, st2)
+                vw = self.view.get(name)
+                if vw is not None:
+                    # x was read through BatchNorm-apply on load: dw (computed on the producer's raw conv output) -> scale . dw + shift (x) S
+                    nb3 = 8 * cout * 4
+                    L.unet_conv3x3_wgrad_fold_fix(_p(dw), _p(vw[0]), _p(vw[1]), _p(dz), cout, _p(self.g[name + "/bias"]), n, ho, wo, cin, cout,
+                                                  _p(self._workspace(nb3, sd)), nb3, st2)
             elif L.unet_conv3x3_mfma_supported(cin, cout) and cin % 64 == 0:
                 nb2 = L.unet_conv3x3_wgrad_mfma_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_mfma,
@@ -677,7 +692,7 @@ class Engine:
                 r_prev = self.saved[prod[0]][1] if rows > 0 else None
                 part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,)) if rows > 0 else None
                 L.unet_convT2x2_dgrad_bf16_ex(_p(dz), cout, int(dz.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[1]), _p(dx), cin,
-                                              n, hi, wi, cin, cout, _p(r_prev), r_prev.shape[-1] if rows > 0 else 0,
+                                              n, hi, wi, cin, cout, _p(r_prev), _ld(r_prev) if rows > 0 else 0,
                                               _p(part), part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:
                     self.bnbwd_part[prod[0]] = (part, rows, 0)
@@ -695,7 +710,7 @@ class Engine:
                     part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
                     self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
                                 _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx.dtype == torch.bfloat16), n, ho, wo, cin, cout,
-                                _p(r_prev), r_prev.shape[-1], int(r_prev.dtype == torch.bfloat16), c0, c1, _p(part), part.numel() * 4, st)
+                                _p(r_prev), _ld(r_prev), int(r_prev.dtype == torch.bfloat16), c0, c1, _p(part), part.numel() * 4, st)
                     self.bnbwd_part[pname] = (part, rows, c0)
                 else:
                     self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
@@ -709,18 +724,14 @@ class Engine:
                     pname, c0, c1 = prod[0], prod[1] * (cin // prod[3]), prod[2] * (cin // prod[3])
                     r_prev = self.saved[pname][1]
                     part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
-                    self._timed("conv3x3_dgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd_fused_bnstats,
+                    self._timed("conv3x3_dgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd_fused,
                                 _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
-                                _p(r_prev), r_prev.shape[-1], c0, c1, _p(part), part.numel() * 4, st)
+                                _p(r_prev), _ld(r_prev), c0, c1, _p(part), part.numel() * 4, st)
                     self.bnbwd_part[pname] = (part, rows, c0)
                 else:
                     self._timed("conv3x3_dgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd_fused,
-                                _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout, st)
-            elif self._use_winograd(name, n, ho, wo):
-                nbw = L.unet_conv3x3_winograd_workspace(n, ho, wo, cin, cout)
-                self._timed("conv3x3_dgrad_winograd", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd,
-                            _p(dz), cout, _p(self._winograd_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
-                            _p(self._workspace(nbw)), nbw, st)
+                                _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
+                                None, 0, 0, 0, None, 0, st)
             elif L.unet_conv3x3_mfma_supported(cout, cin):
                 self._timed("conv3x3_dgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_mfma,
                             _p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
@@ -812,7 +823,6 @@ class Engine:
     def adam_step(self, learning_rate):
         """Keras Adam on the flat buffers (reference UNet/model.py:79,223)."""
         self.iterations += 1
-        self._wino_dirty = True
         self._fused_dirty = True
         self._bf16_dirty = True
         t = self.iterations

@@ -110,10 +110,10 @@ def test_fused_winograd_trio_properties_at_full_size(hip, shape):
     Uc = torch.empty(16 * ci * co, device=DEV); Ucd = torch.empty(16 * ci * co, device=DEV)
     hip.unet_winograd_weight_transform(P(wt), P(Uc), ci, co, 2, ST()); hip.unet_winograd_weight_transform(P(wt), P(Ucd), ci, co, 3, ST())
     y = torch.empty(n, h, w, co, device=DEV); yd = torch.empty_like(y); dx = torch.empty_like(x); dw = torch.empty_like(wt)
-    hip.unet_conv3x3_fwd_winograd_fused(P(x), ci, P(Uc), None, P(y), co, n, h, w, ci, co, 0, ST())
+    hip.unet_conv3x3_fwd_winograd_fused(P(x), ci, None, P(Uc), None, P(y), co, n, h, w, ci, co, 0, None, 0, ST())
     hip.unet_conv3x3_fwd_mfma(P(x), ci, P(wt), None, P(yd), co, n, h, w, ci, co, 0, ST())
     assert ((y - yd).abs().max() / yd.abs().max()).item() < 2e-5
-    hip.unet_conv3x3_dgrad_winograd_fused(P(dz), co, P(Ucd), P(dx), ci, n, h, w, ci, co, ST())
+    hip.unet_conv3x3_dgrad_winograd_fused(P(dz), co, P(Ucd), P(dx), ci, n, h, w, ci, co, None, 0, 0, 0, None, 0, ST())
     nb = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co); ws = ws_bytes(nb)
     hip.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
     dot = lambda a, b: (a.double() * b.double()).sum().item()
@@ -455,54 +455,6 @@ def test_keras_adam_flat(hip):
     assert relerr(vd.cpu().numpy(), ref_v) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 16, 64, 64), (1, 16, 32, 128, 256), (2, 4, 64, 256, 128)])
-def test_conv3x3_winograd_fwd_dgrad(hip, shape):
-    # Winograd F(2x2,3x3): exact-arithmetic-equivalent to the direct conv; fp32 tolerance slightly wider (transforms)
-    n, h, w, ci, co = shape
-    assert hip.unet_winograd_supported(n, h, w, ci, co) == 1
-    rng = np.random.default_rng(ci + co)
-    x = rng.standard_normal((n, ci, h, w))
-    wt = rng.standard_normal((3, 3, ci, co)) / np.sqrt(9 * ci)
-    b = rng.standard_normal(co)
-    dz = rng.standard_normal((n, co, h, w))
-    z_ref = np.maximum(on.conv_same_fwd(x, wt, b), 0)
-    dx_ref, _, _ = on.conv_same_bwd(x, wt, dz)
-    xbuf = torch.zeros(n, h, w, ci + 8, device=DEV); xbuf[..., 4:4 + ci] = to_nhwc(x)
-    xv = xbuf[..., 4:4 + ci]
-    wd, bd, dzd = dev(wt), dev(b), to_nhwc(dz)
-    U = torch.empty(16, ci, co, device=DEV); Ud = torch.empty(16, co, ci, device=DEV)
-    hip.unet_winograd_weight_transform(P(wd), P(U), ci, co, 0, ST())
-    hip.unet_winograd_weight_transform(P(wd), P(Ud), ci, co, 1, ST())
-    nb = hip.unet_conv3x3_winograd_workspace(n, h, w, ci, co)
-    ws = ws_bytes(nb)
-    cat = torch.zeros(n, h, w, 2 * co, device=DEV)
-    outv = cat[..., co:]
-    hip.unet_conv3x3_fwd_winograd(P(xv), ci + 8, P(U), P(bd), P(outv), 2 * co, n, h, w, ci, co, 1, None, P(ws), nb, ST())
-    assert relerr(from_nhwc(outv), z_ref) < 3e-5
-    assert cat[..., :co].abs().max().item() == 0
-    dx = torch.full((n, h, w, ci), 7.0, device=DEV)
-    hip.unet_conv3x3_dgrad_winograd(P(dzd), co, P(Ud), P(dx), ci, n, h, w, ci, co, P(ws), nb, ST())
-    assert relerr(from_nhwc(dx), dx_ref) < 3e-5
-
-
-@pytest.mark.parametrize("shape", [(2, 16, 16, 128, 128), (1, 16, 32, 256, 128), (4, 8, 8, 128, 384)])
-def test_conv3x3_winograd_wgrad(hip, shape):
-    n, h, w, ci, co = shape
-    assert hip.unet_winograd_wgrad_supported(n, h, w, ci, co) == 1
-    rng = np.random.default_rng(ci * 3 + co)
-    x = rng.standard_normal((n, ci, h, w)); dz = rng.standard_normal((n, co, h, w))
-    wt = np.zeros((3, 3, ci, co))
-    _, dw_ref, _ = on.conv_same_bwd(x, wt, dz)
-    xbuf = torch.zeros(n, h, w, ci + 4, device=DEV); xbuf[..., 4:] = to_nhwc(x)
-    xv = xbuf[..., 4:]
-    dzd = to_nhwc(dz)
-    nb = hip.unet_conv3x3_wgrad_winograd_workspace(n, h, w, ci, co)
-    ws = ws_bytes(nb)
-    dw = torch.full((3, 3, ci, co), 7.0, device=DEV)
-    hip.unet_conv3x3_wgrad_winograd(P(xv), ci + 4, None, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
-    assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 3e-5
-
-
 def test_winograd_weight_transform_batch_matches_single(hip):
     # one launch for several layers == the per-layer transforms: mode 2 bit for bit; mode 3 (rotated filter) is obtained by
     # permuting the forward transform's points, which sums the taps in the other order -> equal to rounding
@@ -540,7 +492,7 @@ def test_conv3x3_winograd_fully_fused_fwd_dgrad(hip, shape):
     hip.unet_winograd_weight_transform(P(wd), P(Uc), ci, co, 2, ST())
     cat = torch.zeros(n, h, w, 2 * co, device=DEV)
     outv = cat[..., co:]
-    hip.unet_conv3x3_fwd_winograd_fused(P(xv), ci + 8, P(Uc), P(bd), P(outv), 2 * co, n, h, w, ci, co, 1, ST())
+    hip.unet_conv3x3_fwd_winograd_fused(P(xv), ci + 8, None, P(Uc), P(bd), P(outv), 2 * co, n, h, w, ci, co, 1, None, 0, ST())
     assert relerr(from_nhwc(outv), z_ref) < 3e-5
     assert cat[..., :co].abs().max().item() == 0
     if ci % 64 == 0:
@@ -549,7 +501,7 @@ def test_conv3x3_winograd_fully_fused_fwd_dgrad(hip, shape):
         Ucd = torch.empty(16 * ci * co, device=DEV)
         hip.unet_winograd_weight_transform(P(wd), P(Ucd), ci, co, 3, ST())
         dx = torch.full((n, h, w, ci), 7.0, device=DEV)
-        hip.unet_conv3x3_dgrad_winograd_fused(P(to_nhwc(dz)), co, P(Ucd), P(dx), ci, n, h, w, ci, co, ST())
+        hip.unet_conv3x3_dgrad_winograd_fused(P(to_nhwc(dz)), co, P(Ucd), P(dx), ci, n, h, w, ci, co, None, 0, 0, 0, None, 0, ST())
         assert relerr(from_nhwc(dx), dx_ref) < 3e-5
 
 
@@ -570,9 +522,9 @@ def test_fused_conv_bn_stats_match_bn_train_stats(hip, shape):
     hip.unet_winograd_weight_transform(P(wt), P(Uc), ci, co, 2, ST())
     r = torch.empty(n, h, w, co, device=DEV)
     part = torch.zeros((co // 64) * rows * 128, device=DEV)
-    hip.unet_conv3x3_fwd_winograd_fused_stats(P(x), ci, P(Uc), P(b), P(r), co, n, h, w, ci, co, 1, P(part), part.numel() * 4, ST())
+    hip.unet_conv3x3_fwd_winograd_fused(P(x), ci, None, P(Uc), P(b), P(r), co, n, h, w, ci, co, 1, P(part), part.numel() * 4, ST())
     r2 = torch.empty_like(r)
-    hip.unet_conv3x3_fwd_winograd_fused(P(x), ci, P(Uc), P(b), P(r2), co, n, h, w, ci, co, 1, ST())
+    hip.unet_conv3x3_fwd_winograd_fused(P(x), ci, None, P(Uc), P(b), P(r2), co, n, h, w, ci, co, 1, None, 0, ST())
     assert torch.equal(r, r2)
     npx = n * h * w
     outs = [[torch.zeros(co, device=DEV) for _ in range(4)] for _ in range(2)]
@@ -631,9 +583,9 @@ def test_dgrad_bn_backward_sums_match_reduction(hip, shape, crange):
     hip.unet_winograd_weight_transform(P(wt), P(Ucd), ci, co, 3, ST())
     dx = torch.empty(n, h, w, ci, device=DEV); dx2 = torch.empty_like(dx)
     part = torch.zeros((ci // 64) * rows * 128, device=DEV)
-    hip.unet_conv3x3_dgrad_winograd_fused_bnstats(P(dzin), co, P(Ucd), P(dx), ci, n, h, w, ci, co, P(r_prev), cp, c0, c1,
+    hip.unet_conv3x3_dgrad_winograd_fused(P(dzin), co, P(Ucd), P(dx), ci, n, h, w, ci, co, P(r_prev), cp, c0, c1,
                                                   P(part), part.numel() * 4, ST())
-    hip.unet_conv3x3_dgrad_winograd_fused(P(dzin), co, P(Ucd), P(dx2), ci, n, h, w, ci, co, ST())
+    hip.unet_conv3x3_dgrad_winograd_fused(P(dzin), co, P(Ucd), P(dx2), ci, n, h, w, ci, co, None, 0, 0, 0, None, 0, ST())
     assert torch.equal(dx, dx2)
     npx = n * h * w
     dy = dx[..., c0:c1]
@@ -1043,3 +995,53 @@ def test_conv3x3_bf16_batchnorm_apply_on_load_is_bit_identical_to_two_passes(hip
     wref = wt.to(torch.bfloat16).double().cpu().numpy()
     ref = on.relu_fwd(on.conv_same_fwd(yref.transpose(0, 3, 1, 2), wref, b.double().cpu().numpy())).transpose(0, 2, 3, 1)
     assert relerr(outs[1].cpu().numpy(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 18, 34, 64, 128), (2, 32, 48, 128, 64), (1, 8, 8, 256, 256)])
+def test_winograd_batchnorm_apply_on_load_matches_two_passes(hip, shape):
+    # fp32 fused Winograd forward with BatchNorm-apply on load (scaled weight transform + folded bias + per-channel padding value) ==
+    # the same kernel on the MATERIALISED BatchNorm output, to fp32 rounding: interior and every border / corner pixel (the shift must
+    # cancel exactly where the zero padding of the BatchNorm output contributes nothing), shift chosen large so a leak would be gross;
+    # and against the fp64 oracle.  Second half: the weight gradient on the raw conv output, corrected by unet_conv3x3_wgrad_fold_fix,
+    # == the weight gradient on the materialised tensor.
+    n, h, w, ci, co = shape
+    g = torch.Generator(device=DEV).manual_seed(h * w + ci)
+    ldx = ci + 4
+    r = torch.relu(torch.randn(n, h, w, ldx, device=DEV, generator=g))
+    sc = (torch.rand(ci, device=DEV, generator=g) + 0.5) * (torch.randint(0, 2, (ci,), device=DEV, generator=g).float() * 2 - 1)    # both signs
+    sh = torch.randn(ci, device=DEV, generator=g) * 3 + 2.0
+    wt = torch.randn(3, 3, ci, co, device=DEV, generator=g) * 0.05; b = torch.randn(co, device=DEV, generator=g)
+    y = torch.zeros(n, h, w, ldx, device=DEV)
+    hip.unet_bn_apply(P(r), ldx, P(sc), P(sh), P(y), ldx, n * h * w, ci, ST())
+    Uc = torch.empty(16 * ci * co, device=DEV)
+    hip.unet_winograd_weight_transform(P(wt), P(Uc), ci, co, 2, ST())
+    out_ref = torch.empty(n, h, w, co, device=DEV)
+    hip.unet_conv3x3_fwd_winograd_fused(P(y), ldx, None, P(Uc), P(b), P(out_ref), co, n, h, w, ci, co, 1, None, 0, ST())
+    Uf = torch.empty(16 * ci * co, device=DEV); bf = torch.empty(co, device=DEV); pad = torch.empty(ci + 8, device=DEV)
+    nbf = hip.unet_winograd_weight_fold_workspace(ci, co); wsf = ws_bytes(nbf)
+    hip.unet_winograd_weight_fold(P(wt), P(b), P(sc), P(sh), P(Uf), P(bf), P(pad), ci, co, P(wsf), nbf, ST())
+    out = torch.empty(n, h, w, co, device=DEV)
+    hip.unet_conv3x3_fwd_winograd_fused(P(r), ldx, P(pad), P(Uf), P(bf), P(out), co, n, h, w, ci, co, 1, None, 0, ST())
+    assert torch.allclose(pad[:ci], -sh / sc, rtol=1e-6) and (pad[ci:] == 0).all()
+    yref = (sc.double() * r.double()[..., :ci] + sh.double()).cpu().numpy()
+    ref = on.relu_fwd(on.conv_same_fwd(yref.transpose(0, 3, 1, 2), wt.double().cpu().numpy(), b.double().cpu().numpy())).transpose(0, 2, 3, 1)
+    scale_ = np.abs(ref).max()
+    for name_, o in (("two passes", out_ref), ("on load", out)):
+        err = np.abs(o.cpu().numpy() - ref)
+        assert err.max() < 3e-5 * scale_, (name_, err.max() / scale_)
+        border = np.ones((h, w), bool); border[1:-1, 1:-1] = False
+        assert err[:, border].max() < 3e-5 * scale_, (name_, "border")
+    # ---- weight gradient
+    dz = torch.randn(n, h, w, co, device=DEV, generator=g)
+    if hip.unet_winograd_wgrad_fused_supported(n, h, w, ci, co) == 1:
+        nbw = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co); wsw = ws_bytes(nbw)
+        dw_ref = torch.empty(3, 3, ci, co, device=DEV); dw = torch.empty(3, 3, ci, co, device=DEV)
+        hip.unet_conv3x3_wgrad_winograd_fused(P(y), ldx, P(dz), co, P(dw_ref), n, h, w, ci, co, P(wsw), nbw, ST())
+        hip.unet_conv3x3_wgrad_winograd_fused(P(r), ldx, P(dz), co, P(dw), n, h, w, ci, co, P(wsw), nbw, ST())
+        total = dz.sum((0, 1, 2)).contiguous()
+        ws8 = ws_bytes(8 * co * 4)
+        hip.unet_conv3x3_wgrad_fold_fix(P(dw), P(sc), P(sh), P(dz), co, P(total), n, h, w, ci, co, P(ws8), 8 * co * 4, ST())
+        _, dw64, _ = on.conv_same_bwd(yref.transpose(0, 3, 1, 2), wt.double().cpu().numpy(), dz.double().cpu().numpy().transpose(0, 3, 1, 2))
+        sw = np.abs(dw64).max()
+        assert np.abs(dw_ref.cpu().numpy() - dw64).max() < 3e-5 * sw
+        assert np.abs(dw.cpu().numpy() - dw64).max() < 3e-5 * sw
