@@ -74,7 +74,8 @@ int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, const float* dz
                                       int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* weight gradient of a layer whose input was read through BatchNorm-apply on load (x = scale . r + shift inside the image): dw holds
  * any wgrad kernel's result on the RAW r; in place dw = scale[ci] * dw + shift[ci] * S[tap][co], S = sum of dz over the pixels whose
- * tap lies inside the image (border sums of dz; total = column sums of dz = the bias gradient).  ws: 8 * Cout floats. */
+ * tap lies inside the image (border sums of dz; total = column sums of dz = the bias gradient). */
+size_t unet_conv3x3_wgrad_fold_fix_workspace(int Cout);
 int unet_conv3x3_wgrad_fold_fix(float* dw, const float* scale, const float* shift, const float* dz, int lddz, const float* total,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* ---- bf16 matrix-core 3x3 convolution (BASELINE config 4: bf16 forward/backward, fp32 master weights; the reference keeps

@@ -1277,21 +1277,26 @@ __global__ __launch_bounds__(256) void wino_fold_bias_kernel(const float* __rest
 // inside the image = total - (row excluded by a) - (column excluded by b) + (their corner): a = 0 excludes dz row 0, a = 2 row H-1,
 // b = 0 column 0, b = 2 column W-1.  dz_border_sums_kernel leaves the 4 line sums and 4 corner sums per channel (fp64 accumulation,
 // fixed order); wgrad_fold_fix_kernel applies the two terms to dW in place.
+constexpr int kBorderSegs = 32;            // segments a border line is split into (one workgroup each)
+
+// partial sums: part[line][seg][Co]; line 0..3 = row 0, row H-1, column 0, column W-1 (over all images)
 __global__ __launch_bounds__(256) void dz_border_sums_kernel(const float* __restrict__ dz, int lddz, int N, int H, int W, int Co,
-                                                             float* __restrict__ sums /* [8][Co]: row0, rowH-1, col0, colW-1, 4 corners */) {
-    // block = (line id 0..3, 64-channel group); thread = (channel quad q, pixel lane pl); lines are walked by 16 pixel lanes
-    const int line = blockIdx.x & 3, c0 = (blockIdx.x >> 2) * 64;
-    const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+                                                             float* __restrict__ part) {
+    // block = (line, 64-channel group, segment); thread = (channel quad q, pixel lane pl of 16)
+    const int line = blockIdx.x & 3, cg = (blockIdx.x >> 2) % ((Co + 63) / 64), seg = (blockIdx.x >> 2) / ((Co + 63) / 64);
+    const int c0 = cg * 64, q = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int len = line < 2 ? W : H;
+    const long total = (long)N * len, per = (total + kBorderSegs - 1) / kBorderSegs;
+    const long i0 = seg * per; long i1 = i0 + per; if (i1 > total) i1 = total;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const int c = c0 + 4 * q;
     if (c < Co) {
-        for (int n = 0; n < N; ++n)
-            for (int i = pl; i < len; i += 16) {
-                const int y = line == 0 ? 0 : (line == 1 ? H - 1 : i), x = line == 2 ? 0 : (line == 3 ? W - 1 : i);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(dz + ((size_t)(n * H + y) * W + x) * lddz + c);
-                acc[0] += (double)v[0]; acc[1] += (double)v[1]; acc[2] += (double)v[2]; acc[3] += (double)v[3];
-            }
+        for (long i = i0 + pl; i < i1; i += 16) {
+            const int n = (int)(i / len), k = (int)(i % len);
+            const int y = line == 0 ? 0 : (line == 1 ? H - 1 : k), x = line == 2 ? 0 : (line == 3 ? W - 1 : k);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dz + ((size_t)(n * H + y) * W + x) * lddz + c);
+            acc[0] += (double)v[0]; acc[1] += (double)v[1]; acc[2] += (double)v[2]; acc[3] += (double)v[3];
+        }
     }
     __shared__ double red[16][64];
 #pragma unroll
@@ -1300,18 +1305,28 @@ __global__ __launch_bounds__(256) void dz_border_sums_kernel(const float* __rest
     if (threadIdx.x < 64 && c0 + threadIdx.x < Co) {
         double s = 0.0;
         for (int k = 0; k < 16; ++k) s += red[k][threadIdx.x];
-        sums[(size_t)line * Co + c0 + threadIdx.x] = (float)s;
-        if (line == 0) {                                                   // the four corners: tiny, one thread per channel
-            const int ch = c0 + threadIdx.x;
-            double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
-            for (int n = 0; n < N; ++n) {
-                k00 += (double)dz[((size_t)(n * H + 0) * W + 0) * lddz + ch];         k01 += (double)dz[((size_t)(n * H + 0) * W + W - 1) * lddz + ch];
-                k10 += (double)dz[((size_t)(n * H + H - 1) * W + 0) * lddz + ch];     k11 += (double)dz[((size_t)(n * H + H - 1) * W + W - 1) * lddz + ch];
-            }
-            sums[(size_t)4 * Co + ch] = (float)k00; sums[(size_t)5 * Co + ch] = (float)k01;
-            sums[(size_t)6 * Co + ch] = (float)k10; sums[(size_t)7 * Co + ch] = (float)k11;
-        }
+        part[((size_t)line * kBorderSegs + seg) * Co + c0 + threadIdx.x] = (float)s;
     }
+}
+
+// sums[8][Co]: the four line sums (segments added in order) and the four corner sums
+__global__ __launch_bounds__(256) void dz_border_finalize_kernel(const float* __restrict__ part, const float* __restrict__ dz, int lddz,
+                                                                 int N, int H, int W, int Co, float* __restrict__ sums) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= Co) return;
+#pragma unroll
+    for (int line = 0; line < 4; ++line) {
+        double s = 0.0;
+        for (int k = 0; k < kBorderSegs; ++k) s += (double)part[((size_t)line * kBorderSegs + k) * Co + ch];
+        sums[(size_t)line * Co + ch] = (float)s;
+    }
+    double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        k00 += (double)dz[((size_t)(n * H + 0) * W + 0) * lddz + ch];         k01 += (double)dz[((size_t)(n * H + 0) * W + W - 1) * lddz + ch];
+        k10 += (double)dz[((size_t)(n * H + H - 1) * W + 0) * lddz + ch];     k11 += (double)dz[((size_t)(n * H + H - 1) * W + W - 1) * lddz + ch];
+    }
+    sums[(size_t)4 * Co + ch] = (float)k00; sums[(size_t)5 * Co + ch] = (float)k01;
+    sums[(size_t)6 * Co + ch] = (float)k10; sums[(size_t)7 * Co + ch] = (float)k11;
 }
 
 __global__ __launch_bounds__(256) void wgrad_fold_fix_kernel(float* __restrict__ dw, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -1494,17 +1509,21 @@ extern "C" int unet_winograd_weight_fold(const float* w, const float* bias, cons
 
 // Weight gradient of a layer whose input x was read as scale . r + shift (BatchNorm-apply on load): dw holds the kernel's result on the
 // RAW r (any wgrad kernel, HWIO layout); in place dw = scale[ci] * dw + shift[ci] * S[tap][co], S from the border sums of dz and
-// total = the column sums of dz (the bias gradient).  ws: 8 * Cout floats.
+// total = the column sums of dz (the bias gradient).
+extern "C" size_t unet_conv3x3_wgrad_fold_fix_workspace(int Cout) { return (size_t)(8 + 4 * kBorderSegs) * Cout * sizeof(float); }
 extern "C" int unet_conv3x3_wgrad_fold_fix(float* dw, const float* scale, const float* shift, const float* dz, int lddz, const float* total,
                                            int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(dw && scale && shift && dz && total && ws && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout % 4 == 0 && lddz >= Cout && lddz % 4 == 0);
     UNET_CHECK_ARG(unet_aligned16(dw) && unet_aligned16(dz));
-    if (ws_bytes < (size_t)8 * Cout * sizeof(float)) return UNET_ENOSPC;
+    if (ws_bytes < unet_conv3x3_wgrad_fold_fix_workspace(Cout)) return UNET_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
-    dz_border_sums_kernel<<<(unsigned)(4 * ((Cout + 63) / 64)), 256, 0, st>>>(dz, lddz, N, H, W, Cout, (float*)ws);
+    float* sums = (float*)ws; float* part = sums + (size_t)8 * Cout;
+    dz_border_sums_kernel<<<(unsigned)(4 * ((Cout + 63) / 64) * kBorderSegs), 256, 0, st>>>(dz, lddz, N, H, W, Cout, part);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    dz_border_finalize_kernel<<<(unsigned)((Cout + 255) / 256), 256, 0, st>>>(part, dz, lddz, N, H, W, Cout, sums);
+    rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     const long n4 = (long)9 * Cin * Cout / 4;
-    wgrad_fold_fix_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(dw, scale, shift, (const float*)ws, total, Cin, Cout);
+    wgrad_fold_fix_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(dw, scale, shift, sums, total, Cin, Cout);
     return UNET_LAUNCH_STATUS();
 }
 

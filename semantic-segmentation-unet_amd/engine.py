@@ -664,7 +664,7 @@ class Engine:
                 vw = self.view.get(name)
                 if vw is not None:
                     # x was read through BatchNorm-apply on load: dw (computed on the producer's raw conv output) -> scale . dw + shift (x) S
-                    nb3 = 8 * cout * 4
+                    nb3 = L.unet_conv3x3_wgrad_fold_fix_workspace(cout)
                     L.unet_conv3x3_wgrad_fold_fix(_p(dw), _p(vw[0]), _p(vw[1]), _p(dz), cout, _p(self.g[name + "/bias"]), n, ho, wo, cin, cout,
                                                   _p(self._workspace(nb3, sd)), nb3, st2)
             elif L.unet_conv3x3_mfma_supported(cin, cout) and cin % 64 == 0:

@@ -1039,8 +1039,8 @@ def test_winograd_batchnorm_apply_on_load_matches_two_passes(hip, shape):
         hip.unet_conv3x3_wgrad_winograd_fused(P(y), ldx, P(dz), co, P(dw_ref), n, h, w, ci, co, P(wsw), nbw, ST())
         hip.unet_conv3x3_wgrad_winograd_fused(P(r), ldx, P(dz), co, P(dw), n, h, w, ci, co, P(wsw), nbw, ST())
         total = dz.sum((0, 1, 2)).contiguous()
-        ws8 = ws_bytes(8 * co * 4)
-        hip.unet_conv3x3_wgrad_fold_fix(P(dw), P(sc), P(sh), P(dz), co, P(total), n, h, w, ci, co, P(ws8), 8 * co * 4, ST())
+        nb8 = hip.unet_conv3x3_wgrad_fold_fix_workspace(co); ws8 = ws_bytes(nb8)
+        hip.unet_conv3x3_wgrad_fold_fix(P(dw), P(sc), P(sh), P(dz), co, P(total), n, h, w, ci, co, P(ws8), nb8, ST())
         _, dw64, _ = on.conv_same_bwd(yref.transpose(0, 3, 1, 2), wt.double().cpu().numpy(), dz.double().cpu().numpy().transpose(0, 3, 1, 2))
         sw = np.abs(dw64).max()
         assert np.abs(dw_ref.cpu().numpy() - dw64).max() < 3e-5 * sw
