@@ -40,6 +40,7 @@ class DataParallel:
         self._trigger = {last: i for i, (_, _, last) in enumerate(self.buckets)}
         self._pending = []
         self.force = force            # tests: issue the collectives even with a single rank
+        self.trace = None             # tests / profiling: list of (bucket index, event recorded on the issuing stream right before its all-reduce)
         engine.on_layer_grads_ready = self._on_layer
         # every replica draws its OWN dropout masks (MirroredStrategy replicas do); the init seed stays common -- parameters are
         # broadcast from rank 0 anyway
@@ -63,6 +64,10 @@ class DataParallel:
         if i is None or (self.world_size == 1 and not self.force):
             return
         a, b, _ = self.buckets[i]
+        if self.trace is not None:
+            import torch
+            ev = torch.cuda.Event(enable_timing=True); ev.record()
+            self.trace.append((i, ev))
         self._pending.append(dist.all_reduce(self.engine.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish_step(self):

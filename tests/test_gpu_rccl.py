@@ -35,6 +35,25 @@ for cd in ("bf16", "fp32"):                                 # the mixed-precisio
         lb = b.train_step((img, lab, None, None), dropout_masks=masks).numpy()
         assert la == lb, (cd, la, lb)
     assert torch.equal(a.engine.theta, b.engine.theta)      # bit-identical: SUM over one rank is the identity
+# --- schedule at BASELINE config-2 size (512x512x1, batch 8): the bucket all-reduces are ISSUED from inside the backward pass, on the
+#     side stream, as each bucket's last weight gradient is enqueued -- in GPU-timeline order well before the last weight gradient
+#     finishes (whether RCCL's kernels then find CUs next to the persistent fp32 kernels cannot be seen with one rank: DESIGN.md 7)
+big = model.UNet(2, 8, 1, seed=1)
+big.parallel = par.DataParallel(big.engine, force=True)
+g = torch.Generator().manual_seed(0)
+im8 = torch.randn(8, 1, 512, 512, generator=g).cuda()
+lb8 = torch.nn.functional.one_hot(torch.randint(0, 2, (8, 512, 512), generator=g), 2).to(torch.int32).cuda()
+for _ in range(2):
+    big.train_step((im8, lb8, None, None))
+big.parallel.trace = []
+t0 = torch.cuda.Event(enable_timing=True); t0.record()
+big.train_step((im8, lb8, None, None))
+t1 = torch.cuda.Event(enable_timing=True); t1.record(); torch.cuda.synchronize()
+issued = [t0.elapsed_time(ev) for _, ev in big.parallel.trace]
+total = t0.elapsed_time(t1)
+assert len(issued) == len(big.parallel.buckets) >= 4 and issued == sorted(issued)
+assert issued[0] < 0.75 * total and issued[-1] - issued[0] > 0.15 * total, (issued, total)      # spread over the backward, not bunched at its end
+print("BUCKET_ISSUE_MS", [round(v, 2) for v in issued], "STEP_MS", round(total, 2))
 red = b._reduce_loss(b.parallel, b.train_step((img, lab, None, None), dropout_masks=masks))
 assert np.isfinite(red.numpy())
 b.parallel.average_moving_stats()
