@@ -147,12 +147,6 @@ int unet_convT2x2_dgrad(const float* dz, int lddz, const float* w, float* dx, in
 size_t unet_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_convT2x2_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-/* same result from the wide-tile persistent kernel (convt_stream.hip): W % 16 == 0, Cin % 128 == 0, Cout % 64 == 0; its own
- * workspace size (split partials [splits][2][2][Cout][Cin], summed in fixed order) */
-int unet_convT2x2_wgrad_wide_supported(int N, int H, int W, int Cin, int Cout);
-size_t unet_convT2x2_wgrad_wide_workspace(int N, int H, int W, int Cin, int Cout);
-int unet_convT2x2_wgrad_wide(const float* xin, int ldx, const float* dz, int lddz, float* dw,
-                             int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 
 /* bf16 matrix-core forms of the transposed-conv forward and data gradient (operands rounded to bf16, fp32 accumulation; Cin, Cout
  * multiples of 64).  Weights packed per step from the fp32 master kernel: mode 0 forward operand, mode 1 data-gradient operand.
@@ -167,15 +161,15 @@ int unet_convT2x2_bf16_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_convT2x2_bf16_packed_bytes(int Cin, int Cout);
 int unet_convT2x2_bf16_pack_weights(const float* w, void* packed, int Cin, int Cout, int mode, void* stream);
 int unet_convT2x2_bf16_stats_rows(int N, int H, int W, int Cin, int Cout, int dgrad);
-int unet_convT2x2_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
+int unet_convT2x2_fwd_bf16(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
                               int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream);
-int unet_convT2x2_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
+int unet_convT2x2_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
                                 int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr,
                                 float* stat_part, size_t stat_bytes, void* stream);
 /* weight gradient in the same arithmetic (additionally Cin % 128 == 0): dw[a,b,co,ci] = sum dz[n,2i+a,2j+b,co] * xin[n,i,j,ci] */
 int unet_convT2x2_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_convT2x2_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout);
-int unet_convT2x2_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+int unet_convT2x2_wgrad_bf16(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- BatchNormalization(axis=1), UNet/model.py:36,47 ------------------------------------------------------------- */

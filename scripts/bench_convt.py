@@ -27,7 +27,7 @@ for name, h, ci, co in [("up4", 32, 1024, 512), ("up3", 64, 512, 256), ("up2", 1
     if L.unet_convT2x2_fwd_stream_supported(B, h, h, ci, co) == 1:
         t3 = timeit(lambda: L.unet_convT2x2_fwd_stream(P(x), ci, P(w), P(b), P(out), co, B, h, h, ci, co, ST()))
         print("        fwd (stream kernel) %6.3f ms %6.1f TF" % (t3, fl / t3 / 1e9))
-    if L.unet_convT2x2_wgrad_wide_supported(B, h, h, ci, co) == 1:
+    if hasattr(L, 'unet_convT2x2_wgrad_wide') and L.unet_convT2x2_wgrad_wide_supported(B, h, h, ci, co) == 1:      # UNET_EXPERIMENTAL builds only
         nbw = L.unet_convT2x2_wgrad_wide_workspace(B, h, h, ci, co); wsw = torch.empty(nbw + 256, dtype=torch.uint8, device="cuda")
         t4 = timeit(lambda: L.unet_convT2x2_wgrad_wide(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(wsw), nbw, ST()))
         print("        wgrad (wide kernel) %6.3f ms %6.1f TF" % (t4, fl / t4 / 1e9))
@@ -35,12 +35,12 @@ for name, h, ci, co in [("up4", 32, 1024, 512), ("up3", 64, 512, 256), ("up2", 1
         nbp = L.unet_convT2x2_bf16_packed_bytes(ci, co)
         wp = torch.empty(nbp, dtype=torch.uint8, device="cuda"); wpd = torch.empty(nbp, dtype=torch.uint8, device="cuda")
         L.unet_convT2x2_bf16_pack_weights(P(w), P(wp), ci, co, 0, ST()); L.unet_convT2x2_bf16_pack_weights(P(w), P(wpd), ci, co, 1, ST())
-        t5 = timeit(lambda: L.unet_convT2x2_fwd_bf16_ex(P(x), ci, 0, P(wp), P(b), P(out), co, B, h, h, ci, co, None, 0, ST()))
-        t6 = timeit(lambda: L.unet_convT2x2_dgrad_bf16_ex(P(dz), co, 0, P(wpd), P(dx), ci, B, h, h, ci, co, None, 0, None, 0, ST()))
+        t5 = timeit(lambda: L.unet_convT2x2_fwd_bf16(P(x), ci, 0, P(wp), P(b), P(out), co, B, h, h, ci, co, None, 0, ST()))
+        t6 = timeit(lambda: L.unet_convT2x2_dgrad_bf16(P(dz), co, 0, P(wpd), P(dx), ci, B, h, h, ci, co, None, 0, None, 0, ST()))
         t7 = float("nan")
         if L.unet_convT2x2_wgrad_bf16_supported(B, h, h, ci, co) == 1:
             nbw2 = L.unet_convT2x2_wgrad_bf16_workspace(B, h, h, ci, co); wsw2 = torch.empty(nbw2 + 256, dtype=torch.uint8, device="cuda")
-            t7 = timeit(lambda: L.unet_convT2x2_wgrad_bf16_ex(P(x), ci, 0, P(dz), co, 0, P(dw), B, h, h, ci, co, P(wsw2), nbw2, ST()))
+            t7 = timeit(lambda: L.unet_convT2x2_wgrad_bf16(P(x), ci, 0, P(dz), co, 0, P(dw), B, h, h, ci, co, P(wsw2), nbw2, ST()))
         print("        bf16 kernels: fwd %6.3f ms %6.1f TF | dgrad %6.3f ms %6.1f TF | wgrad %6.3f ms %6.1f TF" % (t5, fl / t5 / 1e9, t6, fl / t6 / 1e9, t7, fl / t7 / 1e9))
     tot[0] += t0; tot[1] += t1; tot[2] += t2
     print("%-4s h%4d %4d->%4d  fwd %6.3f ms %6.1f TF | dgrad %6.3f ms %6.1f TF | wgrad %6.3f ms %6.1f TF" % (name, h, ci, co, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9), flush=True)

@@ -1264,7 +1264,7 @@ extern "C" int unet_convT2x2_bf16_stats_rows(int N, int H, int W, int Cin, int C
 }
 // z[n,2i+a,2j+b,co] = bias[co] + sum_ci x[n,i,j,ci] W[a,b,co,ci] (operands rounded to bf16, fp32 accumulation); H, W: input size;
 // x_bf16: x stored as bf16; stat_part nullable: BatchNorm sums of z, [Cout/64][rows][64][2]
-extern "C" int unet_convT2x2_fwd_bf16_ex(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
+extern "C" int unet_convT2x2_fwd_bf16(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
                                          int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(x && wp && out && unet_convT2x2_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && (!x_bf16 || ldx % 8 == 0) && unet_aligned16(x) && unet_aligned16(wp));
@@ -1273,7 +1273,7 @@ extern "C" int unet_convT2x2_fwd_bf16_ex(const void* x, int ldx, int x_bf16, con
 }
 // dx[n,i,j,ci] = sum_{a,b,co} dz[n,2i+a,2j+b,co] W[a,b,co,ci]; r_prev / stat_part nullable: BatchNorm-backward sums (sum dx, sum dx * r_prev)
 // of the layer that produced x (all Cin channels), [Cin/64][rows][64][2]
-extern "C" int unet_convT2x2_dgrad_bf16_ex(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
+extern "C" int unet_convT2x2_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
                                            int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr,
                                            float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(dz && wpd && dx && unet_convT2x2_bf16_supported(N, H, W, Cin, Cout));
@@ -1481,7 +1481,7 @@ extern "C" size_t unet_convT2x2_wgrad_bf16_workspace(int N, int H, int W, int Ci
     return a.splits > 1 ? (size_t)a.splits * 4 * Cout * Cin * sizeof(float) : 16;
 }
 // dw[a,b,co,ci] = sum_{n,i,j} dz[n,2i+a,2j+b,co] * xin[n,i,j,ci], operands rounded to bf16 (or stored as bf16), fp32 accumulation
-extern "C" int unet_convT2x2_wgrad_bf16_ex(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+extern "C" int unet_convT2x2_wgrad_bf16(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
                                            int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(xin && dz && dw && ws && unet_convT2x2_wgrad_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && (!x_bf16 || ldx % 8 == 0) && (!dz_bf16 || lddz % 8 == 0));

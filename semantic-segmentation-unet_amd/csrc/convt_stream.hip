@@ -489,6 +489,8 @@ int convt_wg_splits(int N, int H, int W, int Cin, int Cout) {
 
 }  // namespace
 
+#ifdef UNET_EXPERIMENTAL      /* wide-tile transposed-conv weight gradient: 22 % faster alone, no faster inside the step (it cannot share a CU with the
+                                 data-gradient stream); kept for A/B builds, not part of include/unet_hip.h */
 extern "C" int unet_convT2x2_wgrad_wide_supported(int N, int H, int W, int Cin, int Cout) {
     return (N > 0 && H > 0 && W > 0 && W % 16 == 0 && Cin % 128 == 0 && Cout % 64 == 0 &&
             (long)2 * W * 4096 * 4 < (1L << 31)) ? 1 : 0;
@@ -524,3 +526,4 @@ extern "C" int unet_convT2x2_wgrad_wide(const float* xin, int ldx, const float* 
     convt_wgrad_reduce_kernel<<<(unsigned)blocks, 256, 0, st>>>((const float*)ws, dw, n4, a.splits, sl);
     return UNET_LAUNCH_STATUS();
 }
+#endif  // UNET_EXPERIMENTAL

@@ -157,7 +157,6 @@ class Engine:
         self.fuse_bn_stats = os.environ.get("UNET_FUSE_BN_STATS", "1") != "0"      # BN sums from the conv epilogue (A/B switch)
         self.bnbwd_part = {}
         self.fuse_pool = os.environ.get("UNET_FUSE_POOL", "1") != "0"             # BN apply + max pool in one pass (A/B switch)
-        self.convt_wgrad_wide = os.environ.get("UNET_CONVT_WGRAD_WIDE", "0") == "1"  # wide-tile kernel: 22% faster alone, no gain next to the dgrad stream
         # contraction precision of the wide 3x3 layers: "fp32" (the reference's arithmetic) or "bf16" (BASELINE config 4: bf16
         # forward/backward on fp32 master weights -- operands rounded to bf16, fp32 accumulation, everything else fp32)
         self.compute_dtype = os.environ.get("UNET_COMPUTE_DTYPE", "fp32")
@@ -370,7 +369,7 @@ class Engine:
             if self._use_bf16_convt(name, n, h, w):
                 rows = L.unet_convT2x2_bf16_stats_rows(n, h, w, cin, cout, 0) if (training and self.fuse_bn_stats) else 0
                 stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
-                L.unet_convT2x2_fwd_bf16_ex(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
+                L.unet_convT2x2_fwd_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
                                             n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:
                     fused_stats = (stat_part, rows)
@@ -639,15 +638,11 @@ class Engine:
             st2 = self._stream()
             if kind == "deconv" and self._use_bf16_convt(name, n, hi, wi) and L.unet_convT2x2_wgrad_bf16_supported(n, hi, wi, cin, cout) == 1:
                 nb2 = L.unet_convT2x2_wgrad_bf16_workspace(n, hi, wi, cin, cout)
-                L.unet_convT2x2_wgrad_bf16_ex(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw),
+                L.unet_convT2x2_wgrad_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw),
                                               n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "deconv":
-                if self.convt_wgrad_wide and L.unet_convT2x2_wgrad_wide_supported(n, hi, wi, cin, cout) == 1:
-                    nb2 = L.unet_convT2x2_wgrad_wide_workspace(n, hi, wi, cin, cout)
-                    L.unet_convT2x2_wgrad_wide(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
-                else:
-                    nb2 = L.unet_convT2x2_wgrad_workspace(n, hi, wi, cin, cout)
-                    L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                nb2 = L.unet_convT2x2_wgrad_workspace(n, hi, wi, cin, cout)
+                L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
                 L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
@@ -691,7 +686,7 @@ class Engine:
                 rows = L.unet_convT2x2_bf16_stats_rows(n, hi, wi, cin, cout, 1) if prod else 0
                 r_prev = self.saved[prod[0]][1] if rows > 0 else None
                 part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,)) if rows > 0 else None
-                L.unet_convT2x2_dgrad_bf16_ex(_p(dz), cout, int(dz.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[1]), _p(dx), cin,
+                L.unet_convT2x2_dgrad_bf16(_p(dz), cout, int(dz.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[1]), _p(dx), cin,
                                               n, hi, wi, cin, cout, _p(r_prev), _ld(r_prev) if rows > 0 else 0,
                                               _p(part), part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:

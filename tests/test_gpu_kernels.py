@@ -149,39 +149,6 @@ def test_convT2x2_fwd_dgrad_wgrad(hip, shape):
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(1, 2, 16, 128, 64), (2, 3, 32, 128, 128), (1, 5, 48, 256, 192), (3, 1, 16, 384, 256),
-                                   (8, 32, 32, 1024, 512), (8, 256, 256, 128, 64)])
-def test_convT2x2_wgrad_wide_matches_first_kernel_and_oracle(hip, shape):
-    # wide-tile persistent weight-gradient kernel: fp64 oracle on the small shapes (1..12 tiles per workgroup, odd tile
-    # counts, both channel-tile widths, padded leading dimensions); the two BASELINE config-2 layers (up_4, up_1) against
-    # the first kernel
-    n, h, w, ci, co = shape
-    assert hip.unet_convT2x2_wgrad_wide_supported(n, h, w, ci, co) == 1
-    g = torch.Generator(device=DEV); g.manual_seed(ci + co + h)
-    x = torch.randn(n, h, w, ci + 8, device=DEV, generator=g)[..., :ci]
-    dz = torch.randn(n, 2 * h, 2 * w, co + 4, device=DEV, generator=g)[..., :co]
-    nb = hip.unet_convT2x2_wgrad_wide_workspace(n, h, w, ci, co)
-    ws = ws_bytes(nb)
-    dw = torch.full((2, 2, co, ci), float("nan"), device=DEV)
-    hip.unet_convT2x2_wgrad_wide(P(x), ci + 8, P(dz), co + 4, P(dw), n, h, w, ci, co, P(ws), nb, ST())
-    nb0 = hip.unet_convT2x2_wgrad_workspace(n, h, w, ci, co)
-    ws0 = ws_bytes(nb0)
-    dw0 = torch.empty(2, 2, co, ci, device=DEV)
-    hip.unet_convT2x2_wgrad(P(x), ci + 8, P(dz), co + 4, P(dw0), n, h, w, ci, co, P(ws0), nb0, ST())
-    assert relerr(dw.cpu().numpy().astype(np.float64), dw0.cpu().numpy().astype(np.float64)) < 2e-5
-    if n * h * w <= 512:
-        xr = x.permute(0, 3, 1, 2).cpu().numpy().astype(np.float64)
-        dzr = dz.permute(0, 3, 1, 2).cpu().numpy().astype(np.float64)
-        _, dw_ref, _ = on.deconv2x2_bwd(xr, np.zeros((2, 2, co, ci)), dzr)
-        assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 2e-5
-    # run-to-run determinism (fixed split order)
-    dw2 = torch.empty_like(dw)
-    hip.unet_convT2x2_wgrad_wide(P(x), ci + 8, P(dz), co + 4, P(dw2), n, h, w, ci, co, P(ws), nb, ST())
-    assert torch.equal(dw, dw2)
-    assert hip.unet_convT2x2_wgrad_wide_supported(n, h, w + 1, ci, co) == 0
-    assert hip.unet_convT2x2_wgrad_wide_supported(n, h, w, ci + 64, co) == 0
-
-
 @pytest.mark.parametrize("shape", [(2, 8, 16, 128, 128), (1, 16, 16, 64, 64), (4, 8, 16, 32, 192), (8, 32, 32, 1024, 512), (8, 256, 256, 128, 64)])
 def test_convT2x2_fwd_stream_matches_igemm_and_oracle(hip, shape):
     # persistent stream kernel for the transposed-conv forward: bit-level agreement is not expected (different summation
@@ -802,7 +769,7 @@ def test_convT2x2_bf16_fwd_dgrad_match_oracle_on_rounded_operands(hip, shape):
     outv = cat[..., co:]                                               # the upper half of a concat buffer
     rows = hip.unet_convT2x2_bf16_stats_rows(n, h, w, ci, co, 0)
     part = torch.full(((co // 64) * rows * 128,), float("nan"), device=DEV)
-    hip.unet_convT2x2_fwd_bf16_ex(P(xv), ci + 8, 0, P(wp), P(bd), P(outv), 2 * co, n, h, w, ci, co, P(part), part.numel() * 4, ST())
+    hip.unet_convT2x2_fwd_bf16(P(xv), ci + 8, 0, P(wp), P(bd), P(outv), 2 * co, n, h, w, ci, co, P(part), part.numel() * 4, ST())
     z = from_nhwc(outv)
     assert relerr(z, z_ref) < 2e-5
     assert torch.isnan(cat[..., :co]).all()
@@ -811,17 +778,17 @@ def test_convT2x2_bf16_fwd_dgrad_match_oracle_on_rounded_operands(hip, shape):
     assert (pv[:, 0] - s1).abs().max().item() < 1e-4 * s1.abs().max().item() + 1e-3
     assert (pv[:, 1] - s2).abs().max().item() < 1e-4 * s2.abs().max().item()
     out2 = torch.empty(n, 2 * h, 2 * w, co, device=DEV)
-    hip.unet_convT2x2_fwd_bf16_ex(P(xv.contiguous().to(torch.bfloat16)), ci, 1, P(wp), P(bd), P(out2), co, n, h, w, ci, co, None, 0, ST())
+    hip.unet_convT2x2_fwd_bf16(P(xv.contiguous().to(torch.bfloat16)), ci, 1, P(wp), P(bd), P(out2), co, n, h, w, ci, co, None, 0, ST())
     assert torch.equal(out2, outv.contiguous())
     # data gradient (+ the producer's BatchNorm-backward sums)
     dx = torch.empty(n, h, w, ci, device=DEV); dx2 = torch.empty_like(dx)
-    hip.unet_convT2x2_dgrad_bf16_ex(P(dzd), co, 0, P(wpd), P(dx), ci, n, h, w, ci, co, None, 0, None, 0, ST())
+    hip.unet_convT2x2_dgrad_bf16(P(dzd), co, 0, P(wpd), P(dx), ci, n, h, w, ci, co, None, 0, None, 0, ST())
     assert relerr(from_nhwc(dx), dx_ref) < 2e-5
     g = torch.Generator(device=DEV); g.manual_seed(1)
     r_prev = torch.randn(n, h, w, ci, device=DEV, generator=g)
     rows2 = hip.unet_convT2x2_bf16_stats_rows(n, h, w, ci, co, 1)
     part2 = torch.full(((ci // 64) * rows2 * 128,), float("nan"), device=DEV)
-    hip.unet_convT2x2_dgrad_bf16_ex(P(dzd.to(torch.bfloat16)), co, 1, P(wpd), P(dx2), ci, n, h, w, ci, co, P(r_prev), ci, P(part2), part2.numel() * 4, ST())
+    hip.unet_convT2x2_dgrad_bf16(P(dzd.to(torch.bfloat16)), co, 1, P(wpd), P(dx2), ci, n, h, w, ci, co, P(r_prev), ci, P(part2), part2.numel() * 4, ST())
     assert torch.equal(dx, dx2)
     pv2 = part2.view(ci // 64, rows2, 64, 2).double().sum(1).view(ci, 2)
     t1 = dx.double().sum((0, 1, 2)); t2 = (dx.double() * r_prev.double()).sum((0, 1, 2))
@@ -848,7 +815,7 @@ def test_convT2x2_bf16_wgrad_matches_oracle_on_rounded_operands(hip, shape):
     for xa, lx, xf, za, lz, zf in ((xv, ci + 8, 0, dzv, co + 8, 0), (xv, ci + 8, 0, dzv, co + 8, 0),
                                    (xv.contiguous().to(torch.bfloat16), ci, 1, dzv.contiguous().to(torch.bfloat16), co, 1)):
         dw = torch.full((2, 2, co, ci), float("nan"), device=DEV)
-        hip.unet_convT2x2_wgrad_bf16_ex(P(xa), lx, xf, P(za), lz, zf, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+        hip.unet_convT2x2_wgrad_bf16(P(xa), lx, xf, P(za), lz, zf, P(dw), n, h, w, ci, co, P(ws), nb, ST())
         outs.append(dw)
     assert relerr(outs[0].cpu().numpy().astype(np.float64), dw_ref) < 2e-5
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

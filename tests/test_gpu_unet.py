@@ -481,3 +481,31 @@ def test_clipped_probability_cross_entropy_mode_matches_oracle():
     assert abs(e.loss_buf[0].item() - loss_ref) < 1e-5 * abs(loss_ref)
     errs = grad_errors(e.export_gradients(), g_ref)
     assert max(errs.values()) < 5e-2 and errs["logits/kernel"] < 5e-5, errs
+
+
+def test_full_size_tile_matches_torch_restatement():
+    # The oracle on a FULL-SIZE tile of BASELINE config 2 (512x512x1, 2 classes; one image -- the torch fp64 restatement needs ~10 s
+    # of host time): eval-mode softmax + argmax mask, training loss, and the gradients nearest the loss tightly, all others to the
+    # branch-decision bound of test_unet_matches_numpy_oracle.  (The per-kernel tiling / persistence logic sees its real launch
+    # shapes here: 4096-tile grids, 17 persistent Winograd launches, the BatchNorm-apply-on-load route.)
+    n, c, k, hw = 1, 1, 2, 512
+    img, lab, prm, masks = make_case(53, n, c, k, hw)
+    model = pkg("model")
+    net = model.UNet(k, n, c)
+    net.engine.load_parameters(prm)
+    ref = ot.TorchUNet(k, n, c, params=prm, dtype=torch.float64)
+    sm = net.get_keras_model()(img)
+    with torch.no_grad():
+        sm_ref = ref.forward(img, False)[0].numpy()
+    assert np.abs(sm - sm_ref).max() < 5e-5
+    ok, undecided, differ = argmax_agreement(sm, sm_ref)
+    assert ok, (undecided, differ)
+    e = net.engine
+    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+    e.backward()
+    loss_ref, _, g_ref, _ = ref.loss_and_grads(img, lab, masks)
+    assert abs(e.loss_buf[0].item() - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    errs = grad_errors(e.export_gradients(), {k2: v.numpy() for k2, v in g_ref.items()})
+    worst = max((v, key) for key, v in errs.items())
+    assert worst[0] < 5e-2, worst
+    assert errs["logits/kernel"] < 5e-5 and errs["dec_1b/gamma"] < 5e-5, errs
