@@ -150,7 +150,7 @@ int unet_convT2x2_wgrad(const float* xin, int ldx, const float* dz, int lddz, fl
 
 /* bf16 matrix-core forms of the transposed-conv forward and data gradient (operands rounded to bf16, fp32 accumulation; Cin, Cout
  * multiples of 64).  Weights packed per step from the fp32 master kernel: mode 0 forward operand, mode 1 data-gradient operand.
- * x_bf16 / dz_bf16: that tensor is stored as bf16.  stat_part nullable: forward -- BatchNorm sums of the output, rows =
+ * x_bf16 / dz_bf16 / out_bf16 / dx_bf16 / r_bf16: that tensor is stored as bf16.  stat_part nullable: forward -- BatchNorm sums of the output, rows =
  * unet_convT2x2_bf16_stats_rows(..., 0) (one per input-pixel tile and tap); data gradient -- with r_prev, the BatchNorm-backward
  * sums (sum dx, sum dx * r_prev) of the layer that produced x, rows = unet_convT2x2_bf16_stats_rows(..., 1). */
 /* every pack of a step in one launch: jobs[njobs][6] int64 = {fp32 kernel, forward operand, data-gradient operand,
@@ -161,11 +161,11 @@ int unet_convT2x2_bf16_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_convT2x2_bf16_packed_bytes(int Cin, int Cout);
 int unet_convT2x2_bf16_pack_weights(const float* w, void* packed, int Cin, int Cout, int mode, void* stream);
 int unet_convT2x2_bf16_stats_rows(int N, int H, int W, int Cin, int Cout, int dgrad);
-int unet_convT2x2_fwd_bf16(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
-                              int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream);
-int unet_convT2x2_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
-                                int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr,
-                                float* stat_part, size_t stat_bytes, void* stream);
+int unet_convT2x2_fwd_bf16(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, void* out, int ldo, int out_bf16,
+                           int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream);
+int unet_convT2x2_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
+                             int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16,
+                             float* stat_part, size_t stat_bytes, void* stream);
 /* weight gradient in the same arithmetic (additionally Cin % 128 == 0): dw[a,b,co,ci] = sum dz[n,2i+a,2j+b,co] * xin[n,i,j,ci] */
 int unet_convT2x2_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_convT2x2_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout);

@@ -35,8 +35,8 @@ for name, h, ci, co in [("up4", 32, 1024, 512), ("up3", 64, 512, 256), ("up2", 1
         nbp = L.unet_convT2x2_bf16_packed_bytes(ci, co)
         wp = torch.empty(nbp, dtype=torch.uint8, device="cuda"); wpd = torch.empty(nbp, dtype=torch.uint8, device="cuda")
         L.unet_convT2x2_bf16_pack_weights(P(w), P(wp), ci, co, 0, ST()); L.unet_convT2x2_bf16_pack_weights(P(w), P(wpd), ci, co, 1, ST())
-        t5 = timeit(lambda: L.unet_convT2x2_fwd_bf16(P(x), ci, 0, P(wp), P(b), P(out), co, B, h, h, ci, co, None, 0, ST()))
-        t6 = timeit(lambda: L.unet_convT2x2_dgrad_bf16(P(dz), co, 0, P(wpd), P(dx), ci, B, h, h, ci, co, None, 0, None, 0, ST()))
+        t5 = timeit(lambda: L.unet_convT2x2_fwd_bf16(P(x), ci, 0, P(wp), P(b), P(out), co, 0, B, h, h, ci, co, None, 0, ST()))
+        t6 = timeit(lambda: L.unet_convT2x2_dgrad_bf16(P(dz), co, 0, P(wpd), P(dx), ci, 0, B, h, h, ci, co, None, 0, 0, None, 0, ST()))
         t7 = float("nan")
         if L.unet_convT2x2_wgrad_bf16_supported(B, h, h, ci, co) == 1:
             nbw2 = L.unet_convT2x2_wgrad_bf16_workspace(B, h, h, ci, co); wsw2 = torch.empty(nbw2 + 256, dtype=torch.uint8, device="cuda")

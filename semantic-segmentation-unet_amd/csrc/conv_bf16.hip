@@ -985,6 +985,7 @@ struct ConvtBf16Args {
     unsigned x_bytes; int in16;
     float* stat_part;
     const float* bn_r; int bn_ldr;               // MODE 2 + STATS 2: the producer's saved activation (all Ncol channels)
+    int out16, r16;                              // the output / the producer's saved activation is stored as bf16 (ldo / bn_ldr in elements)
 };
 
 constexpr int kCtXP = 2 * 2 * 512 * 16;             // [k-step][k half][pixel][8] bf16
@@ -1117,19 +1118,29 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
     // epilogue.  Forward: column n = tap * Cout + co -> output pixel (2 y + a, 2 x + b); gradient: plain [pixel][ci].
+    // A lane holds ONE channel (cb + li) of 16 pixels per row.  fp32 output: one 4-byte store per element.  bf16 output (out16): lanes
+    // 2j and 2j+1 exchange one value per pixel pair (DPP quad_perm swap) so that the even lane stores channels (2j, 2j+1) of the even
+    // pixel and the odd lane the same channel pair of the odd pixel -- 4-byte stores again, half as many.  The producer's saved
+    // activation (STATS 2) of a sub-tile is loaded for all four rows before the arithmetic (one exposed latency per sub-tile, not
+    // four); stored as bf16 (r16) a lane reads the dword holding its channel pair and keeps its half.
     float st1[NCO], st2[NCO];
     const int oH = MODE == 1 ? 2 * p.H : p.H, oW = MODE == 1 ? 2 * p.W : p.W, pstep = MODE == 1 ? 2 : 1;
-    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.N * oH * oW * p.ldo * 4), 0x00020000);
+    const int oes = p.out16 ? 2 : 4, res = p.r16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.N * oH * oW * p.ldo * oes), 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? p.bn_r : p.out), 0,
-                                                                            STATS == 2 ? (int)((size_t)p.N * p.H * p.W * p.bn_ldr * 4) : 0, 0x00020000);
+                                                                            STATS == 2 ? (int)((size_t)p.N * p.H * p.W * p.bn_ldr * res) : 0, 0x00020000);
+    const int lpar = li & 1;
     int ovoff[16], rvoff[16];
     bool colok[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int col = (e & 3) + 8 * (e >> 2) + 4 * lh;
         colok[e] = tx0 + col < p.W;
-        ovoff[e] = colok[e] ? (pstep * col * p.ldo + li) * 4 : (int)0x80000000;
-        rvoff[e] = (STATS == 2 && colok[e]) ? (col * p.bn_ldr + li) * 4 : (int)0x80000000;
+        // out16: the store of pixel pair (e & ~1, e | 1) is issued at the even e by every lane; even lanes write the even pixel, odd lanes the odd one
+        const int colp = (e & ~1) + lpar, colq = (colp & 3) + 8 * (colp >> 2) + 4 * lh;
+        if (p.out16) ovoff[e] = (tx0 + colq < p.W) ? (pstep * colq * p.ldo + (li & ~1)) * 2 : (int)0x80000000;
+        else         ovoff[e] = colok[e] ? (pstep * col * p.ldo + li) * 4 : (int)0x80000000;
+        rvoff[e] = (STATS == 2 && colok[e]) ? (p.r16 ? (col * p.bn_ldr + (li & ~1)) * 2 : (col * p.bn_ldr + li) * 4) : (int)0x80000000;
     }
 #pragma unroll
     for (int c = 0; c < NCO; ++c) {
@@ -1137,27 +1148,47 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
         const int tap = MODE == 1 ? nb / p.Cout : 0, cb = MODE == 1 ? nb % p.Cout : nb;
         const float bv = (MODE == 1 && p.bias) ? p.bias[cb + li] : 0.f;
         st1[c] = 0.f; st2[c] = 0.f;
+        unsigned rvh[4][16];
+        if (STATS == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gy = ty0 + 4 * wv + r;
+                const int sr = (((img * p.H + (gy < p.H ? gy : 0)) * p.W + tx0) * p.bn_ldr + cb) * res;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rvh[r][e] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, gy < p.H ? rvoff[e] : (int)0x80000000, sr, 0);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gy = ty0 + 4 * wv + r;
             if (gy >= p.H) continue;
             const int opix = MODE == 1 ? ((img * oH + 2 * gy + (tap >> 1)) * oW + 2 * tx0 + (tap & 1)) : ((img * p.H + gy) * p.W + tx0);
-            const int so = (opix * p.ldo + cb) * 4;
-            float rv[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) rv[e] = 0.f;
-            if (STATS == 2) {
-                const int sr = (((img * p.H + gy) * p.W + tx0) * p.bn_ldr + cb) * 4;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, rvoff[e], sr, 0));
-            }
+            const int so = (opix * p.ldo + cb) * oes;
+            float vv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v;
                 asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[r][c][e]));
                 v += bv;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd_o, ovoff[e], so, 0);
-                if (STATS != 0 && colok[e]) { st1[c] += v; st2[c] += STATS == 1 ? v * v : v * rv[e]; }
+                vv[e] = v;
+                if (STATS != 0 && colok[e]) {
+                    float rv = 0.f;
+                    if (STATS == 2) rv = p.r16 ? __builtin_bit_cast(float, lpar ? (rvh[r][e] & 0xffff0000u) : (rvh[r][e] << 16)) : __builtin_bit_cast(float, rvh[r][e]);
+                    st1[c] += v; st2[c] += STATS == 1 ? v * v : v * rv;
+                }
+            }
+            if (p.out16) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    // even lane keeps pixel e and receives its neighbour's value of pixel e; odd lane keeps pixel e+1 and receives pixel e+1
+                    const float send = lpar ? vv[e] : vv[e + 1];
+                    const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
+                    const unsigned pk = lpar ? cb_pack2(recv, vv[e + 1]) : cb_pack2(vv[e], recv);
+                    __builtin_amdgcn_raw_buffer_store_b32(pk, srd_o, ovoff[e], so, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[e]), srd_o, ovoff[e], so, 0);
             }
         }
     }
@@ -1216,8 +1247,10 @@ __global__ void convt_bf16_pack_kernel(const float* __restrict__ w, uint16_t* __
 }
 
 int run_convt_bf16(int mode, const void* x, int ldx, int in16, const void* wp, const float* bias, float* out, int ldo,
-                   int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, const float* r_prev, int ldr, hipStream_t st) {
+                   int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, const float* r_prev, int ldr, hipStream_t st,
+                   int out16 = 0, int r16 = 0) {
     ConvtBf16Args a{};
+    a.out16 = out16; a.r16 = r16;
     a.x = (const float*)x; a.wp = (const uint16_t*)wp; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.in16 = in16;
     a.K = mode == 1 ? Cin : 4 * Cout; a.Ncol = mode == 1 ? 4 * Cout : Cin;
@@ -1263,24 +1296,28 @@ extern "C" int unet_convT2x2_bf16_stats_rows(int N, int H, int W, int Cin, int C
     return (dgrad ? 1 : 4) * N * ((H + 15) / 16) * ((W + 31) / 32);
 }
 // z[n,2i+a,2j+b,co] = bias[co] + sum_ci x[n,i,j,ci] W[a,b,co,ci] (operands rounded to bf16, fp32 accumulation); H, W: input size;
-// x_bf16: x stored as bf16; stat_part nullable: BatchNorm sums of z, [Cout/64][rows][64][2]
-extern "C" int unet_convT2x2_fwd_bf16(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, float* out, int ldo,
+// x_bf16 / out_bf16: x / the output stored as bf16 (leading dimensions in elements; ldo even); stat_part nullable: BatchNorm sums of
+// z (taken before the rounding of a bf16 output), [Cout/64][rows][64][2]
+extern "C" int unet_convT2x2_fwd_bf16(const void* x, int ldx, int x_bf16, const void* wp, const float* bias, void* out, int ldo, int out_bf16,
                                          int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream) {
-    UNET_CHECK_ARG(x && wp && out && unet_convT2x2_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(x && wp && out && unet_convT2x2_bf16_supported(N, H, W, Cin, Cout) && (!out_bf16 || (ldo % 2 == 0 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0)));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && (!x_bf16 || ldx % 8 == 0) && unet_aligned16(x) && unet_aligned16(wp));
     UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * 4 * ldo * 4 < ((size_t)1 << 31));
-    return run_convt_bf16(1, x, ldx, x_bf16 ? 1 : 0, wp, bias, out, ldo, N, H, W, Cin, Cout, stat_part, stat_bytes, nullptr, 0, (hipStream_t)stream);
+    return run_convt_bf16(1, x, ldx, x_bf16 ? 1 : 0, wp, bias, (float*)out, ldo, N, H, W, Cin, Cout, stat_part, stat_bytes, nullptr, 0, (hipStream_t)stream, out_bf16 ? 1 : 0, 0);
 }
 // dx[n,i,j,ci] = sum_{a,b,co} dz[n,2i+a,2j+b,co] W[a,b,co,ci]; r_prev / stat_part nullable: BatchNorm-backward sums (sum dx, sum dx * r_prev)
 // of the layer that produced x (all Cin channels), [Cin/64][rows][64][2]
-extern "C" int unet_convT2x2_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, float* dx, int lddx,
-                                           int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr,
+// dx_bf16 / r_bf16: dx / r_prev stored as bf16
+extern "C" int unet_convT2x2_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
+                                           int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16,
                                            float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(dz && wpd && dx && unet_convT2x2_bf16_supported(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG((!dx_bf16 || (lddx % 2 == 0 && (reinterpret_cast<uintptr_t>(dx) & 3u) == 0)) && (!r_bf16 || (ldr % 2 == 0 && (reinterpret_cast<uintptr_t>(r_prev) & 3u) == 0)));
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && (!dz_bf16 || lddz % 8 == 0) && unet_aligned16(dz) && unet_aligned16(wpd));
     UNET_CHECK_ARG((r_prev == nullptr) == (stat_part == nullptr) && (!r_prev || ldr >= Cin));
     UNET_CHECK_ARG((size_t)N * H * W * 4 * lddz * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddx * 4 < ((size_t)1 << 31));
-    return run_convt_bf16(2, dz, lddz, dz_bf16 ? 1 : 0, wpd, nullptr, dx, lddx, N, H, W, Cin, Cout, stat_part, stat_bytes, r_prev, ldr, (hipStream_t)stream);
+    return run_convt_bf16(2, dz, lddz, dz_bf16 ? 1 : 0, wpd, nullptr, (float*)dx, lddx, N, H, W, Cin, Cout, stat_part, stat_bytes, (const float*)r_prev, ldr, (hipStream_t)stream,
+                          dx_bf16 ? 1 : 0, r_bf16 ? 1 : 0);
 }
 
 // ---- transposed-conv weight gradient on the bf16 matrix cores -------------------------------------------------------------------

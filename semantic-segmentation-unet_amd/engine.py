@@ -369,8 +369,10 @@ class Engine:
             if self._use_bf16_convt(name, n, h, w):
                 rows = L.unet_convT2x2_bf16_stats_rows(n, h, w, cin, cout, 0) if (training and self.fuse_bn_stats) else 0
                 stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
+                if self.bf16_activations and self.bf16_storage and rows > 0 and r_out is None and self._dz16_shape(name, n, h, w):
+                    r = self._buf("r16_" + name, (n, 2 * h, 2 * w, cout), torch.bfloat16)
                 L.unet_convT2x2_fwd_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
-                                            n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+                                         int(r.dtype == torch.bfloat16), n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:
                     fused_stats = (stat_part, rows)
             elif L.unet_convT2x2_fwd_stream_supported(n, h, w, cin, cout) == 1 and _ld(x) <= 4096:           # persistent stream kernel
@@ -392,8 +394,7 @@ class Engine:
             if self._use_bf16(name, n, h, w):
                 rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
                 stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
-                # (dec_2b..4b: their saved activation is read by the transposed-conv data gradient's epilogue, which takes fp32)
-                if self.bf16_activations and self.bf16_storage and rows > 0 and name not in ("dec_2b", "dec_3b", "dec_4b") and r_out is None:
+                if self.bf16_activations and self.bf16_storage and rows > 0 and r_out is None:
                     r = self._buf("r16_" + name, (n, h, w, cout), torch.bfloat16)
                 self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), None, None, _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
@@ -686,9 +687,12 @@ class Engine:
                 rows = L.unet_convT2x2_bf16_stats_rows(n, hi, wi, cin, cout, 1) if prod else 0
                 r_prev = self.saved[prod[0]][1] if rows > 0 else None
                 part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,)) if rows > 0 else None
+                # dx is the dy of the producer (dec_(N+1)b): bf16 when that layer's BatchNorm backward takes bf16 dy
+                if rows > 0 and self.bf16_activations and self.bf16_storage and not eval_mode and self._dz16(prod[0], True, eval_mode):
+                    dx = self._buf("dy16_in_" + name, (n, hi, wi, cin), torch.bfloat16)
                 L.unet_convT2x2_dgrad_bf16(_p(dz), cout, int(dz.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[1]), _p(dx), cin,
-                                              n, hi, wi, cin, cout, _p(r_prev), _ld(r_prev) if rows > 0 else 0,
-                                              _p(part), part.numel() * 4 if rows > 0 else 0, st)
+                                           int(dx.dtype == torch.bfloat16), n, hi, wi, cin, cout, _p(r_prev), _ld(r_prev) if rows > 0 else 0,
+                                           int(rows > 0 and r_prev.dtype == torch.bfloat16), _p(part), part.numel() * 4 if rows > 0 else 0, st)
                 if rows > 0:
                     self.bnbwd_part[prod[0]] = (part, rows, 0)
             elif kind == "deconv":
@@ -751,6 +755,11 @@ class Engine:
             return (self._use_bf16_convt(name, n, x.shape[1], x.shape[2])
                     and L.unet_convT2x2_wgrad_bf16_supported(n, x.shape[1], x.shape[2], cin, cout) == 1)
         return False
+
+    def _dz16_shape(self, name, n, h, w):
+        """(transposed conv, input size h x w) its BatchNorm backward will take the bf16-capable entry point"""
+        return (self.compute_dtype == "bf16" and self.bf16_storage and self._use_bf16_convt(name, n, h, w)
+                and self.L.unet_convT2x2_wgrad_bf16_supported(n, h, w, self.cin[name], self.cout[name]) == 1)
 
     def _dx16(self, name, eval_mode):
         """the 3x3 layer's data gradient may be WRITTEN as bf16: every reader of it is a BatchNorm backward that takes bf16 dy"""

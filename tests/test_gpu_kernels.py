@@ -769,7 +769,7 @@ def test_convT2x2_bf16_fwd_dgrad_match_oracle_on_rounded_operands(hip, shape):
     outv = cat[..., co:]                                               # the upper half of a concat buffer
     rows = hip.unet_convT2x2_bf16_stats_rows(n, h, w, ci, co, 0)
     part = torch.full(((co // 64) * rows * 128,), float("nan"), device=DEV)
-    hip.unet_convT2x2_fwd_bf16(P(xv), ci + 8, 0, P(wp), P(bd), P(outv), 2 * co, n, h, w, ci, co, P(part), part.numel() * 4, ST())
+    hip.unet_convT2x2_fwd_bf16(P(xv), ci + 8, 0, P(wp), P(bd), P(outv), 2 * co, 0, n, h, w, ci, co, P(part), part.numel() * 4, ST())
     z = from_nhwc(outv)
     assert relerr(z, z_ref) < 2e-5
     assert torch.isnan(cat[..., :co]).all()
@@ -778,22 +778,34 @@ def test_convT2x2_bf16_fwd_dgrad_match_oracle_on_rounded_operands(hip, shape):
     assert (pv[:, 0] - s1).abs().max().item() < 1e-4 * s1.abs().max().item() + 1e-3
     assert (pv[:, 1] - s2).abs().max().item() < 1e-4 * s2.abs().max().item()
     out2 = torch.empty(n, 2 * h, 2 * w, co, device=DEV)
-    hip.unet_convT2x2_fwd_bf16(P(xv.contiguous().to(torch.bfloat16)), ci, 1, P(wp), P(bd), P(out2), co, n, h, w, ci, co, None, 0, ST())
+    hip.unet_convT2x2_fwd_bf16(P(xv.contiguous().to(torch.bfloat16)), ci, 1, P(wp), P(bd), P(out2), co, 0, n, h, w, ci, co, None, 0, ST())
     assert torch.equal(out2, outv.contiguous())
+    # bf16-stored output (into the upper half of a bf16 concat buffer) == the fp32 output rounded; the fused sums are those of the fp32 values
+    cat16 = torch.full((n, 2 * h, 2 * w, 2 * co), float("nan"), device=DEV, dtype=torch.bfloat16)
+    part16 = torch.full_like(part, float("nan"))
+    hip.unet_convT2x2_fwd_bf16(P(xv), ci + 8, 0, P(wp), P(bd), P(cat16[..., co:]), 2 * co, 1, n, h, w, ci, co, P(part16), part16.numel() * 4, ST())
+    assert torch.equal(cat16[..., co:], outv.to(torch.bfloat16)) and torch.isnan(cat16[..., :co].float()).all()
+    assert torch.equal(part16, part)
     # data gradient (+ the producer's BatchNorm-backward sums)
     dx = torch.empty(n, h, w, ci, device=DEV); dx2 = torch.empty_like(dx)
-    hip.unet_convT2x2_dgrad_bf16(P(dzd), co, 0, P(wpd), P(dx), ci, n, h, w, ci, co, None, 0, None, 0, ST())
+    hip.unet_convT2x2_dgrad_bf16(P(dzd), co, 0, P(wpd), P(dx), ci, 0, n, h, w, ci, co, None, 0, 0, None, 0, ST())
     assert relerr(from_nhwc(dx), dx_ref) < 2e-5
     g = torch.Generator(device=DEV); g.manual_seed(1)
     r_prev = torch.randn(n, h, w, ci, device=DEV, generator=g)
     rows2 = hip.unet_convT2x2_bf16_stats_rows(n, h, w, ci, co, 1)
     part2 = torch.full(((ci // 64) * rows2 * 128,), float("nan"), device=DEV)
-    hip.unet_convT2x2_dgrad_bf16(P(dzd.to(torch.bfloat16)), co, 1, P(wpd), P(dx2), ci, n, h, w, ci, co, P(r_prev), ci, P(part2), part2.numel() * 4, ST())
+    hip.unet_convT2x2_dgrad_bf16(P(dzd.to(torch.bfloat16)), co, 1, P(wpd), P(dx2), ci, 0, n, h, w, ci, co, P(r_prev), ci, 0, P(part2), part2.numel() * 4, ST())
     assert torch.equal(dx, dx2)
     pv2 = part2.view(ci // 64, rows2, 64, 2).double().sum(1).view(ci, 2)
     t1 = dx.double().sum((0, 1, 2)); t2 = (dx.double() * r_prev.double()).sum((0, 1, 2))
     assert (pv2[:, 0] - t1).abs().max().item() < 1e-4 * t1.abs().max().item() + 1e-3
     assert (pv2[:, 1] - t2).abs().max().item() < 1e-4 * t2.abs().max().item() + 1e-3
+    # bf16-stored dx and bf16-stored saved activation: dx == the fp32 result rounded, sums == those against the bf16 values of r_prev
+    dx16 = torch.empty(n, h, w, ci, device=DEV, dtype=torch.bfloat16); r16 = r_prev.to(torch.bfloat16)
+    part3 = torch.full_like(part2, float("nan")); part4 = torch.full_like(part2, float("nan")); dx3 = torch.empty_like(dx)
+    hip.unet_convT2x2_dgrad_bf16(P(dzd), co, 0, P(wpd), P(dx16), ci, 1, n, h, w, ci, co, P(r16), ci, 1, P(part3), part3.numel() * 4, ST())
+    hip.unet_convT2x2_dgrad_bf16(P(dzd), co, 0, P(wpd), P(dx3), ci, 0, n, h, w, ci, co, P(r16.float()), ci, 0, P(part4), part4.numel() * 4, ST())
+    assert torch.equal(dx16, dx.to(torch.bfloat16)) and torch.equal(part3, part4)
 
 
 @pytest.mark.parametrize("shape", [(1, 4, 32, 128, 64), (2, 6, 40, 128, 128), (1, 8, 16, 256, 128), (3, 5, 70, 128, 64), (2, 4, 8, 1024, 512)])
