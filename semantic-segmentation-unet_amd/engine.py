@@ -717,6 +717,8 @@ class Engine:
                                 None, 0, 0, 0, 0, None, 0, st)
             elif self._use_fused(name, ho, wo, dgrad=True):
                 prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
+                if prod is not None and self.saved[prod[0]][1].dtype != torch.float32:
+                    prod = None          # (a size-fallback fp32 layer behind a bf16-storing producer: the producer's BatchNorm backward runs its own reduction)
                 rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, ho, wo, cout, cin) if prod else 0
                 if rows > 0:
                     # dx (or a channel range of it) is the dy of the producer layer's BatchNorm: leave its backward sums too
