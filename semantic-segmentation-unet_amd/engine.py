@@ -171,6 +171,7 @@ class Engine:
         # convention (bf16 activations and activation gradients, fp32 BatchNorm arithmetic: the fused sums are taken from the fp32
         # accumulators before the rounding).  Unlike the storage above this changes what BatchNorm sees (by one bf16 rounding).
         self.bf16_activations = os.environ.get("UNET_BF16_ACTIVATIONS", "1") != "0"
+        self.bf16_convt_activations = os.environ.get("UNET_BF16_CONVT_ACTIVATIONS", "1") != "0"     # ... the transposed convs' too (A/B switch)
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
 
@@ -369,7 +370,7 @@ class Engine:
             if self._use_bf16_convt(name, n, h, w):
                 rows = L.unet_convT2x2_bf16_stats_rows(n, h, w, cin, cout, 0) if (training and self.fuse_bn_stats) else 0
                 stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
-                if self.bf16_activations and self.bf16_storage and rows > 0 and r_out is None and self._dz16_shape(name, n, h, w):
+                if self.bf16_activations and self.bf16_convt_activations and self.bf16_storage and rows > 0 and r_out is None and self._dz16_shape(name, n, h, w):
                     r = self._buf("r16_" + name, (n, 2 * h, 2 * w, cout), torch.bfloat16)
                 L.unet_convT2x2_fwd_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
                                          int(r.dtype == torch.bfloat16), n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
@@ -394,7 +395,8 @@ class Engine:
             if self._use_bf16(name, n, h, w):
                 rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
                 stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
-                if self.bf16_activations and self.bf16_storage and rows > 0 and r_out is None:
+                if (self.bf16_activations and self.bf16_storage and rows > 0 and r_out is None
+                        and L.unet_conv3x3_wgrad_bf16_supported(n, h, w, cin, cout) == 1 and self._use_bf16(name, n, h, w, dgrad=True)):      # = _dz16(name): the BatchNorm backward that reads r takes bf16
                     r = self._buf("r16_" + name, (n, h, w, cout), torch.bfloat16)
                 self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), None, None, _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
@@ -688,7 +690,7 @@ class Engine:
                 r_prev = self.saved[prod[0]][1] if rows > 0 else None
                 part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,)) if rows > 0 else None
                 # dx is the dy of the producer (dec_(N+1)b): bf16 when that layer's BatchNorm backward takes bf16 dy
-                if rows > 0 and self.bf16_activations and self.bf16_storage and not eval_mode and self._dz16(prod[0], True, eval_mode):
+                if rows > 0 and self.bf16_activations and self.bf16_convt_activations and self.bf16_storage and not eval_mode and self._dz16(prod[0], True, eval_mode):
                     dx = self._buf("dy16_in_" + name, (n, hi, wi, cin), torch.bfloat16)
                 L.unet_convT2x2_dgrad_bf16(_p(dz), cout, int(dz.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[1]), _p(dx), cin,
                                            int(dx.dtype == torch.bfloat16), n, hi, wi, cin, cout, _p(r_prev), _ld(r_prev) if rows > 0 else 0,
