@@ -5,6 +5,10 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- FIRST: PyTorch ships its own libamdhip64; loaded before this library, the dynamic linker binds
+#               libunet_hip.so's HIP dependency to that same runtime.  The other order puts two HIP runtimes into the process
+#               and the first kernel launch on a torch stream fails with hipErrorNoDevice (seen: build() then smoke() in one process).
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "unet_hip.h")
 LIB_PATH = os.environ.get("UNET_HIP_LIB") or os.path.join(HERE, "csrc", "libunet_hip.so")     # override: diagnostics only
