@@ -509,3 +509,46 @@ def test_full_size_tile_matches_torch_restatement():
     worst = max((v, key) for key, v in errs.items())
     assert worst[0] < 5e-2, worst
     assert errs["logits/kernel"] < 5e-5 and errs["dec_1b/gamma"] < 5e-5, errs
+
+
+def test_two_replicas_compose_to_the_global_batch_step():
+    # Data-parallel semantics on the real engine without a second GPU: two HIP engines stand for two replicas of a global batch of 2
+    # (one image each, per-replica BatchNorm, own dropout masks, loss / G -- reference UNet/model.py:204-235 under MirroredStrategy);
+    # the all-reduce is played by adding their flat gradient buffers (what parallel.DataParallel's SUM buckets do, tested over
+    # gloo and 1-rank RCCL elsewhere).  The summed gradient must equal the oracle's R = 2 gradient -- with each replica's own branch
+    # decisions imposed, to 1e-4 -- the replicas' losses must add up to the oracle's global loss, and one Keras-Adam step on the
+    # summed gradient must leave both replicas with identical weights.
+    n, c, k, hw = 2, 1, 2, 32
+    img, lab, prm, masks = make_case(61, n, c, k, hw)
+    model = pkg("model")
+    nets, g_ref_sum, loss_ref_sum = [], None, 0.0
+    for r in range(n):
+        net = model.UNet(k, n, c, learning_rate=3e-4)                # global batch 2, this replica holds image r
+        net.engine.load_parameters(prm)
+        e = net.engine
+        sl = slice(r, r + 1)
+        mr = {kk: v[sl] for kk, v in masks.items()}
+        e.forward(torch.as_tensor(img[sl]), training=True, dropout_masks=mr, labels=torch.as_tensor(lab[sl]), global_batch_size=n, want_grad=True)
+        e.backward()
+        torch.cuda.synchronize()
+        relu = {name: (e.saved[name][1].float().permute(0, 3, 1, 2) > 0).cpu().numpy() for name, kind, _, _ in e.layers if kind != "deconv"}
+        pidx = {"pool_%d" % l: e.idx[l].permute(0, 3, 1, 2).cpu().numpy().astype(np.int64) for l in (1, 2, 3, 4)}
+        ref = on.OracleUNet(k, n, c, params=prm, dtype=np.float64)
+        loss_r, _, g_r, _, _ = ref.loss_and_grads(img[sl], lab[sl], mr, relu_masks=relu, pool_idx=pidx)
+        assert abs(e.loss_buf[0].item() - loss_r) < 1e-5 * abs(loss_r)
+        loss_ref_sum += loss_r
+        g_ref_sum = g_r if g_ref_sum is None else {kk: g_ref_sum[kk] + g_r[kk] for kk in g_r}
+        nets.append(net)
+    total = nets[0].engine.grad + nets[1].engine.grad                 # == all_reduce(SUM)
+    loss_sum = nets[0].engine.loss_buf[0].item() + nets[1].engine.loss_buf[0].item()
+    assert abs(loss_sum - loss_ref_sum) < 1e-5 * abs(loss_ref_sum)
+    for net in nets:
+        net.engine.grad.copy_(total)
+    errs = grad_errors(nets[0].engine.export_gradients(), g_ref_sum)
+    for l in (1, 2, 3, 4):
+        errs.pop("up_%d/bias" % l)                                     # exactly zero gradient (see the branch-decision test)
+    worst = max((v, key) for key, v in errs.items())
+    assert worst[0] < 1e-4, sorted(errs.items(), key=lambda t: -t[1])[:5]
+    for net in nets:
+        net.engine.adam_step(3e-4)
+    assert torch.equal(nets[0].engine.theta, nets[1].engine.theta)
