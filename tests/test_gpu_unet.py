@@ -548,7 +548,9 @@ def test_two_replicas_compose_to_the_global_batch_step():
     for l in (1, 2, 3, 4):
         errs.pop("up_%d/bias" % l)                                     # exactly zero gradient (see the branch-decision test)
     worst = max((v, key) for key, v in errs.items())
-    assert worst[0] < 1e-4, sorted(errs.items(), key=lambda t: -t[1])[:5]
+    # (5e-4, not the 1e-4 of the branch-decision test: a replica normalises over ONE 32x32 image here -- 4 samples per channel at
+    # the bottleneck -- and BatchNorm's 1 / sqrt(var + eps) amplifies fp32 rounding accordingly; measured worst tensor 1.6e-4)
+    assert worst[0] < 5e-4, sorted(errs.items(), key=lambda t: -t[1])[:5]
     for net in nets:
         net.engine.adam_step(3e-4)
     assert torch.equal(nets[0].engine.theta, nets[1].engine.theta)
