@@ -21,6 +21,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef UNET_CB_ABLATE
+#define UNET_CB_ABLATE 0        /* diagnostic builds (scripts/build_variant.sh): see conv_bf16_body */
+#endif
+
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -122,6 +126,162 @@ __device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_bas
             for (int c = 0; c < NCO; ++c) CB_MFMA(acc[r][c], fr.a[g & 1], fr.b[bs & 1][a][c]);
         }
         fill(g);          // the caller's share of the next chunk's staging, issued in the shadow of this group's MFMAs
+    }
+}
+
+// Epilogue of one tile (shared by the per-tile and the persistent kernels): bias, ReLU, stores, fused BatchNorm sums.
+// `red` = LDS scratch for the cross-wave sum of the statistics (CT * 8 floats, free of in-flight traffic), `row` = the tile's row of
+// the partial-sum buffer.
+// B16 = 1: the output and the saved activation are known to be bf16 tensors at compile time (the fp32 variants of the loads and
+// stores, and the uniform branches that choose between them per store, drop out).
+template <int NCO, int STATS, int B16 = 0>
+__device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)[4][NCO], int img, int ty0, int tx0, int co0, int row,
+                                            float* red, int tid, int wv, int li, int lh) {
+    constexpr int CT = 32 * NCO;
+    const bool out16 = B16 || p.out16, r16 = B16 || p.r16;
+    // epilogue: accumulator register e of (row r, sub-tile c) = pixel (ty0 + 4 wv + r, tx0 + (e&3) + 8 (e>>2) + 4 lh), channel
+    // co0 + NCO li + c (see the weight image): one buffer store per pixel and lane.  The 16 per-lane offsets (column, channel
+    // group) are computed once, the row goes into the scalar offset; columns past the image edge get an offset the range check
+    // drops.  out16 / r16: the output / the producer's saved activation is a bf16 tensor (same indexing, 2-byte elements).
+    // (A variant with the column part in the scalar offset and scalar branches for the image edge made every launch 15-20 % slower
+    // in a same-box A/B -- 64 basic blocks instead of one straight store stream -- and was dropped.)
+    typedef unsigned ovec_t __attribute__((ext_vector_type(NCO)));
+    typedef unsigned hvec_t __attribute__((ext_vector_type(NCO / 2)));
+    float st1[NCO], st2[NCO], bv[NCO];
+    const int oes = out16 ? 2 : 4, res = r16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.N * p.H * p.W * p.ldo * oes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? p.bn_r : p.out), 0,
+                                                                            STATS == 2 ? (int)((size_t)p.N * p.H * p.W * p.bn_ldr * res) : 0, 0x00020000);
+    const int cl = co0 + NCO * li;                                    // this lane's first channel
+    const bool with_r = STATS == 2 && cl >= p.bn_c0 && cl < p.bn_c1;  // (c0, c1 multiples of 64: all NCO channels or none)
+    // store offset of (row r, element e) = lane part (column 4 lh, the lane's channels) + row + column part, formed per store (two
+    // vector instructions): kept as 16 precomputed registers they would crowd out the saved-activation window below
+    const int vo = (4 * lh * p.ldo + NCO * li) * oes;
+    const int wlim = p.W - tx0 - 4 * lh;                              // column (e & 3) + 8 (e >> 2) of this lane is inside the image iff < wlim
+    // saved-activation loads (STATS 2): lane offset = column 4 lh and the lane's channels, or an offset the range check rejects when
+    // the lane has no channel in [c0, c1); the column part (e & 3) + 8 (e >> 2) goes into the scalar offset; whether a column is
+    // inside the image is uniform up to the half-wave (both halves / only lh = 0 / none): a select between three registers
+    const int vr = with_r ? (4 * lh * p.bn_ldr + (cl - p.bn_c0)) * res : (int)0x80000000, vr_lo = lh ? (int)0x80000000 : vr;
+    const int wrem = p.W - tx0;
+    auto r_voff = [&](int e) { const int c0 = (e & 3) + 8 * (e >> 2); return c0 + 4 < wrem ? vr : (c0 < wrem ? vr_lo : (int)0x80000000); };
+    const float lo = p.relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) { bv[c] = p.bias ? p.bias[cl + c] : 0.f; st1[c] = 0.f; st2[c] = 0.f; }
+    // STATS 2 with a bf16 saved activation (the default storage): the 16 loads of a row are issued TWO rows ahead of the row being
+    // written (rows 0 and 1 before any arithmetic, row r + 2 before row r is processed), so the memory latency is paid about once
+    // per tile instead of eight times -- the per-row half-batches of the fp32 path below cost 0.24 ms of a 0.50 ms launch on
+    // 64->64 @512^2, where the main loop (4 chunks) is too short to hide anything.
+    constexpr int RING = NCO == 4 ? 3 : 4;          // rows of the saved activation in flight (NCO = 2: the whole tile)
+    hvec_t rvh[RING][16];
+    const bool hoist = STATS == 2 && r16 && !(UNET_CB_ABLATE & 2);
+    auto issue_row = [&](int r) {
+        const int gy = ty0 + 4 * wv + r;
+        const int sr = ((img * p.H + (gy < p.H ? gy : 0)) * p.W + tx0) * p.bn_ldr * 2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int vofs = gy < p.H ? r_voff(e) : (int)0x80000000, so_e = sr + ((e & 3) + 8 * (e >> 2)) * p.bn_ldr * 2;
+            if constexpr (NCO == 4) rvh[r % RING][e] = __builtin_amdgcn_raw_buffer_load_b64(srd_r, vofs, so_e, 0);
+            else                    rvh[r % RING][e][0] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, vofs, so_e, 0);
+        }
+    };
+    if (hoist) {
+#pragma unroll
+        for (int r = 0; r < RING - 1; ++r) issue_row(r);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gy = ty0 + 4 * wv + r;
+        const bool row_ok = gy < p.H;                                                // uniform per wave
+        const int pix0 = (img * p.H + gy) * p.W + tx0;
+        const int so = (pix0 * p.ldo + co0) * oes;
+        if (hoist && r + RING - 1 < 4) issue_row(r + RING - 1);
+        if (!row_ok) continue;
+        // STATS 2, fp32 saved activation: two batches of 8 pixels per row, each batch's loads in flight together
+#pragma unroll
+        for (int eh = 0; eh < 2; ++eh) {
+            float rv[8][NCO];
+            if (hoist) {
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8)
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c) {
+                        const unsigned hw = (unsigned)rvh[r % RING][8 * eh + e8][c >> 1];
+                        rv[e8][c] = __builtin_bit_cast(float, (c & 1) ? (hw & 0xffff0000u) : (hw << 16));
+                    }
+            } else if (UNET_CB_ABLATE & 2) {
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8)
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c) rv[e8][c] = 1.f;
+            } else if (STATS == 2) {
+                const int sr = pix0 * p.bn_ldr * res;
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = 8 * eh + e8, so_e = sr + ((e & 3) + 8 * (e >> 2)) * p.bn_ldr * res;
+                    if (r16) {
+                        hvec_t h;
+                        if constexpr (NCO == 4) h = __builtin_amdgcn_raw_buffer_load_b64(srd_r, r_voff(e), so_e, 0);
+                        else                    h[0] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, r_voff(e), so_e, 0);
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c)
+                            rv[e8][c] = __builtin_bit_cast(float, (c & 1) ? ((unsigned)h[c >> 1] & 0xffff0000u) : ((unsigned)h[c >> 1] << 16));
+                    } else {
+                        ovec_t f;
+                        if constexpr (NCO == 4) f = __builtin_amdgcn_raw_buffer_load_b128(srd_r, r_voff(e), so_e, 0);
+                        else                    f = __builtin_amdgcn_raw_buffer_load_b64(srd_r, r_voff(e), so_e, 0);
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c) rv[e8][c] = __builtin_bit_cast(float, (unsigned)f[c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int e = 8 * eh + e8, ce = (e & 3) + 8 * (e >> 2);
+                const bool colok = ce < wlim;
+                float v[NCO];
+#pragma unroll
+                for (int c = 0; c < NCO; ++c) {
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[r][c][e]));
+                    v[c] = fmaxf(v[c] + bv[c], lo);
+                    if (STATS == 1 && colok) { st1[c] += v[c]; st2[c] += v[c] * v[c]; }
+                    if (STATS == 2 && colok) { st1[c] += v[c]; st2[c] += v[c] * rv[e8][c]; }
+                }
+                if ((UNET_CB_ABLATE & 1) && v[0] != 1.2345e38f) continue;
+                const int ovoff = colok ? vo + (so + ce * p.ldo * oes) : (int)0x80000000;
+                if (out16) {
+                    hvec_t h;
+#pragma unroll
+                    for (int c = 0; c < NCO; c += 2) h[c >> 1] = cb_pack2(v[c], v[c + 1]);
+                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b64(h, srd_o, ovoff, 0, 0);
+                    else                    __builtin_amdgcn_raw_buffer_store_b32(h[0], srd_o, ovoff, 0, 0);
+                } else {
+                    ovec_t ov;
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c) ov[c] = __builtin_bit_cast(unsigned, v[c]);
+                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b128(ov, srd_o, ovoff, 0, 0);
+                    else                    __builtin_amdgcn_raw_buffer_store_b64(ov, srd_o, ovoff, 0, 0);
+                }
+            }
+        }
+    }
+    if (STATS != 0) {
+        // per-channel sums of this tile (of the fp32 values, before any rounding of the stored tensor): the two half-waves (same
+        // channels, different pixels), then the four waves through LDS in a fixed order ->
+        // stat_part[channel / 64][row = pixel tile][channel % 64][2]
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) {
+            st1[c] += __shfl_xor(st1[c], 32); st2[c] += __shfl_xor(st2[c], 32);
+            if (lh == 0) { red[((wv * 32 + li) * NCO + c) * 2] = st1[c]; red[((wv * 32 + li) * NCO + c) * 2 + 1] = st2[c]; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (not __syncthreads(): no vmcnt(0) -- a persistent caller has prefetches in flight)
+        if (tid < CT) {                                               // tid = channel within the tile = NCO * lane + c
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) { a += red[(w4 * CT + tid) * 2]; b += red[(w4 * CT + tid) * 2 + 1]; }
+            const int ch = co0 + tid;
+            float* o = p.stat_part + (((size_t)(ch >> 6) * p.n_px + row) * 64 + (ch & 63)) * 2;
+            o[0] = a; o[1] = b;
+        }
     }
 }
 
@@ -259,9 +419,6 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 
-#ifndef UNET_CB_ABLATE
-#define UNET_CB_ABLATE 0
-#endif
     // diagnostic builds (scripts/build_variant.sh): bit 0 = no epilogue stores, bit 1 = no saved-activation loads in the STATS 2
     // epilogue, bit 2 = no chunk loop, bit 3 = no prologue loads
     if (!(UNET_CB_ABLATE & 8)) { issue_x(0); issue_w(0, 0); }
@@ -286,150 +443,127 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
-    // epilogue: accumulator register e of (row r, sub-tile c) = pixel (ty0 + 4 wv + r, tx0 + (e&3) + 8 (e>>2) + 4 lh), channel
-    // co0 + NCO li + c (see the weight image): one buffer store per pixel and lane.  The 16 per-lane offsets (column, channel
-    // group) are computed once, the row goes into the scalar offset; columns past the image edge get an offset the range check
-    // drops.  out16 / r16: the output / the producer's saved activation is a bf16 tensor (same indexing, 2-byte elements).
-    // (A variant with the column part in the scalar offset and scalar branches for the image edge made every launch 15-20 % slower
-    // in a same-box A/B -- 64 basic blocks instead of one straight store stream -- and was dropped.)
-    typedef unsigned ovec_t __attribute__((ext_vector_type(NCO)));
-    typedef unsigned hvec_t __attribute__((ext_vector_type(NCO / 2)));
-    float st1[NCO], st2[NCO], bv[NCO];
-    const int oes = p.out16 ? 2 : 4, res = p.r16 ? 2 : 4;
-    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.N * p.H * p.W * p.ldo * oes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? p.bn_r : p.out), 0,
-                                                                            STATS == 2 ? (int)((size_t)p.N * p.H * p.W * p.bn_ldr * res) : 0, 0x00020000);
-    const int cl = co0 + NCO * li;                                    // this lane's first channel
-    const bool with_r = STATS == 2 && cl >= p.bn_c0 && cl < p.bn_c1;  // (c0, c1 multiples of 64: all NCO channels or none)
-    // store offset of (row r, element e) = lane part (column 4 lh, the lane's channels) + row + column part, formed per store (two
-    // vector instructions): kept as 16 precomputed registers they would crowd out the saved-activation window below
-    const int vo = (4 * lh * p.ldo + NCO * li) * oes;
-    const int wlim = p.W - tx0 - 4 * lh;                              // column (e & 3) + 8 (e >> 2) of this lane is inside the image iff < wlim
-    // saved-activation loads (STATS 2): lane offset = column 4 lh and the lane's channels, or an offset the range check rejects when
-    // the lane has no channel in [c0, c1); the column part (e & 3) + 8 (e >> 2) goes into the scalar offset; whether a column is
-    // inside the image is uniform up to the half-wave (both halves / only lh = 0 / none): a select between three registers
-    const int vr = with_r ? (4 * lh * p.bn_ldr + (cl - p.bn_c0)) * res : (int)0x80000000, vr_lo = lh ? (int)0x80000000 : vr;
-    const int wrem = p.W - tx0;
-    auto r_voff = [&](int e) { const int c0 = (e & 3) + 8 * (e >> 2); return c0 + 4 < wrem ? vr : (c0 < wrem ? vr_lo : (int)0x80000000); };
-    const float lo = p.relu ? 0.f : -INFINITY;
+    cb_epilogue<NCO, STATS>(p, acc, img, ty0, tx0, co0, t % p.n_px, reinterpret_cast<float*>(smem), tid, wv, li, lh);
+}
+
+// ---- persistent form for bf16-stored inputs ------------------------------------------------------------------------------------------
+// The per-tile kernel above pays, per tile and serialised inside the workgroup, a prologue (first loads from HBM: 0.06 ms per launch on
+// 64->64 @512^2), the chunk loop (0.10 ms: only 4 chunks with 64 reduce channels) and the epilogue (0.06 ms).  With the input stored as
+// bf16 the staging needs no conversion, so the patch goes global -> LDS by LDS-DMA exactly like the weights (16 bytes per lane = the 8
+// channels of one pixel and k half: one LDS slot of the [k half][pixel][8] image; lanes outside the image read a channel-indexed zero
+// page), no staging registers, no conversion instructions.  The workgroup then walks tiles t, t + grid, ... and treats (tile, chunk) as
+// ONE stream: while the last chunk of a tile is computed, chunk 0 of the NEXT tile is already on its way into the other LDS stage, so
+// only a workgroup's first tile pays a prologue, and the epilogue's memory latency overlaps the landing of that chunk.
+__device__ __attribute__((aligned(256))) uint16_t g_zero_page_b[4096 + 64];       // zero source that out-of-image patch pixels walk over (per channel)
+
+template <int NCO, int STATS>
+__device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
+    constexpr int CT = 32 * NCO;
+    constexpr int WB = 18 * CT * 16;
+    constexpr int STAGE = kXP + WB;
+    constexpr int NPIECE = WB / 1024, KW = (NPIECE + 3) / 4;
+    constexpr int KX = 5;                                            // 2 planes x 10 pieces of 64 pixels = 20 x-pieces per chunk, 5 per wave
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE + 1024 * NCO];
+    float* const red = reinterpret_cast<float*>(smem + 2 * STAGE);   // statistics scratch of the epilogue: never a DMA target
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int total = p.n_px * p.n_co;
+    const int nchunks = p.Cin / 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
+    const unsigned a_base = lds0 + (unsigned)(lh * kPlane + (4 * wv * kPW + li) * 16);
+    unsigned b_base[NCO];
 #pragma unroll
-    for (int c = 0; c < NCO; ++c) { bv[c] = p.bias ? p.bias[cl + c] : 0.f; st1[c] = 0.f; st2[c] = 0.f; }
-    // STATS 2 with a bf16 saved activation (the default storage): the 16 loads of a row are issued TWO rows ahead of the row being
-    // written (rows 0 and 1 before any arithmetic, row r + 2 before row r is processed), so the memory latency is paid about once
-    // per tile instead of eight times -- the per-row half-batches of the fp32 path below cost 0.24 ms of a 0.50 ms launch on
-    // 64->64 @512^2, where the main loop (4 chunks) is too short to hide anything.
-    constexpr int RING = NCO == 4 ? 3 : 4;          // rows of the saved activation in flight (NCO = 2: the whole tile)
-    hvec_t rvh[RING][16];
-    const bool hoist = STATS == 2 && p.r16 && !(UNET_CB_ABLATE & 2);
-    auto issue_row = [&](int r) {
-        const int gy = ty0 + 4 * wv + r;
-        const int sr = ((img * p.H + (gy < p.H ? gy : 0)) * p.W + tx0) * p.bn_ldr * 2;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int vofs = gy < p.H ? r_voff(e) : (int)0x80000000, so_e = sr + ((e & 3) + 8 * (e >> 2)) * p.bn_ldr * 2;
-            if constexpr (NCO == 4) rvh[r % RING][e] = __builtin_amdgcn_raw_buffer_load_b64(srd_r, vofs, so_e, 0);
-            else                    rvh[r % RING][e][0] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, vofs, so_e, 0);
-        }
+    for (int c = 0; c < NCO; ++c) {
+        const int q = NCO * li + c;
+        b_base[c] = lds0 + (unsigned)(kXP + lh * CT * 16 + ((q & ~15) + ((q + (q >> 4)) & 15)) * 16);
+    }
+    const size_t wchunk = (size_t)18 * p.Cout * 16;
+
+    struct Tile { int t, img, ty0, tx0, co0; };
+    auto tile_at = [&](int logical) {
+        int t = logical;
+        if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);         // consecutive ids of one XCD (grid is a multiple of 8 or == total)
+        Tile c; c.t = t;
+        const int cot = t / p.n_px; int px = t % p.n_px;
+        const int bx = px % p.tbx; px /= p.tbx;
+        const int by = px % p.tby; c.img = px / p.tby;
+        c.co0 = cot * CT; c.ty0 = 16 * by; c.tx0 = 32 * bx;
+        return c;
     };
-    if (hoist) {
+    // per-lane DMA sources of a tile: x-piece id = wv + 4 k -> plane h = id / 10, pixels 64 (id % 10) + lane of the 18 x 34 patch
+    struct Src { const char* x[KX]; const char* w; };
+    auto sources = [&](const Tile& c) {
+        Src s;
 #pragma unroll
-        for (int r = 0; r < RING - 1; ++r) issue_row(r);
+        for (int k = 0; k < KX; ++k) {
+            const int id = wv + 4 * k, h = id / 10, pp = 64 * (id % 10) + lane;
+            const int gy = c.ty0 - 1 + pp / kPW, gx = c.tx0 - 1 + pp % kPW;
+            const bool ok = pp < 18 * kPW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            s.x[k] = ok ? reinterpret_cast<const char*>(p.x) + (((size_t)(c.img * p.H + gy) * p.W + gx) * p.ldx) * 2 + h * 16
+                        : reinterpret_cast<const char*>(g_zero_page_b) + h * 16;
+        }
+        s.w = reinterpret_cast<const char*>(p.wp) + (size_t)c.co0 * 16;
+        return s;
+    };
+    unsigned woff[KW];                                               // weight piece wv + 4 k: (row, 64-column block), swizzled column order (see the per-tile kernel)
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int id = wv + 4 * k;
+        const int row = id / (CT / 64), blk = id % (CT / 64);
+        const int pos = 64 * blk + lane;
+        const int col = (pos & ~15) + ((pos - (pos >> 4)) & 15);
+        woff[k] = (unsigned)((row * p.Cout + col) * 16);
     }
+    auto issue_x1 = [&](const Src& s, int chunk, int stage, int k) {
+        const int id = wv + 4 * k;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s.x[k] + (size_t)chunk * 32),
+                                         (lds_void_b*)(smem + stage * STAGE + (id / 10) * kPlane + (id % 10) * 1024), 16, 0, 0);
+    };
+    auto issue_w1 = [&](const Src& s, int chunk, int stage, int k) {
+        if (NPIECE % 4 == 0 || wv + 4 * k < NPIECE)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s.w + (size_t)chunk * wchunk + woff[k]),
+                                             (lds_void_b*)(smem + stage * STAGE + kXP + (wv + 4 * k) * 1024), 16, 0, 0);
+    };
+    auto fill = [&](const Src& s, int chunk, int stage, int g) {    // this wave's share of a chunk's DMA, spread over the MFMA groups
+        if (g < KX) issue_x1(s, chunk, stage, g);
+        if (2 * g < KW) issue_w1(s, chunk, stage, 2 * g);
+        if (2 * g + 1 < KW) issue_w1(s, chunk, stage, 2 * g + 1);
+    };
+
+    const int G = (int)gridDim.x;
+    Tile cur = tile_at((int)blockIdx.x);
+    {
+        const Src s0 = sources(cur);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int gy = ty0 + 4 * wv + r;
-        const bool row_ok = gy < p.H;                                                // uniform per wave
-        const int pix0 = (img * p.H + gy) * p.W + tx0;
-        const int so = (pix0 * p.ldo + co0) * oes;
-        if (hoist && r + RING - 1 < 4) issue_row(r + RING - 1);
-        if (!row_ok) continue;
-        // STATS 2, fp32 saved activation: two batches of 8 pixels per row, each batch's loads in flight together
-#pragma unroll
-        for (int eh = 0; eh < 2; ++eh) {
-            float rv[8][NCO];
-            if (hoist) {
-#pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8)
-#pragma unroll
-                    for (int c = 0; c < NCO; ++c) {
-                        const unsigned hw = (unsigned)rvh[r % RING][8 * eh + e8][c >> 1];
-                        rv[e8][c] = __builtin_bit_cast(float, (c & 1) ? (hw & 0xffff0000u) : (hw << 16));
-                    }
-            } else if (UNET_CB_ABLATE & 2) {
-#pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8)
-#pragma unroll
-                    for (int c = 0; c < NCO; ++c) rv[e8][c] = 1.f;
-            } else if (STATS == 2) {
-                const int sr = pix0 * p.bn_ldr * res;
-#pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8) {
-                    const int e = 8 * eh + e8, so_e = sr + ((e & 3) + 8 * (e >> 2)) * p.bn_ldr * res;
-                    if (p.r16) {
-                        hvec_t h;
-                        if constexpr (NCO == 4) h = __builtin_amdgcn_raw_buffer_load_b64(srd_r, r_voff(e), so_e, 0);
-                        else                    h[0] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, r_voff(e), so_e, 0);
-#pragma unroll
-                        for (int c = 0; c < NCO; ++c)
-                            rv[e8][c] = __builtin_bit_cast(float, (c & 1) ? ((unsigned)h[c >> 1] & 0xffff0000u) : ((unsigned)h[c >> 1] << 16));
-                    } else {
-                        ovec_t f;
-                        if constexpr (NCO == 4) f = __builtin_amdgcn_raw_buffer_load_b128(srd_r, r_voff(e), so_e, 0);
-                        else                    f = __builtin_amdgcn_raw_buffer_load_b64(srd_r, r_voff(e), so_e, 0);
-#pragma unroll
-                        for (int c = 0; c < NCO; ++c) rv[e8][c] = __builtin_bit_cast(float, (unsigned)f[c]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int e8 = 0; e8 < 8; ++e8) {
-                const int e = 8 * eh + e8, ce = (e & 3) + 8 * (e >> 2);
-                const bool colok = ce < wlim;
-                float v[NCO];
-#pragma unroll
-                for (int c = 0; c < NCO; ++c) {
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[r][c][e]));
-                    v[c] = fmaxf(v[c] + bv[c], lo);
-                    if (STATS == 1 && colok) { st1[c] += v[c]; st2[c] += v[c] * v[c]; }
-                    if (STATS == 2 && colok) { st1[c] += v[c]; st2[c] += v[c] * rv[e8][c]; }
-                }
-                if ((UNET_CB_ABLATE & 1) && v[0] != 1.2345e38f) continue;
-                const int ovoff = colok ? vo + (so + ce * p.ldo * oes) : (int)0x80000000;
-                if (p.out16) {
-                    hvec_t h;
-#pragma unroll
-                    for (int c = 0; c < NCO; c += 2) h[c >> 1] = cb_pack2(v[c], v[c + 1]);
-                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b64(h, srd_o, ovoff, 0, 0);
-                    else                    __builtin_amdgcn_raw_buffer_store_b32(h[0], srd_o, ovoff, 0, 0);
-                } else {
-                    ovec_t ov;
-#pragma unroll
-                    for (int c = 0; c < NCO; ++c) ov[c] = __builtin_bit_cast(unsigned, v[c]);
-                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b128(ov, srd_o, ovoff, 0, 0);
-                    else                    __builtin_amdgcn_raw_buffer_store_b64(ov, srd_o, ovoff, 0, 0);
-                }
-            }
-        }
+        for (int g = 0; g < 18; ++g) fill(s0, 0, 0, g);             // prologue: chunk 0 of the first tile
     }
-    if (STATS != 0) {
-        // per-channel sums of this tile (of the fp32 values, before any rounding of the stored tensor): the two half-waves (same
-        // channels, different pixels), then the four waves through LDS in a fixed order ->
-        // stat_part[channel / 64][row = pixel tile][channel % 64][2]
-        float* red = reinterpret_cast<float*>(smem);                  // free: the last chunk ended with a barrier
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int logical = (int)blockIdx.x; logical < total; logical += G) {
+        Tile nxt = cur;
+        Src sf = sources(cur);                                       // what the DMA stream (one chunk ahead of the MFMAs) reads; recomputed per tile
+                                                                     // rather than kept in registers across the epilogue
+        f32x16 acc[4][NCO];
 #pragma unroll
-        for (int c = 0; c < NCO; ++c) {
-            st1[c] += __shfl_xor(st1[c], 32); st2[c] += __shfl_xor(st2[c], 32);
-            if (lh == 0) { red[((wv * 32 + li) * NCO + c) * 2] = st1[c]; red[((wv * 32 + li) * NCO + c) * 2 + 1] = st2[c]; }
-        }
-        __syncthreads();
-        if (tid < CT) {                                               // tid = channel within the tile = NCO * lane + c
-            float a = 0.f, b = 0.f;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) { a += red[(w4 * CT + tid) * 2]; b += red[(w4 * CT + tid) * 2 + 1]; }
-            const int ch = co0 + tid, row = t % p.n_px;
-            float* o = p.stat_part + (((size_t)(ch >> 6) * p.n_px + row) * 64 + (ch & 63)) * 2;
-            o[0] = a; o[1] = b;
+            for (int c = 0; c < NCO; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+        for (int c = 0; c < nchunks; c += 2) {                       // Cin % 32 == 0: an even number of chunks, chunk c lives in stage c & 1
+            cb_compute<NCO, 0, STAGE>(acc, a_base, b_base, [&](int g) { fill(sf, c + 1, 1, g); });
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            int cn = c + 2;
+            if (cn == nchunks) {                                     // the stream continues with chunk 0 of the workgroup's next tile
+                cn = 0;                                              // (after the last tile: chunk 0 of this one again -- valid memory, never read)
+                if (logical + G < total) { nxt = tile_at(logical + G); sf = sources(nxt); }
+            }
+            cb_compute<NCO, 1, STAGE>(acc, a_base, b_base, [&](int g) { fill(sf, cn, 0, g); });
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        cb_epilogue<NCO, STATS, 1>(p, acc, cur.img, cur.ty0, cur.tx0, cur.co0, cur.t % p.n_px, red, tid, wv, li, lh);
+        cur = nxt;
     }
 }
 
@@ -442,6 +576,13 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_stats_kernel_128(ConvBf16Arg
 __global__ __launch_bounds__(256, 2) void conv_bf16_stats_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 1>(p); }
 __global__ __launch_bounds__(256, 1) void conv_bf16_bnbwd_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 2>(p); }
 __global__ __launch_bounds__(256, 2) void conv_bf16_bnbwd_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 2>(p); }
+// persistent forms (bf16-stored input, no BatchNorm-apply on load)
+__global__ __launch_bounds__(256, 1) void conv_bf16_stream_kernel_128(ConvBf16Args p) { conv_bf16_stream_body<4, 0>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_stream_kernel_64(ConvBf16Args p) { conv_bf16_stream_body<2, 0>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_stream_stats_kernel_128(ConvBf16Args p) { conv_bf16_stream_body<4, 1>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_stream_stats_kernel_64(ConvBf16Args p) { conv_bf16_stream_body<2, 1>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_stream_bnbwd_kernel_128(ConvBf16Args p) { conv_bf16_stream_body<4, 2>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_stream_bnbwd_kernel_64(ConvBf16Args p) { conv_bf16_stream_body<2, 2>(p); }
 // forward with BatchNorm-apply on load (NORM)
 __global__ __launch_bounds__(256, 1) void conv_bf16_norm_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 0, 1>(p); }
 __global__ __launch_bounds__(256, 2) void conv_bf16_norm_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 0, 1>(p); }
@@ -476,6 +617,11 @@ int conv_bf16_cus() {
     return cus;
 }
 
+bool cb_stream_enabled() {
+    static const bool ok = [] { const char* e = getenv("UNET_CB_STREAM"); return !(e && e[0] == '0'); }();      // A/B switch
+    return ok;
+}
+
 struct ConvBf16Stats { int mode; float* part; size_t bytes; const float* r; int ldr, c0, c1, r16; };
 
 int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
@@ -497,6 +643,15 @@ int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, fl
         a.stat_part = stats->part; a.bn_r = stats->r; a.bn_ldr = stats->ldr; a.bn_c0 = stats->c0; a.bn_c1 = stats->c1;
     }
     const dim3 grid((unsigned)(a.n_px * a.n_co));
+    if (in16 && out16 && (mode != 2 || a.r16) && !in_scale && cb_stream_enabled() && Cin <= 4096) {
+        // persistent form: one resident wave of workgroups walks the tiles (the grid is the whole tile count when that is smaller)
+        const long slots = (long)conv_bf16_cus() * (wide ? 1 : 2);
+        const dim3 pgrid((unsigned)((long)grid.x < slots ? (long)grid.x : slots));
+        if (mode == 0) { if (wide) conv_bf16_stream_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_kernel_64<<<pgrid, 256, 0, st>>>(a); }
+        else if (mode == 1) { if (wide) conv_bf16_stream_stats_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_stats_kernel_64<<<pgrid, 256, 0, st>>>(a); }
+        else { if (wide) conv_bf16_stream_bnbwd_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_bnbwd_kernel_64<<<pgrid, 256, 0, st>>>(a); }
+        return UNET_LAUNCH_STATUS();
+    }
     if (in_scale && mode == 0) { if (wide) conv_bf16_norm_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_norm_kernel_64<<<grid, 256, 0, st>>>(a); }
     else if (in_scale && mode == 1) { if (wide) conv_bf16_norm_stats_kernel_128<<<grid, 256, 0, st>>>(a); else conv_bf16_norm_stats_kernel_64<<<grid, 256, 0, st>>>(a); }
     else if (in_scale) return UNET_EINVAL;
