@@ -256,10 +256,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    # UNET_BENCH_REHEARSAL=1: every rank on GPU 0, collectives over gloo -- runs the N>1 code path (rank-sharded synthetic data,
+    # DataParallel buckets, barriers, MAX over ranks) on a ONE-GPU box.  The line is marked "rehearsal": it is not a scaling figure.
+    rehearsal = world > 1 and os.environ.get("UNET_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         if world > 1:
@@ -319,6 +327,8 @@ def main():
                        "global_batch": res["G"], "parallelism": "dp%d" % world},
         }
         out.update(s)
+        if rehearsal:
+            out["rehearsal"] = "all %d ranks share GPU 0, collectives over gloo: exercises the N>1 path, not a scaling measurement" % world
         out["cpu_baseline"] = cpu_baseline_bounded(args) if (world == 1 and not args.no_cpu_baseline) else None
         if extras:
             out["extra_configs"] = extras

@@ -228,8 +228,8 @@ class UNet:
 
     # -- reference UNet/model.py:230-235,252-256: one replica per process here; the cross-replica SUM of the per-replica
     #    losses is an RCCL all-reduce in parallel.DataParallel (reference: dist_strategy.reduce(SUM, ...)).
-    def dist_train_step(self, dist_strategy, inputs):
-        loss = self.train_step(inputs)
+    def dist_train_step(self, dist_strategy, inputs, dropout_masks=None):
+        loss = self.train_step(inputs, dropout_masks=dropout_masks)
         return self._reduce_loss(dist_strategy, loss)
 
     def dist_test_step(self, dist_strategy, inputs):
