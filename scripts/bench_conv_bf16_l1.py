@@ -17,7 +17,12 @@ def timeit(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 bf = torch.bfloat16
-for name, h, ci, co in [("1b", 512, 64, 64), ("dec1a", 512, 128, 64), ("2b", 256, 128, 128), ("dec2a", 256, 256, 128), ("3b", 128, 256, 256), ("4b", 64, 512, 512)]:
+LAYERS = [("1b", 512, 64, 64), ("dec1a", 512, 128, 64), ("2b", 256, 128, 128), ("dec2a", 256, 256, 128), ("3b", 128, 256, 256), ("4b", 64, 512, 512)]
+if "--all" in sys.argv:          # every MFMA 3x3 layer of the 512^2 network (x count in the step)
+    LAYERS = [("1b/dec1b x2", 512, 64, 64), ("2a", 256, 64, 128), ("2b/dec2b x2", 256, 128, 128), ("3a", 128, 128, 256), ("3b/dec3b x2", 128, 256, 256),
+              ("4a", 64, 256, 512), ("4b/dec4b x2", 64, 512, 512), ("bott_a", 32, 512, 1024), ("bott_b", 32, 1024, 1024), ("dec4a", 64, 1024, 512),
+              ("dec3a", 128, 512, 256), ("dec2a", 256, 256, 128), ("dec1a", 512, 128, 64)]
+for name, h, ci, co in LAYERS:
     x = torch.randn(B, h, h, ci, device="cuda").to(bf); w = torch.randn(3, 3, ci, co, device="cuda") * 0.05; b = torch.randn(co, device="cuda")
     out = torch.empty(B, h, h, co, device="cuda", dtype=bf)
     wp = torch.empty(L.unet_conv3x3_bf16_packed_bytes(ci, co), dtype=torch.uint8, device="cuda"); wpd = torch.empty_like(wp)
@@ -36,7 +41,10 @@ for name, h, ci, co in [("1b", 512, 64, 64), ("dec1a", 512, 128, 64), ("2b", 256
     part2 = torch.empty((ci // 64) * rows2 * 128, device="cuda")
     td = timeit(lambda: L.unet_conv3x3_dgrad_bf16(P(dz), co, 1, P(wpd), P(dx), ci, 1, B, h, h, ci, co, P(rp), ci, 1, 0, ci, P(part2), part2.numel() * 4, ST()))
     td0 = timeit(lambda: L.unet_conv3x3_dgrad_bf16(P(dz), co, 1, P(wpd), P(dx), ci, 1, B, h, h, ci, co, None, 0, 0, 0, 0, None, 0, ST()))
+    nbw = L.unet_conv3x3_wgrad_bf16_workspace(B, h, h, ci, co); wsw = torch.empty(nbw + 256, dtype=torch.uint8, device="cuda"); dw = torch.empty_like(w)
+    tw = timeit(lambda: L.unet_conv3x3_wgrad_bf16(P(x), ci, 1, P(dz), co, 1, P(dw), B, h, h, ci, co, P(wsw), nbw, ST()))
     fl = 2.0 * 9 * B * h * h * ci * co
+    print("        wgrad (bf16 x, bf16 dz) %6.3f ms (%5.0f TF)" % (tw, fl / tw / 1e9))
     byf = 2.0 * B * h * h * (ci + co)
     print("%-6s h%4d %4d->%4d | fwd+stats %6.3f ms (%5.0f TF, %4.2f TB/s) plain %6.3f | dgrad+bnbwd %6.3f ms (%5.0f TF, %4.2f TB/s) plain %6.3f"
           % (name, h, ci, co, tf, fl / tf / 1e9, byf / tf / 1e9, tf0, td, fl / td / 1e9, (byf + 2.0 * B * h * h * ci) / td / 1e9, td0), flush=True)

@@ -1048,11 +1048,13 @@ void wgrad_bf16_plan(WgBf16Args& a) {
     const int npairs = a.n_ci * a.n_co;
     a.tbx = (a.W + 31) / 32;
     const int strips = a.N * a.tbx;
-    const int target = (conv_bf16_cus() + npairs - 1) / npairs;          // strip-chunks wanted so that every CU has a workgroup
+    static const int occ = [] { const char* e = getenv("UNET_WGRAD_BF16_OCC"); return e && e[0] == '2' ? 2 : 1; }();   // workgroups per CU (A/B switch)
+    const int slots = conv_bf16_cus() * occ;
+    const int target = (slots + npairs - 1) / npairs;                    // strip-chunks wanted so that every slot has a workgroup
     int cps = (target + strips - 1) / strips; if (cps < 1) cps = 1;
     int rpc = (a.H + cps - 1) / cps; rpc += rpc & 1; if (rpc < 2) rpc = 2;
     a.rpc = rpc; a.cps = (a.H + rpc - 1) / rpc; a.n_sc = strips * a.cps;
-    int splits = conv_bf16_cus() / npairs; if (splits < 1) splits = 1; if (splits > a.n_sc) splits = a.n_sc;
+    int splits = slots / npairs; if (splits < 1) splits = 1; if (splits > a.n_sc) splits = a.n_sc;
     a.splits = splits;
 }
 
