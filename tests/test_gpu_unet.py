@@ -18,7 +18,8 @@ def relerr(a, b):
 
 def make_case(seed, n, c, k, hw):
     rng = np.random.default_rng(seed)
-    img, lab = on.synthetic_batch(n, c, k, hw, hw, seed=seed)
+    h, w = hw if isinstance(hw, tuple) else (hw, hw)                 # (rows, columns) for non-square tiles
+    img, lab = on.synthetic_batch(n, c, k, h, w, seed=seed)
     prm = on.init_params(c, k, seed=seed)
     for key in prm:
         if key.endswith(("bias", "beta")):
@@ -29,7 +30,7 @@ def make_case(seed, n, c, k, hw):
             prm[key] = rng.normal(0.3, 0.1, prm[key].shape).astype(np.float32)
         if key.endswith("moving_var"):
             prm[key] = rng.uniform(0.5, 1.5, prm[key].shape).astype(np.float32)
-    masks = {"drop_4": rng.integers(0, 2, (n, 512, hw // 8, hw // 8)), "drop_b": rng.integers(0, 2, (n, 1024, hw // 16, hw // 16))}
+    masks = {"drop_4": rng.integers(0, 2, (n, 512, h // 8, w // 8)), "drop_b": rng.integers(0, 2, (n, 1024, h // 16, w // 16))}
     return img, lab, prm, masks
 
 
@@ -127,6 +128,29 @@ def test_unet_matches_numpy_oracle(cfg):
     lt_ref, _ = ref.test_step(img, lab)
     assert abs(lt - lt_ref) < 2e-3 * abs(lt_ref)
     assert 0.0 <= float(am.result()) <= 1.0
+
+
+@pytest.mark.parametrize("cfg", [(3, 1, 2, (48, 80)), (1, 3, 6, (16, 176)), (5, 2, 3, (112, 16))])
+def test_non_square_tiles_forward_and_mask_match_oracle(cfg):
+    # rows != columns, odd batch sizes, widths that are not a multiple of the 32-pixel kernel tiles: eval-mode softmax and the
+    # argmax mask (UNet/inference.py:159-166) plus the training-mode loss, against the fp64 oracle
+    n, c, k, (h, w) = cfg
+    img, lab, prm, masks = make_case(71, n, c, k, (h, w))
+    model = pkg("model")
+    net = model.UNet(k, n, c)
+    net.engine.load_parameters(prm)
+    ref = on.OracleUNet(k, n, c, params=prm, dtype=np.float64)
+    sm = net.get_keras_model()(img)
+    sm_ref, _ = ref.forward(img, training=False)
+    assert sm.shape == (n, h, w, k) and np.abs(sm - sm_ref).max() < 2e-5
+    ok, undecided, differ = argmax_agreement(sm, sm_ref)
+    assert ok and differ == 0, (undecided, differ)
+    mask = net.engine.argmax(net.engine.forward(torch.as_tensor(img))).cpu().numpy()
+    assert mask.shape == (n, h, w) and np.array_equal(mask, np.argmax(sm, -1))
+    e = net.engine
+    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+    loss_ref, _, _, _, _ = ref.loss_and_grads(img, lab, masks)
+    assert abs(e.loss_buf[0].item() - loss_ref) < 1e-5 * abs(loss_ref)
 
 
 def test_unet_matches_torch_restatement_at_128():
@@ -424,7 +448,8 @@ def test_bf16_operand_beyond_2gib_falls_back_to_fp32_kernels():
     assert counts.get("conv3x3_dgrad_bf16", 0) + counts.get("conv3x3_dgrad_winograd_fused", 0) == 17, counts
 
 
-@pytest.mark.parametrize("cfg", [(2, 1, 2, 32, "fp32"), (2, 3, 4, 64, "fp32"), (1, 1, 2, 128, "fp32")])
+@pytest.mark.parametrize("cfg", [(2, 1, 2, 32, "fp32"), (2, 3, 4, 64, "fp32"), (1, 1, 2, 128, "fp32"),
+                                 (3, 1, 2, (48, 80), "fp32"), (1, 3, 6, (16, 176), "fp32")])            # non-square tiles, odd batch
 def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
     # End-to-end gradients at 1e-4 instead of 5e-2.  The network is piecewise linear: its gradient is discontinuous only in the
     # branch decisions (ReLU masks, max-pool winners), and fp32 rounding flips a few of those for pre-activations within ~1e-7
