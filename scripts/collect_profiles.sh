@@ -1,0 +1,43 @@
+#!/bin/bash
+# Collect the round's judged profiles on the GPU box:  scripts/collect_profiles.sh <tag>   (run from the repo root under gpurun)
+#   gpurun_out/<tag>_bench_{f32,bf16}_kernel_stats.txt            rocprofv3 --kernel-trace --stats of bench.py (two-stream backward)
+#   gpurun_out/<tag>_bench_{f32,bf16}_exclusive_kernel_stats.txt  the same with --no-overlap (every duration exclusive)
+#   gpurun_out/<tag>_{wino,bf16}_{fwd,dgrad,wgrad}_pmc_traffic.json   FETCH_SIZE / WRITE_SIZE in two separate --pmc passes
+# Only --kernel-trace / --stats / --pmc are used (never combined with other trace domains); python3 itself follows `--`.
+set -e
+tag=$1; root=$(pwd); out=$root/gpurun_out; mkdir -p $out
+cd /tmp; export TMPDIR=/tmp
+BF="--dtype bf16 --channels 3 --classes 4"
+for d in f32 bf16; do
+  extra=""; [ $d = bf16 ] && extra=$BF
+  for mode in "" "--no-overlap"; do
+    name=${tag}_bench_${d}$([ -n "$mode" ] && echo _exclusive)
+    rm -rf /tmp/prof_$name
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $root/bench.py $extra --steps 6 --warmup 2 --no-extra --no-cpu-baseline --no-kernel-events $mode > /tmp/prof_$name.log 2>&1
+    ips=$(grep '^{' /tmp/prof_$name.log | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['value'])")
+    csv=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
+    python3 $root/scripts/kernel_stats_summary.py $csv 8 "$tag, $d, $([ -n "$mode" ] && echo 'SINGLE-STREAM backward (--no-overlap: every duration exclusive)' || echo 'two-stream backward'): rocprofv3 --kernel-trace --stats -- python3 bench.py $extra --steps 6 --warmup 2 --no-extra --no-cpu-baseline --no-kernel-events $mode; $ips images/s under the profiler" > $out/${name}_kernel_stats.txt
+    echo "$name: $ips images/s"
+  done
+done
+# PMC traffic: one whole (last) step of a single-stream run per counter
+for d in f32 bf16; do
+  extra=""; [ $d = bf16 ] && extra=$BF
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_${d}_$c
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${d}_$c -- python3 $root/bench.py $extra --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-kernel-events --no-overlap > /tmp/pmc_${d}_$c.log 2>&1
+    echo "pmc $d $c done"
+  done
+done
+ff=$(find /tmp/pmc_f32_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pmc_f32_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+bf=$(find /tmp/pmc_bf16_FETCH_SIZE -name "*counter_collection.csv" | head -1); bw=$(find /tmp/pmc_bf16_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+cd $root
+# algorithmic bytes per step of the 17 MFMA 3x3 layers: input + output activations + weights, 4 B (fp32) or 2 B (bf16) per element
+A32=7981465600; A16=3990732800
+python3 scripts/pmc_traffic.py $ff $fw wino_fused_stream_stats_kernel 17 "512x512x1/2 classes/batch 8/f32" $A32 > $out/${tag}_wino_fwd_pmc_traffic.json
+python3 scripts/pmc_traffic.py $ff $fw wino_fused_stream_bnbwd_kernel,wino_fused_stream_kernel 17 "512x512x1/2 classes/batch 8/f32" $A32 > $out/${tag}_wino_dgrad_pmc_traffic.json
+python3 scripts/pmc_traffic.py $ff $fw wino_wgrad_fused_kernel 17 "512x512x1/2 classes/batch 8/f32" $A32 > $out/${tag}_wino_wgrad_pmc_traffic.json
+python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_stats_kernel,conv_bf16_stats_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 > $out/${tag}_bf16_fwd_pmc_traffic.json
+python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_bnbwd_kernel,conv_bf16_bnbwd_kernel,conv_bf16_stream_kernel_,conv_bf16_kernel_ 17 "512x512x3/4 classes/batch 8/bf16" $A16 > $out/${tag}_bf16_dgrad_pmc_traffic.json
+python3 scripts/pmc_traffic.py $bf $bw wgrad_bf16_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 > $out/${tag}_bf16_wgrad_pmc_traffic.json
+echo collected

@@ -23,3 +23,14 @@ for i in sel:
     n, s, e, qq = step[i]
     print("%9.1f %9.1f %8.1f  q%-3s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, qq, re.sub(r"\(anonymous namespace\)::|^void ", "", n).split("(")[0][:70]))
 print("# step span %.3f ms, kernel time sum %.3f ms" % ((step[-1][2] - t0) / 1e6, sum(r[2] - r[1] for r in step) / 1e6))
+# union of busy intervals: time in the step during which NO kernel runs, and the largest idle gaps with the kernel that ends them
+iv = sorted((r[1], r[2], r[0]) for r in step)
+busy_end, idle, gaps = iv[0][0], 0.0, []
+for s, e, n in iv:
+    if s > busy_end:
+        idle += s - busy_end
+        gaps.append(((s - busy_end) / 1e3, (s - t0) / 1e3, re.sub(r"\(anonymous namespace\)::|^void ", "", n).split("(")[0][:60]))
+    busy_end = max(busy_end, e)
+print("# GPU idle inside the step (no kernel on any queue): %.3f ms in %d gaps" % (idle / 1e6, len(gaps)))
+for g in sorted(gaps, reverse=True)[:12]:
+    print("#   gap %7.1f us before t=%9.1f us  %s" % g)
