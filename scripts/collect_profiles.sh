@@ -9,20 +9,21 @@ tag=$1; root=$(pwd); out=$root/gpurun_out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 BF="--dtype bf16 --channels 3 --classes 4"
 for d in f32 bf16; do
-  extra=""; [ $d = bf16 ] && extra=$BF
+  extra=""; if [ $d = bf16 ]; then extra=$BF; fi
   for mode in "" "--no-overlap"; do
-    name=${tag}_bench_${d}$([ -n "$mode" ] && echo _exclusive)
+    name=${tag}_bench_${d}; what="two-stream backward"
+    if [ -n "$mode" ]; then name=${name}_exclusive; what="SINGLE-STREAM backward (--no-overlap: every duration exclusive)"; fi
     rm -rf /tmp/prof_$name
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $root/bench.py $extra --steps 6 --warmup 2 --no-extra --no-cpu-baseline --no-kernel-events $mode > /tmp/prof_$name.log 2>&1
     ips=$(grep '^{' /tmp/prof_$name.log | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['value'])")
     csv=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
-    python3 $root/scripts/kernel_stats_summary.py $csv 8 "$tag, $d, $([ -n "$mode" ] && echo 'SINGLE-STREAM backward (--no-overlap: every duration exclusive)' || echo 'two-stream backward'): rocprofv3 --kernel-trace --stats -- python3 bench.py $extra --steps 6 --warmup 2 --no-extra --no-cpu-baseline --no-kernel-events $mode; $ips images/s under the profiler" > $out/${name}_kernel_stats.txt
+    python3 $root/scripts/kernel_stats_summary.py $csv 8 "$tag, $d, $what: rocprofv3 --kernel-trace --stats -- python3 bench.py $extra --steps 6 --warmup 2 --no-extra --no-cpu-baseline --no-kernel-events $mode; $ips images/s under the profiler" > $out/${name}_kernel_stats.txt
     echo "$name: $ips images/s"
   done
 done
 # PMC traffic: one whole (last) step of a single-stream run per counter
 for d in f32 bf16; do
-  extra=""; [ $d = bf16 ] && extra=$BF
+  extra=""; if [ $d = bf16 ]; then extra=$BF; fi
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${d}_$c
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${d}_$c -- python3 $root/bench.py $extra --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-kernel-events --no-overlap > /tmp/pmc_${d}_$c.log 2>&1
@@ -37,7 +38,7 @@ A32=7981465600; A16=3990732800
 python3 scripts/pmc_traffic.py $ff $fw wino_fused_stream_stats_kernel 17 "512x512x1/2 classes/batch 8/f32" $A32 > $out/${tag}_wino_fwd_pmc_traffic.json
 python3 scripts/pmc_traffic.py $ff $fw wino_fused_stream_bnbwd_kernel,wino_fused_stream_kernel 17 "512x512x1/2 classes/batch 8/f32" $A32 > $out/${tag}_wino_dgrad_pmc_traffic.json
 python3 scripts/pmc_traffic.py $ff $fw wino_wgrad_fused_kernel 17 "512x512x1/2 classes/batch 8/f32" $A32 > $out/${tag}_wino_wgrad_pmc_traffic.json
-python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_stats_kernel,conv_bf16_stats_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 > $out/${tag}_bf16_fwd_pmc_traffic.json
-python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_bnbwd_kernel,conv_bf16_bnbwd_kernel,conv_bf16_stream_kernel_,conv_bf16_kernel_ 17 "512x512x3/4 classes/batch 8/bf16" $A16 > $out/${tag}_bf16_dgrad_pmc_traffic.json
+python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_stats_kernel,conv_bf16_stats_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 1 > $out/${tag}_bf16_fwd_pmc_traffic.json
+python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_bnbwd_kernel,conv_bf16_bnbwd_kernel,conv_bf16_stream_kernel_,conv_bf16_kernel_ 17 "512x512x3/4 classes/batch 8/bf16" $A16 1 > $out/${tag}_bf16_dgrad_pmc_traffic.json
 python3 scripts/pmc_traffic.py $bf $bw wgrad_bf16_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 > $out/${tag}_bf16_wgrad_pmc_traffic.json
 echo collected
