@@ -1024,3 +1024,45 @@ def test_winograd_batchnorm_apply_on_load_matches_two_passes(hip, shape):
         sw = np.abs(dw64).max()
         assert np.abs(dw_ref.cpu().numpy() - dw64).max() < 3e-5 * sw
         assert np.abs(dw.cpu().numpy() - dw64).max() < 3e-5 * sw
+
+
+@pytest.mark.parametrize("shape", [(8, 512, 512, 64, 64), (8, 256, 256, 128, 128), (3, 200, 328, 64, 128), (2, 520, 300, 64, 64), (8, 512, 512, 128, 64)])
+def test_conv3x3_bf16_persistent_kernels_equal_the_per_tile_kernels_at_full_size(hip, shape):
+    # The persistent kernels (bf16-stored input, output and saved activation: LDS-DMA patch staging, a workgroup walks tiles t, t + grid,
+    # ... and prefetches the next tile's first chunk under the epilogue) against the per-tile kernels, which the small-shape tests above
+    # hold to the fp64 oracle: the same bf16 values handed over as an fp32 tensor take the per-tile path, and every output element and
+    # every row of fused BatchNorm sums must be BIT-IDENTICAL.  Shapes with several tiles per workgroup (4096 / 1024 tiles on 512 / 256
+    # slots), ragged right / bottom tiles (200 x 328, 520 x 300) and both tile widths -- the multi-tile walk never runs in the small tests.
+    n, h, w, ci, co = shape
+    g = torch.Generator(device=DEV).manual_seed(ci + h)
+    bf = torch.bfloat16
+    x16 = torch.randn(n, h, w, ci, device=DEV, generator=g).to(bf); x32 = x16.float()
+    wt = torch.randn(3, 3, ci, co, device=DEV, generator=g) * 0.05; b = torch.randn(co, device=DEV, generator=g)
+    wp = torch.empty(hip.unet_conv3x3_bf16_packed_bytes(ci, co), dtype=torch.uint8, device=DEV); wpd = torch.empty_like(wp)
+    hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wp), ci, co, 0, ST()); hip.unet_conv3x3_bf16_pack_weights(P(wt), P(wpd), ci, co, 1, ST())
+    rows = hip.unet_conv3x3_bf16_stats_rows(n, h, w, ci, co)
+    for stats in (True, False):
+        outs, parts = [], []
+        for xin, f16 in ((x16, 1), (x32, 0)):
+            out = torch.zeros(n, h, w, co, device=DEV, dtype=bf)
+            part = torch.zeros((co // 64) * rows * 128, device=DEV)
+            hip.unet_conv3x3_fwd_bf16(P(xin), ci, f16, None, None, P(wp), P(b), P(out), co, 1, n, h, w, ci, co, 1,
+                                      P(part) if stats else None, part.numel() * 4 if stats else 0, ST())
+            outs.append(out); parts.append(part)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(parts[0], parts[1]), stats
+        assert outs[0].float().abs().max().item() > 0.1
+    # data gradient (+ the producer's BatchNorm-backward sums): dz as bf16 (persistent) vs fp32 (per tile), dx and r_prev bf16 in both
+    dz16 = (torch.randn(n, h, w, co, device=DEV, generator=g) * 0.1).to(bf); dz32 = dz16.float()
+    rp = torch.randn(n, h, w, ci, device=DEV, generator=g).to(bf)
+    rows2 = hip.unet_conv3x3_bf16_stats_rows(n, h, w, co, ci)
+    for stats in (True, False):
+        outs, parts = [], []
+        for dzin, f16 in ((dz16, 1), (dz32, 0)):
+            dx = torch.zeros(n, h, w, ci, device=DEV, dtype=bf)
+            part = torch.zeros((ci // 64) * rows2 * 128, device=DEV)
+            hip.unet_conv3x3_dgrad_bf16(P(dzin), co, f16, P(wpd), P(dx), ci, 1, n, h, w, ci, co, P(rp) if stats else None, ci if stats else 0, 1,
+                                        0, ci if stats else 0, P(part) if stats else None, part.numel() * 4 if stats else 0, ST())
+            outs.append(dx); parts.append(part)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(parts[0], parts[1]), stats
