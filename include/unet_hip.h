@@ -115,18 +115,21 @@ int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float
                             int N, int H, int W, int Cin, int Cout, int relu, void* stream);
 /* + BatchNorm sums of the output from the strip kernel (Cin <= 4, W % 4 == 0, Cout % 64 == 0): rows > 0 when it applies */
 int unet_conv3x3_fwd_direct_stats_rows(int N, int H, int W, int Cin, int Cout);
-int unet_conv3x3_fwd_direct_stats(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+/* out_bf16: the output tensor is stored as bf16 (ldo in elements; the sums are those of the fp32 values) */
+int unet_conv3x3_fwd_direct_stats(const float* x, int ldx, const float* w, const float* bias, void* out, int ldo, int out_bf16,
                                   int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
 size_t unet_conv3x3_wgrad_direct_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Conv2D(1x1, relu) class map, UNet/model.py:136 (w is [Cin][Cout]) ------------------------------------------- */
-int unet_conv1x1_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+/* x_bf16 / dx_bf16: the Cin-channel side (the last decoder layer's BatchNorm output / its gradient) is stored as bf16, leading
+ * dimension in elements; the arithmetic and the class-map side stay fp32 */
+int unet_conv1x1_fwd(const void* x, int ldx, int x_bf16, const float* w, const float* bias, float* out, int ldo,
                      long P, int Cin, int Cout, int relu, void* stream);
-int unet_conv1x1_dgrad(const float* dz, int lddz, const float* w, float* dx, int lddx, long P, int Cin, int Cout, void* stream);
+int unet_conv1x1_dgrad(const float* dz, int lddz, const float* w, void* dx, int lddx, int dx_bf16, long P, int Cin, int Cout, void* stream);
 size_t unet_conv1x1_wgrad_workspace(long P, int Cin, int Cout);
-int unet_conv1x1_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+int unet_conv1x1_wgrad(const void* xin, int ldx, int x_bf16, const float* dz, int lddz, float* dw,
                        long P, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Conv2DTranspose(2x2, stride 2) of UNet._deconv_layer, UNet/model.py:39-46 (:116,121,126,131) ---------------- */

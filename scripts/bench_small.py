@@ -26,9 +26,9 @@ print("conv3x3 direct wgrad %dch->64   %6.3f ms  %5.2f TB/s (dz read x Cin)" % (
 wk = torch.randn(64, K, device="cuda"); bk = torch.randn(K, device="cuda"); z = torch.empty(B, H, H, K, device="cuda"); dzk = torch.randn(B, H, H, K, device="cuda")
 dx = torch.empty(B, H, H, 64, device="cuda"); dwk = torch.empty_like(wk)
 nb2 = L.unet_conv1x1_wgrad_workspace(npx, 64, K); ws2 = torch.empty(nb2 + 256, dtype=torch.uint8, device="cuda")
-t = timeit(lambda: L.unet_conv1x1_fwd(P(y), 64, P(wk), P(bk), P(z), K, npx, 64, K, 1, ST()))
+t = timeit(lambda: L.unet_conv1x1_fwd(P(y), 64, 0, P(wk), P(bk), P(z), K, npx, 64, K, 1, ST()))
 print("conv1x1 fwd   64->%d           %6.3f ms  %5.2f TB/s (input read)" % (K, t, big / t / 1e9))
-t = timeit(lambda: L.unet_conv1x1_dgrad(P(dzk), K, P(wk), P(dx), 64, npx, 64, K, ST()))
+t = timeit(lambda: L.unet_conv1x1_dgrad(P(dzk), K, P(wk), P(dx), 64, 0, npx, 64, K, ST()))
 print("conv1x1 dgrad 64->%d           %6.3f ms  %5.2f TB/s (dx write)" % (K, t, big / t / 1e9))
-t = timeit(lambda: L.unet_conv1x1_wgrad(P(y), 64, P(dzk), K, P(dwk), npx, 64, K, P(ws2), nb2, ST()))
+t = timeit(lambda: L.unet_conv1x1_wgrad(P(y), 64, 0, P(dzk), K, P(dwk), npx, 64, K, P(ws2), nb2, ST()))
 print("conv1x1 wgrad 64->%d           %6.3f ms  %5.2f TB/s (input read)" % (K, t, big / t / 1e9))

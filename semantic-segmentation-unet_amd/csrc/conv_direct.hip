@@ -10,12 +10,30 @@ namespace {
 
 constexpr int CI_CHUNK = 8;
 
+// channel quad q of a pixel row whose elements are fp32 (16 B) or, B16, bf16 (8 B; `base` then points at 2-byte elements): the bf16
+// activation-storage mode keeps the first layer's conv output and the class-map layer's input / input gradient as bf16 tensors
+template <int B16> __device__ __forceinline__ f32x4 ld_quad(const float* base, size_t elem) {
+    if constexpr (B16) {
+        const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+        return f32x4{__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                     __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u)};
+    } else return *reinterpret_cast<const f32x4*>(base + elem);
+}
+template <int B16> __device__ __forceinline__ void st_quad(float* base, size_t elem, f32x4 v) {
+    if constexpr (B16) {
+        uint2 h;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h.x) : "v"(v[0]), "v"(v[1]));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h.y) : "v"(v[2]), "v"(v[3]));
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem) = h;
+    } else *reinterpret_cast<f32x4*>(base + elem) = v;
+}
+
 // ---- 3x3 'same' conv, small Cin, forward ---------------------------------------------------------------------
 // Cin = 1..4 (the first layer): the 9*Cin weight quads live in registers and a thread walks a strip of 4 consecutive
 // pixels of one image row, so the 3x6 input window is loaded once per strip and each output quad costs 9*Cin FMAs x 4 plus
 // its store (the generic kernel below spends ~100 instructions per output quad on tap addressing and LDS weight reads,
 // which capped it at 1.5 TB/s of the 6.3 the output stream could take).
-template <int CIN>
+template <int CIN, int OUT16>
 __global__ __launch_bounds__(256) void conv3x3_direct_fwd_strip_kernel(const float* __restrict__ x, int ldx,
         const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int ldo,
         int N, int H, int W, int Cout, int relu, float* __restrict__ stat_part) {
@@ -50,7 +68,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_fwd_strip_kernel(const flo
                 for (int ci = 0; ci < CIN; ++ci) v[r][c][ci] = ok ? row[(size_t)gx * ldx + ci] : 0.f;
             }
         }
-        float* o = out + ((size_t)(n * H + y) * W + x0) * ldo + 4 * q;
+        const size_t o = ((size_t)(n * H + y) * W + x0) * ldo + 4 * q;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             f32x4 acc = bv;
@@ -61,8 +79,8 @@ __global__ __launch_bounds__(256) void conv3x3_direct_fwd_strip_kernel(const flo
 #pragma unroll
                     for (int ci = 0; ci < CIN; ++ci) acc += v[r][px + c][ci] * wr[3 * r + c][ci];
             acc[0] = fmaxf(acc[0], lo); acc[1] = fmaxf(acc[1], lo); acc[2] = fmaxf(acc[2], lo); acc[3] = fmaxf(acc[3], lo);
-            *reinterpret_cast<f32x4*>(o + (size_t)px * ldo) = acc;
-            st1 += acc; st2 += acc * acc;
+            st_quad<OUT16>(out, o + (size_t)px * ldo, acc);
+            st1 += acc; st2 += acc * acc;                         // (sums of the fp32 values, before any rounding of the stored tensor)
         }
     }
     if (stat_part) {            // one row of partials per block, layout of unet_bn_train_finalize_partials: [C/64][rows][64][2]
@@ -279,6 +297,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 // ---- 1x1 conv, small Cout (class map) -------------------------------------------------------------------------
 // forward: 16 lanes per pixel, each lane takes channel quads sub, sub+16, ...; partial dots reduced by shuffles.
+template <int X16>
 __global__ __launch_bounds__(256) void conv1x1_narrow_fwd_kernel(const float* __restrict__ x, int ldx,
         const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int ldo,
         long P, int Cin, int K, int relu) {
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_fwd_kernel(const float* __
 #pragma unroll
                 for (int u = 0; u < PU; ++u) {
                     const long pix = base + u < P ? base + u : P - 1;
-                    xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)pix * ldx + 4 * cq);
+                    xv[u] = ld_quad<X16>(x, (size_t)pix * ldx + 4 * cq);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -338,6 +357,7 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_fwd_kernel(const float* __
 }
 
 // dgrad: dx[p][ci quad] = sum_k dz[p][k] * w[ci][k]
+template <int DX16>
 __global__ __launch_bounds__(256) void conv1x1_narrow_dgrad_kernel(const float* __restrict__ dz, int lddz,
         const float* __restrict__ w, float* __restrict__ dx, int lddx, long P, int Cin, int K) {
     extern __shared__ __attribute__((aligned(16))) float sW[];        // [Cin][K]
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_dgrad_kernel(const float* 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[e] += g[k] * wr[e][k];
                 }
-            *reinterpret_cast<f32x4*>(dx + (size_t)pix * lddx + 4 * cq) = acc;
+            st_quad<DX16>(dx, (size_t)pix * lddx + 4 * cq, acc);
         }
         return;
     }
@@ -380,11 +400,12 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_dgrad_kernel(const float* 
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += g * sW[(4 * cq + e) * K + k];
         }
-        *reinterpret_cast<f32x4*>(dx + (size_t)pix * lddx + 4 * cq) = acc;
+        st_quad<DX16>(dx, (size_t)pix * lddx + 4 * cq, acc);
     }
 }
 
 // wgrad: part[blk][ci][k] = sum over the block's pixels of x[p][ci] * dz[p][k]   (k0..k0+8 per pass)
+template <int X16>
 __global__ __launch_bounds__(256) void conv1x1_narrow_wgrad_kernel(const float* __restrict__ x, int ldx,
         const float* __restrict__ dz, int lddz, float* __restrict__ part, long P, int Cin, int K, long pix_per_block) {
     extern __shared__ __attribute__((aligned(16))) float sR[];        // [npl][4*tpp][8]
@@ -407,7 +428,7 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_wgrad_kernel(const float* 
                 f32x4 xv[4]; float g[4][8];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    xv[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(pix + u * (long)npl) * ldx + 4 * qq);
+                    xv[u] = ld_quad<X16>(x, (size_t)(pix + u * (long)npl) * ldx + 4 * qq);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) g[u][j] = (k0 + j < K) ? dz[(size_t)(pix + u * (long)npl) * lddz + k0 + j] : 0.f;
                 }
@@ -421,7 +442,7 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_wgrad_kernel(const float* 
                         }
             }
             for (; pix < p1; pix += npl) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)pix * ldx + 4 * qq);
+                const f32x4 xv = ld_quad<X16>(x, (size_t)pix * ldx + 4 * qq);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (k0 + j < K) {
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_wgrad_kernel(const float* 
 }  // namespace
 
 static int direct_fwd_launch(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
-                             int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+                             int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream, int out_bf16 = 0) {
     UNET_CHECK_ARG(x && w && out && N > 0 && H > 0 && W > 0 && Cin > 0 && ldx >= Cin && ldo >= Cout);
     const int tpp = Cout / 4;
     UNET_CHECK_ARG(Cout % 4 == 0 && tpp >= 1 && tpp <= 256 && 256 % tpp == 0 && ldo % 4 == 0 && unet_aligned16(out));
@@ -470,13 +491,13 @@ static int direct_fwd_launch(const float* x, int ldx, const float* w, const floa
             if (stat_bytes < (size_t)(Cout / 64) * b1 * 128 * sizeof(float)) return UNET_ENOSPC;
             sm = (size_t)ppb * Cout * 2 * sizeof(float);
         }
-        if (Cin == 1)      conv3x3_direct_fwd_strip_kernel<1><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part);
-        else if (Cin == 2) conv3x3_direct_fwd_strip_kernel<2><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part);
-        else if (Cin == 3) conv3x3_direct_fwd_strip_kernel<3><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part);
-        else               conv3x3_direct_fwd_strip_kernel<4><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part);
+#define UNET_STRIP(CI) do { if (out_bf16) conv3x3_direct_fwd_strip_kernel<CI, 1><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part); \
+                            else          conv3x3_direct_fwd_strip_kernel<CI, 0><<<(int)b1, 256, sm, st>>>(x, ldx, w, bias, out, ldo, N, H, W, Cout, relu, stat_part); } while (0)
+        if (Cin == 1) UNET_STRIP(1); else if (Cin == 2) UNET_STRIP(2); else if (Cin == 3) UNET_STRIP(3); else UNET_STRIP(4);
+#undef UNET_STRIP
         return UNET_LAUNCH_STATUS();
     }
-    if (stat_part) return UNET_EINVAL;
+    if (stat_part || out_bf16) return UNET_EINVAL;
     conv3x3_direct_fwd_kernel<<<(int)blocks, 256, smem, (hipStream_t)stream>>>(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, relu);
     return UNET_LAUNCH_STATUS();
 }
@@ -494,11 +515,12 @@ extern "C" int unet_conv3x3_fwd_direct_stats_rows(int N, int H, int W, int Cin, 
     return (int)b1;
 }
 
-// forward + BatchNorm sums of the output (stat_part: (Cout/64) * rows * 128 floats; finish with unet_bn_train_finalize_partials)
-extern "C" int unet_conv3x3_fwd_direct_stats(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+// forward + BatchNorm sums of the output (stat_part: (Cout/64) * rows * 128 floats; finish with unet_bn_train_finalize_partials);
+// out_bf16: the output tensor is stored as bf16 (ldo in elements; the sums are those of the fp32 values)
+extern "C" int unet_conv3x3_fwd_direct_stats(const float* x, int ldx, const float* w, const float* bias, void* out, int ldo, int out_bf16,
         int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(stat_part && unet_conv3x3_fwd_direct_stats_rows(N, H, W, Cin, Cout) > 0 && unet_aligned16(w));
-    return direct_fwd_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, stat_bytes, stream);
+    return direct_fwd_launch(x, ldx, w, bias, (float*)out, ldo, N, H, W, Cin, Cout, relu, stat_part, stat_bytes, stream, out_bf16 ? 1 : 0);
 }
 
 static int direct_wgrad_blocks(long P) { long b = (P + 1023) / 1024; if (b > 1024) b = 1024; if (b < 1) b = 1; return (int)b; }
@@ -531,21 +553,24 @@ extern "C" int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float*
     return UNET_LAUNCH_STATUS();
 }
 
-extern "C" int unet_conv1x1_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+// x_bf16 / dx_bf16 below: the 64-channel side of the class-map layer is stored as bf16 (leading dimension in elements); arithmetic fp32
+extern "C" int unet_conv1x1_fwd(const void* x, int ldx, int x_bf16, const float* w, const float* bias, float* out, int ldo,
                                 long P, int Cin, int Cout, int relu, void* stream) {
     UNET_CHECK_ARG(x && w && out && P > 0 && Cin > 0 && Cout > 0 && Cin % 4 == 0 && ldx % 4 == 0 && ldx >= Cin && ldo >= Cout);
     UNET_CHECK_ARG(unet_aligned16(x) && (size_t)Cin * Cout * 4 <= 64 * 1024);
     long blocks = (P + 63) / 64; if (blocks > 4096) blocks = 4096;
-    conv1x1_narrow_fwd_kernel<<<(int)blocks, 256, (size_t)Cin * Cout * 4, (hipStream_t)stream>>>(x, ldx, w, bias, out, ldo, P, Cin, Cout, relu);
+    if (x_bf16) conv1x1_narrow_fwd_kernel<1><<<(int)blocks, 256, (size_t)Cin * Cout * 4, (hipStream_t)stream>>>((const float*)x, ldx, w, bias, out, ldo, P, Cin, Cout, relu);
+    else        conv1x1_narrow_fwd_kernel<0><<<(int)blocks, 256, (size_t)Cin * Cout * 4, (hipStream_t)stream>>>((const float*)x, ldx, w, bias, out, ldo, P, Cin, Cout, relu);
     return UNET_LAUNCH_STATUS();
 }
 
-extern "C" int unet_conv1x1_dgrad(const float* dz, int lddz, const float* w, float* dx, int lddx,
+extern "C" int unet_conv1x1_dgrad(const float* dz, int lddz, const float* w, void* dx, int lddx, int dx_bf16,
                                   long P, int Cin, int Cout, void* stream) {
     UNET_CHECK_ARG(dz && w && dx && P > 0 && Cin > 0 && Cout > 0 && Cin % 4 == 0 && lddx % 4 == 0 && lddx >= Cin && lddz >= Cout);
     UNET_CHECK_ARG(unet_aligned16(dx) && (size_t)Cin * Cout * 4 <= 64 * 1024);
     long blocks = (P * (Cin / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
-    conv1x1_narrow_dgrad_kernel<<<(int)blocks, 256, (size_t)Cin * Cout * 4, (hipStream_t)stream>>>(dz, lddz, w, dx, lddx, P, Cin, Cout);
+    if (dx_bf16) conv1x1_narrow_dgrad_kernel<1><<<(int)blocks, 256, (size_t)Cin * Cout * 4, (hipStream_t)stream>>>(dz, lddz, w, (float*)dx, lddx, P, Cin, Cout);
+    else         conv1x1_narrow_dgrad_kernel<0><<<(int)blocks, 256, (size_t)Cin * Cout * 4, (hipStream_t)stream>>>(dz, lddz, w, (float*)dx, lddx, P, Cin, Cout);
     return UNET_LAUNCH_STATUS();
 }
 
@@ -553,7 +578,7 @@ extern "C" size_t unet_conv1x1_wgrad_workspace(long P, int Cin, int Cout) {
     return (size_t)direct_wgrad_blocks(P) * Cin * Cout * sizeof(float);
 }
 
-extern "C" int unet_conv1x1_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+extern "C" int unet_conv1x1_wgrad(const void* xin, int ldx, int x_bf16, const float* dz, int lddz, float* dw,
                                   long P, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(xin && dz && dw && ws && P > 0 && Cin > 0 && Cout > 0 && Cin % 4 == 0 && ldx % 4 == 0);
     const int nq = Cin / 4, tpp = nq < 256 ? nq : 256;
@@ -562,7 +587,8 @@ extern "C" int unet_conv1x1_wgrad(const float* xin, int ldx, const float* dz, in
     if (ws_bytes < unet_conv1x1_wgrad_workspace(P, Cin, Cout)) return UNET_ENOSPC;
     const long ppb = (P + blocks - 1) / blocks;
     const size_t smem = (size_t)(256 / tpp) * 4 * tpp * 8 * sizeof(float);
-    conv1x1_narrow_wgrad_kernel<<<blocks, 256, smem, (hipStream_t)stream>>>(xin, ldx, dz, lddz, (float*)ws, P, Cin, Cout, ppb);
+    if (x_bf16) conv1x1_narrow_wgrad_kernel<1><<<blocks, 256, smem, (hipStream_t)stream>>>((const float*)xin, ldx, dz, lddz, (float*)ws, P, Cin, Cout, ppb);
+    else        conv1x1_narrow_wgrad_kernel<0><<<blocks, 256, smem, (hipStream_t)stream>>>((const float*)xin, ldx, dz, lddz, (float*)ws, P, Cin, Cout, ppb);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     const long n = (long)Cin * Cout;
     sum_partials_kernel<<<unet_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>((const float*)ws, dw, n, blocks);

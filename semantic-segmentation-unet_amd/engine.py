@@ -151,6 +151,10 @@ class Engine:
         # BatchNorm output; the consumer reads the conv output r through scaled weights, a folded bias and a per-channel padding
         # value (unet_winograd_weight_fold), its weight gradient is corrected by unet_conv3x3_wgrad_fold_fix.  UNET_BN_ON_LOAD=0: two passes.
         self.bn_on_load = os.environ.get("UNET_BN_ON_LOAD", "1") != "0"
+        # bf16 activation storage also at the two ends of the network (the first layer's conv output, the class-map layer's input and
+        # input gradient): the kernels there compute in fp32 on fp32 weights, only the 64-channel tensors they exchange with the bf16
+        # layers are stored as bf16 (A/B switch)
+        self.bf16_edge_activations = os.environ.get("UNET_BF16_EDGE_ACTIVATIONS", "1") != "0"
         self._gamma_zero = None
         self.view = {}
         self._fused_U, self._fused_dirty = None, True
@@ -389,7 +393,7 @@ class Engine:
                 L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
         elif kind == "conv1":
             r = self._buf("r_" + name, (n, h, w, cout))
-            L.unet_conv1x1_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
+            L.unet_conv1x1_fwd(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
         else:
             r = r_out if r_out is not None else self._buf("r_" + name, (n, h, w, cout))
             if self._use_bf16(name, n, h, w):
@@ -427,7 +431,10 @@ class Engine:
                 rows = L.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
                 if rows > 0:
                     stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
-                    L.unet_conv3x3_fwd_direct_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, 1,
+                    if (self.compute_dtype == "bf16" and self.bf16_storage and self.bf16_activations and self.bf16_edge_activations
+                            and r_out is None and cout % 8 == 0):
+                        r = self._buf("r16_" + name, (n, h, w, cout), torch.bfloat16)
+                    L.unet_conv3x3_fwd_direct_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), int(r.dtype == torch.bfloat16), n, h, w, cin, cout, 1,
                                                     _p(stat_part), stat_part.numel() * 4, st)
                     fused_stats = (stat_part, rows)
                 else:
@@ -559,7 +566,14 @@ class Engine:
                 cat_view = (cs[0], cs[1])
             else:
                 f("up_%d" % lvl, cur, cat[..., ch:], training)
-            yb = self._ybuf("dec_%db" % lvl, (n, hh, ww, ch), "up_%d" % (lvl - 1)) if lvl > 1 else self._buf("y_dec_1b", (n, hh, ww, ch))
+            if lvl > 1:
+                yb = self._ybuf("dec_%db" % lvl, (n, hh, ww, ch), "up_%d" % (lvl - 1))
+            elif training and want_grad and self.compute_dtype == "bf16" and self.bf16_storage and self.bf16_activations and self.bf16_edge_activations:
+                # the class-map conv computes in fp32: storing its input as bf16 changes the result, so only the training step does it
+                # (bf16 activation storage, Keras mixed_bfloat16 semantics); inference keeps the fp32 tensor
+                yb = self._buf("y16_dec_1b", (n, hh, ww, ch), torch.bfloat16)
+            else:
+                yb = self._buf("y_dec_1b", (n, hh, ww, ch))
             cur = pair("dec_%da" % lvl, "dec_%db" % lvl, cat, cat_view, hh, ww, ch, yb)
         yl = f("logits", cur, self._buf("y_logits", (n, h, w, self.K)), training)
         prob = self._buf("softmax", (n, h, w, self.K))
@@ -592,8 +606,8 @@ class Engine:
         dz16 = self._dz16(name, need_dx, eval_mode)
         dz = self._buf("dz16_" + name, tuple(r.shape), torch.bfloat16) if dz16 else self._buf("dz_" + name, tuple(r.shape))
         pre = self.bnbwd_part.pop(name, None) if not eval_mode else None
-        if dz16:
-            # one entry point for the three forms (plain / pooled / sums from the consumer's data gradient), dz stored as bf16
+        if dz16 or (not eval_mode and (dy.dtype == torch.bfloat16 or r.dtype == torch.bfloat16)):
+            # one entry point for the three forms (plain / pooled / sums from the consumer's data gradient), any of dy / r / dz stored as bf16
             part_ptr, rows = None, 0
             if pre is not None:
                 part, rows, c0 = pre
@@ -603,7 +617,7 @@ class Engine:
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
             L.unet_bn_bwd_any(_p(dy), _ld(dy), _p(pdy), _ld(pdy) if pdy is not None else 0, _p(pidx), n, ho, wo, _p(r), _ld(r),
-                              _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 0 if kind == "deconv" else 1, _p(dz), cout, 1,
+                              _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 0 if kind == "deconv" else 1, _p(dz), cout, int(dz.dtype == torch.bfloat16),
                               _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]), _p(self.g[name + "/bias"]), part_ptr, rows,
                               _p(ws), nb, st, int(r.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16),
                               int(pdy is not None and pdy.dtype == torch.bfloat16))
@@ -648,7 +662,7 @@ class Engine:
                 L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
-                L.unet_conv1x1_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                L.unet_conv1x1_wgrad(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif (self.compute_dtype == "bf16" and n * ho * wo * max(cin, cout) * 4 < 2 ** 31
                   and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1):
                 nb2 = L.unet_conv3x3_wgrad_bf16_workspace(n, ho, wo, cin, cout)
@@ -700,7 +714,7 @@ class Engine:
             elif kind == "deconv":
                 L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
-                L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, P, cin, cout, st)
+                L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, int(dx.dtype == torch.bfloat16), P, cin, cout, st)
             elif self._use_bf16(name, n, ho, wo, dgrad=True):
                 prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
                 rows = L.unet_conv3x3_bf16_stats_rows(n, ho, wo, cout, cin) if prod else 0
@@ -767,12 +781,18 @@ class Engine:
 
     def _dx16(self, name, eval_mode):
         """the 3x3 layer's data gradient may be WRITTEN as bf16: every reader of it is a BatchNorm backward that takes bf16 dy"""
-        if self.compute_dtype != "bf16" or not (self.bf16_storage and self.bf16_activations) or eval_mode or self.kind[name] != "conv3":
+        if self.compute_dtype != "bf16" or not (self.bf16_storage and self.bf16_activations) or eval_mode:
+            return False
+        if self.kind[name] == "conv1":                                  # class map: its input gradient is dec_1b's dy
+            return self.bf16_edge_activations and self.cin[name] % 8 == 0 and self._dz16("dec_1b", True, eval_mode)
+        if self.kind[name] != "conv3":
             return False
         n, ho, wo, _ = self.saved[name][1].shape
         if not self._use_bf16(name, n, ho, wo, dgrad=True):            # the fp32 kernels (size fallback) write fp32
             return False
-        need1 = lambda nm: self._dz16(nm, nm != "conv_1a", eval_mode)
+        # a reader takes bf16 dy when its BatchNorm backward goes through the unified entry point: its dz is bf16, or (the first layer, whose
+        # weight gradient is the fp32 stencil kernel) its saved conv output is
+        need1 = lambda nm: self._dz16(nm, nm != "conv_1a", eval_mode) or (nm in self.saved and self.saved[nm][1].dtype == torch.bfloat16)
         if name.startswith("dec_") and name.endswith("a"):             # [skip, upsampled]: conv_Nb (through the fused pool path) and up_N
             lvl = int(name[4])
             return lvl != 4 and self.fuse_pool and need1("conv_%db" % lvl) and need1("up_%d" % lvl)

@@ -196,6 +196,20 @@ def test_first_layer_direct_conv(hip, cin, w):
     dw = torch.empty(3, 3, cin, co, device=DEV)
     hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dzd), co, P(dw), n, h, w, cin, co, P(ws), nb, ST())
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 1e-5
+    rows = hip.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, co)
+    if rows > 0:
+        # + BatchNorm sums, output stored as fp32 or bf16: the bf16 tensor is the fp32 one rounded (nearest even), the sums identical
+        # (they are taken before the rounding)
+        res = []
+        for o16 in (0, 1):
+            o = torch.zeros(n, h, w, co, device=DEV, dtype=torch.bfloat16 if o16 else torch.float32)
+            part = torch.zeros((co // 64) * rows * 128, device=DEV)
+            hip.unet_conv3x3_fwd_direct_stats(P(xd), cin, P(wd), P(bd), P(o), co, o16, n, h, w, cin, co, 1, P(part), part.numel() * 4, ST())
+            res.append((o, part))
+        assert torch.equal(res[0][0], out) and torch.equal(res[0][0].to(torch.bfloat16), res[1][0]) and torch.equal(res[0][1], res[1][1])
+        sums = res[0][1].view(co // 64, rows, 64, 2).sum(1).reshape(co, 2).cpu().numpy().astype(np.float64)
+        zr = z_ref.transpose(0, 2, 3, 1).reshape(-1, co)
+        assert relerr(sums[:, 0], zr.sum(0)) < 1e-5 and relerr(sums[:, 1], (zr * zr).sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("k", [2, 6, 11])
@@ -209,16 +223,30 @@ def test_conv1x1_class_map(hip, k):
     xd, wd, bd, dzd = to_nhwc(x), dev(wt), dev(b), to_nhwc(dz)
     pix = n * h * w
     out = torch.empty(n, h, w, k, device=DEV)
-    hip.unet_conv1x1_fwd(P(xd), ci, P(wd), P(bd), P(out), k, pix, ci, k, 1, ST())
+    hip.unet_conv1x1_fwd(P(xd), ci, 0, P(wd), P(bd), P(out), k, pix, ci, k, 1, ST())
     assert relerr(from_nhwc(out), z_ref) < 1e-5
     dx = torch.empty(n, h, w, ci, device=DEV)
-    hip.unet_conv1x1_dgrad(P(dzd), k, P(wd), P(dx), ci, pix, ci, k, ST())
+    hip.unet_conv1x1_dgrad(P(dzd), k, P(wd), P(dx), ci, 0, pix, ci, k, ST())
     assert relerr(from_nhwc(dx), dx_ref) < 1e-5
     nb = hip.unet_conv1x1_wgrad_workspace(pix, ci, k)
     ws = ws_bytes(nb)
     dw = torch.empty(1, 1, ci, k, device=DEV)
-    hip.unet_conv1x1_wgrad(P(xd), ci, P(dzd), k, P(dw), pix, ci, k, P(ws), nb, ST())
+    hip.unet_conv1x1_wgrad(P(xd), ci, 0, P(dzd), k, P(dw), pix, ci, k, P(ws), nb, ST())
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 1e-5
+    # the Cin-channel side stored as bf16 (bf16 activation storage): same values handed over as bf16 and as fp32 tensors give
+    # bit-identical class maps and weight gradients; a bf16 input gradient is the fp32 one rounded
+    x16 = xd.to(torch.bfloat16); x32 = x16.float()
+    o16, o32 = torch.empty_like(out), torch.empty_like(out)
+    hip.unet_conv1x1_fwd(P(x16), ci, 1, P(wd), P(bd), P(o16), k, pix, ci, k, 1, ST())
+    hip.unet_conv1x1_fwd(P(x32), ci, 0, P(wd), P(bd), P(o32), k, pix, ci, k, 1, ST())
+    assert torch.equal(o16, o32)
+    dx16 = torch.empty(n, h, w, ci, device=DEV, dtype=torch.bfloat16)
+    hip.unet_conv1x1_dgrad(P(dzd), k, P(wd), P(dx16), ci, 1, pix, ci, k, ST())
+    assert torch.equal(dx16, dx.to(torch.bfloat16))
+    dw16, dw32 = torch.empty_like(dw), torch.empty_like(dw)
+    hip.unet_conv1x1_wgrad(P(x16), ci, 1, P(dzd), k, P(dw16), pix, ci, k, P(ws), nb, ST())
+    hip.unet_conv1x1_wgrad(P(x32), ci, 0, P(dzd), k, P(dw32), pix, ci, k, P(ws), nb, ST())
+    assert torch.equal(dw16, dw32)
 
 
 @pytest.mark.parametrize("c,relu", [(64, 1), (256, 0), (2, 1), (6, 1), (4, 1)])
