@@ -119,7 +119,7 @@ int unet_conv3x3_fwd_direct_stats_rows(int N, int H, int W, int Cin, int Cout);
 int unet_conv3x3_fwd_direct_stats(const float* x, int ldx, const float* w, const float* bias, void* out, int ldo, int out_bf16,
                                   int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
 size_t unet_conv3x3_wgrad_direct_workspace(int N, int H, int W, int Cin, int Cout);
-int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const void* dz, int lddz, int dz_bf16, float* dw,
                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Conv2D(1x1, relu) class map, UNet/model.py:136 (w is [Cin][Cout]) ------------------------------------------- */

@@ -21,7 +21,7 @@ nb = L.unet_conv3x3_wgrad_direct_workspace(B, H, H, C, 64); ws = torch.empty(nb 
 big = npx * 64 * 4.0
 t = timeit(lambda: L.unet_conv3x3_fwd_direct(P(x1), C, P(w1), P(b1), P(y), 64, B, H, H, C, 64, 1, ST()))
 print("conv3x3 direct fwd   %dch->64   %6.3f ms  %5.2f TB/s (output write)" % (C, t, big / t / 1e9))
-t = timeit(lambda: L.unet_conv3x3_wgrad_direct(P(x1), C, P(dz), 64, P(dw1), B, H, H, C, 64, P(ws), nb, ST()))
+t = timeit(lambda: L.unet_conv3x3_wgrad_direct(P(x1), C, P(dz), 64, 0, P(dw1), B, H, H, C, 64, P(ws), nb, ST()))
 print("conv3x3 direct wgrad %dch->64   %6.3f ms  %5.2f TB/s (dz read x Cin)" % (C, t, C * big / t / 1e9))
 wk = torch.randn(64, K, device="cuda"); bk = torch.randn(K, device="cuda"); z = torch.empty(B, H, H, K, device="cuda"); dzk = torch.randn(B, H, H, K, device="cuda")
 dx = torch.empty(B, H, H, 64, device="cuda"); dwk = torch.empty_like(wk)

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_fwd_kernel(const float* __
 }
 
 // ---- 3x3 conv, small Cin, weight gradient: blockIdx.y = ci, per-block partials -> fixed-order reduce ----------
+template <int Z16>
 __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const float* __restrict__ x, int ldx,
         const float* __restrict__ dz, int lddz, float* __restrict__ part, int N, int H, int W, int Cin, int Cout,
         long pix_per_block) {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const float* 
             long t = pix; const int x0 = (int)(t % W); t /= W; const int y = (int)(t % H); const int n = (int)(t / H);
             f32x4 g[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const f32x4*>(dz + (size_t)(pix + u) * lddz + 4 * q);
+            for (int u = 0; u < 4; ++u) g[u] = ld_quad<Z16>(dz, (size_t)(pix + u) * lddz + 4 * q);
             float v[3][6];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const float* 
     } else {
         for (long pix = p0 + pl; pix < p1; pix += npl) {
             long t = pix; const int xx = (int)(t % W); t /= W; const int y = (int)(t % H); const int n = (int)(t / H);
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dz + (size_t)pix * lddz + 4 * q);
+            const f32x4 g = ld_quad<Z16>(dz, (size_t)pix * lddz + 4 * q);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int gy = y + tap / 3 - 1, gx = xx + tap % 3 - 1;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_kernel(const float* 
 
 // the same for 2..4 input channels in ONE pass over dz (the per-channel grid above reads dz once per input channel): a thread keeps
 // 9 x CIN accumulator quads; requires the 4-pixel strip geometry (W % 4 == 0, block ranges multiples of 4)
-template <int CIN>
+template <int CIN, int Z16>
 __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_multi_kernel(const float* __restrict__ x, int ldx,
         const float* __restrict__ dz, int lddz, float* __restrict__ part, int N, int H, int W, int Cout, long pix_per_block) {
     extern __shared__ __attribute__((aligned(16))) float sR[];        // [pl][9][Cout]
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_wgrad_multi_kernel(const f
         long t = pix; const int x0 = (int)(t % W); t /= W; const int y = (int)(t % H); const int n = (int)(t / H);
         f32x4 g[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const f32x4*>(dz + (size_t)(pix + u) * lddz + 4 * q);
+        for (int u = 0; u < 4; ++u) g[u] = ld_quad<Z16>(dz, (size_t)(pix + u) * lddz + 4 * q);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int gy = y + r - 1;
@@ -529,8 +530,10 @@ extern "C" size_t unet_conv3x3_wgrad_direct_workspace(int N, int H, int W, int C
     return (size_t)direct_wgrad_blocks((long)N * H * W) * 9 * Cin * Cout * sizeof(float);
 }
 
-extern "C" int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+// dz_bf16: dz is stored as bf16 (lddz in elements); products and sums in fp32
+extern "C" int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const void* dzv, int lddz, int dz_bf16, float* dw,
                                          int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    const float* dz = (const float*)dzv;
     UNET_CHECK_ARG(xin && dz && dw && ws && N > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 65535);
     const int tpp = Cout / 4;
     UNET_CHECK_ARG(Cout % 4 == 0 && tpp >= 1 && tpp <= 256 && 256 % tpp == 0 && lddz % 4 == 0 && unet_aligned16(dz));
@@ -542,11 +545,14 @@ extern "C" int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const float*
     UNET_CHECK_ARG(smem <= 64 * 1024);
     hipStream_t st = (hipStream_t)stream;
     if (Cin >= 2 && Cin <= 4 && W % 4 == 0) {                       // every block range is whole 4-pixel strips (ppb % 4 == 0, P % 4 == 0)
-        if (Cin == 2)      conv3x3_direct_wgrad_multi_kernel<2><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb);
-        else if (Cin == 3) conv3x3_direct_wgrad_multi_kernel<3><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb);
-        else               conv3x3_direct_wgrad_multi_kernel<4><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb);
-    } else
-        conv3x3_direct_wgrad_kernel<<<dim3(blocks, Cin), 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cin, Cout, ppb);
+#define UNET_WG(CI) do { if (dz_bf16) conv3x3_direct_wgrad_multi_kernel<CI, 1><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb); \
+                         else         conv3x3_direct_wgrad_multi_kernel<CI, 0><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb); } while (0)
+        if (Cin == 2) UNET_WG(2); else if (Cin == 3) UNET_WG(3); else UNET_WG(4);
+#undef UNET_WG
+    } else if (dz_bf16)
+        conv3x3_direct_wgrad_kernel<1><<<dim3(blocks, Cin), 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cin, Cout, ppb);
+    else
+        conv3x3_direct_wgrad_kernel<0><<<dim3(blocks, Cin), 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cin, Cout, ppb);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     const long n = 9L * Cin * Cout;
     sum_partials_kernel<<<unet_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>((const float*)ws, dw, n, blocks);

@@ -685,7 +685,8 @@ class Engine:
                             _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             else:
                 nb2 = L.unet_conv3x3_wgrad_direct_workspace(n, ho, wo, cin, cout)
-                L.unet_conv3x3_wgrad_direct(_p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                L.unet_conv3x3_wgrad_direct(_p(x), _ld(x), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw), n, ho, wo, cin, cout,
+                                            _p(self._workspace(nb2, sd)), nb2, st2)
             if self.on_layer_grads_ready is not None:
                 self.on_layer_grads_ready(name)          # under the stream the gradients were produced on
 
@@ -767,6 +768,9 @@ class Engine:
         x, r = self.saved[name]
         n, ho, wo, _ = r.shape
         if kind == "conv3":
+            if (not need_dx and self.bf16_activations and self.bf16_edge_activations and cin % 64 != 0 and cout % 8 == 0
+                    and r.dtype == torch.bfloat16):
+                return True              # the first layer: its weight gradient (the fp32 stencil kernel) reads dz in either storage
             return (n * ho * wo * max(cin, cout) * 4 < 2 ** 31 and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1
                     and (not need_dx or self._use_bf16(name, n, ho, wo, dgrad=True)))
         if kind == "deconv":

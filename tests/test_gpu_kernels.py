@@ -194,8 +194,14 @@ def test_first_layer_direct_conv(hip, cin, w):
     nb = hip.unet_conv3x3_wgrad_direct_workspace(n, h, w, cin, co)
     ws = ws_bytes(nb)
     dw = torch.empty(3, 3, cin, co, device=DEV)
-    hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dzd), co, P(dw), n, h, w, cin, co, P(ws), nb, ST())
+    hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dzd), co, 0, P(dw), n, h, w, cin, co, P(ws), nb, ST())
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 1e-5
+    # dz stored as bf16: the same (bf16-representable) values as a bf16 and as an fp32 tensor give the same bits
+    dz16 = dzd.to(torch.bfloat16); dz32 = dz16.float()
+    dwa, dwb = torch.empty_like(dw), torch.empty_like(dw)
+    hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dz16), co, 1, P(dwa), n, h, w, cin, co, P(ws), nb, ST())
+    hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dz32), co, 0, P(dwb), n, h, w, cin, co, P(ws), nb, ST())
+    assert torch.equal(dwa, dwb)
     rows = hip.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, co)
     if rows > 0:
         # + BatchNorm sums, output stored as fp32 or bf16: the bf16 tensor is the fp32 one rounded (nearest even), the sums identical
