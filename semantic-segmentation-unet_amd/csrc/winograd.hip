@@ -1178,7 +1178,14 @@ __global__ __launch_bounds__(256) void wino_partial_reduce_kernel(const float* _
 int wgrad_fused_splits(int N, int H, int W, int Ci, int Co) {
     const int blocks = (Ci / 64) * (Co / 64);
     const long nchunks = (long)N * (H / 2) * ((W / 2 + 7) / 8);
-    long sp = 256 / blocks; if (sp < 1) sp = 1; if (sp > nchunks) sp = nchunks;
+    // Workgroups on the chip: at most one per CU, and by default (UNET_WGRAD_CUS, A/B switch) about 32 CUs are left to the OTHER stream --
+    // the main stream's HBM-bound BatchNorm passes (and, data-parallel, RCCL's kernels) cannot share a CU with these 512-register
+    // workgroups, so a weight gradient that fills every CU serialises them behind itself.  Same-box A/B of the step: 44.33 -> 44.05 ms.
+    // A layer whose block count cannot get near the wanted number keeps the full grid (1024 -> 512: 128 blocks x 2).
+    static const int want = [] { const char* e = getenv("UNET_WGRAD_CUS"); const int v = e ? atoi(e) : 0; return v >= 32 && v <= 256 ? v : 224; }();
+    long sp = 256 / blocks; if (sp < 1) sp = 1;
+    if (blocks * sp > want && blocks * (want / blocks) >= 192) sp = want / blocks;
+    if (sp > nchunks) sp = nchunks;
     return (int)sp;
 }
 
