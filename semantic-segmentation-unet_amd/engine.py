@@ -136,6 +136,8 @@ class Engine:
         self.loss_buf = torch.zeros(2, dtype=torch.float32, device=self.dev)             # [loss, correct]
         self.dropout_seed = seed
         self.ce_clip_eps = CE_CLIP_EPS
+        self._eval_folded = set()               # layers whose eval-mode (moving-statistics) BatchNorm-on-load fold is current
+        self._eval_coefs = set()                # (layer, destination) pairs whose eval-mode scale / shift are current
         self.init_parameters(seed)
         self.on_layer_grads_ready = None        # hook(name) for data-parallel bucketing (parallel.py)
         self.profile = None                     # bench.py: {"conv3x3_fwd": [(ev0, ev1, flops)], ...} when enabled
@@ -294,6 +296,7 @@ class Engine:
         """theta was written from outside (broadcast, checkpoint): every cached transform of the kernels is stale."""
         self._fused_dirty = True
         self._bf16_dirty = True
+        self._eval_folded.clear(); self._eval_coefs.clear()
         self._gamma_zero = None                 # re-checked lazily (BatchNorm-apply on load needs every gamma != 0)
 
     def load_parameters(self, values):
@@ -413,9 +416,16 @@ class Engine:
                 if in_view is not None:
                     # BatchNorm-apply on load: scaled weight transform, folded bias, per-channel padding value (this step's coefficients)
                     uc, bias_eff, pad = self._fold_buffers(name)
-                    nbf = L.unet_winograd_weight_fold_workspace(cin, cout)
-                    L.unet_winograd_weight_fold(_p(w_), _p(b_), _p(in_view[0]), _p(in_view[1]), _p(uc), _p(bias_eff), _p(pad), cin, cout,
-                                                _p(self._workspace(nbf)), nbf, st)
+                    if training or name not in self._eval_folded:
+                        # (inference: the coefficients come from the moving statistics -- constants until the parameters change -- so
+                        # the fold of one forward serves every later tile)
+                        nbf = L.unet_winograd_weight_fold_workspace(cin, cout)
+                        L.unet_winograd_weight_fold(_p(w_), _p(b_), _p(in_view[0]), _p(in_view[1]), _p(uc), _p(bias_eff), _p(pad), cin, cout,
+                                                    _p(self._workspace(nbf)), nbf, st)
+                        if training:
+                            self._eval_folded.discard(name)
+                        else:
+                            self._eval_folded.add(name)
                 else:
                     uc, bias_eff, pad = self._fused_kernels(name)[0], b_, None
                 # (with stat_part the conv kernel also leaves the BatchNorm sums of its output: one activation read less per layer)
@@ -452,8 +462,11 @@ class Engine:
             ws = self._workspace(nb)
             L.unet_bn_train_stats(_p(r), _ld(r), P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM, BN_MOVING_VAR_UNBIASED,
                                   _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(sc_out), _p(sh_out), _p(ws), nb, st)
-        else:
+        elif (name, sc_out.data_ptr()) not in self._eval_coefs:             # (inference: constants until the parameters change)
             L.unet_bn_eval_coeffs(_p(gm), _p(bt), _p(mm), _p(mv), BN_EPS, cout, _p(sc_out), _p(sh_out), st)
+            self._eval_coefs.add((name, sc_out.data_ptr()))
+        if training:
+            self._eval_coefs.clear()            # the batch statistics' coefficients went into the same buffers
         self.saved[name] = (x, r)
         self.view[name] = in_view
         self.coef[name] = (sc_out, sh_out)
@@ -857,6 +870,7 @@ class Engine:
         self.iterations += 1
         self._fused_dirty = True
         self._bf16_dirty = True
+        self._eval_folded.clear(); self._eval_coefs.clear()
         t = self.iterations
         alpha = learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
         self.L.unet_adam_keras(_p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v), self.n_flat, alpha,

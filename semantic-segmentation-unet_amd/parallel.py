@@ -86,3 +86,5 @@ class DataParallel:
             for t in self.engine.moving.values():
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 t.div_(self.world_size)
+            if hasattr(self.engine, "parameters_changed"):
+                self.engine.parameters_changed()         # cached eval-mode folds of the moving statistics are stale

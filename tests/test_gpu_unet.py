@@ -579,3 +579,28 @@ def test_two_replicas_compose_to_the_global_batch_step():
     for net in nets:
         net.engine.adam_step(3e-4)
     assert torch.equal(nets[0].engine.theta, nets[1].engine.theta)
+
+
+def test_inference_fold_cache_follows_the_parameters():
+    # Inference keeps the BatchNorm-on-load folds of one forward for the following tiles (the moving statistics are constants between
+    # parameter changes).  The cache must not survive anything that changes them: a training step, load_parameters, a checkpoint load.
+    n, c, k, hw = 1, 1, 2, 64
+    img, lab, prm, masks = make_case(83, n, c, k, hw)
+    model = pkg("model")
+    net = model.UNet(k, n, c, learning_rate=1e-2)
+    e = net.engine
+    e.load_parameters(prm)
+    x = torch.as_tensor(img)
+    p0 = e.forward(x).clone()
+    assert len(e._eval_folded) > 0 or not e.bn_on_load                    # the fp32 route folds 13 layers
+    assert torch.equal(e.forward(x), p0)                                   # second tile: served from the cached folds, same bits
+    for _ in range(3):
+        net.train_step((img, lab, None, None), dropout_masks=masks)        # weights AND moving statistics move
+    assert len(e._eval_folded) == 0
+    p1 = e.forward(x).clone()
+    ref = on.OracleUNet(k, n, c, params=e.export_parameters(), dtype=np.float64)
+    sm_ref, _ = ref.forward(img, training=False)
+    assert np.abs(p1.cpu().numpy() - sm_ref).max() < 2e-5                  # the folds were rebuilt from the new parameters
+    assert not torch.equal(p1, p0)
+    e.load_parameters(prm)
+    assert len(e._eval_folded) == 0 and torch.equal(e.forward(x), p0)
