@@ -1178,11 +1178,11 @@ __global__ __launch_bounds__(256) void wino_partial_reduce_kernel(const float* _
 int wgrad_fused_splits(int N, int H, int W, int Ci, int Co) {
     const int blocks = (Ci / 64) * (Co / 64);
     const long nchunks = (long)N * (H / 2) * ((W / 2 + 7) / 8);
-    // Workgroups on the chip: at most one per CU, and by default (UNET_WGRAD_CUS, A/B switch) about 32 CUs are left to the OTHER stream --
-    // the main stream's HBM-bound BatchNorm passes (and, data-parallel, RCCL's kernels) cannot share a CU with these 512-register
-    // workgroups, so a weight gradient that fills every CU serialises them behind itself.  Same-box A/B of the step: 44.33 -> 44.05 ms.
-    // A layer whose block count cannot get near the wanted number keeps the full grid (1024 -> 512: 128 blocks x 2).
-    static const int want = [] { const char* e = getenv("UNET_WGRAD_CUS"); const int v = e ? atoi(e) : 0; return v >= 32 && v <= 256 ? v : 224; }();
+    // Workgroups on the chip: one per CU.  UNET_WGRAD_CUS=224 (A/B switch) leaves ~4 CUs per XCD to the OTHER stream -- the main stream's
+    // BatchNorm passes (and, data-parallel, RCCL's kernels) cannot share a CU with these 512-register workgroups and otherwise queue
+    // behind a chip-filling grid: the step gains 0.3 ms of 44.1 (the passes then run beside the weight gradient, but at 1.3-2.1 TB/s:
+    // DESIGN.md), while the kernel itself is 12 % slower when timed alone -- not the default.
+    static const int want = [] { const char* e = getenv("UNET_WGRAD_CUS"); const int v = e ? atoi(e) : 0; return v >= 32 && v <= 256 ? v : 256; }();
     long sp = 256 / blocks; if (sp < 1) sp = 1;
     if (blocks * sp > want && blocks * (want / blocks) >= 192) sp = want / blocks;
     if (sp > nchunks) sp = nchunks;
