@@ -44,12 +44,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table: ~2.5 PF dense bf16 (spec)
 WINOGRAD_MULT_RATIO = 2.25           # F(2x2,3x3): 36 direct multiplies per tile and channel pair -> 16
 
 FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16?, offline PMC traffic file)
-    "conv3x3_fwd_winograd_fused": ("wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "r02c_wino_fwd_pmc_traffic.json"),
-    "conv3x3_dgrad_winograd_fused": ("wino_fused_stream_kernel / _bnstats (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "r02c_wino_dgrad_pmc_traffic.json"),
-    "conv3x3_wgrad_winograd_fused": ("wino_wgrad_fused_kernel (3x3 conv weight gradient, Winograd F(2x2,3x3), reduce over tiles on v_mfma_f32_32x32x2_f32)", True, False, "r02c_wino_wgrad_pmc_traffic.json"),
-    "conv3x3_fwd_bf16": ("conv_bf16_stream_stats_kernel_{128,64} (3x3 conv forward + BatchNorm sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02c_bf16_fwd_pmc_traffic.json"),
-    "conv3x3_dgrad_bf16": ("conv_bf16_stream_bnbwd_kernel_{128,64} (3x3 conv data gradient + producer BatchNorm-backward sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02c_bf16_dgrad_pmc_traffic.json"),
-    "conv3x3_wgrad_bf16": ("wgrad_bf16_kernel (3x3 conv weight gradient, pixel contraction on v_mfma_f32_32x32x16_bf16)", False, True, "r02c_bf16_wgrad_pmc_traffic.json"),
+    "conv3x3_fwd_winograd_fused": ("wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "r02d_wino_fwd_pmc_traffic.json"),
+    "conv3x3_dgrad_winograd_fused": ("wino_fused_stream_kernel / _bnstats (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "r02d_wino_dgrad_pmc_traffic.json"),
+    "conv3x3_wgrad_winograd_fused": ("wino_wgrad_fused_kernel (3x3 conv weight gradient, Winograd F(2x2,3x3), reduce over tiles on v_mfma_f32_32x32x2_f32)", True, False, "r02d_wino_wgrad_pmc_traffic.json"),
+    "conv3x3_fwd_bf16": ("conv_bf16_stream_stats_kernel_{128,64} (3x3 conv forward + BatchNorm sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_fwd_pmc_traffic.json"),
+    "conv3x3_dgrad_bf16": ("conv_bf16_stream_bnbwd_kernel_{128,64} (3x3 conv data gradient + producer BatchNorm-backward sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_dgrad_pmc_traffic.json"),
+    "conv3x3_wgrad_bf16": ("wgrad_bf16_kernel (3x3 conv weight gradient, pixel contraction on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_wgrad_pmc_traffic.json"),
 }
 
 
