@@ -711,7 +711,7 @@ struct WgBf16Args {
     int n_ci, n_co, splits, tbx, rpc, cps, n_sc;
     unsigned x_bytes, dz_bytes;
     int x16, z16;                // xin / dz stored as bf16 (ldx / lddz in elements)
-    int ablate;                  // diagnostics (UNET_WGRAD_BF16_ABLATE): 1 = no MFMA stream, 2 = no staging loads (results are wrong)
+    int ablate;                  // diagnostics (UNET_WGRAD_BF16_ABLATE): 1 = no MFMA stream, 2 = no staging loads, 4 = no conversion + LDS writes, 8 = no barrier (results are wrong)
 };
 
 constexpr int kWgXRow = 2 * 36 * 64, kWgDzRow = kWgXRow;            // bytes of one staged row: 2 channel groups x 36 pixels (34 / 32 used) x 64 B
@@ -737,8 +737,16 @@ __device__ __forceinline__ void wg_wait_tied2(int n, bf16x8& a, bf16x8& b0, bf16
                  default: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b0), "+v"(b1)); }
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgBf16Args p) {
-    __shared__ __attribute__((aligned(1024))) char smem[kWgXRing + 4 * kWgDzRow];
+// DMA = 1 (both operands stored as bf16): the staged rows are copies of memory, so they go global -> LDS by LDS-DMA (16 bytes per lane,
+// five 1 KB pieces per row and wave; out-of-image pixels and rows read a zero page) -- no staging registers, no conversions, no ds_write
+// (ablation of the register path on 512->512 @64^2, ms per launch: MFMA stream 0.096, staging loads 0.022, conversion + LDS writes 0.046
+// -- nine ds_write_b64 per lane and step from ONE wave per SIMD run at a fraction of the LDS store rate -- barrier 0.005, fixed 0.035).
+// The rings grow to 8 input rows / 6 dz rows and the DMA of pass s + 3 is issued at step s: two steps of latency cover instead of one.
+template <int DMA>
+__device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
+    constexpr int XR = DMA ? 8 : 6, ZR = DMA ? 6 : 4;                // ring rows: input / dz
+    constexpr int kXRingB = XR * kWgXRow;
+    __shared__ __attribute__((aligned(1024))) char smem[(XR + ZR) * kWgXRow];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -765,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgBf16Args p) {
     const int g4 = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
     const unsigned frag_lane = (unsigned)((8 * (g4 >> 1) + q4) * 64 + (16 * (g4 & 1) + 4 * pp) * 2);
     const unsigned a_lane = lds0 + cisub * (36 * 64) + frag_lane;
-    const unsigned b_lane = lds0 + kWgXRing + cosub * (36 * 64) + frag_lane;
+    const unsigned b_lane = lds0 + kXRingB + cosub * (36 * 64) + frag_lane;
 
     const int xes = p.x16 ? 2 : 4, zes = p.z16 ? 2 : 4;
     const char* xb_ptr = reinterpret_cast<const char*>(p.x) + (size_t)ci0 * xes;
@@ -804,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgBf16Args p) {
     };
     // convert and write pass j
     auto commit = [&](const f32x4 (&sg)[9], int j) {
-        const int slot = is_x ? (2 * j + rho) % 6 : 6 + 2 * ((j + 1) & 1) + rho;       // dz slots follow the 6 input-row slots
+        const int slot = is_x ? (2 * j + rho) % XR : XR + 2 * ((j + 1) & 1) + rho;     // dz slots follow the input-row slots
         const unsigned wb = lds0 + wr_lane + (unsigned)(slot * kWgXRow);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -819,8 +827,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgBf16Args p) {
     auto compute = [&](int s) {
         unsigned xb[4], zb[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xb[r] = a_lane + (unsigned)(((2 * s + r) % 6) * kWgXRow);
-        zb[0] = b_lane + (unsigned)(((s & 1) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
+        for (int r = 0; r < 4; ++r) xb[r] = a_lane + (unsigned)(((2 * s + r) % XR) * kWgXRow);
+        zb[0] = b_lane + (unsigned)(((s % (ZR / 2)) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
         // One asm block per step (generated: 80 transposing reads, 36 MFMAs, counted waits; LDS operations retire in order).  The
         // fragments live in fixed registers v[88:111] -- A buffers four deep, B two -- because a 128-bit MFMA operand has to be
         // assembled from two 64-bit reads: as separate asm statements that took compiler copies plus s_nop padding in front of
@@ -983,12 +991,58 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgBf16Args p) {
             : "memory", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111");
     };
 
+    // DMA form: a row slot (2 groups x 36 pixels x 64 B = 288 16-byte pieces) is filled by five wave-instructions; piece 64 k + lane =
+    // (group, pixel, 16-byte quarter of the pixel's 32 channels) -- the LDS image is a copy of memory
+    constexpr int NI = 5;
+    unsigned poff[NI]; unsigned pok = 0;                              // per-lane source offset inside the image row 0 / validity bits (per strip)
+    int dgrp[NI], dpix[NI], dj[NI];
+    if constexpr (DMA) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int P = 64 * k + lane;
+            dgrp[k] = P / 144; const int rem = P % 144; dpix[k] = rem >> 2; dj[k] = rem & 3;
+        }
+    }
+    auto dma_issue = [&](int j) {
+        const int row = is_x ? y0 - 1 + 2 * j + rho : y0 + 2 * (j - 1) + rho;
+        const bool rok = is_x ? (row >= 0 && row < p.H) : (row >= y0 && row < y_end);
+        const int slot = is_x ? (2 * j + rho) % XR : XR + 2 * ((j + 2) % 3) + rho;        // dz rows of step j - 1: slots 2 ((j - 1) % 3), + 1
+        const char* rb = role_ptr + (size_t)(rok ? row : 0) * role_rowbytes;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const char* src = (rok && ((pok >> k) & 1)) ? rb + poff[k] : reinterpret_cast<const char*>(g_zero_page_b) + dj[k] * 16;
+            if (k < 4 || lane < 32)                                   // pieces 288 .. 319 would land in the next slot
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void_b*)(smem + slot * kWgXRow + 1024 * k), 16, 0, 0);
+        }
+    };
+
     for (int sc = split; sc < p.n_sc; sc += p.splits) {
         const int strip = sc / p.cps, chunk = sc % p.cps;
         const int img = strip / p.tbx, x0 = 32 * (strip % p.tbx);
         y0 = chunk * p.rpc;
         y_end = y0 + p.rpc < p.H ? y0 + p.rpc : p.H;
         const int steps = (y_end - y0 + 1) / 2;
+        if constexpr (DMA) {
+            pok = 0;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int gx = is_x ? x0 - 1 + dpix[k] : x0 + dpix[k];
+                const bool ok = 64 * k + lane < 288 && dpix[k] < (is_x ? 34 : 32) && gx >= 0 && gx < p.W;
+                poff[k] = ok ? (unsigned)((((size_t)img * p.H * p.W + gx) * (is_x ? p.ldx : p.lddz)) * 2 + dgrp[k] * 64 + dj[k] * 16) : 0u;
+                pok |= ok ? (1u << k) : 0u;
+            }
+            // fill: passes 0, 1 landed, pass 2 in flight.  (The previous strip ended with a barrier and drained its DMAs.)
+            dma_issue(0); dma_issue(1); dma_issue(2);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NI) : "memory");
+            for (int s = 0; s < steps; ++s) {
+                if (!(p.ablate & 2)) dma_issue(s + 3);
+                if (!(p.ablate & 1)) compute(s);
+                // pass s + 2 (issued one step ago) has to be here for step s + 1; pass s + 3 stays in flight
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NI) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // DMAs still in flight target slots the next strip fills
+            continue;
+        }
         // per-thread offsets inside a row (the row goes into the scalar offset); columns outside the image / the patch: rejected
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -1005,7 +1059,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgBf16Args p) {
         for (int s = 0; s < steps; ++s) {
             if (!(p.ablate & 2)) issue(stg[0], s + 2);
             if (!(p.ablate & 1)) compute(s);
-            commit(stg[0], s + 2); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!(p.ablate & 4)) commit(stg[0], s + 2);
+            if (!(p.ablate & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // passes still in flight belong to nobody
     }
@@ -1024,6 +1079,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgBf16Args p) {
             o_base[((size_t)t * p.Cin + ci) * p.Cout + co0 + 32 * cosub + li] = v;
         }
 }
+
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgBf16Args p) { wgrad_bf16_body<0>(p); }
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(WgBf16Args p) { wgrad_bf16_body<1>(p); }
 
 __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits, int sl) {
     __shared__ f32x4 part[256];
@@ -1088,7 +1146,9 @@ extern "C" int unet_conv3x3_wgrad_bf16(const void* xin, int ldx, int x_bf16, con
     { const char* e = getenv("UNET_WGRAD_BF16_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     a.x_bytes = (unsigned)((size_t)N * H * W * ldx * (a.x16 ? 2 : 4)); a.dz_bytes = (unsigned)((size_t)N * H * W * lddz * (a.z16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
-    wgrad_bf16_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
+    static const bool dma = [] { const char* e = getenv("UNET_WGRAD_BF16_DMA"); return !(e && e[0] == '0'); }();      // A/B switch
+    if (dma && a.x16 && a.z16) wgrad_bf16_dma_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
+    else                       wgrad_bf16_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     if (a.splits > 1) {
         const long n4 = (long)9 * Cin * Cout / 4;
