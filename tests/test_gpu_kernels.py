@@ -1100,3 +1100,24 @@ def test_conv3x3_bf16_persistent_kernels_equal_the_per_tile_kernels_at_full_size
             outs.append(dx); parts.append(part)
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1]) and torch.equal(parts[0], parts[1]), stats
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 40, 128, 64, 0), (1, 7, 33, 64, 128, 8), (3, 9, 20, 64, 64, 24), (8, 512, 512, 64, 64, 0), (8, 64, 64, 512, 512, 0),
+                                   (2, 32, 32, 1024, 1024, 0), (5, 104, 136, 128, 64, 0), (8, 256, 256, 128, 128, 64)])
+def test_conv3x3_bf16_wgrad_dma_staging_equals_register_staging(hip, shape):
+    # Both operands stored as bf16 take the LDS-DMA staging (rows copied global -> LDS, zero page outside the image, 8 / 6-row rings);
+    # the same values as fp32 tensors take the register staging the oracle tests above cover: dW must be BIT-IDENTICAL.  Odd heights
+    # (a last step with one row), widths below / not a multiple of the 32-pixel strip, padded leading dimensions, row chunks and
+    # split partial sums (full-size layers), 256 channel pairs without splits.
+    n, h, w, ci, co, pad = shape
+    g = torch.Generator(device=DEV).manual_seed(h * w + ci)
+    x16 = torch.randn(n, h, w, ci + pad, device=DEV, generator=g).to(torch.bfloat16)
+    z16 = (torch.randn(n, h, w, co + pad, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    x32, z32 = x16.float(), z16.float()
+    nbw = hip.unet_conv3x3_wgrad_bf16_workspace(n, h, w, ci, co); ws = ws_bytes(nbw)
+    dwa = torch.zeros(3, 3, ci, co, device=DEV); dwb = torch.zeros_like(dwa)
+    hip.unet_conv3x3_wgrad_bf16(P(x16), ci + pad, 1, P(z16), co + pad, 1, P(dwa), n, h, w, ci, co, P(ws), nbw, ST())
+    hip.unet_conv3x3_wgrad_bf16(P(x32), ci + pad, 0, P(z32), co + pad, 0, P(dwb), n, h, w, ci, co, P(ws), nbw, ST())
+    torch.cuda.synchronize()
+    assert torch.equal(dwa, dwb)
+    assert dwa.abs().max().item() > 0 and torch.isfinite(dwa).all()
