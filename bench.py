@@ -49,7 +49,7 @@ FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16?, offl
     "conv3x3_wgrad_winograd_fused": ("wino_wgrad_fused_kernel (3x3 conv weight gradient, Winograd F(2x2,3x3), reduce over tiles on v_mfma_f32_32x32x2_f32)", True, False, "r02d_wino_wgrad_pmc_traffic.json"),
     "conv3x3_fwd_bf16": ("conv_bf16_stream_stats_kernel_{128,64} (3x3 conv forward + BatchNorm sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_fwd_pmc_traffic.json"),
     "conv3x3_dgrad_bf16": ("conv_bf16_stream_bnbwd_kernel_{128,64} (3x3 conv data gradient + producer BatchNorm-backward sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_dgrad_pmc_traffic.json"),
-    "conv3x3_wgrad_bf16": ("wgrad_bf16_kernel (3x3 conv weight gradient, pixel contraction on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_wgrad_pmc_traffic.json"),
+    "conv3x3_wgrad_bf16": ("wgrad_bf16_dma_kernel (3x3 conv weight gradient, pixel contraction on v_mfma_f32_32x32x16_bf16, LDS-DMA staging)", False, True, "r02d_bf16_wgrad_pmc_traffic.json"),
 }
 
 
