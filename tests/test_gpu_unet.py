@@ -482,7 +482,8 @@ def test_bf16_operand_beyond_2gib_falls_back_to_fp32_kernels():
 
 
 @pytest.mark.parametrize("cfg", [(2, 1, 2, 32, "fp32"), (2, 3, 4, 64, "fp32"), (1, 1, 2, 128, "fp32"),
-                                 (3, 1, 2, (48, 80), "fp32"), (1, 3, 6, (16, 176), "fp32")])            # non-square tiles, odd batch
+                                 (3, 1, 2, (48, 80), "fp32"), (1, 3, 6, (16, 176), "fp32"),             # non-square tiles, odd batch
+                                 (1, 2, 11, 32, "fp32"), (5, 4, 3, 32, "fp32")])                        # other channel / class counts
 def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
     # End-to-end gradients at 1e-4 instead of 5e-2.  The network is piecewise linear: its gradient is discontinuous only in the
     # branch decisions (ReLU masks, max-pool winners), and fp32 rounding flips a few of those for pre-activations within ~1e-7
@@ -518,7 +519,11 @@ def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
         assert np.abs(g_hip["up_%d/bias" % l]).max() < 1e-5 * np.abs(g_hip["up_%d/kernel" % l]).max()
         assert np.abs(g_ref["up_%d/bias" % l]).max() < 1e-10 * np.abs(g_ref["up_%d/kernel" % l]).max()
     worst = max((v, key) for key, v in errs.items())
-    assert worst[0] < 1e-4, sorted(errs.items(), key=lambda t: -t[1])[:6]
+    # (a single 32 x 32 image leaves the bottleneck's BatchNorm 4 samples per channel: 1 / sqrt(var + eps) amplifies fp32 rounding there
+    # -- the same 5e-4 as the one-image replicas of test_two_replicas_compose_to_the_global_batch_step; measured 1.3e-4)
+    hh, ww = hw if isinstance(hw, tuple) else (hw, hw)
+    tol = 5e-4 if n * (hh // 16) * (ww // 16) <= 4 else 1e-4
+    assert worst[0] < tol, sorted(errs.items(), key=lambda t: -t[1])[:6]
 
 
 def test_clipped_probability_cross_entropy_mode_matches_oracle():
