@@ -46,6 +46,14 @@ struct ConvBf16Args {
 constexpr int kPW = 34, kPlane = 640 * 16, kXP = 2 * kPlane;        // patch row length (pixels), bytes of one k-half plane, of the patch
 
 #define CB_RD128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
+// A read of the interleaved x image: the lanes whose k half sits in the upper 16-byte slot of its pixel are a wave-wide constant per
+// fragment (an SGPR pair from a ballot), so the slot select is one v_cndmask next to the read and costs no vector register
+#define CB_RD128_SEL(dst, base0, base1, lanemask, off) do { unsigned t_; asm volatile("v_cndmask_b32 %1, %2, %3, %4\n\tds_read_b128 %0, %1 offset:%5" \
+                                                        : "=&v"(dst), "=&v"(t_) : "v"(base0), "v"(base1), "s"(lanemask), "n"(off)); } while (0)
+// (the 64-channel-tile kernels are at their register budget and the 18 SGPR pairs spill there: they take the lane's own 18-bit mask and
+// two VALU instructions per read instead; same-box A/B of 64->64 @512^2 data gradient + sums: 0.246 vs 0.233 ms)
+#define CB_RD128_BFE(dst, base, mask, bit, off) do { unsigned t_; asm volatile("v_bfe_u32 %1, %3, %4, 1\n\tv_lshl_add_u32 %1, %1, 4, %2\n\tds_read_b128 %0, %1 offset:%5" \
+                                                        : "=&v"(dst), "=&v"(t_) : "v"(base), "v"(mask), "n"(bit), "n"(off)); } while (0)
 #define CB_MFMA(accv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(accv) : "v"(av), "v"(bv) : "memory")
 
 template <int NCO> struct CbFrags { bf16x8 a[2]; bf16x8 b[2][3][NCO]; };
@@ -80,11 +88,17 @@ template <> __device__ __forceinline__ void cb_wait_ab<2>(int issued, bf16x8& a,
 // one chunk (16 input channels x 9 taps) from LDS stage ST: 36 * NCO MFMAs per wave.  Groups (bs, q) = (column shift, patch
 // row); group g issues the A fragment of group g + 1 and its share of the next column shift's B fragments, waits for its own
 // (counted: LDS operations retire in order) and runs its MFMAs.
-template <int NCO, int ST, int STAGE_BYTES, class Fill>
-__device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_base0, const unsigned (&b_base0)[NCO], Fill&& fill) {
+// XL = 1 (the persistent kernels): the x image is [pixel][k half][8] -- 32 bytes per pixel, the two halves of a pixel swapped where bit 3 of
+// the pixel index is set (keeps the 16 lanes of a ds_read_b128 group on 16 different 16-byte slots although the lane stride is 32 bytes).
+// The A fragment of group g is pixel P0 + d_g of this lane; asel[g] = the lanes whose k half sits in the upper slot (a ballot, SGPR pair).
+template <int NCO, int ST, int STAGE_BYTES, int XL = 0, class Fill>
+__device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_base0, const unsigned (&b_base0)[NCO], Fill&& fill,
+                                           const unsigned long long* asel = nullptr, unsigned amask = 0) {
     constexpr int CT = 32 * NCO;
     constexpr int AO = 0, BO = 0;                                   // (the stage offset does not fit the 16-bit immediate)
+    constexpr int APX = XL ? 32 : 16;                                // bytes between consecutive pixels in the A read address
     const unsigned a_base = a_base0 + ST * STAGE_BYTES;
+    const unsigned a_base16 = a_base + 16;
     unsigned b_base[NCO];                                           // one base per sub-tile: its columns sit swizzled in the image
 #pragma unroll
     for (int c = 0; c < NCO; ++c) b_base[c] = b_base0[c] + ST * STAGE_BYTES;
@@ -93,14 +107,17 @@ __device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_bas
 #pragma unroll
     for (int k = 0; k < 3 * NCO; ++k)
         CB_RD128(fr.b[0][k / NCO][k % NCO], b_base[k % NCO], BO + (3 * (k / NCO) + 0) * 2 * CT * 16);
-    CB_RD128(fr.a[0], a_base, AO + 0);
+    if (XL && NCO == 2) CB_RD128_BFE(fr.a[0], a_base, amask, 0, AO + 0);
+    else if (XL) CB_RD128_SEL(fr.a[0], a_base, a_base16, asel[0], AO + 0); else CB_RD128(fr.a[0], a_base, AO + 0);
 #pragma unroll
     for (int g = 0; g < 18; ++g) {
         const int bs = g / 6, q = g % 6;
         int issued = 0;
         if (g + 1 < 18) {
             const int bs2 = (g + 1) / 6, q2 = (g + 1) % 6;
-            CB_RD128(fr.a[(g + 1) & 1], a_base, AO + (q2 * kPW + bs2) * 16);
+            if (XL && NCO == 2) CB_RD128_BFE(fr.a[(g + 1) & 1], a_base, amask, g + 1, AO + (q2 * kPW + bs2) * APX);
+            else if (XL) CB_RD128_SEL(fr.a[(g + 1) & 1], a_base, a_base16, asel[g + 1], AO + (q2 * kPW + bs2) * APX);
+            else    CB_RD128(fr.a[(g + 1) & 1], a_base, AO + (q2 * kPW + bs2) * APX);
             ++issued;
         }
         if (bs < 2) {
@@ -479,7 +496,15 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
     const int total = p.n_px * p.n_co;
     const int nchunks = p.Cin / 16;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
-    const unsigned a_base = lds0 + (unsigned)(lh * kPlane + (4 * wv * kPW + li) * 16);
+    // x image of a stage: [patch pixel 0..639][2 x 16 B]: slot (h ^ bit 3 of the pixel index) holds k half h (see cb_compute, XL = 1)
+    const int P0 = 4 * wv * kPW + li;
+    const unsigned a_base = lds0 + (unsigned)(P0 * 32);
+    unsigned long long asel[18];                                     // fragment g: the lanes that read the upper slot (wave-uniform: SGPR pairs)
+#pragma unroll
+    for (int g = 0; g < 18; ++g) asel[g] = __builtin_amdgcn_ballot_w64(((((P0 + (g % 6) * kPW + g / 6) >> 3) & 1) ^ lh) != 0);
+    unsigned amask = 0;
+#pragma unroll
+    for (int g = 0; g < 18; ++g) amask |= (unsigned)((((P0 + (g % 6) * kPW + g / 6) >> 3) & 1) ^ lh) << g;
     unsigned b_base[NCO];
 #pragma unroll
     for (int c = 0; c < NCO; ++c) {
@@ -499,13 +524,15 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
         c.co0 = cot * CT; c.ty0 = 16 * by; c.tx0 = 32 * bx;
         return c;
     };
-    // per-lane DMA sources of a tile: x-piece id = wv + 4 k -> plane h = id / 10, pixels 64 (id % 10) + lane of the 18 x 34 patch
+    // per-lane DMA sources of a tile: x-piece id = wv + 4 k covers patch pixels 32 id .. 32 id + 31, two lanes per pixel: the instruction
+    // reads 32 x 32 contiguous bytes.  (16 bytes per lane from 64 different pixels -- one k half per instruction -- cost 0.03-0.07 ms
+    // per launch more: four times the L2 requests for the same bytes.)
     struct Src { const char* x[KX]; const char* w; };
     auto sources = [&](const Tile& c) {
         Src s;
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
-            const int id = wv + 4 * k, h = id / 10, pp = 64 * (id % 10) + lane;
+            const int id = wv + 4 * k, pp = 32 * id + (lane >> 1), h = (lane & 1) ^ ((pp >> 3) & 1);
             const int gy = c.ty0 - 1 + pp / kPW, gx = c.tx0 - 1 + pp % kPW;
             const bool ok = pp < 18 * kPW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             s.x[k] = ok ? reinterpret_cast<const char*>(p.x) + (((size_t)(c.img * p.H + gy) * p.W + gx) * p.ldx) * 2 + h * 16
@@ -526,7 +553,7 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
     auto issue_x1 = [&](const Src& s, int chunk, int stage, int k) {
         const int id = wv + 4 * k;
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s.x[k] + (size_t)chunk * 32),
-                                         (lds_void_b*)(smem + stage * STAGE + (id / 10) * kPlane + (id % 10) * 1024), 16, 0, 0);
+                                         (lds_void_b*)(smem + stage * STAGE + id * 1024), 16, 0, 0);
     };
     auto issue_w1 = [&](const Src& s, int chunk, int stage, int k) {
         if (NPIECE % 4 == 0 || wv + 4 * k < NPIECE)
@@ -559,14 +586,14 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
         for (int c = 0; c < nchunks; c += 2) {                       // Cin % 32 == 0: an even number of chunks, chunk c lives in stage c & 1
-            cb_compute<NCO, 0, STAGE>(acc, a_base, b_base, [&](int g) { fill(sf, c + 1, 1, g); });
+            cb_compute<NCO, 0, STAGE, 1>(acc, a_base, b_base, [&](int g) { fill(sf, c + 1, 1, g); }, asel, amask);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             int cn = c + 2;
             if (cn == nchunks) {                                     // the stream continues with chunk 0 of the workgroup's next tile
                 cn = 0;                                              // (after the last tile: chunk 0 of this one again -- valid memory, never read)
                 if (logical + G < total) { nxt = tile_at(logical + G); sf = sources(nxt); }
             }
-            cb_compute<NCO, 1, STAGE>(acc, a_base, b_base, [&](int g) { fill(sf, cn, 0, g); });
+            cb_compute<NCO, 1, STAGE, 1>(acc, a_base, b_base, [&](int g) { fill(sf, cn, 0, g); }, asel, amask);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
