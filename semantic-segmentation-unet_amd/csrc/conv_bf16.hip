@@ -1242,7 +1242,13 @@ struct ConvtBf16Args {
 
 constexpr int kCtXP = 2 * 2 * 512 * 16;             // [k-step][k half][pixel][8] bf16
 
-template <int NCO, int STATS, int MODE>
+// XDMA = 1 (the input is a bf16 tensor): the chunk's input image is filled by LDS-DMA, 64 contiguous bytes (the pixel's 32 channels of
+// the chunk) per pixel and 16 pixels per wave-instruction, and laid out [pixel][4 x 16 B] with the four pieces of a pixel rotated by
+// (pixel >> 2) & 3 (XOR): the A fragment of (k-step ks, k half lh) is piece 2 ks + lh, and with a 64-byte lane stride only that XOR keeps
+// the 16 lanes of a ds_read_b128 group on 16 different slots.  The rotation depends on the lane alone (pixel = 32 row + lane column and
+// 32 row / 4 = 0 mod 4), so the read addresses stay two per-lane constants.  (The first DMA form of these kernels copied the plane
+// layout of the register path -- 16 bytes per lane from 64 different pixels -- and gained nothing: four times the L2 requests.)
+template <int NCO, int STATS, int MODE, int XDMA = 0>
 __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
     constexpr int CT = 32 * NCO;
     constexpr int WB = 2 * 2 * CT * 16;
@@ -1277,7 +1283,9 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
     // image [k-step = f >> 2][k half = (f >> 1) & 1][pixel][16 B], low / high 8 bytes by f & 1
     const unsigned wr_base = lds0 + (unsigned)(((f >> 2) * 2 + ((f >> 1) & 1)) * 8192 + (tid >> 3) * 16 + (f & 1) * 8);
-    const unsigned a_base = lds0 + (unsigned)(lh * 8192 + (4 * wv * 32 + li) * 16);
+    const unsigned a_base = XDMA ? lds0 + (unsigned)((4 * wv * 32 + li) * 64 + ((lh ^ ((li >> 2) & 3)) * 16))
+                                 : lds0 + (unsigned)(lh * 8192 + (4 * wv * 32 + li) * 16);
+    const unsigned a_base_k1 = XDMA ? lds0 + (unsigned)((4 * wv * 32 + li) * 64 + (((2 + lh) ^ ((li >> 2) & 3)) * 16)) : a_base + 16384;
     const unsigned b_base = lds0 + (unsigned)(kCtXP + lh * CT * 16 + li * 16);
     unsigned woff[KW];
 #pragma unroll
@@ -1289,16 +1297,36 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
     const size_t wchunk = (size_t)4 * p.Ncol * 16;
     const char* wsrc = reinterpret_cast<const char*>(p.wp);
 
-    f32x4 stg[16];
-    auto issue_x = [&](int chunk) {
+    f32x4 stg[XDMA ? 1 : 16];
+    // XDMA: this wave's 8 pieces of a chunk cover pixels 16 (wv + 4 k) .. + 15, four lanes per pixel
+    const char* dsrc[8];
+    if constexpr (XDMA) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pp = 16 * (wv + 4 * k) + (lane >> 2), j = (lane & 3) ^ ((pp >> 2) & 3);
+            const int gy = ty0 + (pp >> 5), gx = tx0 + (pp & 31);
+            const size_t pix = MODE == 2 ? ((size_t)(img * 2 * p.H + 2 * gy) * (2 * p.W) + 2 * gx) : ((size_t)(img * p.H + gy) * p.W + gx);
+            dsrc[k] = (gy < p.H && gx < p.W) ? reinterpret_cast<const char*>(p.x) + pix * p.ldx * 2 + j * 16 : nullptr;
+        }
+    }
+    auto issue_x = [&](int chunk, int stage) {
         int so;
         if (MODE == 2) {       // chunk = 32 channels of one tap (a, b): the tap's pixel offset and the channel offset are scalars
             const int k0 = chunk * 32, tap = k0 / p.Cout, c0 = k0 % p.Cout;
             so = (((tap >> 1) * 2 * p.W + (tap & 1)) * p.ldx + c0) * es;
         } else so = chunk * 32 * es;
+        if constexpr (XDMA) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            stg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff[j], so, 0));
+            for (int k = 0; k < 8; ++k) {
+                const char* src = dsrc[k] ? dsrc[k] + so : reinterpret_cast<const char*>(g_zero_page_b) + (lane & 3) * 16;
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src),
+                                                 (lds_void_b*)(smem + stage * STAGE + (wv + 4 * k) * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                stg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff[j], so, 0));
+        }
     };
     auto issue_w = [&](int chunk, int stage) {
         const char* src = wsrc + (size_t)chunk * wchunk;
@@ -1309,9 +1337,10 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
                                                  (lds_void_b*)(smem + stage * STAGE + kCtXP + (wv + 4 * k) * 1024), 16, 0, 0);
     };
     auto write_x = [&](int stage) {
+        if constexpr (XDMA) return;
         const unsigned wb = wr_base + (unsigned)(stage * STAGE);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < (XDMA ? 1 : 16); ++j) {
             uint2 v; v.x = cb_pack2_pinned(stg[j].x, stg[j].y); v.y = cb_pack2_pinned(stg[j].z, stg[j].w);
             if (p.in16) {
                 v.x = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].z : stg[j].x); v.y = __builtin_bit_cast(unsigned, (f & 1) ? stg[j].w : stg[j].y);
@@ -1327,14 +1356,17 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
     // one chunk from stage ST: 2 k-steps x (4 pixel rows x NCO column tiles); all 8 + 2 NCO fragment reads up front, consumed in order
-    auto compute = [&](unsigned ab, unsigned bb) {
+    auto compute = [&](unsigned ab, unsigned bb, unsigned ab1) {
         bf16x8 fa[2][4], fb[2][NCO];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int c = 0; c < NCO; ++c) CB_RD128(fb[ks][c], bb, ks * 2 * CT * 16 + c * 512);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) CB_RD128(fa[ks][r], ab, ks * 16384 + r * 512);
+            for (int r = 0; r < 4; ++r) {
+                if (XDMA) { if (ks == 0) CB_RD128(fa[ks][r], ab, r * 2048); else CB_RD128(fa[ks][r], ab1, r * 2048); }
+                else CB_RD128(fa[ks][r], ab, ks * 16384 + r * 512);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -1353,17 +1385,17 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
             }
     };
 
-    issue_x(0); issue_w(0, 0);
+    issue_x(0, 0); issue_w(0, 0);
     write_x(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int c = 0; c < nchunks; c += 2) {                            // K % 64 == 0: an even number of chunks
-        issue_x(c + 1); issue_w(c + 1, 1);
-        compute(a_base, b_base);
+        issue_x(c + 1, 1); issue_w(c + 1, 1);
+        compute(a_base, b_base, a_base_k1);
         write_x(1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int cn = c + 2 < nchunks ? c + 2 : c;
-        issue_x(cn); issue_w(cn, 0);
-        compute(a_base + STAGE, b_base + STAGE);
+        issue_x(cn, 0); issue_w(cn, 0);
+        compute(a_base + STAGE, b_base + STAGE, a_base_k1 + STAGE);
         write_x(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -1479,6 +1511,15 @@ __global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_kernel_128(ConvtBf16A
 __global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 0, 2>(p); }
 __global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_bnbwd_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 2, 2>(p); }
 __global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_bnbwd_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 2, 2>(p); }
+// bf16-stored input: LDS-DMA staging
+__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_dma_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 0, 1, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_dma_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 0, 1, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_stats_dma_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 1, 1, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_stats_dma_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 1, 1, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_dma_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 0, 2, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_dma_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 0, 2, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_bnbwd_dma_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 2, 2, 1>(p); }
+__global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_bnbwd_dma_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 2, 2, 1>(p); }
 
 // B[K][Ncol] of the GEMM -> bf16 [K/32][k-step][k half][Ncol][8]; the Keras kernel [2][2][Cout][Cin] is B^T for the forward
 // (k = ci, column = tap * Cout + co) and B itself for the data gradient (k = tap * Cout + co, column = ci)
@@ -1516,6 +1557,17 @@ int run_convt_bf16(int mode, const void* x, int ldx, int in16, const void* wp, c
         if (stat_bytes < (size_t)(chans / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
     }
     const dim3 grid((unsigned)(a.n_px * a.n_co));
+    static const bool dma = [] { const char* e = getenv("UNET_CONVT_BF16_DMA"); return !(e && e[0] == '0'); }();      // A/B switch
+    if (dma && in16) {
+        if (mode == 1) {
+            if (stat_part) { if (wide) convt_bf16_fwd_stats_dma_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_fwd_stats_dma_kernel_64<<<grid, 256, 0, st>>>(a); }
+            else           { if (wide) convt_bf16_fwd_dma_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_fwd_dma_kernel_64<<<grid, 256, 0, st>>>(a); }
+        } else {
+            if (stat_part) { if (wide) convt_bf16_dgrad_bnbwd_dma_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_dgrad_bnbwd_dma_kernel_64<<<grid, 256, 0, st>>>(a); }
+            else           { if (wide) convt_bf16_dgrad_dma_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_dgrad_dma_kernel_64<<<grid, 256, 0, st>>>(a); }
+        }
+        return UNET_LAUNCH_STATUS();
+    }
     if (mode == 1) {
         if (stat_part) { if (wide) convt_bf16_fwd_stats_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_fwd_stats_kernel_64<<<grid, 256, 0, st>>>(a); }
         else           { if (wide) convt_bf16_fwd_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_fwd_kernel_64<<<grid, 256, 0, st>>>(a); }
