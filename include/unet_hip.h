@@ -216,12 +216,13 @@ int unet_bn_bwd_from_partials(const float* dy, int lddy, const float* r, int ldr
                               float* dbias, const float* part_sums, int rows, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- MaxPool2D(2), UNet/model.py:50-53; Dropout(0.5), UNet/model.py:60-63 ---------------------------------------- */
-int unet_maxpool2x2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C, void* stream);
-int unet_maxpool2x2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx,
-                        int N, int H, int W, int C, int accumulate, void* stream);
-/* mask (nullable, dense [P][C] bytes) overrides the counter-based RNG keyed by (seed, element index) */
-int unet_dropout(const float* x, int ldx, float* out, int ldo, long P, int C, const uint8_t* mask,
-                 uint32_t seed, float rate, void* stream);
+/* t_bf16 (these three): the activation tensors are stored as bf16 (leading dimensions in elements, C % 4 == 0) */
+int unet_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int N, int H, int W, int C, int t_bf16, void* stream);
+int unet_maxpool2x2_bwd(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx,
+                        int N, int H, int W, int C, int accumulate, int t_bf16, void* stream);
+/* Dropout(0.5), UNet/model.py:62: out = x * keep / (1 - rate); mask nullable -> counter hash of (seed, element) */
+int unet_dropout(const void* x, int ldx, void* out, int ldo, long P, int C, const uint8_t* mask,
+                 uint32_t seed, float rate, int t_bf16, void* stream);
 
 /* ---- Softmax(axis=-1) + CategoricalCrossentropy + loss reduction + accuracy, UNet/model.py:142,77,211-215,226 ----- */
 /* ce_clip_eps = 0: cross-entropy from the softmax's logits; > 0 (Keras: 1e-7): the probability path of

@@ -15,8 +15,26 @@ template <int VEC> __device__ __forceinline__ void vstore(float* p, const float 
     else *p = v[0];
 }
 
+// the same on a tensor stored as bf16 (B16: `p` addresses 2-byte elements; VEC == 4 only): level 4 of the bf16 mode keeps the tensors
+// around its dropout / unfused pool as bf16 like every other level
+template <int VEC, int B16> __device__ __forceinline__ void tload(float (&v)[VEC], const float* base, size_t elem) {
+    if constexpr (B16) {
+        const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+        v[0] = __builtin_bit_cast(float, h.x << 16); v[1] = __builtin_bit_cast(float, h.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, h.y << 16); v[3] = __builtin_bit_cast(float, h.y & 0xffff0000u);
+    } else vload<VEC>(v, base + elem);
+}
+template <int VEC, int B16> __device__ __forceinline__ void tstore(float* base, size_t elem, const float (&v)[VEC]) {
+    if constexpr (B16) {
+        uint2 h;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h.x) : "v"(v[0]), "v"(v[1]));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h.y) : "v"(v[2]), "v"(v[3]));
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem) = h;
+    } else vstore<VEC>(base + elem, v);
+}
+
 // ---- max-pool 2x2 stride 2; ties -> first max in row-major window order (a*2+b) --------------------------------
-template <int VEC>
+template <int VEC, int B16>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
         uint8_t* __restrict__ idx, int N, int H, int W, int C) {
     const int H2 = H / 2, W2 = W / 2, nq = C / VEC;
@@ -29,19 +47,19 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
             float v[VEC];
-            vload<VEC>(v, x + ((size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1)) * ldx + cq * VEC);
+            tload<VEC, B16>(v, x, ((size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1)) * ldx + cq * VEC);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 if (pos == 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)pos; }
             }
         }
-        vstore<VEC>(y + (size_t)opix * ldy + cq * VEC, best);
+        tstore<VEC, B16>(y, (size_t)opix * ldy + cq * VEC, best);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) idx[(size_t)opix * C + cq * VEC + e] = bi[e];
     }
 }
 
-template <int VEC>
+template <int VEC, int B16>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, int lddy, const uint8_t* __restrict__ idx,
         float* __restrict__ dx, int lddx, int N, int H, int W, int C, int accumulate) {
     const int H2 = H / 2, W2 = W / 2, nq = C / VEC;
@@ -50,28 +68,28 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         long t = i; const int cq = (int)(t % nq); t /= nq;
         const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const int n = (int)(t / H2);
         const long opix = ((long)n * H2 + oy) * W2 + ox;
-        float g[VEC]; vload<VEC>(g, dy + (size_t)opix * lddy + cq * VEC);
+        float g[VEC]; tload<VEC, B16>(g, dy, (size_t)opix * lddy + cq * VEC);
         uint8_t bi[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) bi[e] = idx[(size_t)opix * C + cq * VEC + e];
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
-            float* dst = dx + ((size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1)) * lddx + cq * VEC;
+            const size_t dst = ((size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1)) * lddx + cq * VEC;
             float v[VEC];
-            if (accumulate) vload<VEC>(v, dst);
+            if (accumulate) tload<VEC, B16>(v, dx, dst);
             else {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] = 0.f;
             }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) if (bi[e] == pos) v[e] += g[e];
-            vstore<VEC>(dst, v);
+            tstore<VEC, B16>(dx, dst, v);
         }
     }
 }
 
 // ---- dropout: out = x * keep / (1 - rate); keep from an explicit mask (tests) or the counter hash --------------
-template <int VEC>
+template <int VEC, int B16>
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo,
         long P, int C, const uint8_t* __restrict__ mask, uint32_t seed, float rate, float scale) {
     const int nq = C / VEC;
@@ -79,14 +97,14 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     const uint32_t thr = (uint32_t)((double)rate * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)rate * 4294967296.0);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const long pix = i / nq; const int c0 = (int)(i - pix * nq) * VEC;
-        float v[VEC]; vload<VEC>(v, x + (size_t)pix * ldx + c0);
+        float v[VEC]; tload<VEC, B16>(v, x, (size_t)pix * ldx + c0);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const uint64_t el = (uint64_t)pix * C + c0 + e;
             const bool keep = mask ? (mask[el] != 0) : (unet_hash32(seed, el) >= thr);
             v[e] = keep ? v[e] * scale : 0.f;
         }
-        vstore<VEC>(out + (size_t)pix * ldo + c0, v);
+        tstore<VEC, B16>(out, (size_t)pix * ldo + c0, v);
     }
 }
 
@@ -258,34 +276,44 @@ int grid_for(long total, int cap) { long b = (total + 255) / 256; if (b > cap) b
 
 }  // namespace
 
-extern "C" int unet_maxpool2x2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+// t_bf16 (these three): the activation tensors are stored as bf16 (leading dimensions in elements, C % 4 == 0); idx / mask unchanged
+extern "C" int unet_maxpool2x2_fwd(const void* xv, int ldx, void* yv, int ldy, uint8_t* idx, int N, int H, int W, int C, int t_bf16, void* stream) {
+    const float* x = (const float*)xv; float* y = (float*)yv;
     UNET_CHECK_ARG(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && ldx >= C && ldy >= C);
     const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && unet_aligned16(x) && unet_aligned16(y);
+    UNET_CHECK_ARG(!t_bf16 || v4);
     const long total = (long)N * (H / 2) * (W / 2) * (v4 ? C / 4 : C);
-    if (v4) maxpool_fwd_kernel<4><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, idx, N, H, W, C);
-    else    maxpool_fwd_kernel<1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, idx, N, H, W, C);
+    if (t_bf16)  maxpool_fwd_kernel<4, 1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, idx, N, H, W, C);
+    else if (v4) maxpool_fwd_kernel<4, 0><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, idx, N, H, W, C);
+    else         maxpool_fwd_kernel<1, 0><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, idx, N, H, W, C);
     return UNET_LAUNCH_STATUS();
 }
 
 // H, W are the dims of dx (the pool input); dy is [N, H/2, W/2, C].
-extern "C" int unet_maxpool2x2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx,
-                                   int N, int H, int W, int C, int accumulate, void* stream) {
+extern "C" int unet_maxpool2x2_bwd(const void* dyv, int lddy, const uint8_t* idx, void* dxv, int lddx,
+                                   int N, int H, int W, int C, int accumulate, int t_bf16, void* stream) {
+    const float* dy = (const float*)dyv; float* dx = (float*)dxv;
     UNET_CHECK_ARG(dy && dx && idx && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && lddx >= C && lddy >= C);
     const bool v4 = C % 4 == 0 && lddx % 4 == 0 && lddy % 4 == 0 && unet_aligned16(dx) && unet_aligned16(dy);
+    UNET_CHECK_ARG(!t_bf16 || v4);
     const long total = (long)N * (H / 2) * (W / 2) * (v4 ? C / 4 : C);
-    if (v4) maxpool_bwd_kernel<4><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(dy, lddy, idx, dx, lddx, N, H, W, C, accumulate);
-    else    maxpool_bwd_kernel<1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(dy, lddy, idx, dx, lddx, N, H, W, C, accumulate);
+    if (t_bf16)  maxpool_bwd_kernel<4, 1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(dy, lddy, idx, dx, lddx, N, H, W, C, accumulate);
+    else if (v4) maxpool_bwd_kernel<4, 0><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(dy, lddy, idx, dx, lddx, N, H, W, C, accumulate);
+    else         maxpool_bwd_kernel<1, 0><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(dy, lddy, idx, dx, lddx, N, H, W, C, accumulate);
     return UNET_LAUNCH_STATUS();
 }
 
-extern "C" int unet_dropout(const float* x, int ldx, float* out, int ldo, long P, int C, const uint8_t* mask,
-                            uint32_t seed, float rate, void* stream) {
+extern "C" int unet_dropout(const void* xv, int ldx, void* outv, int ldo, long P, int C, const uint8_t* mask,
+                            uint32_t seed, float rate, int t_bf16, void* stream) {
+    const float* x = (const float*)xv; float* out = (float*)outv;
     UNET_CHECK_ARG(x && out && P > 0 && C > 0 && ldx >= C && ldo >= C && rate >= 0.f && rate < 1.f);
     const float scale = 1.f / (1.f - rate);
     const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(out);
+    UNET_CHECK_ARG(!t_bf16 || v4);
     const long total = P * (v4 ? C / 4 : C);
-    if (v4) dropout_kernel<4><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, out, ldo, P, C, mask, seed, rate, scale);
-    else    dropout_kernel<1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, out, ldo, P, C, mask, seed, rate, scale);
+    if (t_bf16)  dropout_kernel<4, 1><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, out, ldo, P, C, mask, seed, rate, scale);
+    else if (v4) dropout_kernel<4, 0><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, out, ldo, P, C, mask, seed, rate, scale);
+    else         dropout_kernel<1, 0><<<grid_for(total, 8192), 256, 0, (hipStream_t)stream>>>(x, ldx, out, ldo, P, C, mask, seed, rate, scale);
     return UNET_LAUNCH_STATUS();
 }
 

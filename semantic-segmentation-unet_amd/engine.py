@@ -157,6 +157,9 @@ class Engine:
         # input gradient): the kernels there compute in fp32 on fp32 weights, only the 64-channel tensors they exchange with the bf16
         # layers are stored as bf16 (A/B switch)
         self.bf16_edge_activations = os.environ.get("UNET_BF16_EDGE_ACTIVATIONS", "1") != "0"
+        # level 4 (whose skip goes through the dropout and the unfused pool kernels) stores its concat / pooled tensors and their gradients
+        # as bf16 like levels 1-3 (A/B switch)
+        self.bf16_level4 = os.environ.get("UNET_BF16_LEVEL4", "1") != "0"
         self._gamma_zero = None
         self.view = {}
         self._fused_U, self._fused_dirty = None, True
@@ -489,7 +492,7 @@ class Engine:
         if masks is not None:
             m = masks[key]
         seed = (self.dropout_seed * 1000003 + self.iterations * 2 + (0 if key == "drop_4" else 1)) & 0xFFFFFFFF
-        self.L.unet_dropout(_p(t), _ld(t), _p(t), _ld(t), n * h * w, c, _p(m), seed, DROPOUT_RATE, self._stream())
+        self.L.unet_dropout(_p(t), _ld(t), _p(t), _ld(t), n * h * w, c, _p(m), seed, DROPOUT_RATE, int(t.dtype == torch.bfloat16), self._stream())
 
     def _prep_masks(self, dropout_masks):
         """NCHW 0/1 arrays (the oracle's convention) -> dense NHWC uint8 device tensors."""
@@ -544,7 +547,8 @@ class Engine:
             # the concat buffer [skip, upsampled] and the pooled tensor feed 3x3 layers only (dec_Na / the next level's first conv):
             # bf16 storage applies to them as well (levels 1-3; level 4 goes through the dropout and the unfused pool kernels)
             nxt = "conv_%da" % (lvl + 1) if lvl < 4 else "bott_a"
-            c16 = (self.compute_dtype == "bf16" and self.bf16_storage and self.bf16_storage_cat and self.fuse_pool and lvl < 4
+            c16 = (self.compute_dtype == "bf16" and self.bf16_storage and self.bf16_storage_cat and self.fuse_pool
+                   and (lvl < 4 or (self.bf16_activations and self.bf16_level4))     # level 4: its dropout / unfused pool kernels take bf16 too
                    and self._use_bf16("dec_%da" % lvl, n, hh, ww) and self._use_bf16(nxt, n, hh // 2, ww // 2)
                    and L.unet_conv3x3_wgrad_bf16_supported(n, hh, ww, 2 * ch, ch) == 1)
             cat = self._buf(("cat16_%d" if c16 else "cat_%d") % lvl, (n, hh, ww, 2 * ch), torch.bfloat16 if c16 else torch.float32)
@@ -556,7 +560,8 @@ class Engine:
             if not fuse_pool:
                 if lvl == 4 and training:
                     self._dropout(skip, "drop_4", self.masks)
-                L.unet_maxpool2x2_fwd(_p(skip), _ld(skip), _p(pooled), ch, _p(idx), n, hh, ww, ch, st)
+                assert skip.dtype == pooled.dtype
+                L.unet_maxpool2x2_fwd(_p(skip), _ld(skip), _p(pooled), ch, _p(idx), n, hh, ww, ch, int(skip.dtype == torch.bfloat16), st)
             self.idx[lvl] = idx
             cur, cur_view = pooled, None
         hh, ww = cur.shape[1], cur.shape[2]
@@ -812,14 +817,26 @@ class Engine:
         need1 = lambda nm: self._dz16(nm, nm != "conv_1a", eval_mode) or (nm in self.saved and self.saved[nm][1].dtype == torch.bfloat16)
         if name.startswith("dec_") and name.endswith("a"):             # [skip, upsampled]: conv_Nb (through the fused pool path) and up_N
             lvl = int(name[4])
-            return lvl != 4 and self.fuse_pool and need1("conv_%db" % lvl) and need1("up_%d" % lvl)
+            if lvl == 4:     # skip half -> pool-backward accumulate + dropout kernels (either storage), then conv_4b's BatchNorm backward
+                return self._lvl4_grad16() and need1("up_4")
+            return self.fuse_pool and need1("conv_%db" % lvl) and need1("up_%d" % lvl)
         if name.startswith("conv_") and name.endswith("a"):            # pooled gradient of the level above, formed inside its BatchNorm backward
             lvl = int(name[5])
             return lvl >= 2 and self.fuse_pool and need1("conv_%db" % (lvl - 1))
-        if name == "bott_a":                                           # goes through the separate pool-backward + dropout kernels (fp32)
-            return False
+        if name == "bott_a":                                           # read by the separate pool-backward kernel, added into dec_4a's skip gradient
+            return self._lvl4_grad16()
         prod = PRODUCER.get(name)
         return prod is not None and prod[3] == 1 and need1(prod[0])
+
+    def _lvl4_grad16(self):
+        """dec_4a's and bott_a's data gradients are both bf16 or both fp32: the pool-backward kernel adds one into the other"""
+        if not (self.bf16_level4 and "dec_4a" in self.saved and "bott_a" in self.saved):
+            return False
+        ok = True
+        for nm in ("dec_4a", "bott_a"):
+            n, ho, wo, _ = self.saved[nm][1].shape
+            ok = ok and self._use_bf16(nm, n, ho, wo, dgrad=True)
+        return ok and self.saved["dec_4a"][0].dtype == torch.bfloat16        # the forward took the bf16 level-4 tensors
 
     def input_gradient_eval(self, dprob):
         """After forward(training=False): gradient of sum(dprob * softmax) w.r.t. the input image, fp32 [N,C,H,W].
@@ -856,7 +873,8 @@ class Engine:
             if self.fuse_pool and not eval_mode and lvl != 4 and ch % 4 == 0:
                 d = self._block_bwd("conv_%db" % lvl, ds, pool_grad=(d, self.idx[lvl]))       # no separate pool-backward pass
             else:
-                L.unet_maxpool2x2_bwd(_p(d), _ld(d), _p(self.idx[lvl]), _p(ds), _ld(ds), n, hh, ww, ch, 1, st)
+                assert d.dtype == ds.dtype, (lvl, d.dtype, ds.dtype)
+                L.unet_maxpool2x2_bwd(_p(d), _ld(d), _p(self.idx[lvl]), _p(ds), _ld(ds), n, hh, ww, ch, 1, int(ds.dtype == torch.bfloat16), st)
                 if lvl == 4 and not eval_mode:
                     self._dropout(ds, "drop_4", self.masks)
                 d = b("conv_%db" % lvl, ds)

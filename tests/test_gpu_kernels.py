@@ -317,7 +317,7 @@ def test_bn_apply_maxpool_fused_equals_separate(hip):
     y1, y2 = cat1[..., :c], cat2[..., :c]
     hip.unet_bn_apply_maxpool(P(r), c, P(sc), P(sh), P(y1), 2 * c, P(p1), c, P(i1), n, h, w, c, ST())
     hip.unet_bn_apply(P(r), c, P(sc), P(sh), P(y2), 2 * c, n * h * w, c, ST())
-    hip.unet_maxpool2x2_fwd(P(y2), 2 * c, P(p2), c, P(i2), n, h, w, c, ST())
+    hip.unet_maxpool2x2_fwd(P(y2), 2 * c, P(p2), c, P(i2), n, h, w, c, 0, ST())
     assert torch.equal(cat1, cat2) and torch.equal(p1, p2) and torch.equal(i1, i2)
     assert (i1 == 0).float().mean().item() > 0.27                              # 0.234 strict wins + 1/16 all-zero windows (ties -> first position)
 
@@ -330,7 +330,7 @@ def test_bn_bwd_pooled_equals_pool_backward_then_bn_bwd(hip):
     r = torch.relu(torch.randn(n, h, w, c, device=DEV, generator=g))
     y = r * 1.3
     pooled = torch.empty(n, h // 2, w // 2, c, device=DEV); idx = torch.empty(n, h // 2, w // 2, c, dtype=torch.uint8, device=DEV)
-    hip.unet_maxpool2x2_fwd(P(y), c, P(pooled), c, P(idx), n, h, w, c, ST())
+    hip.unet_maxpool2x2_fwd(P(y), c, P(pooled), c, P(idx), n, h, w, c, 0, ST())
     dcat = torch.randn(n, h, w, 2 * c, device=DEV, generator=g); dskip = dcat[..., :c]
     pdy = torch.randn(n, h // 2, w // 2, c, device=DEV, generator=g)
     gm = torch.rand(c, device=DEV, generator=g) + 0.5
@@ -345,7 +345,7 @@ def test_bn_bwd_pooled_equals_pool_backward_then_bn_bwd(hip):
                                    P(dz), c, P(dg), P(db), P(dbias), P(ws), nb, ST())
         else:
             d2 = dcat.clone(); ds2 = d2[..., :c]
-            hip.unet_maxpool2x2_bwd(P(pdy), c, P(idx), P(ds2), 2 * c, n, h, w, c, 1, ST())
+            hip.unet_maxpool2x2_bwd(P(pdy), c, P(idx), P(ds2), 2 * c, n, h, w, c, 1, 0, ST())
             hip.unet_bn_bwd(P(ds2), 2 * c, P(r), c, P(gm), P(mean), P(invstd), npx, c, 1, P(dz), c, P(dg), P(db), P(dbias), P(ws), nb, ST())
         out.append((dz, dg, db, dbias))
     # (the fused form walks one 2x2 window per lane, the plain form one pixel per lane: the per-channel sums are added in a different
@@ -367,14 +367,26 @@ def test_maxpool_fwd_bwd_with_ties(hip):
     xv = cat[..., :c]
     y = torch.empty(n, h // 2, w // 2, c, device=DEV)
     idx = torch.empty(n, h // 2, w // 2, c, dtype=torch.uint8, device=DEV)
-    hip.unet_maxpool2x2_fwd(P(xv), 2 * c, P(y), c, P(idx), n, h, w, c, ST())
+    hip.unet_maxpool2x2_fwd(P(xv), 2 * c, P(y), c, P(idx), n, h, w, c, 0, ST())
     assert np.array_equal(from_nhwc(y), y_ref)
     assert np.array_equal(idx.cpu().numpy().transpose(0, 3, 1, 2), idx_ref)
     dcat = torch.zeros(n, h, w, 2 * c, device=DEV); dcat[..., :c] = to_nhwc(base)
     dv = dcat[..., :c]
-    hip.unet_maxpool2x2_bwd(P(to_nhwc(dy)), c, P(idx), P(dv), 2 * c, n, h, w, c, 1, ST())
+    hip.unet_maxpool2x2_bwd(P(to_nhwc(dy)), c, P(idx), P(dv), 2 * c, n, h, w, c, 1, 0, ST())
     assert relerr(from_nhwc(dv), dx_ref + base) < 1e-6
     assert dcat[..., c:].abs().max().item() == 0
+    # the same tensors stored as bf16 (level 4 of the bf16 mode): pooling picks existing values -> equal to the fp32 kernel on the
+    # bf16 values, indices included; the backward accumulate rounds its one sum per element to bf16
+    cat16 = cat.to(torch.bfloat16); y16 = torch.empty(n, h // 2, w // 2, c, device=DEV, dtype=torch.bfloat16); idx16 = torch.empty_like(idx)
+    hip.unet_maxpool2x2_fwd(P(cat16[..., :c]), 2 * c, P(y16), c, P(idx16), n, h, w, c, 1, ST())
+    y32 = torch.empty_like(y); idx32 = torch.empty_like(idx); cat32 = cat16.float()
+    hip.unet_maxpool2x2_fwd(P(cat32[..., :c]), 2 * c, P(y32), c, P(idx32), n, h, w, c, 0, ST())
+    assert torch.equal(y16.float(), y32) and torch.equal(idx16, idx32)
+    dy16 = to_nhwc(dy).to(torch.bfloat16); dcat16 = dcat.clone().zero_(); dcat16[..., :c] = to_nhwc(base); dcat16 = dcat16.to(torch.bfloat16)
+    ref16 = dcat16.float().clone()
+    hip.unet_maxpool2x2_bwd(P(dy16.float()), c, P(idx), P(ref16[..., :c]), 2 * c, n, h, w, c, 1, 0, ST())
+    hip.unet_maxpool2x2_bwd(P(dy16), c, P(idx), P(dcat16[..., :c]), 2 * c, n, h, w, c, 1, 1, ST())
+    assert torch.equal(dcat16, ref16.to(torch.bfloat16))
 
 
 def test_dropout_mask_and_rng(hip):
@@ -382,13 +394,17 @@ def test_dropout_mask_and_rng(hip):
     x = torch.randn(pix, c, device=DEV)
     mask = (torch.rand(pix, c, device=DEV) < 0.5).to(torch.uint8)
     out = torch.empty_like(x)
-    hip.unet_dropout(P(x), c, P(out), c, pix, c, P(mask), 0, 0.5, ST())
+    hip.unet_dropout(P(x), c, P(out), c, pix, c, P(mask), 0, 0.5, 0, ST())
     assert torch.equal(out, x * mask.float() * 2.0)
     o1, o2, o3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-    hip.unet_dropout(P(x), c, P(o1), c, pix, c, None, 123, 0.5, ST())
-    hip.unet_dropout(P(x), c, P(o2), c, pix, c, None, 123, 0.5, ST())
-    hip.unet_dropout(P(x), c, P(o3), c, pix, c, None, 124, 0.5, ST())
+    hip.unet_dropout(P(x), c, P(o1), c, pix, c, None, 123, 0.5, 0, ST())
+    hip.unet_dropout(P(x), c, P(o2), c, pix, c, None, 123, 0.5, 0, ST())
+    hip.unet_dropout(P(x), c, P(o3), c, pix, c, None, 124, 0.5, 0, ST())
     assert torch.equal(o1, o2)                                    # same (seed, index) -> same mask (backward regenerates it)
+    x16 = x.to(torch.bfloat16); o16 = torch.empty_like(x16)       # bf16 tensors: the same mask, the kept values doubled exactly
+    hip.unet_dropout(P(x16), c, P(o16), c, pix, c, None, 123, 0.5, 1, ST())
+    assert torch.equal(o16 != 0, (o1 != 0) & (x16 != 0)) or torch.equal((o16 != 0) | (x16 == 0), (o1 != 0) | (x16 == 0))
+    assert torch.equal(o16[o16 != 0].float(), (x16.float() * 2.0)[o16 != 0])
     keep = (o1 != 0).float().mean().item()
     assert abs(keep - 0.5) < 0.005
     assert (o1 != o3).float().mean().item() > 0.3
