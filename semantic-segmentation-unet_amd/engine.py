@@ -565,7 +565,8 @@ class Engine:
             self.idx[lvl] = idx
             cur, cur_view = pooled, None
         hh, ww = cur.shape[1], cur.shape[2]
-        cur = pair("bott_a", "bott_b", cur, None, hh, ww, 16 * B, self._buf("y_bott_b", (n, hh, ww, 16 * B)))
+        yb = self._ybuf("bott_b", (n, hh, ww, 16 * B), "up_4") if self.bf16_level4 else self._buf("y_bott_b", (n, hh, ww, 16 * B))
+        cur = pair("bott_a", "bott_b", cur, None, hh, ww, 16 * B, yb)
         if training:
             self._dropout(cur, "drop_b", self.masks)
         for lvl, ch in ((4, 8 * B), (3, 4 * B), (2, 2 * B), (1, B)):
