@@ -357,6 +357,63 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_fwd_kernel(const float* __
     }
 }
 
+// Forward for the shape the network has (Cin = 64 .. 512, K <= 8): Cin / 8 lanes per pixel, a lane owns 8 channels (one 16-byte load of a
+// bf16 tensor, two of an fp32 one) with its 8 x K weights in registers, the K partial dots are reduced over the pixel's lanes by xor
+// shuffles and lane k stores class k.  (The 16-lanes-per-pixel kernel above reads the weights from LDS per element and spends most of
+// its instructions on 16-value shuffle trees: 146 us for 8 x 512^2 x 64 -> 4, three times the time its 268 MB take on HBM.)
+template <int X16, int LPP>          // LPP = lanes per pixel = Cin / 8 (8, 16, 32 or 64)
+__global__ __launch_bounds__(256) void conv1x1_narrow_fwd8_kernel(const float* __restrict__ x, int ldx,
+        const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int ldo, long P, int K, int relu) {
+    const int sub = threadIdx.x % LPP;                               // this lane's channel octet
+    float wr[8][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[e][k] = k < K ? w[(8 * sub + e) * K + k] : 0.f;
+    const float bk = (bias && sub < K) ? bias[sub] : 0.f;
+    constexpr int PPB = 256 / LPP;                                   // pixels per block pass
+    const long stride = (long)gridDim.x * PPB;
+    for (long pix0 = (long)blockIdx.x * PPB + threadIdx.x / LPP; pix0 < P + 0; pix0 += 2 * stride) {     // two pixels per trip (both loads first)
+        const long pa = pix0, pb = pix0 + stride < P ? pix0 + stride : pix0;
+        float xa[8], xb[8];
+        if constexpr (X16) {
+            const uint4 ha = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x) + (size_t)pa * ldx + 8 * sub);
+            const uint4 hb = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x) + (size_t)pb * ldx + 8 * sub);
+            const unsigned ua[4] = {ha.x, ha.y, ha.z, ha.w}, ub[4] = {hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xa[2 * j] = __builtin_bit_cast(float, ua[j] << 16); xa[2 * j + 1] = __builtin_bit_cast(float, ua[j] & 0xffff0000u);
+                xb[2 * j] = __builtin_bit_cast(float, ub[j] << 16); xb[2 * j + 1] = __builtin_bit_cast(float, ub[j] & 0xffff0000u);
+            }
+        } else {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + (size_t)pa * ldx + 8 * sub), a1 = *reinterpret_cast<const f32x4*>(x + (size_t)pa * ldx + 8 * sub + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(x + (size_t)pb * ldx + 8 * sub), b1 = *reinterpret_cast<const f32x4*>(x + (size_t)pb * ldx + 8 * sub + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xa[j] = a0[j]; xa[4 + j] = a1[j]; xb[j] = b0[j]; xb[4 + j] = b1[j]; }
+        }
+        float sa[8], sb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sa[k] = 0.f; sb[k] = 0.f;
+            if (k < K) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sa[k] = fmaf(xa[e], wr[e][k], sa[k]); sb[k] = fmaf(xb[e], wr[e][k], sb[k]); }
+#pragma unroll
+                for (int o = 1; o < LPP; o <<= 1) { sa[k] += __shfl_xor(sa[k], o); sb[k] += __shfl_xor(sb[k], o); }
+            }
+        }
+        float va = 0.f, vb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k == sub) { va = sa[k]; vb = sb[k]; }
+        if (sub < K) {
+            va += bk; vb += bk;
+            if (relu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+            out[(size_t)pa * ldo + sub] = va;
+            if (pix0 + stride < P) out[(size_t)pb * ldo + sub] = vb;
+        }
+    }
+}
+
 // dgrad: dx[p][ci quad] = sum_k dz[p][k] * w[ci][k]
 template <int DX16>
 __global__ __launch_bounds__(256) void conv1x1_narrow_dgrad_kernel(const float* __restrict__ dz, int lddz,
@@ -564,6 +621,13 @@ extern "C" int unet_conv1x1_fwd(const void* x, int ldx, int x_bf16, const float*
                                 long P, int Cin, int Cout, int relu, void* stream) {
     UNET_CHECK_ARG(x && w && out && P > 0 && Cin > 0 && Cout > 0 && Cin % 4 == 0 && ldx % 4 == 0 && ldx >= Cin && ldo >= Cout);
     UNET_CHECK_ARG(unet_aligned16(x) && (size_t)Cin * Cout * 4 <= 64 * 1024);
+    static const bool fwd8 = [] { const char* e = getenv("UNET_CONV1X1_FWD8"); return !(e && e[0] == '0'); }();      // A/B switch
+    if (fwd8 && Cin == 64 && Cout <= 8 && ldx % 8 == 0) {            // the network's class map: 8 lanes per pixel, weights in registers
+        long b8 = (P + 63) / 64; if (b8 > 8192) b8 = 8192;           // (32 pixels per block pass, two pixels per trip)
+        if (x_bf16) conv1x1_narrow_fwd8_kernel<1, 8><<<(int)b8, 256, 0, (hipStream_t)stream>>>((const float*)x, ldx, w, bias, out, ldo, P, Cout, relu);
+        else        conv1x1_narrow_fwd8_kernel<0, 8><<<(int)b8, 256, 0, (hipStream_t)stream>>>((const float*)x, ldx, w, bias, out, ldo, P, Cout, relu);
+        return UNET_LAUNCH_STATUS();
+    }
     long blocks = (P + 63) / 64; if (blocks > 4096) blocks = 4096;
     if (x_bf16) conv1x1_narrow_fwd_kernel<1><<<(int)blocks, 256, (size_t)Cin * Cout * 4, (hipStream_t)stream>>>((const float*)x, ldx, w, bias, out, ldo, P, Cin, Cout, relu);
     else        conv1x1_narrow_fwd_kernel<0><<<(int)blocks, 256, (size_t)Cin * Cout * 4, (hipStream_t)stream>>>((const float*)x, ldx, w, bias, out, ldo, P, Cin, Cout, relu);
