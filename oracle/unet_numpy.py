@@ -34,6 +34,66 @@ class Contract:
     ce_from_softmax_logits: bool = True   # graph-mode Keras CE sees the Softmax op and uses its logits
     ce_clip_eps: float = 1e-7        # used only when ce_from_softmax_logits is False
     pool_first_max: bool = True      # max-pool gradient goes to the first max in row-major window order
+    # "fp32": the reference's arithmetic.  "bf16": the mixed-precision policy the reference keeps commented out
+    # (UNet/train.py:52-54) as BASELINE config 4 states it -- bf16 forward/backward on fp32 master weights; the exact
+    # rounding points are `Bf16Plan` below.  There is no reference implementation of this mode to be faithful to: the
+    # plan IS the contract, and the device path is tested against it.
+    compute_dtype: str = "fp32"
+
+
+def bf16_round(a):
+    """Round to bfloat16 (nearest, ties to even) and return in the array's own dtype -- what `v_cvt_pk_bf16_f32` does to an fp32
+    value (a float64 input goes through float32 first, as a device value would)."""
+    a = np.asarray(a)
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32)
+    u = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).astype(np.uint32)
+    return u.view(np.float32).astype(a.dtype)
+
+
+@dataclass(frozen=True)
+class Bf16Plan:
+    """Where the bf16 mode (Contract.compute_dtype == "bf16") rounds to bfloat16.  Everything else -- accumulation, bias, ReLU,
+    BatchNorm arithmetic and statistics, pooling, dropout, loss, Adam, master weights -- is fp32 on the device (fp64 here).
+
+    contract        layers whose contractions (forward, data gradient, weight gradient) take BOTH operands rounded to bf16 with exact
+                    products and wide accumulation: the 17 wide 3x3 layers and the 4 transposed convs (UNet/model.py:88-134 minus conv_1a;
+                    the first layer, Cin = number_channels, and the 1x1 class map stay fp32)
+    r_bf16          layers whose conv output r (post-ReLU, what BatchNorm reads) is STORED as bf16 in a training step.  The BatchNorm
+                    batch statistics are taken from the unrounded values (the conv epilogue sums its fp32 accumulators); BatchNorm
+                    apply, the ReLU mask and the BatchNorm backward read the rounded tensor
+    y_bf16          layers whose BatchNorm output is stored as bf16 although its reader computes in fp32 (training step only).  (Every
+                    other BatchNorm output feeds only bf16 contractions, where storage rounding and operand rounding coincide.)
+    dz_bf16         layers whose BatchNorm-backward output dz (gradient w.r.t. the conv output, ReLU mask applied) is stored as bf16; the
+                    bias gradient sum(dz) is taken before the rounding
+    dx_bf16         layers whose data gradient (the dy of the layers below) is stored as bf16
+    sums_from_dgrad layers whose BatchNorm-backward sums (sum dy, sum dy*r) are taken from the UNROUNDED data gradient of their one
+                    consumer (its kernel's epilogue); all other layers reduce the stored (rounded) dy.  The element-wise part of the
+                    BatchNorm backward always reads the stored dy.
+    lvl4_accumulate_bf16   the level-4 skip gradient: pooled gradient of the bottleneck added into dec_4a's skip-half gradient and the
+                    sum stored as bf16 (levels 1-3 add the two in fp32 inside conv_Nb's BatchNorm backward without storing the sum)
+    """
+    contract: frozenset
+    r_bf16: frozenset
+    y_bf16: frozenset
+    dz_bf16: frozenset
+    dx_bf16: frozenset
+    sums_from_dgrad: frozenset
+    lvl4_accumulate_bf16: bool = True
+
+    @staticmethod
+    def default():
+        wide = [n for n, k, ci, co in layer_table(64, 64) if k in ("conv3", "deconv") and n != "conv_1a"]
+        lv = (1, 2, 3, 4)
+        return Bf16Plan(
+            contract=frozenset(wide),
+            r_bf16=frozenset(wide + ["conv_1a"]),
+            y_bf16=frozenset(["dec_1b"]),
+            dz_bf16=frozenset(wide + ["conv_1a"]),
+            # every data gradient but the transposed conv in front of the dropout (up_4 -> bott_b) and the first layer's (not computed)
+            dx_bf16=frozenset([n for n in wide if n != "up_4"] + ["logits"]),
+            sums_from_dgrad=frozenset(["conv_%da" % l for l in lv] + ["dec_%da" % l for l in lv] + ["up_%d" % l for l in lv]
+                                      + ["bott_a"] + ["dec_%db" % l for l in (2, 3, 4)]))
 
 
 BASE = 64            # UNet._BASELINE_FEATURE_DEPTH   UNet/model.py:20
@@ -246,7 +306,7 @@ class OracleUNet:
     """Restatement of class UNet (UNet/model.py:19-256) on numpy arrays."""
 
     def __init__(self, number_classes, global_batch_size, number_channels, learning_rate=3e-4, label_smoothing=0,
-                 params=None, seed=0, dtype=np.float64, contract=None):
+                 params=None, seed=0, dtype=np.float64, contract=None, plan=None):
         self.number_classes = number_classes
         self.global_batch_size = global_batch_size
         self.number_channels = number_channels
@@ -254,6 +314,9 @@ class OracleUNet:
         self.label_smoothing = label_smoothing
         self.dtype = dtype
         self.contract = contract or Contract()
+        # bf16 mode: `plan` names every rounding point (default: Bf16Plan.default(), the device path's default training plan)
+        self.plan = (plan or Bf16Plan.default()) if self.contract.compute_dtype == "bf16" else None
+        assert plan is None or self.plan is not None, "a Bf16Plan needs Contract(compute_dtype='bf16')"
         self.layers = layer_table(number_channels, number_classes)
         src = params if params is not None else init_params(number_channels, number_classes, seed)
         self.params = {k: np.array(v, dtype=dtype) for k, v in src.items()}
@@ -266,12 +329,25 @@ class OracleUNet:
     def _block_fwd(self, name, kind, x, training, cache):
         P = self.params
         w, b = P[name + "/kernel"], P[name + "/bias"]
+        pl = self.plan
+        if pl is not None and name in pl.contract:
+            x, w = bf16_round(x), bf16_round(w)          # both operands of the contraction; products exact, wide accumulation
         if kind == "deconv":
             r = deconv2x2_fwd(x, w, b)
         else:
             r = relu_fwd(conv_same_fwd(x, w, b))
         if training:
-            y, bnc = bn_train_fwd(r, P[name + "/gamma"], P[name + "/beta"], self.contract.bn_eps)
+            gamma, beta = P[name + "/gamma"], P[name + "/beta"]
+            if pl is not None and name in pl.r_bf16:
+                # statistics from the unrounded conv output (epilogue sums), everything downstream reads the stored bf16 tensor
+                _, (_, inv, mu, var) = bn_train_fwd(r, gamma, beta, self.contract.bn_eps)
+                r = bf16_round(r)
+                xhat = (r - mu[None, :, None, None]) * inv[None, :, None, None]
+                y, bnc = gamma[None, :, None, None] * xhat + beta[None, :, None, None], (xhat, inv, mu, var)
+            else:
+                y, bnc = bn_train_fwd(r, gamma, beta, self.contract.bn_eps)
+            if pl is not None and name in pl.y_bf16:
+                y = bf16_round(y)
             cache[name] = (x, r, bnc)
         else:
             y = bn_eval_fwd(r, P[name + "/gamma"], P[name + "/beta"], P[name + "/moving_mean"],
@@ -315,18 +391,45 @@ class OracleUNet:
             keep.update(loc)
         return softmax, c
 
-    def _block_bwd(self, name, kind, dy, cache, grads, relu_masks=None):
+    def _block_bwd(self, name, kind, dy, cache, grads, relu_masks=None, dy_sums=None):
+        """dy: gradient w.r.t. the layer's BatchNorm output as the layer reads it.  Returns the data gradient (bf16 mode: as STORED,
+        see Bf16Plan.dx_bf16) and, second, the same gradient before any storage rounding (what a fused epilogue sums).
+        dy_sums = the unrounded dy (bf16 mode, Bf16Plan.sums_from_dgrad): sum(dy), sum(dy * r) come from it."""
         P = self.params
+        pl = self.plan
         x, r, bnc = cache[name]
-        dr, dg, dbt = bn_train_bwd(dy, P[name + "/gamma"], bnc)
-        grads[name + "/gamma"], grads[name + "/beta"] = dg, dbt
-        if kind == "deconv":
-            dx, dw, db = deconv2x2_bwd(x, P[name + "/kernel"], dr)
+        w = P[name + "/kernel"]
+        if pl is None:
+            dr, dg, dbt = bn_train_bwd(dy, P[name + "/gamma"], bnc)
         else:
-            dz = dr * (relu_masks[name] if relu_masks is not None else (r > 0))
-            dx, dw, db = conv_same_bwd(x, P[name + "/kernel"], dz)
+            xhat, inv, mu, _ = bnc
+            m = dy.shape[0] * dy.shape[2] * dy.shape[3]
+            ds = dy_sums if (dy_sums is not None and name in pl.sums_from_dgrad) else dy
+            dbt = ds.sum(axis=(0, 2, 3))
+            dg = (ds * xhat).sum(axis=(0, 2, 3))          # = invstd * (sum ds*r - mean * sum ds), r the stored tensor
+            g = (P[name + "/gamma"] * inv)[None, :, None, None]
+            dr = g * (dy - dbt[None, :, None, None] / m - xhat * dg[None, :, None, None] / m)
+        grads[name + "/gamma"], grads[name + "/beta"] = dg, dbt
+        dz = dr if kind == "deconv" else dr * (relu_masks[name] if relu_masks is not None else (r > 0))
+        db = dz.sum(axis=(0, 2, 3))                       # bias gradient: before the storage rounding of dz
+        if pl is not None and name in pl.dz_bf16:
+            dz = bf16_round(dz)
+        cache[name + "/dz"] = dz                          # as stored: what the weight / data gradient kernels read
+        if pl is not None and name in pl.contract:
+            w = bf16_round(w)                             # (x was saved rounded, dz is rounded: dz_bf16 >= contract)
+            assert name in pl.dz_bf16
+        if kind == "deconv":
+            dx, dw, _ = deconv2x2_bwd(x, w, dz)
+        else:
+            dx, dw, _ = conv_same_bwd(x, w, dz)
         grads[name + "/kernel"], grads[name + "/bias"] = dw, db
-        return dx
+        if pl is not None:
+            return (bf16_round(dx) if name in pl.dx_bf16 else dx), dx
+        return dx, dx
+
+    # one layer at a time, on tensors supplied by the caller (tests feed the device run's own stored tensors: "teacher forcing")
+    layer_forward = _block_fwd
+    layer_backward = _block_bwd
 
     def loss_and_grads(self, images, labels, dropout_masks, relu_masks=None, pool_idx=None):
         """Forward (training=True) + loss + gradients of every trainable tensor.  UNet/model.py:208-219.
@@ -341,31 +444,42 @@ class OracleUNet:
         dl = ce_loss_bwd(p, y, self.global_batch_size, self.contract)
         L = {n: k for n, k, _, _ in self.layers}
         g = {}
-        b = lambda name, d: self._block_bwd(name, L[name], d, c, g, relu_masks)
+        pl = self.plan
+        R = bf16_round if pl is not None else (lambda t: t)
+        b = lambda name, d, sums=None: self._block_bwd(name, L[name], d, c, g, relu_masks, sums)
         scale = 1.0 / (1.0 - self.contract.dropout_rate)
         d = np.ascontiguousarray(dl.transpose(0, 3, 1, 2))
-        d = b("logits", d)
+        d, du = b("logits", d)
 
-        def dec(d, a, bb, up, nskip):
-            d = b(a, b(bb, d))
-            dskip, dup = d[:, :nskip], d[:, nskip:]
-            return dskip, b(up, np.ascontiguousarray(dup))
+        def dec(d, du, a, bb, up, nskip):
+            d, du = b(bb, d, du)
+            d, du = b(a, d, du)
+            dskip = d[:, :nskip]
+            d, du = b(up, np.ascontiguousarray(d[:, nskip:]), np.ascontiguousarray(du[:, nskip:]))
+            return dskip, d, du
 
-        ds1, d = dec(d, "dec_1a", "dec_1b", "up_1", BASE)
-        ds2, d = dec(d, "dec_2a", "dec_2b", "up_2", 2 * BASE)
-        ds3, d = dec(d, "dec_3a", "dec_3b", "up_3", 4 * BASE)
-        ds4, d = dec(d, "dec_4a", "dec_4b", "up_4", 8 * BASE)
+        ds1, d, du = dec(d, None, "dec_1a", "dec_1b", "up_1", BASE)     # dec_1b reduces its own (stored) dy: the class map's kernel sums nothing
+        ds2, d, du = dec(d, du, "dec_2a", "dec_2b", "up_2", 2 * BASE)
+        ds3, d, du = dec(d, du, "dec_3a", "dec_3b", "up_3", 4 * BASE)
+        ds4, d, du = dec(d, du, "dec_4a", "dec_4b", "up_4", 8 * BASE)
         d = d * c["drop_b"] * scale
-        d = b("bott_a", b("bott_b", d))
+        d, du = b("bott_b", d)
+        d, du = b("bott_a", d, du)
         d = maxpool2x2_bwd(d, c["pool_4"]) + ds4
+        if pl is not None and pl.lvl4_accumulate_bf16:
+            d = R(d)
         d = d * c["drop_4"] * scale
-        d = b("conv_4a", b("conv_4b", d))
+        d, du = b("conv_4b", d)
+        d, du = b("conv_4a", d, du)
         d = maxpool2x2_bwd(d, c["pool_3"]) + ds3
-        d = b("conv_3a", b("conv_3b", d))
+        d, du = b("conv_3b", d)
+        d, du = b("conv_3a", d, du)
         d = maxpool2x2_bwd(d, c["pool_2"]) + ds2
-        d = b("conv_2a", b("conv_2b", d))
+        d, du = b("conv_2b", d)
+        d, du = b("conv_2a", d, du)
         d = maxpool2x2_bwd(d, c["pool_1"]) + ds1
-        dimg = b("conv_1a", b("conv_1b", d))
+        d, du = b("conv_1b", d)
+        dimg, _ = b("conv_1a", d, du)
         return loss, softmax, g, c, dimg
 
     def train_step(self, images, labels, dropout_masks):

@@ -723,9 +723,6 @@ class Engine:
                 rows = L.unet_convT2x2_bf16_stats_rows(n, hi, wi, cin, cout, 1) if prod else 0
                 r_prev = self.saved[prod[0]][1] if rows > 0 else None
                 part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,)) if rows > 0 else None
-                # dx is the dy of the producer (dec_(N+1)b): bf16 when that layer's BatchNorm backward takes bf16 dy
-                if rows > 0 and self.bf16_activations and self.bf16_convt_activations and self.bf16_storage and not eval_mode and self._dz16(prod[0], True, eval_mode):
-                    dx = self._buf("dy16_in_" + name, (n, hi, wi, cin), torch.bfloat16)
                 L.unet_convT2x2_dgrad_bf16(_p(dz), cout, int(dz.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[1]), _p(dx), cin,
                                            int(dx.dtype == torch.bfloat16), n, hi, wi, cin, cout, _p(r_prev), _ld(r_prev) if rows > 0 else 0,
                                            int(rows > 0 and r_prev.dtype == torch.bfloat16), _p(part), part.numel() * 4 if rows > 0 else 0, st)
@@ -808,6 +805,13 @@ class Engine:
             return False
         if self.kind[name] == "conv1":                                  # class map: its input gradient is dec_1b's dy
             return self.bf16_edge_activations and self.cin[name] % 8 == 0 and self._dz16("dec_1b", True, eval_mode)
+        if self.kind[name] == "deconv":
+            # dx is the dy of the producer (dec_(N+1)b): bf16 when that layer's BatchNorm backward takes bf16 dy and this kernel leaves its sums
+            n, hi, wi, _ = self.saved[name][0].shape
+            prod = PRODUCER.get(name) if self.fuse_bn_stats else None
+            return (prod is not None and self.bf16_convt_activations and self._use_bf16_convt(name, n, hi, wi)
+                    and self.L.unet_convT2x2_bf16_stats_rows(n, hi, wi, self.cin[name], self.cout[name], 1) > 0
+                    and self._dz16(prod[0], True, eval_mode))
         if self.kind[name] != "conv3":
             return False
         n, ho, wo, _ = self.saved[name][1].shape
