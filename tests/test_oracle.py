@@ -154,3 +154,49 @@ def test_ce_clip_path_numpy_backward_matches_torch_autograd():
         lt.backward()
         assert abs(float(lt) - loss) < 1e-12 * abs(loss)
         assert np.abs(zt.grad.numpy() - dl).max() < 1e-12 * np.abs(dl).max() + 1e-18
+
+
+def test_bf16_round_is_round_to_nearest_even_like_torch():
+    # known answers: 1 + 2^-8 is a tie between 1.0 and 1 + 2^-7 -> even mantissa (1.0); 1 + 3*2^-8 ties up to 1 + 2^-6
+    x = np.array([1.0, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, 1.0 + 2.0 ** -8 + 2.0 ** -20, -1.0 - 2.0 ** -8, 0.0, 3.0e38, 1e-40], np.float32)
+    want = np.array([1.0, 1.0, 1.0 + 2.0 ** -6, 1.0 + 2.0 ** -7, -1.0, 0.0, 3.0e38, 1e-40], np.float32)
+    got = on.bf16_round(x)
+    assert np.array_equal(got[:6], want[:6])
+    r = np.random.default_rng(0).standard_normal(200000).astype(np.float32) * np.float32(37.0)
+    assert np.array_equal(on.bf16_round(r), torch.from_numpy(r).to(torch.bfloat16).float().numpy())
+    assert np.array_equal(on.bf16_round(on.bf16_round(r)), on.bf16_round(r))                 # idempotent
+    assert on.bf16_round(r.astype(np.float64)).dtype == np.float64
+
+
+def test_bf16_oracle_mode_reduces_to_the_reference_arithmetic_and_documents_its_noise_floor():
+    n, c, k, hw = 2, 3, 4, 32
+    img, lab = on.synthetic_batch(n, c, k, hw, hw, seed=3)
+    prm = on.init_params(c, k, seed=3)
+    rng = np.random.default_rng(1)
+    masks = {"drop_4": rng.integers(0, 2, (n, 512, hw // 8, hw // 8)), "drop_b": rng.integers(0, 2, (n, 1024, hw // 16, hw // 16))}
+    l32, _, g32, _, _ = on.OracleUNet(k, n, c, params=prm).loss_and_grads(img, lab, masks)
+    con = on.Contract(compute_dtype="bf16")
+    # a plan that rounds nothing IS the fp32 contract
+    e = frozenset()
+    l0, _, g0, _, _ = on.OracleUNet(k, n, c, params=prm, contract=con, plan=on.Bf16Plan(e, e, e, e, e, e, False)).loss_and_grads(img, lab, masks)
+    assert l0 == l32 and all(np.array_equal(g0[kk], g32[kk]) for kk in g32)
+    # the default plan: close to the reference arithmetic in the loss, gradients at the bf16 noise level
+    ref64 = on.OracleUNet(k, n, c, params=prm, contract=con)
+    l16, _, g16, c16, _ = ref64.loss_and_grads(img, lab, masks)
+    assert abs(l16 - l32) < 1e-2 * abs(l32)
+    a, b = g16["logits/kernel"].ravel(), g32["logits/kernel"].ravel()
+    assert a @ b / np.linalg.norm(a) / np.linalg.norm(b) > 0.95
+    # every stored tensor the plan names is bf16-valued
+    for name in ref64.plan.r_bf16:
+        assert np.array_equal(on.bf16_round(c16[name][1]), c16[name][1]), name
+    for name in ref64.plan.dz_bf16:
+        assert np.array_equal(on.bf16_round(c16[name + "/dz"]), c16[name + "/dz"]), name
+    # two faithful evaluations of the SAME plan (float32 vs float64 accumulation), same branch decisions, end far more than 1e-3
+    # apart: a rounding turns a difference delta << ulp into one ulp on a fraction delta / ulp of the elements (rms sqrt(delta ulp)),
+    # so free-running end-to-end comparisons of this mode are bounded by the quantisation level, not by the accumulation error
+    relu = {name: c16[name][1] > 0 for name, kind, _, _ in ref64.layers if kind != "deconv"}
+    pidx = {"pool_%d" % l: c16["pool_%d" % l] for l in (1, 2, 3, 4)}
+    _, _, ga, _, _ = ref64.loss_and_grads(img, lab, masks, relu_masks=relu, pool_idx=pidx)
+    _, _, gb, _, _ = on.OracleUNet(k, n, c, params=prm, contract=con, dtype=np.float32).loss_and_grads(img, lab, masks, relu_masks=relu, pool_idx=pidx)
+    rel = [np.linalg.norm(gb[kk] - ga[kk]) / np.linalg.norm(ga[kk]) for kk in ga if kk.endswith("kernel")]
+    assert np.median(rel) > 2e-3, np.median(rel)
