@@ -11,7 +11,8 @@
  *   - weights keep the Keras layouts: Conv2D kernel HWIO [kh][kw][Cin][Cout]; Conv2DTranspose kernel [kh][kw][Cout][Cin];
  *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued asynchronously;
  *   - return value: 0 ok, UNET_EINVAL (-1) bad argument, UNET_ENOSPC (-2) workspace too small, >0 a hipError_t;
- *   - no global mutable state: callable concurrently from different streams/threads;
+ *   - no global mutable state and no environment variables: every option is an argument; the library caches only immutable device
+ *     properties (CU count, occupancy of its own kernels), so calls are safe from different streams/threads;
  *   - `*_workspace()` return the scratch bytes the matching call needs for the same shape arguments.
  */
 #ifndef UNET_HIP_H
@@ -26,6 +27,9 @@ extern "C" {
 #define UNET_EINVAL (-1)
 #define UNET_ENOSPC (-2)
 
+/* Bumped whenever an exported signature changes; a loader must refuse a library whose unet_hip_abi_version() differs
+ * (2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
+#define UNET_HIP_ABI_VERSION 2
 int unet_hip_abi_version(void);
 
 /* ---- Conv2D(3x3, 'same', relu) of UNet._conv_layer, UNet/model.py:28-35 (18 instances, :88-134) ------------------ */
@@ -69,9 +73,12 @@ int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Uc
 /* fused Winograd weight gradient: raw rows through LDS, per-lane transforms in registers, G^T dU G in the epilogue;
  * needs H, W even and Cin, Cout multiples of 64 */
 int unet_winograd_wgrad_fused_supported(int N, int H, int W, int Cin, int Cout);
-size_t unet_conv3x3_wgrad_winograd_fused_workspace(int N, int H, int W, int Cin, int Cout);
+/* max_workgroups: cap on the persistent grid, 0 = one workgroup per CU.  A data-parallel caller passes ~224 so that the collective's
+ * kernels (tf.distribute's all-reduce inside apply_gradients, UNet/model.py:223 under UNet/train.py:57-61) find free CUs while this
+ * chip-filling kernel runs; the same value must be given to the _workspace() query. */
+size_t unet_conv3x3_wgrad_winograd_fused_workspace(int N, int H, int W, int Cin, int Cout, int max_workgroups);
 int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, const float* dz, int lddz, float* dw,
-                                      int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+                                      int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream);
 /* weight gradient of a layer whose input was read through BatchNorm-apply on load (x = scale . r + shift inside the image): dw holds
  * any wgrad kernel's result on the RAW r; in place dw = scale[ci] * dw + shift[ci] * S[tap][co], S = sum of dz over the pixels whose
  * tap lies inside the image (border sums of dz; total = column sums of dz = the bias gradient). */

@@ -28,8 +28,8 @@ for name, h, ci, co in shapes:
     wok = wwok = False          # (the unfused Winograd pipeline left the default library: UNET_EXPERIMENTAL builds only)
     Uc = torch.empty(16 * ci * co, device="cuda"); Ucd = torch.empty(16 * ci * co, device="cuda")
     L.unet_winograd_weight_transform(P(w), P(Uc), ci, co, 2, ST()); L.unet_winograd_weight_transform(P(w), P(Ucd), ci, co, 3, ST())
-    nbq = L.unet_conv3x3_wgrad_winograd_fused_workspace(B, h, h, ci, co); wsq = torch.empty(nbq + 256, dtype=torch.uint8, device="cuda")
-    fns = {"fwgrad": lambda: L.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(wsq), nbq, ST()),
+    nbq = L.unet_conv3x3_wgrad_winograd_fused_workspace(B, h, h, ci, co, 0); wsq = torch.empty(nbq + 256, dtype=torch.uint8, device="cuda")
+    fns = {"fwgrad": lambda: L.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, 0, P(wsq), nbq, ST()),
            "ffwd": lambda: L.unet_conv3x3_fwd_winograd_fused(P(x), ci, None, P(Uc), P(b), P(out), co, B, h, h, ci, co, 1, None, 0, ST()),
            "fdgrad": lambda: L.unet_conv3x3_dgrad_winograd_fused(P(dz), co, P(Ucd), P(dx), ci, B, h, h, ci, co, None, 0, 0, 0, None, 0, ST()),
            "fwd": lambda: L.unet_conv3x3_fwd_mfma(P(x), ci, P(w), P(b), P(out), co, B, h, h, ci, co, 1, ST()),

@@ -1,11 +1,17 @@
 #!/bin/bash
 # Diagnostic builds: scripts/build_variant.sh <name> <source.hip> "<extra -D flags>"  ->  csrc/libunet_hip_<name>.so
-# (the other objects are the regular build's; load with UNET_HIP_LIB=<path>).  Never used by the product path.
+# (load with UNET_HIP_LIB=<path>; _lib.py still checks its ABI version).  Never used by the product path.
+# The other objects are the regular build's: the regular library is (re)built first, so every object corresponds to the sources in the
+# tree (content stamps, _build.py) and no stale *.o from an earlier tree can be linked in.
 set -e
-cd "$(dirname "$0")/../semantic-segmentation-unet_amd/csrc"
+root="$(cd "$(dirname "$0")/.." && pwd)"
+python3 "$root/semantic-segmentation-unet_amd/_build.py" > /dev/null
+cd "$root/semantic-segmentation-unet_amd/csrc"
 name=$1; src=$2; flags=$3
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function $flags -c $src -o /tmp/variant_$name.o
 objs=""
-for o in *.o; do if [ "$o" != "${src%.hip}.o" ]; then objs="$objs $o"; fi; done
+for s in $(python3 -c "import sys; sys.path.insert(0, '$root/semantic-segmentation-unet_amd'); import _build; print(' '.join(_build.SOURCES))"); do
+    if [ "$s" != "$src" ]; then objs="$objs ${s%.hip}.o"; fi
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o libunet_hip_$name.so $objs /tmp/variant_$name.o
 echo built libunet_hip_$name.so

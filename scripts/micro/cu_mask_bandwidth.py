@@ -50,9 +50,9 @@ for name, cus in [("256 via mask", range(256)), ("128 strided (every 2nd)", rang
 # ---- the same BatchNorm pass while the fused Winograd weight gradient (MFMA-bound, one 512-register workgroup per CU) runs beside it
 ci = co = 128; hh = 256
 x = torch.randn(n, hh, hh, ci, device="cuda"); dz = torch.randn(n, hh, hh, co, device="cuda"); dw = torch.empty(3, 3, ci, co, device="cuda")
-nb = L.unet_conv3x3_wgrad_winograd_fused_workspace(n, hh, hh, ci, co); ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
+nb = L.unet_conv3x3_wgrad_winograd_fused_workspace(n, hh, hh, ci, co, 0); ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
 def wg(stream):
-    return lambda: L.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), n, hh, hh, ci, co, P(ws), nb, ctypes.c_void_p(stream.cuda_stream))
+    return lambda: L.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), n, hh, hh, ci, co, 0, P(ws), nb, ctypes.c_void_p(stream.cuda_stream))
 tw = timeit(wg(full), full)
 print("weight gradient 128->128 @256^2 alone: %.3f ms (grid per UNET_WGRAD_CUS)" % tw, flush=True)
 A = [i for i in range(256) if i % 8 == 0]; B = [i for i in range(256) if i % 8 != 0]

@@ -9,10 +9,10 @@ ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, h, ci, co in [("bott_b", 32, 1024, 1024), ("4b", 64, 512, 512), ("2b", 256, 128, 128)]:
     B = 8
     x = torch.randn(B, h, h, ci, device="cuda"); dz = torch.randn(B, h, h, co, device="cuda"); dw = torch.empty(3, 3, ci, co, device="cuda")
-    nb = L.unet_conv3x3_wgrad_winograd_fused_workspace(B, h, h, ci, co)
+    nb = L.unet_conv3x3_wgrad_winograd_fused_workspace(B, h, h, ci, co, 0)
     ws = torch.zeros(nb + 256, dtype=torch.uint8, device="cuda")
     for _ in range(3):
-        L.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(ws), nb, ST())
+        L.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, 0, P(ws), nb, ST())
     torch.cuda.synchronize()
     t = ws[nb:nb + 40].view(torch.int64).tolist()
     n = max(t[4], 1)

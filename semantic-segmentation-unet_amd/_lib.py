@@ -41,6 +41,13 @@ class UnetHipError(RuntimeError):
     pass
 
 
+def header_abi_version(path=HEADER):
+    m = re.search(r"#define\s+UNET_HIP_ABI_VERSION\s+(\d+)", open(path).read())
+    if not m:
+        raise UnetHipError("include/unet_hip.h does not define UNET_HIP_ABI_VERSION")
+    return int(m.group(1))
+
+
 class _Lib:
     def __init__(self):
         if not os.path.exists(LIB_PATH):
@@ -51,6 +58,13 @@ class _Lib:
                 raise UnetHipError("%s was not built from the sources/flags in this tree (content stamp mismatch); "
                                    "run build() (python __graft_entry__.py)" % LIB_PATH)
         self.cdll = ctypes.CDLL(LIB_PATH)
+        # ALWAYS (also for a UNET_HIP_LIB diagnostic build): the binary must speak the header's ABI version -- functions are bound by
+        # name, so an older library would silently take arguments in the wrong slots
+        want = header_abi_version()
+        self.cdll.unet_hip_abi_version.restype = ctypes.c_int
+        got = self.cdll.unet_hip_abi_version()
+        if got != want:
+            raise UnetHipError("%s speaks ABI version %d, include/unet_hip.h declares %d: rebuild it" % (LIB_PATH, got, want))
         self.protos = parse_header()
         for name, (res, args) in self.protos.items():
             fn = getattr(self.cdll, name)          # AttributeError = header/library mismatch: fail loudly

@@ -652,10 +652,6 @@ int conv_bf16_cus() {
     return cus;
 }
 
-bool cb_stream_enabled() {
-    static const bool ok = [] { const char* e = getenv("UNET_CB_STREAM"); return !(e && e[0] == '0'); }();      // A/B switch
-    return ok;
-}
 
 struct ConvBf16Stats { int mode; float* part; size_t bytes; const float* r; int ldr, c0, c1, r16; };
 
@@ -678,7 +674,7 @@ int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, fl
         a.stat_part = stats->part; a.bn_r = stats->r; a.bn_ldr = stats->ldr; a.bn_c0 = stats->c0; a.bn_c1 = stats->c1;
     }
     const dim3 grid((unsigned)(a.n_px * a.n_co));
-    if (in16 && out16 && (mode != 2 || a.r16) && !in_scale && cb_stream_enabled() && Cin <= 4096) {
+    if (in16 && out16 && (mode != 2 || a.r16) && !in_scale && Cin <= 4096) {
         // persistent form: one resident wave of workgroups walks the tiles (the grid is the whole tile count when that is smaller)
         const long slots = (long)conv_bf16_cus() * (wide ? 1 : 2);
         const dim3 pgrid((unsigned)((long)grid.x < slots ? (long)grid.x : slots));
@@ -738,7 +734,6 @@ struct WgBf16Args {
     int n_ci, n_co, splits, tbx, rpc, cps, n_sc;
     unsigned x_bytes, dz_bytes;
     int x16, z16;                // xin / dz stored as bf16 (ldx / lddz in elements)
-    int ablate;                  // diagnostics (UNET_WGRAD_BF16_ABLATE): 1 = no MFMA stream, 2 = no staging loads, 4 = no conversion + LDS writes, 8 = no barrier (results are wrong)
 };
 
 constexpr int kWgXRow = 2 * 36 * 64, kWgDzRow = kWgXRow;            // bytes of one staged row: 2 channel groups x 36 pixels (34 / 32 used) x 64 B
@@ -1062,8 +1057,8 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
             dma_issue(0); dma_issue(1); dma_issue(2);
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NI) : "memory");
             for (int s = 0; s < steps; ++s) {
-                if (!(p.ablate & 2)) dma_issue(s + 3);
-                if (!(p.ablate & 1)) compute(s);
+                if (!(UNET_CB_ABLATE & 2)) dma_issue(s + 3);
+                if (!(UNET_CB_ABLATE & 1)) compute(s);
                 // pass s + 2 (issued one step ago) has to be here for step s + 1; pass s + 3 stays in flight
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NI) : "memory");
             }
@@ -1084,10 +1079,10 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
         issue(stg[0], 1); commit(stg[0], 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int s = 0; s < steps; ++s) {
-            if (!(p.ablate & 2)) issue(stg[0], s + 2);
-            if (!(p.ablate & 1)) compute(s);
-            if (!(p.ablate & 4)) commit(stg[0], s + 2);
-            if (!(p.ablate & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!(UNET_CB_ABLATE & 2)) issue(stg[0], s + 2);
+            if (!(UNET_CB_ABLATE & 1)) compute(s);
+            if (!(UNET_CB_ABLATE & 4)) commit(stg[0], s + 2);
+            if (!(UNET_CB_ABLATE & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // passes still in flight belong to nobody
     }
@@ -1133,8 +1128,7 @@ void wgrad_bf16_plan(WgBf16Args& a) {
     const int npairs = a.n_ci * a.n_co;
     a.tbx = (a.W + 31) / 32;
     const int strips = a.N * a.tbx;
-    static const int occ = [] { const char* e = getenv("UNET_WGRAD_BF16_OCC"); return e && e[0] == '2' ? 2 : 1; }();   // workgroups per CU (A/B switch)
-    const int slots = conv_bf16_cus() * occ;
+    const int slots = conv_bf16_cus();                                   // one workgroup per CU (two: 4-12 % faster alone, nothing in the step -- DESIGN.md 3b)
     const int target = (slots + npairs - 1) / npairs;                    // strip-chunks wanted so that every slot has a workgroup
     int cps = (target + strips - 1) / strips; if (cps < 1) cps = 1;
     int rpc = (a.H + cps - 1) / cps; rpc += rpc & 1; if (rpc < 2) rpc = 2;
@@ -1170,11 +1164,11 @@ extern "C" int unet_conv3x3_wgrad_bf16(const void* xin, int ldx, int x_bf16, con
     a.x16 = x_bf16 ? 1 : 0; a.z16 = dz_bf16 ? 1 : 0;
     wgrad_bf16_plan(a);
     a.out = a.splits > 1 ? (float*)ws : dw;
-    { const char* e = getenv("UNET_WGRAD_BF16_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     a.x_bytes = (unsigned)((size_t)N * H * W * ldx * (a.x16 ? 2 : 4)); a.dz_bytes = (unsigned)((size_t)N * H * W * lddz * (a.z16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
-    static const bool dma = [] { const char* e = getenv("UNET_WGRAD_BF16_DMA"); return !(e && e[0] == '0'); }();      // A/B switch
-    if (dma && a.x16 && a.z16) wgrad_bf16_dma_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
+    // both operands stored as bf16: the staged rows are plain copies of memory -> LDS-DMA staging; otherwise the register-staged
+    // kernel converts fp32 operands on the way into LDS
+    if (a.x16 && a.z16) wgrad_bf16_dma_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
     else                       wgrad_bf16_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     if (a.splits > 1) {
@@ -1557,8 +1551,7 @@ int run_convt_bf16(int mode, const void* x, int ldx, int in16, const void* wp, c
         if (stat_bytes < (size_t)(chans / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
     }
     const dim3 grid((unsigned)(a.n_px * a.n_co));
-    static const bool dma = [] { const char* e = getenv("UNET_CONVT_BF16_DMA"); return !(e && e[0] == '0'); }();      // A/B switch
-    if (dma && in16) {
+    if (in16) {                                     // bf16-stored input: LDS-DMA staging (64 contiguous bytes per pixel)
         if (mode == 1) {
             if (stat_part) { if (wide) convt_bf16_fwd_stats_dma_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_fwd_stats_dma_kernel_64<<<grid, 256, 0, st>>>(a); }
             else           { if (wide) convt_bf16_fwd_dma_kernel_128<<<grid, 256, 0, st>>>(a); else convt_bf16_fwd_dma_kernel_64<<<grid, 256, 0, st>>>(a); }
@@ -1800,9 +1793,12 @@ __global__ __launch_bounds__(256, 1) void convt_wgrad_bf16_kernel_64(CtWgBf16Arg
 
 void convt_wgrad_bf16_plan(CtWgBf16Args& a) {
     // 64-output-channel tiles by default: 128 AGPRs + 103 VGPRs, so the kernel shares a CU with the other stream's kernels (the
-    // 128-channel tile takes all 256 AGPRs; alone it is as fast, in the step 0.13 ms slower).  UNET_CONVT_WGRAD_NARROW=0: A/B switch
-    static const int narrow = [] { const char* e = getenv("UNET_CONVT_WGRAD_NARROW"); return e ? atoi(e) : 1; }();
-    const int cot = (a.Cout % 128 == 0 && !narrow) ? 128 : 64;
+    // 128-channel tile takes all 256 AGPRs; alone it is as fast, in the step 0.13 ms slower -- compile with -DUNET_CONVT_WGRAD_WIDE to get it)
+#ifdef UNET_CONVT_WGRAD_WIDE
+    const int cot = a.Cout % 128 == 0 ? 128 : 64;
+#else
+    const int cot = 64;
+#endif
     a.n_co = a.Cout / cot; a.n_ci = a.Cin / 128;
     a.tbx = (a.W + 31) / 32; a.n_units = a.N * a.H * a.tbx;
     const int npairs = a.n_co * a.n_ci;

@@ -621,8 +621,7 @@ extern "C" int unet_conv1x1_fwd(const void* x, int ldx, int x_bf16, const float*
                                 long P, int Cin, int Cout, int relu, void* stream) {
     UNET_CHECK_ARG(x && w && out && P > 0 && Cin > 0 && Cout > 0 && Cin % 4 == 0 && ldx % 4 == 0 && ldx >= Cin && ldo >= Cout);
     UNET_CHECK_ARG(unet_aligned16(x) && (size_t)Cin * Cout * 4 <= 64 * 1024);
-    static const bool fwd8 = [] { const char* e = getenv("UNET_CONV1X1_FWD8"); return !(e && e[0] == '0'); }();      // A/B switch
-    if (fwd8 && Cin == 64 && Cout <= 8 && ldx % 8 == 0) {            // the network's class map: 8 lanes per pixel, weights in registers
+    if (Cin == 64 && Cout <= 8 && ldx % 8 == 0) {            // the network's class map: 8 lanes per pixel, weights in registers
         long b8 = (P + 63) / 64; if (b8 > 8192) b8 = 8192;           // (32 pixels per block pass, two pixels per trip)
         if (x_bf16) conv1x1_narrow_fwd8_kernel<1, 8><<<(int)b8, 256, 0, (hipStream_t)stream>>>((const float*)x, ldx, w, bias, out, ldo, P, Cout, relu);
         else        conv1x1_narrow_fwd8_kernel<0, 8><<<(int)b8, 256, 0, (hipStream_t)stream>>>((const float*)x, ldx, w, bias, out, ldo, P, Cout, relu);

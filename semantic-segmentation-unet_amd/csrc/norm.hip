@@ -590,14 +590,9 @@ bool make_plan(long P, int C, int ld_a, int ld_b, int ld_c, bool aligned, Plan* 
 
 int nblk_for(long P) { (void)P; return (int)MAX_BLOCKS; }        // workspace is sized for the largest grid
 
-// UNET_BN_WIDE (diagnostic A/B switch): 1 = 8 channels per lane for every tensor mix the shapes allow (default), 0 = only when a tensor is
-// stored as bf16.  With one lane layout for both storages the sums are added in one order, so bf16 storage of dz / y stays
-// bit-identical to fp32 storage.
-bool bn_wide_always() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("UNET_BN_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
+// 8 channels per lane for every tensor mix the shapes allow: with one lane layout for both storages the sums are added in one order,
+// so bf16 storage of dz / y stays bit-identical to fp32 storage.
+constexpr bool bn_wide_always() { return true; }
 
 int bn_cus() {
     static int cus = 0;

@@ -1175,14 +1175,14 @@ __global__ __launch_bounds__(256) void wino_partial_reduce_kernel(const float* _
     }
 }
 
-int wgrad_fused_splits(int N, int H, int W, int Ci, int Co) {
+int wgrad_fused_splits(int N, int H, int W, int Ci, int Co, int max_workgroups) {
     const int blocks = (Ci / 64) * (Co / 64);
     const long nchunks = (long)N * (H / 2) * ((W / 2 + 7) / 8);
-    // Workgroups on the chip: one per CU.  UNET_WGRAD_CUS=224 (A/B switch) leaves ~4 CUs per XCD to the OTHER stream -- the main stream's
-    // BatchNorm passes (and, data-parallel, RCCL's kernels) cannot share a CU with these 512-register workgroups and otherwise queue
-    // behind a chip-filling grid: the step gains 0.3 ms of 44.1 (the passes then run beside the weight gradient, but at 1.3-2.1 TB/s:
-    // DESIGN.md), while the kernel itself is 12 % slower when timed alone -- not the default.
-    static const int want = [] { const char* e = getenv("UNET_WGRAD_CUS"); const int v = e ? atoi(e) : 0; return v >= 32 && v <= 256 ? v : 256; }();
+    // Workgroups on the chip: one per CU by default (max_workgroups = 0).  A caller's cap of 224 leaves ~4 CUs per XCD to the OTHER
+    // stream -- the main stream's BatchNorm passes and, data-parallel, RCCL's kernels cannot share a CU with these 512-register workgroups
+    // and otherwise queue behind a chip-filling grid: the single-GPU step gains 0.3 ms of 44.1 (the passes then run beside the weight
+    // gradient, but at 1.3-2.1 TB/s: DESIGN.md), while the kernel itself is 12 % slower when timed alone.
+    const int want = (max_workgroups >= 32 && max_workgroups <= 256) ? max_workgroups : 256;
     long sp = 256 / blocks; if (sp < 1) sp = 1;
     if (blocks * sp > want && blocks * (want / blocks) >= 192) sp = want / blocks;
     if (sp > nchunks) sp = nchunks;
@@ -1362,14 +1362,10 @@ int wino_stream_cus() {
     static const int cus = [] { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256; return n; }();
     return cus;
 }
-bool wino_stream_enabled() {
-    static const bool ok = [] { const char* e = getenv("UNET_WINO_STREAM"); return !(e && e[0] == '0'); }();   // A/B switch
-    return ok;
-}
 // rows of statistics partials per 64-channel tile the persistent kernel would write (0: shape not taken by it / grid not a
 // multiple of the n-tile count)
 int wino_stats_rows(int N, int H, int W, int K, int Nout) {
-    if (!(wino_stream_enabled() && K % 16 == 0 && K >= 32 && H % 2 == 0 && W % 2 == 0 && Nout % 64 == 0)) return 0;
+    if (!(K % 16 == 0 && K >= 32 && H % 2 == 0 && W % 2 == 0 && Nout % 64 == 0)) return 0;
     const int nt = Nout / 64;
     const long blocks = (long)N * ((H / 2 + 7) / 8) * ((W / 2 + 7) / 8) * nt;
     const long grid = blocks < wino_stream_cus() ? blocks : wino_stream_cus();
@@ -1386,7 +1382,7 @@ int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, 
     a.tby = (H / 2 + 7) / 8; a.tbx = (W / 2 + 7) / 8; a.nt = Nout / 64; a.stat_part = stat_part;
     const long blocks = (long)N * a.tby * a.tbx * a.nt;
     if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
-    if (wino_stream_enabled() && K % 16 == 0 && K >= 32) {
+    if (K % 16 == 0 && K >= 32) {
         const int cus = wino_stream_cus();
         const dim3 grid((unsigned)(blocks < cus ? blocks : cus));
         if (bb) {
@@ -1460,22 +1456,23 @@ extern "C" int unet_winograd_wgrad_fused_supported(int N, int H, int W, int Cin,
     return (N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 64 == 0 && Cout % 64 == 0) ? 1 : 0;
 }
 
-extern "C" size_t unet_conv3x3_wgrad_winograd_fused_workspace(int N, int H, int W, int Cin, int Cout) {
-    return (size_t)wgrad_fused_splits(N, H, W, Cin, Cout) * 9 * Cin * Cout * sizeof(float);
+extern "C" size_t unet_conv3x3_wgrad_winograd_fused_workspace(int N, int H, int W, int Cin, int Cout, int max_workgroups) {
+    return (size_t)wgrad_fused_splits(N, H, W, Cin, Cout, max_workgroups) * 9 * Cin * Cout * sizeof(float);
 }
 
-// dw[a][b][ci][co] = sum_{n,y,x} xin[n, y+a-1, x+b-1, ci] * dz[n,y,x,co] via the fused Winograd-domain kernel
+// dw[a][b][ci][co] = sum_{n,y,x} xin[n, y+a-1, x+b-1, ci] * dz[n,y,x,co] via the fused Winograd-domain kernel.
+// max_workgroups: cap on the persistent grid (0 or out of [32, 256]: one workgroup per CU); honoured when it still leaves >= 192
 extern "C" int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, const float* dz, int lddz, float* dw,
-        int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+        int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(xin && dz && dw && ws && unet_winograd_wgrad_fused_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0);
     UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
-    if (ws_bytes < unet_conv3x3_wgrad_winograd_fused_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
+    if (ws_bytes < unet_conv3x3_wgrad_winograd_fused_workspace(N, H, W, Cin, Cout, max_workgroups)) return UNET_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     WinoWgradArgs a{};
     a.x = xin; a.dz = dz; a.ws = (float*)ws; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Ci = Cin; a.Co = Cout;
     a.mt = Cin / 64; a.nt = Cout / 64; a.tbx = (W / 2 + 7) / 8; a.nchunks = N * (H / 2) * a.tbx;
-    a.splits = wgrad_fused_splits(N, H, W, Cin, Cout);
+    a.splits = wgrad_fused_splits(N, H, W, Cin, Cout, max_workgroups);
     wino_wgrad_fused_kernel<<<dim3((unsigned)(a.mt * a.nt * a.splits)), 256, 0, st>>>(a);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     const long n4 = 9L * Cin * Cout / 4;

@@ -16,12 +16,12 @@ HBM layout
 """
 import ctypes
 import math
-import os
 
 import numpy as np
 import torch
 
 from ._lib import lib
+from .plan import BF16, EngineOptions, PRODUCER, build_plan, layer_table      # noqa: F401  (layer_table / PRODUCER re-exported)
 
 BASE = 64                      # UNet._BASELINE_FEATURE_DEPTH  (reference UNet/model.py:20)
 SIZE_FACTOR = 16               # UNet.SIZE_FACTOR              (reference UNet/model.py:25)
@@ -35,23 +35,6 @@ ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-7
 CE_CLIP_EPS = 0.0              # 0: CE from the softmax's logits (graph-mode Keras); 1e-7: Keras' clipped-probability path
 
 
-def layer_table(number_channels, number_classes):
-    """(name, kind, Cin, Cout) in Keras layer-creation order (reference UNet/model.py:85-136)."""
-    C, K, B = number_channels, number_classes, BASE
-    return [
-        ("conv_1a", "conv3", C, B), ("conv_1b", "conv3", B, B),
-        ("conv_2a", "conv3", B, 2 * B), ("conv_2b", "conv3", 2 * B, 2 * B),
-        ("conv_3a", "conv3", 2 * B, 4 * B), ("conv_3b", "conv3", 4 * B, 4 * B),
-        ("conv_4a", "conv3", 4 * B, 8 * B), ("conv_4b", "conv3", 8 * B, 8 * B),
-        ("bott_a", "conv3", 8 * B, 16 * B), ("bott_b", "conv3", 16 * B, 16 * B),
-        ("up_4", "deconv", 16 * B, 8 * B), ("dec_4a", "conv3", 16 * B, 8 * B), ("dec_4b", "conv3", 8 * B, 8 * B),
-        ("up_3", "deconv", 8 * B, 4 * B), ("dec_3a", "conv3", 8 * B, 4 * B), ("dec_3b", "conv3", 4 * B, 4 * B),
-        ("up_2", "deconv", 4 * B, 2 * B), ("dec_2a", "conv3", 4 * B, 2 * B), ("dec_2b", "conv3", 2 * B, 2 * B),
-        ("up_1", "deconv", 2 * B, B), ("dec_1a", "conv3", 2 * B, B), ("dec_1b", "conv3", B, B),
-        ("logits", "conv1", B, K),
-    ]
-
-
 def kernel_shape(kind, cin, cout):
     return {"conv3": (3, 3, cin, cout), "conv1": (1, 1, cin, cout), "deconv": (2, 2, cout, cin)}[kind]
 
@@ -59,17 +42,6 @@ def kernel_shape(kind, cin, cout):
 BACKWARD_ORDER = ["logits", "dec_1b", "dec_1a", "up_1", "dec_2b", "dec_2a", "up_2", "dec_3b", "dec_3a", "up_3",
                   "dec_4b", "dec_4a", "up_4", "bott_b", "bott_a", "conv_4b", "conv_4a", "conv_3b", "conv_3a",
                   "conv_2b", "conv_2a", "conv_1b", "conv_1a"]
-
-
-# layer -> (producer, first, last, parts): the layer's input channels [first/parts, last/parts) of its Cin are EXACTLY the BatchNorm
-# output of `producer` and feed nothing else, so the layer's data gradient over that range is the producer's dy
-PRODUCER = {"bott_b": ("bott_a", 0, 1, 1)}
-for _l in (1, 2, 3, 4):
-    PRODUCER["conv_%db" % _l] = ("conv_%da" % _l, 0, 1, 1)
-    PRODUCER["dec_%db" % _l] = ("dec_%da" % _l, 0, 1, 1)
-    PRODUCER["dec_%da" % _l] = ("up_%d" % _l, 1, 2, 2)          # concat [skip, upsampled] (UNet/model.py:55-58): upper half
-for _l in (1, 2, 3):
-    PRODUCER["up_%d" % _l] = ("dec_%db" % (_l + 1), 0, 1, 1)   # (up_4's input went through the dropout: no direct producer)
 
 
 def flat_layout(number_channels, number_classes):
@@ -104,12 +76,17 @@ def _ld(t):
 
 
 class Engine:
-    def __init__(self, number_classes, number_channels, device="cuda", seed=0):
+    def __init__(self, number_classes, number_channels, device="cuda", seed=0, options=None):
         self.K, self.C = number_classes, number_channels
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("the U-Net hot path runs on an MI355X only (device must be cuda); no CPU fallback exists")
         self.L = lib()
+        # every switch of the schedule lives in ONE options object (plan.EngineOptions; UNET_* diagnostics variables are read once, here);
+        # routes and storage precisions are decided per shape by plan.build_plan and only looked up below
+        self.opt = options if options is not None else EngineOptions.from_env()
+        self._plans = {}
+        self.pl = None
         self.layers = layer_table(number_channels, number_classes)
         self.kind = {n: k for n, k, _, _ in self.layers}
         self.cin = {n: ci for n, _, ci, _ in self.layers}
@@ -138,51 +115,49 @@ class Engine:
         self.ce_clip_eps = CE_CLIP_EPS
         self._eval_folded = set()               # layers whose eval-mode (moving-statistics) BatchNorm-on-load fold is current
         self._eval_coefs = set()                # (layer, destination) pairs whose eval-mode scale / shift are current
-        self.init_parameters(seed)
-        self.on_layer_grads_ready = None        # hook(name) for data-parallel bucketing (parallel.py)
-        self.profile = None                     # bench.py: {"conv3x3_fwd": [(ev0, ev1, flops)], ...} when enabled
-        # Backward runs two HIP streams: the critical chain dgrad(L) -> bn_bwd(L-1) -> dgrad(L-1) ... on the caller's
-        # stream, every weight gradient on `side` (it is needed only by the all-reduce / Adam).  The persistent wgrad
-        # workgroups (106 KB LDS) co-reside with igemm workgroups and with the HBM-bound BN streams.
-        self.overlap_wgrad = True
-        # 3x3 route: "fused" = fully fused Winograd F(2x2,3x3) kernels wherever they apply (default, fastest on every layer shape
-        # measured), "direct" = the implicit-GEMM MFMA kernels (also the fallback for odd tile sizes)
-        self.conv_route = os.environ.get("UNET_CONV_ROUTE", "fused")
-        self.wgrad_route = os.environ.get("UNET_WGRAD_ROUTE", "fused")
-        # BatchNorm-apply on load (fp32 fused route): a layer whose only consumer is a fused Winograd conv does not materialise its
-        # BatchNorm output; the consumer reads the conv output r through scaled weights, a folded bias and a per-channel padding
-        # value (unet_winograd_weight_fold), its weight gradient is corrected by unet_conv3x3_wgrad_fold_fix.  UNET_BN_ON_LOAD=0: two passes.
-        self.bn_on_load = os.environ.get("UNET_BN_ON_LOAD", "1") != "0"
-        # bf16 activation storage also at the two ends of the network (the first layer's conv output, the class-map layer's input and
-        # input gradient): the kernels there compute in fp32 on fp32 weights, only the 64-channel tensors they exchange with the bf16
-        # layers are stored as bf16 (A/B switch)
-        self.bf16_edge_activations = os.environ.get("UNET_BF16_EDGE_ACTIVATIONS", "1") != "0"
-        # level 4 (whose skip goes through the dropout and the unfused pool kernels) stores its concat / pooled tensors and their gradients
-        # as bf16 like levels 1-3 (A/B switch)
-        self.bf16_level4 = os.environ.get("UNET_BF16_LEVEL4", "1") != "0"
         self._gamma_zero = None
         self.view = {}
         self._fused_U, self._fused_dirty = None, True
-        self.fuse_bn_stats = os.environ.get("UNET_FUSE_BN_STATS", "1") != "0"      # BN sums from the conv epilogue (A/B switch)
-        self.bnbwd_part = {}
-        self.fuse_pool = os.environ.get("UNET_FUSE_POOL", "1") != "0"             # BN apply + max pool in one pass (A/B switch)
-        # contraction precision of the wide 3x3 layers: "fp32" (the reference's arithmetic) or "bf16" (BASELINE config 4: bf16
-        # forward/backward on fp32 master weights -- operands rounded to bf16, fp32 accumulation, everything else fp32)
-        self.compute_dtype = os.environ.get("UNET_COMPUTE_DTYPE", "fp32")
         self._bf16_W, self._bf16_dirty = {}, True
-        # bf16 mode, stage 2: tensors whose ONLY readers are bf16 contractions are stored as bf16 -- the BatchNorm outputs between
-        # the two convs of a block and every dz.  The producing kernel rounds exactly as the consumers' staging would have, so
-        # results are bit-identical to fp32 storage (tests assert that); only the bytes moved change.
-        self.bf16_storage = os.environ.get("UNET_BF16_STORAGE", "1") != "0"
-        self.bf16_storage_cat = os.environ.get("UNET_BF16_STORAGE_CAT", "1") != "0"    # ... the concat / pooled tensors too (A/B switch)
-        # stage 3 (default on; UNET_BF16_ACTIVATIONS=0 restores stage 2): in training ALSO keep the wide layers' conv outputs r (what
-        # BatchNorm reads) and the activation gradients dy the data-gradient kernels write as bf16 -- the Keras mixed_bfloat16
-        # convention (bf16 activations and activation gradients, fp32 BatchNorm arithmetic: the fused sums are taken from the fp32
-        # accumulators before the rounding).  Unlike the storage above this changes what BatchNorm sees (by one bf16 rounding).
-        self.bf16_activations = os.environ.get("UNET_BF16_ACTIVATIONS", "1") != "0"
-        self.bf16_convt_activations = os.environ.get("UNET_BF16_CONVT_ACTIVATIONS", "1") != "0"     # ... the transposed convs' too (A/B switch)
+        self.bnbwd_part = {}
+        self.init_parameters(seed)
+        self.on_layer_grads_ready = None        # hook(name) for data-parallel bucketing (parallel.py)
+        self.profile = None                     # bench.py: {"conv3x3_fwd": [(ev0, ev1, flops)], ...} when enabled
+        # Backward runs two HIP streams (opt.overlap_wgrad): the critical chain dgrad(L) -> bn_bwd(L-1) -> dgrad(L-1) ... on the caller's
+        # stream, every weight gradient on `side` (it is needed only by the all-reduce / Adam).
         self.side = torch.cuda.Stream(device=self.dev)
         self._ws_side = None
+
+    # the arithmetic mode is the one option callers set after construction (model.UNet(compute_dtype=...))
+    @property
+    def compute_dtype(self):
+        return self.opt.compute_dtype
+
+    @compute_dtype.setter
+    def compute_dtype(self, v):
+        if v not in ("fp32", "bf16"):
+            raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
+        self.opt.compute_dtype = v
+
+    @property
+    def overlap_wgrad(self):
+        return self.opt.overlap_wgrad
+
+    @overlap_wgrad.setter
+    def overlap_wgrad(self, v):
+        self.opt.overlap_wgrad = bool(v)
+
+    def plan(self, n, h, w, training=False, want_grad=False):
+        """The step plan for images [n, C, h, w] (plan.StepPlan): kernel family per layer and direction, storage precision per tensor.
+        Built once per shape / mode / option set and cached."""
+        key = (n, h, w, bool(training), bool(want_grad), self.opt.key(), self._gamma_nonzero() if self._needs_gamma_check() else True)
+        pl = self._plans.get(key)
+        if pl is None:
+            pl = self._plans[key] = build_plan(self.opt, self.C, self.K, n, h, w, training, want_grad, self.L, gamma_ok=key[-1])
+        return pl
+
+    def _needs_gamma_check(self):
+        return self.opt.bn_on_load and self.opt.compute_dtype == "fp32" and self.opt.conv_route == "fused" and self.opt.wgrad_route == "fused"
 
     def _timed(self, key, flops, fn, *args):
         """Call fn(*args); when profiling is on, bracket it with HIP events on the launch stream."""
@@ -214,37 +189,6 @@ class Engine:
             vals[name + "/moving_var"] = np.ones(cout, np.float32)
         self.load_parameters(vals)
 
-    def _use_fused(self, name, h, w, dgrad=False):
-        """fully fused Winograd kernel: H, W even, reduce channels % 8 == 0, output channels % 64 == 0"""
-        cin, cout = self.cin[name], self.cout[name]
-        k, nn = (cout, cin) if dgrad else (cin, cout)
-        return (self.conv_route == "fused" and self.kind[name] == "conv3" and h % 2 == 0 and w % 2 == 0
-                and k % 8 == 0 and nn % 64 == 0)
-
-    def _ybuf(self, name, shape, consumer):
-        """BatchNorm-output buffer of `name`, read only by the 3x3 layer `consumer`: bf16 when that layer contracts in bf16."""
-        n, h, w, _ = shape
-        if self.compute_dtype == "bf16" and self.bf16_storage:
-            ci, co = self.cin[consumer], self.cout[consumer]
-            if self.kind[consumer] == "deconv":
-                ok = self._use_bf16_convt(consumer, n, h, w) and self.L.unet_convT2x2_wgrad_bf16_supported(n, h, w, ci, co) == 1
-            else:
-                ok = self._use_bf16(consumer, n, h, w) and self.L.unet_conv3x3_wgrad_bf16_supported(n, h, w, ci, co) == 1
-            if ok:
-                return self._buf("y16_" + name, shape, torch.bfloat16)
-        return self._buf("y_" + name, shape)
-
-    def _use_bf16(self, name, n, h, w, dgrad=False):
-        if self.compute_dtype != "bf16" or self.kind[name] != "conv3":
-            return False
-        cin, cout = self.cin[name], self.cout[name]
-        k, nn = (cout, cin) if dgrad else (cin, cout)
-        # the bf16 kernels address their tensors with 32-bit buffer offsets: every operand (leading dimension <= max(Cin, Cout):
-        # a concat input IS the layer's Cin) must stay below 2 GiB, larger problems fall back to the fp32 kernels
-        if n * h * w * max(cin, cout) * 4 >= 2 ** 31:
-            return False
-        return self.L.unet_conv3x3_bf16_supported(n, h, w, k, nn) == 1
-
     def _bf16_kernels(self, name):
         """(forward operand, data-gradient operand): the layer's fp32 master kernel packed to bf16, refreshed after every
         parameter change."""
@@ -268,11 +212,6 @@ class Engine:
             self.L.unet_bf16_pack_weights_batch(_p(self._bf16_jobs), self._bf16_jobs.shape[0], self._bf16_blocks, self._stream())
             self._bf16_dirty = False
         return self._bf16_W[name]
-
-    def _use_bf16_convt(self, name, n, h, w):
-        return (self.compute_dtype == "bf16" and self.kind[name] == "deconv"
-                and n * h * w * 4 * self.cout[name] * 4 < 2 ** 31 and n * h * w * self.cin[name] * 4 < 2 ** 31
-                and self.L.unet_convT2x2_bf16_supported(n, h, w, self.cin[name], self.cout[name]) == 1)
 
     def _fused_kernels(self, name):
         """(Uc forward, Uc dgrad) in the chunked layout of the fused kernel.  The buffers are persistent; after a parameter
@@ -352,13 +291,6 @@ class Engine:
             self._gamma_zero = any(bool((self.p[n + "/gamma"] == 0).any().item()) for n, _, _, _ in self.layers)
         return not self._gamma_zero
 
-    def _can_defer(self, name, consumer, n, h, w):
-        """`name`'s BatchNorm output feeds only the 3x3 layer `consumer` (spatial size h x w), which runs the fp32 fused Winograd
-        forward and weight-gradient kernels: the output need not be materialised (BatchNorm-apply on load)."""
-        return (self.bn_on_load and self.compute_dtype == "fp32" and self.wgrad_route == "fused" and self._use_fused(consumer, h, w)
-                and self.L.unet_winograd_wgrad_fused_supported(n, h, w, self.cin[consumer], self.cout[consumer]) == 1
-                and self._gamma_nonzero())
-
     def _fold_buffers(self, name):
         cin, cout = self.cin[name], self.cout[name]
         return (self._buf("Ufold_" + name, (16 * cin * cout,)), self._buf("bfold_" + name, (cout,)), self._buf("pad_" + name, (cin + 8,)))
@@ -368,90 +300,84 @@ class Engine:
         materialised (its consumer applies it on load) and the conv output r is returned instead.
         in_view = (scale, shift) per input channel: x is a producer's conv output (BatchNorm-apply on load, fused Winograd route);
         r_out: where the conv output goes (default: the layer's own buffer); stat_out = (scale, shift) destinations of the BatchNorm
-        coefficients (default: self.stat[name][2:4])."""
+        coefficients (default: self.stat[name][2:4]).  Kernel family and storage precisions: self.pl.layer[name]."""
         L, st = self.L, self._stream()
-        kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
+        lp = self.pl.layer[name]
+        kind, cin, cout = lp.kind, lp.cin, lp.cout
         n, h, w, _ = x.shape
+        assert (h, w) == (lp.hi, lp.wi) and (in_view is not None) == lp.x_on_load and (y_out is None) == lp.defer_y, name
         w_, b_ = self.p[name + "/kernel"], self.p[name + "/bias"]
         fused_stats = None
-        assert in_view is None or (kind == "conv3" and self._use_fused(name, h, w) and not self._use_bf16(name, n, h, w))
-        if kind == "deconv":
-            r = r_out if r_out is not None else self._buf("r_" + name, (n, 2 * h, 2 * w, cout))
-            if self._use_bf16_convt(name, n, h, w):
-                rows = L.unet_convT2x2_bf16_stats_rows(n, h, w, cin, cout, 0) if (training and self.fuse_bn_stats) else 0
-                stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
-                if self.bf16_activations and self.bf16_convt_activations and self.bf16_storage and rows > 0 and r_out is None and self._dz16_shape(name, n, h, w):
-                    r = self._buf("r16_" + name, (n, 2 * h, 2 * w, cout), torch.bfloat16)
-                L.unet_convT2x2_fwd_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
-                                         int(r.dtype == torch.bfloat16), n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
-                if rows > 0:
-                    fused_stats = (stat_part, rows)
-            elif L.unet_convT2x2_fwd_stream_supported(n, h, w, cin, cout) == 1 and _ld(x) <= 4096:           # persistent stream kernel
-                rows = L.unet_convT2x2_fwd_stream_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
-                if rows > 0:
-                    stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
-                    L.unet_convT2x2_fwd_stream_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
-                                                     _p(stat_part), stat_part.numel() * 4, st)
-                    fused_stats = (stat_part, rows)
-                else:
-                    L.unet_convT2x2_fwd_stream(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
-            else:
-                L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
-        elif kind == "conv1":
-            r = self._buf("r_" + name, (n, h, w, cout))
-            L.unet_conv1x1_fwd(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
+        r16 = lp.r == BF16
+        assert not (r16 and r_out is not None)
+        if r_out is not None:
+            r = r_out
         else:
-            r = r_out if r_out is not None else self._buf("r_" + name, (n, h, w, cout))
-            if self._use_bf16(name, n, h, w):
-                rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
-                stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
-                if (self.bf16_activations and self.bf16_storage and rows > 0 and r_out is None
-                        and L.unet_conv3x3_wgrad_bf16_supported(n, h, w, cin, cout) == 1 and self._use_bf16(name, n, h, w, dgrad=True)):      # = _dz16(name): the BatchNorm backward that reads r takes bf16
-                    r = self._buf("r16_" + name, (n, h, w, cout), torch.bfloat16)
-                self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
-                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), None, None, _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
-                            int(r.dtype == torch.bfloat16), n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
-                if rows > 0:
-                    fused_stats = (stat_part, rows)
-            elif self._use_fused(name, h, w):
-                rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
-                stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
-                if in_view is not None:
-                    # BatchNorm-apply on load: scaled weight transform, folded bias, per-channel padding value (this step's coefficients)
-                    uc, bias_eff, pad = self._fold_buffers(name)
-                    if training or name not in self._eval_folded:
-                        # (inference: the coefficients come from the moving statistics -- constants until the parameters change -- so
-                        # the fold of one forward serves every later tile)
-                        nbf = L.unet_winograd_weight_fold_workspace(cin, cout)
-                        L.unet_winograd_weight_fold(_p(w_), _p(b_), _p(in_view[0]), _p(in_view[1]), _p(uc), _p(bias_eff), _p(pad), cin, cout,
-                                                    _p(self._workspace(nbf)), nbf, st)
-                        if training:
-                            self._eval_folded.discard(name)
-                        else:
-                            self._eval_folded.add(name)
-                else:
-                    uc, bias_eff, pad = self._fused_kernels(name)[0], b_, None
-                # (with stat_part the conv kernel also leaves the BatchNorm sums of its output: one activation read less per layer)
-                self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused,
-                            _p(x), _ld(x), _p(pad), _p(uc), _p(bias_eff), _p(r), _ld(r), n, h, w, cin, cout, 1,
-                            _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
-                if rows > 0:
-                    fused_stats = (stat_part, rows)
-            elif L.unet_conv3x3_mfma_supported(cin, cout):
-                self._timed("conv3x3_fwd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
-                            _p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, 1, st)
+            r = self._buf(("r16_" if r16 else "r_") + name, (n, lp.ho, lp.wo, cout), torch.bfloat16 if r16 else torch.float32)
+        part = lambda rows: self._buf("bnpart_" + name, ((cout // 64) * rows * 128,)) if rows > 0 else None
+        if lp.fwd == "convt_bf16":
+            rows = L.unet_convT2x2_bf16_stats_rows(n, h, w, cin, cout, 0) if lp.fwd_stats else 0
+            stat_part = part(rows)
+            L.unet_convT2x2_fwd_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
+                                     int(r16), n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+            fused_stats = (stat_part, rows) if rows > 0 else None
+        elif lp.fwd == "convt_stream" and _ld(x) <= 4096:                       # persistent stream kernel
+            rows = L.unet_convT2x2_fwd_stream_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
+            if rows > 0:
+                stat_part = part(rows)
+                L.unet_convT2x2_fwd_stream_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
+                                                 _p(stat_part), stat_part.numel() * 4, st)
+                fused_stats = (stat_part, rows)
             else:
-                rows = L.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, cout) if (training and self.fuse_bn_stats) else 0
-                if rows > 0:
-                    stat_part = self._buf("bnpart_" + name, ((cout // 64) * rows * 128,))
-                    if (self.compute_dtype == "bf16" and self.bf16_storage and self.bf16_activations and self.bf16_edge_activations
-                            and r_out is None and cout % 8 == 0):
-                        r = self._buf("r16_" + name, (n, h, w, cout), torch.bfloat16)
-                    L.unet_conv3x3_fwd_direct_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), int(r.dtype == torch.bfloat16), n, h, w, cin, cout, 1,
-                                                    _p(stat_part), stat_part.numel() * 4, st)
-                    fused_stats = (stat_part, rows)
-                else:
-                    L.unet_conv3x3_fwd_direct(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, 1, st)
+                L.unet_convT2x2_fwd_stream(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
+        elif kind == "deconv":
+            L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
+        elif kind == "conv1":
+            L.unet_conv1x1_fwd(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
+        elif lp.fwd == "bf16":
+            rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
+            stat_part = part(rows)
+            self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
+                        _p(x), _ld(x), int(x.dtype == torch.bfloat16), None, None, _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
+                        int(r16), n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+            fused_stats = (stat_part, rows) if rows > 0 else None
+        elif lp.fwd == "winograd":
+            rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
+            stat_part = part(rows)
+            if in_view is not None:
+                # BatchNorm-apply on load: scaled weight transform, folded bias, per-channel padding value (this step's coefficients)
+                uc, bias_eff, pad = self._fold_buffers(name)
+                if training or name not in self._eval_folded:
+                    # (inference: the coefficients come from the moving statistics -- constants until the parameters change -- so
+                    # the fold of one forward serves every later tile)
+                    nbf = L.unet_winograd_weight_fold_workspace(cin, cout)
+                    L.unet_winograd_weight_fold(_p(w_), _p(b_), _p(in_view[0]), _p(in_view[1]), _p(uc), _p(bias_eff), _p(pad), cin, cout,
+                                                _p(self._workspace(nbf)), nbf, st)
+                    if training:
+                        self._eval_folded.discard(name)
+                    else:
+                        self._eval_folded.add(name)
+            else:
+                uc, bias_eff, pad = self._fused_kernels(name)[0], b_, None
+            # (with stat_part the conv kernel also leaves the BatchNorm sums of its output: one activation read less per layer)
+            self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused,
+                        _p(x), _ld(x), _p(pad), _p(uc), _p(bias_eff), _p(r), _ld(r), n, h, w, cin, cout, 1,
+                        _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+            fused_stats = (stat_part, rows) if rows > 0 else None
+        elif lp.fwd == "mfma":
+            self._timed("conv3x3_fwd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
+                        _p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, 1, st)
+        else:
+            rows = L.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
+            if rows > 0:
+                stat_part = part(rows)
+                L.unet_conv3x3_fwd_direct_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), int(r16), n, h, w, cin, cout, 1,
+                                                _p(stat_part), stat_part.numel() * 4, st)
+                fused_stats = (stat_part, rows)
+            else:
+                assert not r16
+                L.unet_conv3x3_fwd_direct(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, 1, st)
+        assert fused_stats is not None or not r16, name            # a bf16-stored r has its sums taken before the rounding
         P = r.shape[0] * r.shape[1] * r.shape[2]
         s = self.stat[name]
         sc_out, sh_out = stat_out if stat_out is not None else (s[2], s[3])
@@ -525,37 +451,41 @@ class Engine:
         self.view = {}
         self.coef = {}
         self.masks = self._prep_masks(dropout_masks) if training else None
+        pl = self.pl = self.plan(n, h, w, training, want_grad)
+        if training:
+            self._eval_folded.clear()           # the moving statistics move: no eval-mode fold survives a training forward
         B = BASE
         f = self._block_fwd
+        tdt = lambda d: torch.bfloat16 if d == BF16 else torch.float32
         cur, cur_view = x0, None
         self.idx = {}
         self.cat = {}
         self.catstat = {}
 
+        def ybuf(name, shape):
+            """buffer for the layer's materialised BatchNorm output, in the precision the plan stores it"""
+            d = pl.layer[name].y
+            return self._buf(("y16_" if d == BF16 else "y_") + name, shape, tdt(d))
+
         def pair(a_name, b_name, xin, xin_view, hh, ww, ch, b_out, **kw):
             """the two convs of a block: a -> b.  a's BatchNorm output feeds only b, so with BatchNorm-apply on load it is never
             materialised: b reads a's conv output through (scale, shift)."""
-            if self._can_defer(a_name, b_name, n, hh, ww):
+            if pl.layer[a_name].defer_y:
                 ra = f(a_name, xin, None, training, in_view=xin_view)
                 sa = self.stat[a_name]
                 return f(b_name, ra, b_out, training, in_view=(sa[2], sa[3]), **kw)
-            ya = f(a_name, xin, self._ybuf(a_name, (n, hh, ww, ch), b_name), training, in_view=xin_view)
+            ya = f(a_name, xin, ybuf(a_name, (n, hh, ww, ch)), training, in_view=xin_view)
             return f(b_name, ya, b_out, training, **kw)
 
         for lvl, ch in ((1, B), (2, 2 * B), (3, 4 * B), (4, 8 * B)):
             hh, ww = cur.shape[1], cur.shape[2]
-            # the concat buffer [skip, upsampled] and the pooled tensor feed 3x3 layers only (dec_Na / the next level's first conv):
-            # bf16 storage applies to them as well (levels 1-3; level 4 goes through the dropout and the unfused pool kernels)
-            nxt = "conv_%da" % (lvl + 1) if lvl < 4 else "bott_a"
-            c16 = (self.compute_dtype == "bf16" and self.bf16_storage and self.bf16_storage_cat and self.fuse_pool
-                   and (lvl < 4 or (self.bf16_activations and self.bf16_level4))     # level 4: its dropout / unfused pool kernels take bf16 too
-                   and self._use_bf16("dec_%da" % lvl, n, hh, ww) and self._use_bf16(nxt, n, hh // 2, ww // 2)
-                   and L.unet_conv3x3_wgrad_bf16_supported(n, hh, ww, 2 * ch, ch) == 1)
-            cat = self._buf(("cat16_%d" if c16 else "cat_%d") % lvl, (n, hh, ww, 2 * ch), torch.bfloat16 if c16 else torch.float32)
+            # the concat buffer [skip, upsampled] and the pooled tensor feed 3x3 layers only (dec_Na / the next level's first conv)
+            c16 = pl.cat[lvl] == BF16
+            cat = self._buf(("cat16_%d" if c16 else "cat_%d") % lvl, (n, hh, ww, 2 * ch), tdt(pl.cat[lvl]))
             self.cat[lvl] = cat
-            pooled = self._buf(("pool16_%d" if c16 else "pool_%d") % lvl, (n, hh // 2, ww // 2, ch), torch.bfloat16 if c16 else torch.float32)
+            pooled = self._buf(("pool16_%d" if c16 else "pool_%d") % lvl, (n, hh // 2, ww // 2, ch), tdt(pl.cat[lvl]))
             idx = self._buf("idx_%d" % lvl, (n, hh // 2, ww // 2, ch), torch.uint8)
-            fuse_pool = self.fuse_pool and not (lvl == 4 and training)   # level 4 drops out between BN and pool (UNet/model.py:105-107)
+            fuse_pool = pl.fuse_pool[lvl]
             skip = pair("conv_%da" % lvl, "conv_%db" % lvl, cur, cur_view, hh, ww, ch, cat[..., :ch], pool=(pooled, idx) if fuse_pool else None)
             if not fuse_pool:
                 if lvl == 4 and training:
@@ -565,15 +495,14 @@ class Engine:
             self.idx[lvl] = idx
             cur, cur_view = pooled, None
         hh, ww = cur.shape[1], cur.shape[2]
-        yb = self._ybuf("bott_b", (n, hh, ww, 16 * B), "up_4") if self.bf16_level4 else self._buf("y_bott_b", (n, hh, ww, 16 * B))
-        cur = pair("bott_a", "bott_b", cur, None, hh, ww, 16 * B, yb)
+        cur = pair("bott_a", "bott_b", cur, None, hh, ww, 16 * B, ybuf("bott_b", (n, hh, ww, 16 * B)))
         if training:
             self._dropout(cur, "drop_b", self.masks)
         for lvl, ch in ((4, 8 * B), (3, 4 * B), (2, 2 * B), (1, B)):
             cat = self.cat[lvl]
             hh, ww = cat.shape[1], cat.shape[2]
             cat_view = None
-            if self._can_defer("up_%d" % lvl, "dec_%da" % lvl, n, hh, ww):
+            if pl.layer["up_%d" % lvl].defer_y:
                 # the transposed conv writes its output r straight into the upper half of the concat buffer; dec_Na reads the whole
                 # buffer through per-channel coefficients: (1, 0) for the materialised skip half, up_N's BatchNorm for the upper half
                 cs = self.bufs.get("catstat_%d" % lvl)
@@ -585,15 +514,9 @@ class Engine:
                 cat_view = (cs[0], cs[1])
             else:
                 f("up_%d" % lvl, cur, cat[..., ch:], training)
-            if lvl > 1:
-                yb = self._ybuf("dec_%db" % lvl, (n, hh, ww, ch), "up_%d" % (lvl - 1))
-            elif training and want_grad and self.compute_dtype == "bf16" and self.bf16_storage and self.bf16_activations and self.bf16_edge_activations:
-                # the class-map conv computes in fp32: storing its input as bf16 changes the result, so only the training step does it
-                # (bf16 activation storage, Keras mixed_bfloat16 semantics); inference keeps the fp32 tensor
-                yb = self._buf("y16_dec_1b", (n, hh, ww, ch), torch.bfloat16)
-            else:
-                yb = self._buf("y_dec_1b", (n, hh, ww, ch))
-            cur = pair("dec_%da" % lvl, "dec_%db" % lvl, cat, cat_view, hh, ww, ch, yb)
+            # (dec_1b: the class-map conv computes in fp32, so storing its input as bf16 changes the result -- only the training step of
+            # the mixed-precision mode does it (Keras mixed_bfloat16 semantics); inference keeps the fp32 tensor: plan.py)
+            cur = pair("dec_%da" % lvl, "dec_%db" % lvl, cat, cat_view, hh, ww, ch, ybuf("dec_%db" % lvl, (n, hh, ww, ch)))
         yl = f("logits", cur, self._buf("y_logits", (n, h, w, self.K)), training)
         prob = self._buf("softmax", (n, h, w, self.K))
         P = n * h * w
@@ -613,18 +536,23 @@ class Engine:
         return prob
 
     # ------------------------------------------------------------------------------------------------ backward
-    def _block_bwd(self, name, dy, need_dx=True, eval_mode=False, pool_grad=None):
+    def _block_bwd(self, name, dy, eval_mode=False, pool_grad=None):
         """dy: NHWC view = gradient w.r.t. the layer's BN output.  Returns gradient w.r.t. the layer input (or None).
-        eval_mode: BN used its moving statistics (an affine map) and no parameter gradients are wanted."""
+        eval_mode: BN used its moving statistics (an affine map) and no parameter gradients are wanted.  Kernel families and the
+        storage of dz / dx: self.pl.layer[name] (the plan of the forward pass this backward belongs to)."""
         L, st = self.L, self._stream()
-        kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
+        lp = self.pl.layer[name]
+        kind, cin, cout = lp.kind, lp.cin, lp.cout
         x, r = self.saved[name]
         n, ho, wo, _ = r.shape
         P = n * ho * wo
         s = self.stat[name]
-        dz16 = self._dz16(name, need_dx, eval_mode)
+        dz16 = lp.dz == BF16
+        need_dx = lp.dx is not None
+        assert not (eval_mode and (dz16 or self.pl.training))
         dz = self._buf("dz16_" + name, tuple(r.shape), torch.bfloat16) if dz16 else self._buf("dz_" + name, tuple(r.shape))
         pre = self.bnbwd_part.pop(name, None) if not eval_mode else None
+        assert (pre is not None) == (lp.sums_from_dgrad and not eval_mode), name
         if dz16 or (not eval_mode and (dy.dtype == torch.bfloat16 or r.dtype == torch.bfloat16)):
             # one entry point for the three forms (plain / pooled / sums from the consumer's data gradient), any of dy / r / dz stored as bf16
             part_ptr, rows = None, 0
@@ -668,13 +596,15 @@ class Engine:
         w_, dw = self.p[name + "/kernel"], self.g[name + "/kernel"]
         hi, wi = x.shape[1], x.shape[2]
         dx = None
+        overlap = self.opt.overlap_wgrad
+        z16 = int(dz.dtype == torch.bfloat16)
 
         def wgrad():
-            sd = self.overlap_wgrad
+            sd = overlap
             st2 = self._stream()
-            if kind == "deconv" and self._use_bf16_convt(name, n, hi, wi) and L.unet_convT2x2_wgrad_bf16_supported(n, hi, wi, cin, cout) == 1:
+            if lp.wgrad == "convt_bf16":
                 nb2 = L.unet_convT2x2_wgrad_bf16_workspace(n, hi, wi, cin, cout)
-                L.unet_convT2x2_wgrad_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw),
+                L.unet_convT2x2_wgrad_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
                                               n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "deconv":
                 nb2 = L.unet_convT2x2_wgrad_workspace(n, hi, wi, cin, cout)
@@ -682,166 +612,80 @@ class Engine:
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
                 L.unet_conv1x1_wgrad(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
-            elif (self.compute_dtype == "bf16" and n * ho * wo * max(cin, cout) * 4 < 2 ** 31
-                  and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1):
+            elif lp.wgrad == "bf16":
                 nb2 = L.unet_conv3x3_wgrad_bf16_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16,
-                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw),
+                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
                             n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
-            elif self.wgrad_route == "fused" and L.unet_winograd_wgrad_fused_supported(n, ho, wo, cin, cout) == 1:
-                nb2 = L.unet_conv3x3_wgrad_winograd_fused_workspace(n, ho, wo, cin, cout)
+            elif lp.wgrad == "winograd":
+                cap = int(self.opt.wgrad_workgroups)
+                nb2 = L.unet_conv3x3_wgrad_winograd_fused_workspace(n, ho, wo, cin, cout, cap)
                 self._timed("conv3x3_wgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_winograd_fused,
-                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
                 vw = self.view.get(name)
                 if vw is not None:
                     # x was read through BatchNorm-apply on load: dw (computed on the producer's raw conv output) -> scale . dw + shift (x) S
                     nb3 = L.unet_conv3x3_wgrad_fold_fix_workspace(cout)
                     L.unet_conv3x3_wgrad_fold_fix(_p(dw), _p(vw[0]), _p(vw[1]), _p(dz), cout, _p(self.g[name + "/bias"]), n, ho, wo, cin, cout,
                                                   _p(self._workspace(nb3, sd)), nb3, st2)
-            elif L.unet_conv3x3_mfma_supported(cin, cout) and cin % 64 == 0:
+            elif lp.wgrad == "mfma":
                 nb2 = L.unet_conv3x3_wgrad_mfma_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_mfma,
                             _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             else:
                 nb2 = L.unet_conv3x3_wgrad_direct_workspace(n, ho, wo, cin, cout)
-                L.unet_conv3x3_wgrad_direct(_p(x), _ld(x), _p(dz), cout, int(dz.dtype == torch.bfloat16), _p(dw), n, ho, wo, cin, cout,
+                L.unet_conv3x3_wgrad_direct(_p(x), _ld(x), _p(dz), cout, z16, _p(dw), n, ho, wo, cin, cout,
                                             _p(self._workspace(nb2, sd)), nb2, st2)
             if self.on_layer_grads_ready is not None:
                 self.on_layer_grads_ready(name)          # under the stream the gradients were produced on
 
-        if self.overlap_wgrad and not eval_mode:
+        if overlap and not eval_mode:
             self.side.wait_stream(torch.cuda.current_stream())       # dz (and this layer's bias/gamma/beta grads) ready
             with torch.cuda.stream(self.side):
                 wgrad()
         if need_dx:
-            if self._dx16(name, eval_mode):
-                dx = self._buf("dy16_in_" + name, (n, hi, wi, cin), torch.bfloat16)
-            else:
-                dx = self._buf("dy_in_" + name, (n, hi, wi, cin))
-            if kind == "deconv" and self._use_bf16_convt(name, n, hi, wi):
-                prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
-                rows = L.unet_convT2x2_bf16_stats_rows(n, hi, wi, cin, cout, 1) if prod else 0
-                r_prev = self.saved[prod[0]][1] if rows > 0 else None
-                part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,)) if rows > 0 else None
-                L.unet_convT2x2_dgrad_bf16(_p(dz), cout, int(dz.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[1]), _p(dx), cin,
-                                           int(dx.dtype == torch.bfloat16), n, hi, wi, cin, cout, _p(r_prev), _ld(r_prev) if rows > 0 else 0,
-                                           int(rows > 0 and r_prev.dtype == torch.bfloat16), _p(part), part.numel() * 4 if rows > 0 else 0, st)
-                if rows > 0:
-                    self.bnbwd_part[prod[0]] = (part, rows, 0)
+            dx16 = lp.dx == BF16
+            dx = self._buf(("dy16_in_" if dx16 else "dy_in_") + name, (n, hi, wi, cin), torch.bfloat16 if dx16 else torch.float32)
+            # a data gradient whose output (or a channel range of it) is exactly the dy of the producer layer's BatchNorm also leaves
+            # that layer's backward sums (sum dy, sum dy * r): no reduction pass there
+            prod = lp.leaves_sums_for if not eval_mode else None
+            r_prev = part = None
+            rows, c0, c1 = 0, 0, 0
+            if prod is not None:
+                pname, c0, c1 = prod
+                r_prev = self.saved[pname][1]
+                rows = (L.unet_convT2x2_bf16_stats_rows(n, hi, wi, cin, cout, 1) if lp.dgrad == "convt_bf16"
+                        else L.unet_conv3x3_bf16_stats_rows(n, ho, wo, cout, cin) if lp.dgrad == "bf16"
+                        else L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, ho, wo, cout, cin))
+                assert rows > 0
+                part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
+                self.bnbwd_part[pname] = (part, rows, c0)
+            nbp = part.numel() * 4 if part is not None else 0
+            ldr_prev = _ld(r_prev) if r_prev is not None else 0
+            r16_prev = int(r_prev is not None and r_prev.dtype == torch.bfloat16)
+            fl = 2.0 * 9 * n * ho * wo * cin * cout
+            if lp.dgrad == "convt_bf16":
+                L.unet_convT2x2_dgrad_bf16(_p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx16), n, hi, wi, cin, cout,
+                                           _p(r_prev), ldr_prev, r16_prev, _p(part), nbp, st)
             elif kind == "deconv":
                 L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
-                L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, int(dx.dtype == torch.bfloat16), P, cin, cout, st)
-            elif self._use_bf16(name, n, ho, wo, dgrad=True):
-                prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
-                rows = L.unet_conv3x3_bf16_stats_rows(n, ho, wo, cout, cin) if prod else 0
-                z16 = int(dz.dtype == torch.bfloat16)
-                if rows > 0:
-                    pname, c0, c1 = prod[0], prod[1] * (cin // prod[3]), prod[2] * (cin // prod[3])
-                    r_prev = self.saved[pname][1]
-                    part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
-                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
-                                _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx.dtype == torch.bfloat16), n, ho, wo, cin, cout,
-                                _p(r_prev), _ld(r_prev), int(r_prev.dtype == torch.bfloat16), c0, c1, _p(part), part.numel() * 4, st)
-                    self.bnbwd_part[pname] = (part, rows, c0)
-                else:
-                    self._timed("conv3x3_dgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_bf16,
-                                _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx.dtype == torch.bfloat16), n, ho, wo, cin, cout,
-                                None, 0, 0, 0, 0, None, 0, st)
-            elif self._use_fused(name, ho, wo, dgrad=True):
-                prod = PRODUCER.get(name) if (self.fuse_bn_stats and not eval_mode) else None
-                if prod is not None and self.saved[prod[0]][1].dtype != torch.float32:
-                    prod = None          # (a size-fallback fp32 layer behind a bf16-storing producer: the producer's BatchNorm backward runs its own reduction)
-                rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, ho, wo, cout, cin) if prod else 0
-                if rows > 0:
-                    # dx (or a channel range of it) is the dy of the producer layer's BatchNorm: leave its backward sums too
-                    pname, c0, c1 = prod[0], prod[1] * (cin // prod[3]), prod[2] * (cin // prod[3])
-                    r_prev = self.saved[pname][1]
-                    part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
-                    self._timed("conv3x3_dgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd_fused,
-                                _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
-                                _p(r_prev), _ld(r_prev), c0, c1, _p(part), part.numel() * 4, st)
-                    self.bnbwd_part[pname] = (part, rows, c0)
-                else:
-                    self._timed("conv3x3_dgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_winograd_fused,
-                                _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
-                                None, 0, 0, 0, None, 0, st)
-            elif L.unet_conv3x3_mfma_supported(cout, cin):
-                self._timed("conv3x3_dgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_dgrad_mfma,
-                            _p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
+                L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, int(dx16), P, cin, cout, st)
+            elif lp.dgrad == "bf16":
+                self._timed("conv3x3_dgrad_bf16", fl, L.unet_conv3x3_dgrad_bf16,
+                            _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx16), n, ho, wo, cin, cout,
+                            _p(r_prev), ldr_prev, r16_prev, c0, c1, _p(part), nbp, st)
+            elif lp.dgrad == "winograd":
+                self._timed("conv3x3_dgrad_winograd_fused", fl, L.unet_conv3x3_dgrad_winograd_fused,
+                            _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
+                            _p(r_prev), ldr_prev, c0, c1, _p(part), nbp, st)
+            elif lp.dgrad == "mfma":
+                self._timed("conv3x3_dgrad", fl, L.unet_conv3x3_dgrad_mfma, _p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
             else:                                   # first layer (Cin = number_channels): only the ERF probe needs it
                 L.unet_conv3x3_dgrad_direct(_p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
-        if not self.overlap_wgrad and not eval_mode:
+        if not overlap and not eval_mode:
             wgrad()
         return dx
-
-    def _dz16(self, name, need_dx=True, eval_mode=False):
-        """the layer's BatchNorm backward takes the unified bf16-capable entry point (dz stored as bf16; dy / r may be bf16)"""
-        if self.compute_dtype != "bf16" or not self.bf16_storage or eval_mode or name not in self.saved:
-            return False
-        L = self.L
-        kind, cin, cout = self.kind[name], self.cin[name], self.cout[name]
-        x, r = self.saved[name]
-        n, ho, wo, _ = r.shape
-        if kind == "conv3":
-            if (not need_dx and self.bf16_activations and self.bf16_edge_activations and cin % 64 != 0 and cout % 8 == 0
-                    and r.dtype == torch.bfloat16):
-                return True              # the first layer: its weight gradient (the fp32 stencil kernel) reads dz in either storage
-            return (n * ho * wo * max(cin, cout) * 4 < 2 ** 31 and L.unet_conv3x3_wgrad_bf16_supported(n, ho, wo, cin, cout) == 1
-                    and (not need_dx or self._use_bf16(name, n, ho, wo, dgrad=True)))
-        if kind == "deconv":
-            return (self._use_bf16_convt(name, n, x.shape[1], x.shape[2])
-                    and L.unet_convT2x2_wgrad_bf16_supported(n, x.shape[1], x.shape[2], cin, cout) == 1)
-        return False
-
-    def _dz16_shape(self, name, n, h, w):
-        """(transposed conv, input size h x w) its BatchNorm backward will take the bf16-capable entry point"""
-        return (self.compute_dtype == "bf16" and self.bf16_storage and self._use_bf16_convt(name, n, h, w)
-                and self.L.unet_convT2x2_wgrad_bf16_supported(n, h, w, self.cin[name], self.cout[name]) == 1)
-
-    def _dx16(self, name, eval_mode):
-        """the 3x3 layer's data gradient may be WRITTEN as bf16: every reader of it is a BatchNorm backward that takes bf16 dy"""
-        if self.compute_dtype != "bf16" or not (self.bf16_storage and self.bf16_activations) or eval_mode:
-            return False
-        if self.kind[name] == "conv1":                                  # class map: its input gradient is dec_1b's dy
-            return self.bf16_edge_activations and self.cin[name] % 8 == 0 and self._dz16("dec_1b", True, eval_mode)
-        if self.kind[name] == "deconv":
-            # dx is the dy of the producer (dec_(N+1)b): bf16 when that layer's BatchNorm backward takes bf16 dy and this kernel leaves its sums
-            n, hi, wi, _ = self.saved[name][0].shape
-            prod = PRODUCER.get(name) if self.fuse_bn_stats else None
-            return (prod is not None and self.bf16_convt_activations and self._use_bf16_convt(name, n, hi, wi)
-                    and self.L.unet_convT2x2_bf16_stats_rows(n, hi, wi, self.cin[name], self.cout[name], 1) > 0
-                    and self._dz16(prod[0], True, eval_mode))
-        if self.kind[name] != "conv3":
-            return False
-        n, ho, wo, _ = self.saved[name][1].shape
-        if not self._use_bf16(name, n, ho, wo, dgrad=True):            # the fp32 kernels (size fallback) write fp32
-            return False
-        # a reader takes bf16 dy when its BatchNorm backward goes through the unified entry point: its dz is bf16, or (the first layer, whose
-        # weight gradient is the fp32 stencil kernel) its saved conv output is
-        need1 = lambda nm: self._dz16(nm, nm != "conv_1a", eval_mode) or (nm in self.saved and self.saved[nm][1].dtype == torch.bfloat16)
-        if name.startswith("dec_") and name.endswith("a"):             # [skip, upsampled]: conv_Nb (through the fused pool path) and up_N
-            lvl = int(name[4])
-            if lvl == 4:     # skip half -> pool-backward accumulate + dropout kernels (either storage), then conv_4b's BatchNorm backward
-                return self._lvl4_grad16() and need1("up_4")
-            return self.fuse_pool and need1("conv_%db" % lvl) and need1("up_%d" % lvl)
-        if name.startswith("conv_") and name.endswith("a"):            # pooled gradient of the level above, formed inside its BatchNorm backward
-            lvl = int(name[5])
-            return lvl >= 2 and self.fuse_pool and need1("conv_%db" % (lvl - 1))
-        if name == "bott_a":                                           # read by the separate pool-backward kernel, added into dec_4a's skip gradient
-            return self._lvl4_grad16()
-        prod = PRODUCER.get(name)
-        return prod is not None and prod[3] == 1 and need1(prod[0])
-
-    def _lvl4_grad16(self):
-        """dec_4a's and bott_a's data gradients are both bf16 or both fp32: the pool-backward kernel adds one into the other"""
-        if not (self.bf16_level4 and "dec_4a" in self.saved and "bott_a" in self.saved):
-            return False
-        ok = True
-        for nm in ("dec_4a", "bott_a"):
-            n, ho, wo, _ = self.saved[nm][1].shape
-            ok = ok and self._use_bf16(nm, n, ho, wo, dgrad=True)
-        return ok and self.saved["dec_4a"][0].dtype == torch.bfloat16        # the forward took the bf16 level-4 tensors
 
     def input_gradient_eval(self, dprob):
         """After forward(training=False): gradient of sum(dprob * softmax) w.r.t. the input image, fp32 [N,C,H,W].
@@ -859,7 +703,8 @@ class Engine:
         """Gradients of the loss computed by the last forward(training=True, labels=..., want_grad=True) -> self.grad.
         eval_mode=True instead propagates `dy_logits` through the eval-mode graph down to the input image."""
         L, st = self.L, self._stream()
-        b = lambda name, dy, need_dx=True: self._block_bwd(name, dy, need_dx=need_dx, eval_mode=eval_mode)
+        b = lambda name, dy: self._block_bwd(name, dy, eval_mode=eval_mode)
+        assert self.pl is not None and self.pl.training == (not eval_mode), "backward() follows the forward pass of the same mode"
         B = BASE
         d = b("logits", self.bufs["dy_logits"])
         for lvl, ch in ((1, B), (2, 2 * B), (3, 4 * B), (4, 8 * B)):
@@ -875,7 +720,7 @@ class Engine:
             dcat = self.bufs["dcat_%d" % lvl]
             ds = dcat[..., :ch]
             n, hh, ww, _ = ds.shape
-            if self.fuse_pool and not eval_mode and lvl != 4 and ch % 4 == 0:
+            if self.opt.fuse_pool and not eval_mode and lvl != 4 and ch % 4 == 0:
                 d = self._block_bwd("conv_%db" % lvl, ds, pool_grad=(d, self.idx[lvl]))       # no separate pool-backward pass
             else:
                 assert d.dtype == ds.dtype, (lvl, d.dtype, ds.dtype)
@@ -883,8 +728,8 @@ class Engine:
                 if lvl == 4 and not eval_mode:
                     self._dropout(ds, "drop_4", self.masks)
                 d = b("conv_%db" % lvl, ds)
-            d = b("conv_%da" % lvl, d, need_dx=(lvl != 1 or eval_mode))
-        if self.overlap_wgrad and not eval_mode:
+            d = b("conv_%da" % lvl, d)          # (training: the first layer's data gradient is not computed -- plan.py)
+        if self.opt.overlap_wgrad and not eval_mode:
             torch.cuda.current_stream().wait_stream(self.side)        # every weight gradient done before Adam
         return d
 

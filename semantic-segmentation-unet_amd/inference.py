@@ -5,8 +5,9 @@ Flags are the reference's (UNet/inference.py:234-241).  Behaviour kept: image ->
 (:201-206); reflect-pad bottom/right to a multiple of 16 (:30-47,143-157); images larger than 1024 px go through the
 tiled path: zones of responsibility of 1024 - 2*radius with a halo of `radius` clamped at the borders, eval forward per
 tile, halo stripped, pasted (:54-129); mask = argmax over classes, first maximum wins (:107,166), cast to
-uint8/uint16/int32 by its maximum (:215-220).  The argmax runs on the device (`unet_argmax`).  I/O: .npy always;
-.tif/.png when Pillow is importable (the reference uses scikit-image, absent here).
+uint8/uint16/int32 by its maximum (:215-220), written as the reference's imsave call asks (:221-227): a deflate-compressed BigTIFF
+in 1024 x 1024 tiles (tifffile when importable, else the writer below).  The argmax runs on the device (`unet_argmax`).  Reading:
+.npy, or anything Pillow opens (the reference uses scikit-image, absent here).
 """
 import argparse
 import os
@@ -76,12 +77,80 @@ def _read(path):
     return np.array(Image.open(path))
 
 
-def _write(path, mask):
+def _write_bigtiff_tiled(path, mask, tile=1024, level=6):
+    """The file `skimage.io.imsave(path, mask, compress=6, bigtiff=True, tile=(1024, 1024))` asks tifffile for (reference
+    UNet/inference.py:221-222): a little-endian BigTIFF, one image, 1024 x 1024 tiles (edge tiles zero-padded to full size), every tile
+    zlib-deflated at level 6 (Compression = 8, Adobe deflate), one sample per pixel, MinIsBlack."""
+    import struct
+    import zlib
+    assert mask.ndim == 2 and mask.dtype in (np.uint8, np.uint16, np.int32)
+    h, w = mask.shape
+    ty, tx = (h + tile - 1) // tile, (w + tile - 1) // tile
+    tiles = []
+    for j in range(ty):
+        for i in range(tx):
+            t = np.zeros((tile, tile), mask.dtype)
+            blk = mask[j * tile:(j + 1) * tile, i * tile:(i + 1) * tile]
+            t[:blk.shape[0], :blk.shape[1]] = blk
+            tiles.append(zlib.compress(t.astype(mask.dtype.newbyteorder("<")).tobytes(), level))
+    n = len(tiles)
+    # (tag, type, count, value): types 3 = SHORT, 4 = LONG, 16 = LONG8; tags in ascending order
+    fmt = 2 if mask.dtype == np.int32 else 1
+    entries = [(256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, mask.dtype.itemsize * 8), (259, 3, 1, 8), (262, 3, 1, 1), (277, 3, 1, 1),
+               (284, 3, 1, 1), (322, 4, 1, tile), (323, 4, 1, tile), (324, 16, n, None), (325, 16, n, None), (339, 3, 1, fmt)]
+    ifd_off = 16
+    ifd_len = 8 + 20 * len(entries) + 8
+    arrays_off = ifd_off + ifd_len                    # tile offsets, then byte counts (only out of line when n > 1)
+    data_off = arrays_off + (16 * n if n > 1 else 0)
+    offs, cur = [], data_off
+    for t in tiles:
+        offs.append(cur)
+        cur += len(t) + (len(t) & 1)                  # word-aligned tiles
+    with open(path, "wb") as f:
+        f.write(struct.pack("<2sHHHQ", b"II", 43, 8, 0, ifd_off))
+        f.write(struct.pack("<Q", len(entries)))
+        for tag, typ, cnt, val in entries:
+            if tag == 324:
+                val = offs[0] if n == 1 else arrays_off
+            elif tag == 325:
+                val = len(tiles[0]) if n == 1 else arrays_off + 8 * n
+            f.write(struct.pack("<HHQQ", tag, typ, cnt, val))
+        f.write(struct.pack("<Q", 0))
+        if n > 1:
+            f.write(struct.pack("<%dQ" % n, *offs))
+            f.write(struct.pack("<%dQ" % n, *[len(t) for t in tiles]))
+        for t in tiles:
+            f.write(t)
+            if len(t) & 1:
+                f.write(b"\0")
+
+
+def _write(path, mask, image_format="tif"):
     if path.endswith(".npy"):
         np.save(path, mask)
         return
-    from PIL import Image
-    Image.fromarray(mask).save(path)
+    if "tif" in image_format:                         # UNet/inference.py:221-222
+        try:
+            import tifffile                           # what scikit-image's imsave delegates to
+            tifffile.imwrite(path, mask, bigtiff=True, tile=(TILE_SIZE, TILE_SIZE), compression="zlib", compressionargs={"level": 6})
+        except ImportError:
+            _write_bigtiff_tiled(path, mask, TILE_SIZE, 6)
+        return
+    from PIL import Image                             # UNet/inference.py:224-227 (compress where the format has it)
+    try:
+        Image.fromarray(mask).save(path, compress_level=6)
+    except TypeError:
+        Image.fromarray(mask).save(path)
+
+
+def mask_dtype(max_label):
+    """uint8 / uint16 / int32 by the largest label, the reference's rule (UNet/inference.py:215-220): 0..255 -> uint8,
+    256..65535 -> uint16, anything else stays the arg-max's int32"""
+    if 0 <= max_label <= 255:
+        return np.uint8
+    if 255 < max_label < 65536:
+        return np.uint16
+    return np.int32
 
 
 def inference(checkpoint_filepath, image_folder, output_folder, number_classes, number_channels, image_format, compute_dtype=None):
@@ -98,9 +167,8 @@ def inference(checkpoint_filepath, image_folder, output_folder, number_classes, 
             seg = _inference_tiling(img, unet, TILE_SIZE)
         else:
             seg = _inference(img, unet)
-        mx = int(seg.max())
-        seg = seg.astype(np.uint8 if mx < 255 else (np.uint16 if mx < 65536 else np.int32))
-        _write(os.path.join(output_folder, name), seg)
+        seg = seg.astype(mask_dtype(int(seg.max())))
+        _write(os.path.join(output_folder, name), seg, image_format)
 
 
 def main(argv=None):

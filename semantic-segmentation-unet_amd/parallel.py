@@ -21,6 +21,8 @@ from .engine import BACKWARD_ORDER
 
 
 class DataParallel:
+    OVERLAP_WORKGROUPS = 224
+
     def __init__(self, engine, bucket_bytes=25 * 1024 * 1024, process_group=None, broadcast=True, force=False):
         assert dist.is_initialized(), "torch.distributed must be initialised (backend nccl == RCCL on ROCm)"
         self.engine = engine
@@ -46,6 +48,12 @@ class DataParallel:
         # broadcast from rank 0 anyway
         if hasattr(engine, "dropout_seed"):
             engine.dropout_seed = engine.dropout_seed * self.world_size + self.rank
+        # Overlap-ready by construction: the fused Winograd weight gradient is a persistent grid of 512-register workgroups that owns every
+        # CU it gets, so a collective's kernels enqueued behind it would wait for it to drain.  With more than one replica it is capped
+        # at OVERLAP_WORKGROUPS (~4 CUs per XCD stay free); tests/test_gpu_overlap.py shows on one GPU that a side-stream copy kernel then
+        # completes under the weight gradients, and does not without the cap.  (No N > 1 hardware run has confirmed it for RCCL itself.)
+        if (self.world_size > 1 or force) and hasattr(engine, "opt") and not engine.opt.wgrad_workgroups:
+            engine.opt.wgrad_workgroups = self.OVERLAP_WORKGROUPS
         if broadcast and (self.world_size > 1 or force):
             self.broadcast_state()
 

@@ -11,6 +11,9 @@ batches(batch_size) -> iterator of (images [B,C,H,W] fp32, labels [B,H,W,K] int3
 generator, UNet/imagereader.py:338-343).  Batches are pinned host tensors so the H2D copy is asynchronous.
 `batches(batch_size, classmap=True, pin=False)` yields the uint8 class map [B,H,W] instead of the one-hot, unpinned: the
 form `feed.DeviceFeed` stages itself and expands to the same one-hot on the device.
+
+A reader with the reference's OWN surface -- per-sample `generator()` (UNet/imagereader.py:338-355), e.g. the kept LMDB
+`ImageReader` -- plugs in through `from_sample_generator()` / directly as `train_model(train_reader=...)`.
 """
 import os
 
@@ -144,6 +147,82 @@ class TileFolderReader(_Base):
                 i, l = self._load(self.names[next(keys)], classmap, raw)
                 imgs.append(i); labs.append(l)
             yield pin_(torch.as_tensor(np.stack(imgs))), pin_(torch.as_tensor(np.stack(labs)))
+
+
+class SampleGeneratorReader(_Base):
+    """Adapter for a reader with the REFERENCE's surface (UNet/imagereader.py:87-355): `startup()`, `shutdown()`,
+    `get_image_size()` -> [H, W, C], `get_image_count()`, and `generator()` yielding one sample at a time as
+    `(image fp32 [C,H,W] z-scored, label int32 one-hot [H,W,K])` until the reader is shut down (:338-343) -- what the reference wraps
+    in `tf.data.Dataset.from_generator(...).batch(global_batch)` (:348-355, UNet/train.py:84-90).  `batches()` does that batching.
+
+    Such a reader owns its workers (the reference forks `num_workers` processes that share one output queue), shuffling,
+    class balancing and augmentation (constructor arguments, UNet/train.py:66-76): every `batches()` iterator of this adapter
+    draws from that ONE sample stream under a lock (`worker` / `num_workers` only say how many consumers there are), and
+    `augments_itself` tells the train loop not to augment a second time on the device.  `classmap=True` hands the labels over as
+    the uint8 class map (`argmax` of an exact one-hot) for the device feed's on-device expansion."""
+    augments_itself = True
+
+    def __init__(self, reader):
+        import threading
+        self.reader = reader
+        self.balance_classes = True             # whatever the wrapped reader was built with is what happens
+        self._lock = threading.Lock()
+        self._gen = None
+
+    def startup(self):
+        self.reader.startup()
+
+    def shutdown(self):
+        self.reader.shutdown()
+
+    def get_image_count(self):
+        return self.reader.get_image_count()
+
+    def get_image_size(self):
+        return tuple(self.reader.get_image_size())
+
+    def _next_sample(self):
+        with self._lock:
+            if self._gen is None:
+                self._gen = self.reader.generator()
+            return next(self._gen)              # StopIteration once the reader was shut down
+
+    def batches(self, batch_size, classmap=False, pin=True, raw=False, worker=0, num_workers=1):
+        if raw:
+            raise ValueError("a sample-generator reader normalises (and augments) inside its own workers: raw tiles are not available")
+        pin_ = _pin if pin else (lambda t: t)
+        h, w, c = self.get_image_size()
+        while True:
+            imgs, labs = [], []
+            try:
+                for _ in range(batch_size):
+                    img, lab = self._next_sample()
+                    img, lab = np.asarray(img), np.asarray(lab)
+                    if img.dtype != np.float32 or img.shape != (c, h, w):
+                        raise IOError("reader sample: expected a float32 image [C,H,W] = {}, got {} {}".format((c, h, w), img.dtype, img.shape))
+                    if lab.dtype != np.int32 or lab.ndim != 3 or lab.shape[:2] != (h, w):
+                        raise IOError("reader sample: expected an int32 one-hot label [H,W,K], got {} {}".format(lab.dtype, lab.shape))
+                    imgs.append(img)
+                    labs.append(lab.argmax(-1).astype(np.uint8) if classmap else lab)
+            except StopIteration:
+                if not imgs:
+                    return
+            # (a final short batch is handed on, like Dataset.batch() without drop_remainder)
+            yield pin_(torch.as_tensor(np.stack(imgs))), pin_(torch.as_tensor(np.stack(labs)))
+            if len(imgs) < batch_size:
+                return
+
+
+def from_sample_generator(reader):
+    """-> a batch source for train_model / DeviceFeed from a reference-style per-sample reader (see SampleGeneratorReader)."""
+    return SampleGeneratorReader(reader)
+
+
+def as_batch_reader(reader):
+    """train_model accepts either this build's batch readers or a reference-style reader object (generator(), no batches())."""
+    if not hasattr(reader, "batches") and hasattr(reader, "generator"):
+        return from_sample_generator(reader)
+    return reader
 
 
 def round_robin(iterators):

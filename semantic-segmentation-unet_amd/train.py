@@ -86,6 +86,9 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
     reader_count = max(1, int(reader_count))
     total_workers = reader_count * world
     worker_ids = [rank * reader_count + w for w in range(reader_count)]
+    # a reader with the reference's own surface (per-sample generator(), UNet/imagereader.py:338-355) is batched by an adapter
+    train_reader = readers.as_batch_reader(train_reader) if train_reader is not None else None
+    test_reader = readers.as_batch_reader(test_reader) if test_reader is not None else None
     if train_reader is None:
         train_reader = readers.TileFolderReader(train_lmdb_filepath, number_classes, shuffle=True, seed=0,
                                                 balance_classes=bool(balance_classes))
@@ -113,7 +116,7 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
         use_feed = os.environ.get("UNET_FEED", "1") != "0"
         if use_feed:
             from .feed import DeviceFeed
-            if use_augmentation:
+            if use_augmentation and not getattr(train_reader, "augments_itself", False):
                 # the reference augments inside its reader processes (UNet/imagereader.py:283-301, settings :79-85), ~31 images/s
                 # per host core; here the raw tiles go to the device and the same sequence runs as HIP kernels (augment.py)
                 from .augment import AugmentingFeed, DeviceAugmenter

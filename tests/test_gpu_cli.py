@@ -38,6 +38,22 @@ def test_train_cli_then_inference_cli(tmp_path):
     assert m_small.shape == small.shape and m_small.dtype == np.uint8
     assert m_big.shape == big.shape and m_big.max() <= 1
 
+    # the same image as a uint16 TIFF (the reference's data/ format): --image_format tif reads it and writes the mask as the reference's
+    # imsave call asks (deflate BigTIFF in 1024-tiles, UNet/inference.py:221-222); same mask as the .npy run
+    from PIL import Image
+    timgs = tmp_path / "timgs"; timgs.mkdir()
+    small16 = np.clip(small, 0, 65535).astype(np.uint16)
+    Image.fromarray(small16).save(str(timgs / "small.tif"))
+    np.save(imgs / "small16.npy", small16)
+    inf.main(["--checkpoint_filepath", os.path.join(out, "checkpoint", "ckpt"), "--image_folder", str(timgs),
+              "--output_folder", str(tmp_path / "tmasks"), "--number_classes", "2", "--number_channels", "1"])
+    inf.main(["--checkpoint_filepath", os.path.join(out, "checkpoint", "ckpt"), "--image_folder", str(imgs),
+              "--output_folder", str(tmp_path / "masks"), "--number_classes", "2", "--number_channels", "1", "--image_format", "npy"])
+    raw = open(tmp_path / "tmasks" / "small.tif", "rb").read(4)
+    assert raw == b"II+\x00"
+    m_tif = np.array(Image.open(str(tmp_path / "tmasks" / "small.tif")))
+    assert m_tif.dtype == np.uint8 and np.array_equal(m_tif, np.load(tmp_path / "masks" / "small16.npy"))
+
     # oracle on the small image: same z-score, reflect pad to x16, eval forward, argmax, crop
     tfc = pkg("tf_checkpoint")
     ck = tfc.read_bundle(os.path.join(out, "checkpoint", "ckpt"))

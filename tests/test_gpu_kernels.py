@@ -114,8 +114,8 @@ def test_fused_winograd_trio_properties_at_full_size(hip, shape):
     hip.unet_conv3x3_fwd_mfma(P(x), ci, P(wt), None, P(yd), co, n, h, w, ci, co, 0, ST())
     assert ((y - yd).abs().max() / yd.abs().max()).item() < 2e-5
     hip.unet_conv3x3_dgrad_winograd_fused(P(dz), co, P(Ucd), P(dx), ci, n, h, w, ci, co, None, 0, 0, 0, None, 0, ST())
-    nb = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co); ws = ws_bytes(nb)
-    hip.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+    nb = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co, 0); ws = ws_bytes(nb)
+    hip.unet_conv3x3_wgrad_winograd_fused(P(x), ci, P(dz), co, P(dw), n, h, w, ci, co, 0, P(ws), nb, ST())
     dot = lambda a, b: (a.double() * b.double()).sum().item()
     a0, a1, a2 = dot(y, dz), dot(x, dx), dot(wt, dw)
     scale = float(np.sqrt(dot(y, y) * dot(dz, dz)))
@@ -633,10 +633,10 @@ def test_conv3x3_winograd_fused_wgrad(hip, shape):
     xbuf = torch.zeros(n, h, w, ci + 4, device=DEV); xbuf[..., 4:] = to_nhwc(x)
     xv = xbuf[..., 4:]
     dzd = to_nhwc(dz)
-    nb = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co)
+    nb = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co, 0)
     ws = ws_bytes(nb)
     dw = torch.full((3, 3, ci, co), 7.0, device=DEV)
-    hip.unet_conv3x3_wgrad_winograd_fused(P(xv), ci + 4, P(dzd), co, P(dw), n, h, w, ci, co, P(ws), nb, ST())
+    hip.unet_conv3x3_wgrad_winograd_fused(P(xv), ci + 4, P(dzd), co, P(dw), n, h, w, ci, co, 0, P(ws), nb, ST())
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 3e-5
 
 
@@ -1063,10 +1063,10 @@ def test_winograd_batchnorm_apply_on_load_matches_two_passes(hip, shape):
     # ---- weight gradient
     dz = torch.randn(n, h, w, co, device=DEV, generator=g)
     if hip.unet_winograd_wgrad_fused_supported(n, h, w, ci, co) == 1:
-        nbw = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co); wsw = ws_bytes(nbw)
+        nbw = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co, 0); wsw = ws_bytes(nbw)
         dw_ref = torch.empty(3, 3, ci, co, device=DEV); dw = torch.empty(3, 3, ci, co, device=DEV)
-        hip.unet_conv3x3_wgrad_winograd_fused(P(y), ldx, P(dz), co, P(dw_ref), n, h, w, ci, co, P(wsw), nbw, ST())
-        hip.unet_conv3x3_wgrad_winograd_fused(P(r), ldx, P(dz), co, P(dw), n, h, w, ci, co, P(wsw), nbw, ST())
+        hip.unet_conv3x3_wgrad_winograd_fused(P(y), ldx, P(dz), co, P(dw_ref), n, h, w, ci, co, 0, P(wsw), nbw, ST())
+        hip.unet_conv3x3_wgrad_winograd_fused(P(r), ldx, P(dz), co, P(dw), n, h, w, ci, co, 0, P(wsw), nbw, ST())
         total = dz.sum((0, 1, 2)).contiguous()
         nb8 = hip.unet_conv3x3_wgrad_fold_fix_workspace(co); ws8 = ws_bytes(nb8)
         hip.unet_conv3x3_wgrad_fold_fix(P(dw), P(sc), P(sh), P(dz), co, P(total), n, h, w, ci, co, P(ws8), nb8, ST())

@@ -365,8 +365,8 @@ def test_bf16_storage_is_bit_identical_to_fp32_storage(shape):
     res = []
     for storage in (False, True):
         net = model.UNet(k, n, c, learning_rate=1e-3, seed=0, compute_dtype="bf16")
-        net.engine.bf16_storage = storage
-        net.engine.bf16_activations = False          # (stage 3 rounds r / dy themselves: covered by the next test)
+        net.engine.opt.bf16_storage = storage
+        net.engine.opt.bf16_activations = False          # (stage 3 rounds r / dy themselves: covered by the next test)
         losses = [float(net.train_step(batch).numpy()) for _ in range(3)]
         g1 = net.engine.grad.clone()
         prob = net.engine.forward(img.cuda(), training=False).clone()
@@ -390,13 +390,13 @@ def test_bf16_activation_storage_tracks_the_stage2_bf16_mode():
     lab = torch.nn.functional.one_hot(cls, k).to(torch.int32)
     batch = (img.cuda(), lab.cuda(), None, None)
     ref = model.UNet(k, n, c, learning_rate=1e-3, seed=0, compute_dtype="bf16")
-    ref.engine.bf16_activations = False
+    ref.engine.opt.bf16_activations = False
     l_ref = float(ref.train_step(batch).numpy())
     assert not any(name.startswith(("r16_", "dy16_")) for name in ref.engine.bufs)
     runs = []
     for _ in range(2):
         net = model.UNet(k, n, c, learning_rate=1e-3, seed=0, compute_dtype="bf16")
-        assert net.engine.bf16_activations
+        assert net.engine.opt.bf16_activations
         l0 = float(net.train_step(batch).numpy())
         runs.append((l0, net.engine.grad.clone(), net))
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
@@ -618,7 +618,7 @@ def test_inference_fold_cache_follows_the_parameters():
     e.load_parameters(prm)
     x = torch.as_tensor(img)
     p0 = e.forward(x).clone()
-    assert len(e._eval_folded) > 0 or not e.bn_on_load                    # the fp32 route folds 13 layers
+    assert len(e._eval_folded) > 0 or not e.opt.bn_on_load                    # the fp32 route folds 13 layers
     assert torch.equal(e.forward(x), p0)                                   # second tile: served from the cached folds, same bits
     for _ in range(3):
         net.train_step((img, lab, None, None), dropout_masks=masks)        # weights AND moving statistics move

@@ -187,3 +187,19 @@ def test_reader_count_feeds_several_worker_streams(tmp_path):
     with pytest.raises(ValueError):            # a reader without class balancing must not silently ignore --balance_classes 1
         train.train_model(str(tmp_path), 2, 1, None, None, 0, 2, 1, 3e-4, 4, 0, train_reader=tr, test_reader=te, quiet=True,
                           unet_factory=ScriptedUNet)
+
+
+def test_train_model_takes_a_reference_style_reader_object(tmp_path):
+    # train_model(train_reader=<object with the reference ImageReader's surface>) (UNet/train.py:66-90): batched by the adapter, fed
+    # through the DeviceFeed, started and shut down by the loop, NOT augmented a second time on the device
+    from test_feed import FakeReferenceReader
+    train = pkg("train")
+    ScriptedUNet.script = [0.5, 0.6]
+    tr = FakeReferenceReader(64, 16, 16, 1, 2, seed=1)
+    te = FakeReferenceReader(4, 16, 16, 1, 2, seed=2)
+    out = train.train_model(str(tmp_path), 2, 1, None, None, 1, 2, 0, 3e-4, 3, 1,
+                            train_reader=tr, test_reader=te, quiet=True, unet_factory=ScriptedUNet)
+    trace = ScriptedUNet.last.finish()
+    assert np.allclose(out, [0.5, 0.6]) and trace["train_steps"] == [4, 4] and trace["test_steps"] == [3, 3]
+    assert tr.started and tr.stopped and te.started and te.stopped
+    assert tr.handed_out >= 2 * 8
