@@ -21,6 +21,11 @@ stream and a bracketed launch would include shared time.
     peak for a Winograd kernel and is NOT a roofline fraction;
   * `traffic`: HBM bytes per launch from separate rocprofv3 --pmc passes committed under profiles/ (`traffic_source`:
     "offline PMC" -- it is read from that file, not measured by this run), null when no pass exists for the family.
+`kernels` lists every instrumented family of the sampled steps: the matrix-core ones as above, and the HBM-bound passes (BatchNorm
+apply / backward / statistics, pool, dropout, softmax-CE, Adam, first layer, class map: `"bound": "hbm"`) as ALGORITHMIC bytes (every
+tensor the pass reads or writes, once) / exclusive HIP-event time, against the guide's measured copy bandwidth (6.29 TB/s) and the 8 TB/s
+spec.  With N > 1, `distributed` carries world size, backend and -- from one traced, untimed step -- when each gradient bucket's
+all-reduce was issued and passed.  The sampled single-stream steps (one in eight) are INSIDE the timed region (they cost ~0.2 % of `value`).
 `step_executed_frac` = executed FLOPs of the whole step (3x3 Winograd layers / 2.25 + everything else) / step time / peak.
 `cpu_baseline` times the oracle's torch-CPU fp32 restatement of the same train step on the host cores (rank 0, N=1 only):
 config 2 at batch 8, 1 warm-up + 3 timed steps -- a reported baseline, not the target.
@@ -50,6 +55,25 @@ FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16?, offl
     "conv3x3_fwd_bf16": ("conv_bf16_stream_stats_kernel_{128,64} (3x3 conv forward + BatchNorm sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_fwd_pmc_traffic.json"),
     "conv3x3_dgrad_bf16": ("conv_bf16_stream_bnbwd_kernel_{128,64} (3x3 conv data gradient + producer BatchNorm-backward sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_dgrad_pmc_traffic.json"),
     "conv3x3_wgrad_bf16": ("wgrad_bf16_dma_kernel (3x3 conv weight gradient, pixel contraction on v_mfma_f32_32x32x16_bf16, LDS-DMA staging)", False, True, "r02d_bf16_wgrad_pmc_traffic.json"),
+}
+
+
+PEAK_HBM_SPEC_GBS = 8000.0           # same guide: HBM3E ~8 TB/s spec
+PEAK_HBM_COPY_GBS = 6290.0           # ... and its measured copy bandwidth (the figure HBM-bound kernels are priced against)
+
+HBM_FAMILY = {   # engine profile key -> description; `work` of these launches is ALGORITHMIC BYTES: every tensor the pass reads / writes, once
+    "bn_apply": "bn_apply_kernel / bn_apply_pool_kernel (BatchNorm apply [+ 2x2 max pool]: r -> y [, pooled, winners])",
+    "bn_bwd": "bn_bwd_reduce_*/bn_bwd_apply_* (BatchNorm backward: [reduce pass over dy, r] + apply pass dy, r -> dz; pooled layers add the un-pooled gradient on the fly)",
+    "bn_stats": "bn_stats_kernel (BatchNorm statistics pass; only the class-map layer has no conv epilogue to take them from)",
+    "pool": "maxpool_fwd/bwd_kernel (level 4: the dropout sits between BatchNorm and pool)",
+    "dropout": "dropout_kernel (in place, mask from a counter hash)",
+    "softmax_ce": "softmax_ce_kernel (softmax + cross-entropy + d logits, K classes)",
+    "adam": "adam_keras_kernel (flat buffers: theta, g, m, v -> theta, m, v)",
+    "first_layer_fwd": "conv3x3_direct_*_stats (first layer, Cin = image channels: VALU stencil + BatchNorm sums)",
+    "first_layer_wgrad": "conv3x3_wgrad_direct (first layer weight gradient)",
+    "classmap_fwd": "conv1x1_narrow_fwd8_kernel (class map 64 -> K)",
+    "classmap_dgrad": "conv1x1_narrow_dgrad_kernel",
+    "classmap_wgrad": "conv1x1_narrow_wgrad_kernel",
 }
 
 
@@ -170,6 +194,21 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
     step = net.train_step if world == 1 else (lambda inp: net.dist_train_step(net.parallel, inp))   # N>1: + the loss SUM (X2)
     for _ in range(warmup):
         step(inputs)
+    buckets = None
+    if world > 1:
+        # one extra untimed step with the collectives traced: when each gradient bucket's all-reduce was ISSUED (event on the weight-gradient
+        # stream right in front of it) and by when the compute stream had passed the wait for it, from the start of the step
+        net.parallel.trace, net.parallel.done_trace = [], []
+        t0e = torch.cuda.Event(enable_timing=True); t0e.record()
+        step(inputs)
+        t1e = torch.cuda.Event(enable_timing=True); t1e.record(); torch.cuda.synchronize()
+        buckets = {"bucket_mb": [round((b - a) * 4 / 1e6, 2) for a, b, _ in net.parallel.buckets],
+                   "closes_behind": [last for _, _, last in net.parallel.buckets],
+                   "issued_ms": [round(t0e.elapsed_time(ev), 3) for _, ev in net.parallel.trace],
+                   "passed_ms": [round(t0e.elapsed_time(ev), 3) for _, ev in net.parallel.done_trace],
+                   "step_ms": round(t0e.elapsed_time(t1e), 3),
+                   "wgrad_workgroups": net.engine.opt.wgrad_workgroups}
+        net.parallel.trace = net.parallel.done_trace = None
     prof = {} if kernel_events else None
     sampled = 0
     barrier()
@@ -189,6 +228,13 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
         for key, evs in prof.items():
             ms = sum(a.elapsed_time(b) for a, b, _ in evs)
             fl = sum(f for _, _, f in evs)
+            if key in HBM_FAMILY:           # HBM-bound pass: algorithmic bytes / exclusive time against the measured-copy and the spec bandwidth
+                gbs = fl / (ms * 1e-3) / 1e9
+                kernels[key] = {"bound": "hbm", "kernel": HBM_FAMILY[key], "launches_per_step": len(evs) // sampled,
+                                "ms_per_step": round(ms / sampled, 3), "algorithmic_mb_per_step": round(fl / sampled / 1e6, 1),
+                                "achieved_gbs": round(gbs, 1), "frac_of_copy_bw": round(gbs / PEAK_HBM_COPY_GBS, 4),
+                                "frac_of_spec_bw": round(gbs / PEAK_HBM_SPEC_GBS, 4), "exclusive": True}
+                continue
             desc, wino, bf16, _ = FAMILY.get(key, (key, False, False, None))
             eff = fl / (ms * 1e-3) / 1e12
             ex = eff / WINOGRAD_MULT_RATIO if wino else eff
@@ -198,7 +244,7 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
                             "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4), "exclusive": True}
     del net
     torch.cuda.empty_cache()
-    return {"dt": dt, "kernels": kernels, "final_loss": final_loss, "sampled_steps": sampled, "G": G}
+    return {"dt": dt, "kernels": kernels, "final_loss": final_loss, "sampled_steps": sampled, "G": G, "buckets": buckets}
 
 
 def roofline_of(kernels, workload_key):
@@ -329,6 +375,9 @@ def main():
                        "global_batch": res["G"], "parallelism": "dp%d" % world},
         }
         out.update(s)
+        if world > 1:
+            out["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                  "gradient_allreduce": res["buckets"]}
         if rehearsal:
             out["rehearsal"] = "all %d ranks share GPU 0, collectives over gloo: exercises the N>1 path, not a scaling measurement" % world
         out["cpu_baseline"] = cpu_baseline_bounded(args) if (world == 1 and not args.no_cpu_baseline) else None

@@ -1218,11 +1218,23 @@ int run_wino(const float* x, int ldx, const float* U, const float* bias, float* 
 // pad[c] = -t[c] / s[c] instead of 0 makes a padded tap contribute s W pad = -t W, which cancels the uniform shift term
 // exactly where the zero padding of y would have contributed nothing.  So the unchanged kernel, given
 //     Uc' = s . transform(W),   bias' = bias + sum_{taps, c} t[c] W[tap][c][:],   pad,
-// computes the convolution of the BatchNorm OUTPUT without that tensor ever being written or read.  (s[c] = 0 has no padding
-// value: the fold writes pad = 0 there; such a channel's border pixels would be off by its shift term, so the engine keeps the
-// two-pass form whenever a gamma is exactly 0 -- checked when parameters are loaded.)
+// computes the convolution of the BatchNorm OUTPUT without that tensor ever being written or read.
+// Conditioning.  pad = -t / s grows as the BatchNorm scale s = gamma / sqrt(var + eps) shrinks (a dead / pruned channel: gamma ~ 0 with
+// beta = O(1)), but every use of it is multiplied by s again: the input transform's rounding error is |pad| * 2^-24-ish, the products carry
+// the factor s, so the error of the layer output is ~ |t| |W| 2^-24 per channel whatever |s| is -- relative to the shift term itself,
+// never to the vanishing s * r term (tests: |gamma| in {0, 1e-30, 1e-6, 1e-4, 1e-2}, both signs, against the fp64 oracle at the usual
+// 2e-5).  Only s == 0 has no padding value at all and |pad| > ~1e37 overflows the 4-term sums of the transform; both are fenced HERE,
+// on the device, every time the fold runs (every step): |s| is floored at kFoldScaleFloor * max(1, |t|) -- the folded layer then
+// computes with s' instead of s, an absolute change of the output below 1e-30 * sum |r W|, far under fp32 resolution of any output
+// the shift term reaches -- so pad is always finite, |pad| <= 1e30, and no host-side gamma check or fallback route is needed.
 //
 // one thread = 8 consecutive input channels x one output channel (the batch kernel's work item): forward layout only
+constexpr float kFoldScaleFloor = 1e-30f;
+__device__ __forceinline__ float fold_scale(float sc, float sh) {
+    const float smin = kFoldScaleFloor * fmaxf(1.f, fabsf(sh));
+    return fabsf(sc) < smin ? copysignf(smin, sc) : sc;
+}
+
 __global__ __launch_bounds__(256) void wino_weight_fold_kernel(const float* __restrict__ w, const float* __restrict__ scale,
         const float* __restrict__ shift, float* __restrict__ uf, float* __restrict__ part, float* __restrict__ pad, int Ci, int Co) {
     const size_t plane = (size_t)Ci * Co;
@@ -1235,7 +1247,7 @@ __global__ __launch_bounds__(256) void wino_weight_fold_kernel(const float* __re
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int ci = 8 * c8 + e;
-        const float sc = scale[ci], sh = shift[ci];
+        const float sh = shift[ci], sc = fold_scale(scale[ci], sh);
         float g[3][3], gs = 0.f;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -1255,7 +1267,7 @@ __global__ __launch_bounds__(256) void wino_weight_fold_kernel(const float* __re
             t[4 * r + 0][e] = s[r][0]; t[4 * r + 1][e] = 0.5f * (s[r][0] + s[r][1] + s[r][2]);
             t[4 * r + 2][e] = 0.5f * (s[r][0] - s[r][1] + s[r][2]); t[4 * r + 3][e] = s[r][2];
         }
-        if (co == 0) pad[ci] = sc != 0.f ? -sh / sc : 0.f;
+        if (co == 0) pad[ci] = -sh / sc;
     }
     const size_t offf = ((size_t)c8 * Co + co) * 8;                                   // [k/8][n=co][k%8]
 #pragma unroll

@@ -115,7 +115,6 @@ class Engine:
         self.ce_clip_eps = CE_CLIP_EPS
         self._eval_folded = set()               # layers whose eval-mode (moving-statistics) BatchNorm-on-load fold is current
         self._eval_coefs = set()                # (layer, destination) pairs whose eval-mode scale / shift are current
-        self._gamma_zero = None
         self.view = {}
         self._fused_U, self._fused_dirty = None, True
         self._bf16_W, self._bf16_dirty = {}, True
@@ -150,24 +149,27 @@ class Engine:
     def plan(self, n, h, w, training=False, want_grad=False):
         """The step plan for images [n, C, h, w] (plan.StepPlan): kernel family per layer and direction, storage precision per tensor.
         Built once per shape / mode / option set and cached."""
-        key = (n, h, w, bool(training), bool(want_grad), self.opt.key(), self._gamma_nonzero() if self._needs_gamma_check() else True)
+        key = (n, h, w, bool(training), bool(want_grad), self.opt.key())
         pl = self._plans.get(key)
         if pl is None:
-            pl = self._plans[key] = build_plan(self.opt, self.C, self.K, n, h, w, training, want_grad, self.L, gamma_ok=key[-1])
+            pl = self._plans[key] = build_plan(self.opt, self.C, self.K, n, h, w, training, want_grad, self.L)
         return pl
 
-    def _needs_gamma_check(self):
-        return self.opt.bn_on_load and self.opt.compute_dtype == "fp32" and self.opt.conv_route == "fused" and self.opt.wgrad_route == "fused"
-
-    def _timed(self, key, flops, fn, *args):
-        """Call fn(*args); when profiling is on, bracket it with HIP events on the launch stream."""
+    def _timed(self, key, work, fn, *args):
+        """Call fn(*args); when profiling is on, bracket it with HIP events on the launch stream.  work: the launch's algorithmic FLOPs
+        (matrix-core families) or algorithmic HBM bytes (the HBM-bound families: tensors read + written once, `_nb`)."""
         if self.profile is None:
             return fn(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn(*args)
         e1.record()
-        self.profile.setdefault(key, []).append((e0, e1, flops))
+        self.profile.setdefault(key, []).append((e0, e1, work))
+
+    @staticmethod
+    def _nb(*tensors):
+        """algorithmic bytes of NHWC views read or written once (the logical elements, not the leading dimension)"""
+        return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
     # ------------------------------------------------------------------------------------------------ parameters
     def trainable_names(self):
@@ -239,7 +241,6 @@ class Engine:
         self._fused_dirty = True
         self._bf16_dirty = True
         self._eval_folded.clear(); self._eval_coefs.clear()
-        self._gamma_zero = None                 # re-checked lazily (BatchNorm-apply on load needs every gamma != 0)
 
     def load_parameters(self, values):
         """values: {keras-style name: array in the Keras layout}.  Resets nothing else."""
@@ -284,13 +285,6 @@ class Engine:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def _gamma_nonzero(self):
-        """BatchNorm-apply on load divides by the BatchNorm scale (pad = -shift / scale): usable while no gamma is exactly 0.
-        Checked (one host sync) after parameters were written from outside, not after optimizer steps."""
-        if self._gamma_zero is None:
-            self._gamma_zero = any(bool((self.p[n + "/gamma"] == 0).any().item()) for n, _, _, _ in self.layers)
-        return not self._gamma_zero
-
     def _fold_buffers(self, name):
         cin, cout = self.cin[name], self.cout[name]
         return (self._buf("Ufold_" + name, (16 * cin * cout,)), self._buf("bfold_" + name, (cout,)), self._buf("pad_" + name, (cin + 8,)))
@@ -333,7 +327,8 @@ class Engine:
         elif kind == "deconv":
             L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
         elif kind == "conv1":
-            L.unet_conv1x1_fwd(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
+            self._timed("classmap_fwd", self._nb(x, r), L.unet_conv1x1_fwd,
+                        _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(w_), _p(b_), _p(r), cout, n * h * w, cin, cout, 1, st)
         elif lp.fwd == "bf16":
             rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
             stat_part = part(rows)
@@ -371,8 +366,8 @@ class Engine:
             rows = L.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
             if rows > 0:
                 stat_part = part(rows)
-                L.unet_conv3x3_fwd_direct_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), int(r16), n, h, w, cin, cout, 1,
-                                                _p(stat_part), stat_part.numel() * 4, st)
+                self._timed("first_layer_fwd", self._nb(x, r), L.unet_conv3x3_fwd_direct_stats,
+                            _p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), int(r16), n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4, st)
                 fused_stats = (stat_part, rows)
             else:
                 assert not r16
@@ -389,8 +384,8 @@ class Engine:
         elif training:
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_train_stats(_p(r), _ld(r), P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM, BN_MOVING_VAR_UNBIASED,
-                                  _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(sc_out), _p(sh_out), _p(ws), nb, st)
+            self._timed("bn_stats", self._nb(r), L.unet_bn_train_stats, _p(r), _ld(r), P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM,
+                        BN_MOVING_VAR_UNBIASED, _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(sc_out), _p(sh_out), _p(ws), nb, st)
         elif (name, sc_out.data_ptr()) not in self._eval_coefs:             # (inference: constants until the parameters change)
             L.unet_bn_eval_coeffs(_p(gm), _p(bt), _p(mm), _p(mv), BN_EPS, cout, _p(sc_out), _p(sh_out), st)
             self._eval_coefs.add((name, sc_out.data_ptr()))
@@ -402,14 +397,16 @@ class Engine:
         if y_out is None:                       # deferred: the consumer applies (sc_out, sh_out) on load
             return r
         if r.dtype == torch.bfloat16 or y_out.dtype == torch.bfloat16:
-            L.unet_bn_apply_any(_p(r), _ld(r), int(r.dtype == torch.bfloat16), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), int(y_out.dtype == torch.bfloat16),
-                                _p(pool[0]) if pool is not None else None, cout, _p(pool[1]) if pool is not None else None,
-                                r.shape[0], r.shape[1], r.shape[2], cout, st)
+            self._timed("bn_apply", self._nb(r, y_out, *(pool or ())), L.unet_bn_apply_any,
+                        _p(r), _ld(r), int(r.dtype == torch.bfloat16), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), int(y_out.dtype == torch.bfloat16),
+                        _p(pool[0]) if pool is not None else None, cout, _p(pool[1]) if pool is not None else None,
+                        r.shape[0], r.shape[1], r.shape[2], cout, st)
         elif pool is not None:         # (pooled, idx): BN apply and the level's max pool in one pass
-            L.unet_bn_apply_maxpool(_p(r), _ld(r), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
-                                    r.shape[0], r.shape[1], r.shape[2], cout, st)
+            self._timed("bn_apply", self._nb(r, y_out, *pool), L.unet_bn_apply_maxpool,
+                        _p(r), _ld(r), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), _p(pool[0]), cout, _p(pool[1]),
+                        r.shape[0], r.shape[1], r.shape[2], cout, st)
         else:
-            L.unet_bn_apply(_p(r), _ld(r), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), P, cout, st)
+            self._timed("bn_apply", self._nb(r, y_out), L.unet_bn_apply, _p(r), _ld(r), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), P, cout, st)
         return y_out
 
     def _dropout(self, t, key, masks, backward=False):
@@ -418,7 +415,8 @@ class Engine:
         if masks is not None:
             m = masks[key]
         seed = (self.dropout_seed * 1000003 + self.iterations * 2 + (0 if key == "drop_4" else 1)) & 0xFFFFFFFF
-        self.L.unet_dropout(_p(t), _ld(t), _p(t), _ld(t), n * h * w, c, _p(m), seed, DROPOUT_RATE, int(t.dtype == torch.bfloat16), self._stream())
+        self._timed("dropout", 2 * self._nb(t), self.L.unet_dropout,
+                    _p(t), _ld(t), _p(t), _ld(t), n * h * w, c, _p(m), seed, DROPOUT_RATE, int(t.dtype == torch.bfloat16), self._stream())
 
     def _prep_masks(self, dropout_masks):
         """NCHW 0/1 arrays (the oracle's convention) -> dense NHWC uint8 device tensors."""
@@ -491,7 +489,8 @@ class Engine:
                 if lvl == 4 and training:
                     self._dropout(skip, "drop_4", self.masks)
                 assert skip.dtype == pooled.dtype
-                L.unet_maxpool2x2_fwd(_p(skip), _ld(skip), _p(pooled), ch, _p(idx), n, hh, ww, ch, int(skip.dtype == torch.bfloat16), st)
+                self._timed("pool", self._nb(skip, pooled, idx), L.unet_maxpool2x2_fwd,
+                            _p(skip), _ld(skip), _p(pooled), ch, _p(idx), n, hh, ww, ch, int(skip.dtype == torch.bfloat16), st)
             self.idx[lvl] = idx
             cur, cur_view = pooled, None
         hh, ww = cur.shape[1], cur.shape[2]
@@ -530,8 +529,9 @@ class Engine:
             G = global_batch_size if global_batch_size else n
             scale = 1.0 / (float(G) * h * w)                       # sum_n / G then mean over H,W  (UNet/model.py:213-215)
             dl = self._buf("dy_logits", (n, h, w, self.K)) if want_grad else None
-            L.unet_softmax_ce(_p(yl), self.K, _p(lab), _p(prob), _p(dl), self.K, P, self.K, float(label_smoothing), scale,
-                              scale, float(self.ce_clip_eps), _p(self.loss_buf[0:1]), _p(self.loss_buf[1:2]), _p(ws), nb, st)
+            self._timed("softmax_ce", self._nb(yl, lab, prob, dl), L.unet_softmax_ce,
+                        _p(yl), self.K, _p(lab), _p(prob), _p(dl), self.K, P, self.K, float(label_smoothing), scale,
+                        scale, float(self.ce_clip_eps), _p(self.loss_buf[0:1]), _p(self.loss_buf[1:2]), _p(ws), nb, st)
             self._labels_keepalive = lab
         return prob
 
@@ -563,11 +563,12 @@ class Engine:
             assert not (pool_grad is not None and pre is not None)
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_bwd_any(_p(dy), _ld(dy), _p(pdy), _ld(pdy) if pdy is not None else 0, _p(pidx), n, ho, wo, _p(r), _ld(r),
-                              _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 0 if kind == "deconv" else 1, _p(dz), cout, int(dz.dtype == torch.bfloat16),
-                              _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]), _p(self.g[name + "/bias"]), part_ptr, rows,
-                              _p(ws), nb, st, int(r.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16),
-                              int(pdy is not None and pdy.dtype == torch.bfloat16))
+            self._timed("bn_bwd", (1 if pre is not None else 2) * self._nb(dy, r, pdy, pidx if pdy is not None else None) + self._nb(dz), L.unet_bn_bwd_any,
+                        _p(dy), _ld(dy), _p(pdy), _ld(pdy) if pdy is not None else 0, _p(pidx), n, ho, wo, _p(r), _ld(r),
+                        _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 0 if kind == "deconv" else 1, _p(dz), cout, int(dz.dtype == torch.bfloat16),
+                        _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]), _p(self.g[name + "/bias"]), part_ptr, rows,
+                        _p(ws), nb, st, int(r.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16),
+                        int(pdy is not None and pdy.dtype == torch.bfloat16))
         elif eval_mode:
             L.unet_bn_eval_bwd(_p(dy), _ld(dy), _p(r), _ld(r), _p(self.coef[name][0]), _p(dz), cout, P, cout, 0 if kind == "deconv" else 1, st)
         elif pre is not None:
@@ -575,24 +576,27 @@ class Engine:
             part, rows, c0 = pre
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_bwd_from_partials(_p(dy), _ld(dy), _p(r), _ld(r), _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
-                                        0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
-                                        _p(self.g[name + "/bias"]), ctypes.c_void_p(part.data_ptr() + (c0 // 64) * rows * 128 * 4), rows,
-                                        _p(ws), nb, st)
+            self._timed("bn_bwd", self._nb(dy, r, dz), L.unet_bn_bwd_from_partials,
+                        _p(dy), _ld(dy), _p(r), _ld(r), _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
+                        0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
+                        _p(self.g[name + "/bias"]), ctypes.c_void_p(part.data_ptr() + (c0 // 64) * rows * 128 * 4), rows,
+                        _p(ws), nb, st)
         elif pool_grad is not None:
             # dy = skip gradient + un-pooled gradient of the level below, formed inside the BatchNorm-backward kernels
             pdy, pidx = pool_grad
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_bwd_pooled(_p(dy), _ld(dy), _p(pdy), _ld(pdy), _p(pidx), n, ho, wo, _p(r), _ld(r), _p(self.p[name + "/gamma"]),
-                                 _p(s[0]), _p(s[1]), cout, 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
-                                 _p(self.g[name + "/bias"]), _p(ws), nb, st)
+            self._timed("bn_bwd", 2 * self._nb(dy, r, pdy, pidx) + self._nb(dz), L.unet_bn_bwd_pooled,
+                        _p(dy), _ld(dy), _p(pdy), _ld(pdy), _p(pidx), n, ho, wo, _p(r), _ld(r), _p(self.p[name + "/gamma"]),
+                        _p(s[0]), _p(s[1]), cout, 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
+                        _p(self.g[name + "/bias"]), _p(ws), nb, st)
         else:
             nb = L.unet_bn_workspace(P, cout)
             ws = self._workspace(nb)
-            L.unet_bn_bwd(_p(dy), _ld(dy), _p(r), _ld(r), _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
-                          0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
-                          _p(self.g[name + "/bias"]), _p(ws), nb, st)
+            self._timed("bn_bwd", 2 * self._nb(dy, r) + self._nb(dz), L.unet_bn_bwd,
+                        _p(dy), _ld(dy), _p(r), _ld(r), _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
+                        0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
+                        _p(self.g[name + "/bias"]), _p(ws), nb, st)
         w_, dw = self.p[name + "/kernel"], self.g[name + "/kernel"]
         hi, wi = x.shape[1], x.shape[2]
         dx = None
@@ -611,7 +615,8 @@ class Engine:
                 L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
-                L.unet_conv1x1_wgrad(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                self._timed("classmap_wgrad", self._nb(x, dz), L.unet_conv1x1_wgrad,
+                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif lp.wgrad == "bf16":
                 nb2 = L.unet_conv3x3_wgrad_bf16_workspace(n, ho, wo, cin, cout)
                 self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16,
@@ -634,8 +639,8 @@ class Engine:
                             _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             else:
                 nb2 = L.unet_conv3x3_wgrad_direct_workspace(n, ho, wo, cin, cout)
-                L.unet_conv3x3_wgrad_direct(_p(x), _ld(x), _p(dz), cout, z16, _p(dw), n, ho, wo, cin, cout,
-                                            _p(self._workspace(nb2, sd)), nb2, st2)
+                self._timed("first_layer_wgrad", self._nb(x, dz), L.unet_conv3x3_wgrad_direct,
+                            _p(x), _ld(x), _p(dz), cout, z16, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             if self.on_layer_grads_ready is not None:
                 self.on_layer_grads_ready(name)          # under the stream the gradients were produced on
 
@@ -670,7 +675,7 @@ class Engine:
             elif kind == "deconv":
                 L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
-                L.unet_conv1x1_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, int(dx16), P, cin, cout, st)
+                self._timed("classmap_dgrad", self._nb(dz, dx), L.unet_conv1x1_dgrad, _p(dz), cout, _p(w_), _p(dx), cin, int(dx16), P, cin, cout, st)
             elif lp.dgrad == "bf16":
                 self._timed("conv3x3_dgrad_bf16", fl, L.unet_conv3x3_dgrad_bf16,
                             _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx16), n, ho, wo, cin, cout,
@@ -724,7 +729,8 @@ class Engine:
                 d = self._block_bwd("conv_%db" % lvl, ds, pool_grad=(d, self.idx[lvl]))       # no separate pool-backward pass
             else:
                 assert d.dtype == ds.dtype, (lvl, d.dtype, ds.dtype)
-                L.unet_maxpool2x2_bwd(_p(d), _ld(d), _p(self.idx[lvl]), _p(ds), _ld(ds), n, hh, ww, ch, 1, int(ds.dtype == torch.bfloat16), st)
+                self._timed("pool", self._nb(d, self.idx[lvl]) + 2 * self._nb(ds), L.unet_maxpool2x2_bwd,
+                            _p(d), _ld(d), _p(self.idx[lvl]), _p(ds), _ld(ds), n, hh, ww, ch, 1, int(ds.dtype == torch.bfloat16), st)
                 if lvl == 4 and not eval_mode:
                     self._dropout(ds, "drop_4", self.masks)
                 d = b("conv_%db" % lvl, ds)
@@ -741,8 +747,9 @@ class Engine:
         self._eval_folded.clear(); self._eval_coefs.clear()
         t = self.iterations
         alpha = learning_rate * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
-        self.L.unet_adam_keras(_p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v), self.n_flat, alpha,
-                               ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self._stream())
+        self._timed("adam", 7.0 * 4 * self.n_flat, self.L.unet_adam_keras,          # reads theta, g, m, v; writes theta, m, v
+                    _p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v), self.n_flat, alpha,
+                    ADAM_BETA1, ADAM_BETA2, ADAM_EPS, self._stream())
 
     def argmax(self, prob):
         n, h, w, k = prob.shape

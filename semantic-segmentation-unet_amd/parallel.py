@@ -20,6 +20,20 @@ import torch.distributed as dist
 from .engine import BACKWARD_ORDER
 
 
+def make_buckets(layer_range, bucket_bytes):
+    """contiguous buckets of the flat gradient buffer in gradient-readiness order (logits ... conv_1a): [(start, end, last layer)];
+    a bucket closes behind the layer that takes it past `bucket_bytes`"""
+    buckets, start = [], None
+    for name in BACKWARD_ORDER:
+        a, b = layer_range[name]
+        if start is None:
+            start = a
+        if (b - start) * 4 >= bucket_bytes or name == BACKWARD_ORDER[-1]:
+            buckets.append((start, b, name))
+            start = None
+    return buckets
+
+
 class DataParallel:
     OVERLAP_WORKGROUPS = 224
 
@@ -29,29 +43,23 @@ class DataParallel:
         self.group = process_group
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
-        # contiguous buckets in gradient-readiness order (logits ... conv_1a)
-        self.buckets = []            # (start, end, last_layer_name)
-        start = None
-        for name in BACKWARD_ORDER:
-            a, b = engine.layer_range[name]
-            if start is None:
-                start = a
-            if (b - start) * 4 >= bucket_bytes or name == BACKWARD_ORDER[-1]:
-                self.buckets.append((start, b, name))
-                start = None
+        self.buckets = make_buckets(engine.layer_range, bucket_bytes)            # (start, end, last_layer_name)
         self._trigger = {last: i for i, (_, _, last) in enumerate(self.buckets)}
         self._pending = []
         self.force = force            # tests: issue the collectives even with a single rank
         self.trace = None             # tests / profiling: list of (bucket index, event recorded on the issuing stream right before its all-reduce)
+        self.done_trace = None        # ... and (bucket index, event on the compute stream right behind the wait for that all-reduce)
         engine.on_layer_grads_ready = self._on_layer
         # every replica draws its OWN dropout masks (MirroredStrategy replicas do); the init seed stays common -- parameters are
         # broadcast from rank 0 anyway
         if hasattr(engine, "dropout_seed"):
             engine.dropout_seed = engine.dropout_seed * self.world_size + self.rank
-        # Overlap-ready by construction: the fused Winograd weight gradient is a persistent grid of 512-register workgroups that owns every
-        # CU it gets, so a collective's kernels enqueued behind it would wait for it to drain.  With more than one replica it is capped
-        # at OVERLAP_WORKGROUPS (~4 CUs per XCD stay free); tests/test_gpu_overlap.py shows on one GPU that a side-stream copy kernel then
-        # completes under the weight gradients, and does not without the cap.  (No N > 1 hardware run has confirmed it for RCCL itself.)
+        # Overlap-ready by construction: the fused Winograd weight gradient is a persistent grid of 512-register workgroups, one per CU.  A
+        # bucket's all-reduce is released right behind its last weight gradient, into a natural gap of the side stream, so its kernels START
+        # at once (tests/test_gpu_overlap.py measures 0.02-0.35 ms release-to-completion for a stand-in kernel, capped or not); but they then
+        # hold their CUs for the 0.2-1.4 ms a 25 MB bucket takes over xGMI, and a 256-workgroup weight gradient launched meanwhile would run
+        # its last workgroups as a second wave.  With more than one replica the grid is therefore capped at OVERLAP_WORKGROUPS (~4 CUs per XCD
+        # stay free; +12 % on the kernel alone, 0.3 ms gained in the single-GPU step).  (No N > 1 hardware run has confirmed it for RCCL.)
         if (self.world_size > 1 or force) and hasattr(engine, "opt") and not engine.opt.wgrad_workgroups:
             engine.opt.wgrad_workgroups = self.OVERLAP_WORKGROUPS
         if broadcast and (self.world_size > 1 or force):
@@ -76,11 +84,14 @@ class DataParallel:
             import torch
             ev = torch.cuda.Event(enable_timing=True); ev.record()
             self.trace.append((i, ev))
-        self._pending.append(dist.all_reduce(self.engine.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._pending.append((i, dist.all_reduce(self.engine.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def finish_step(self):
-        for w in self._pending:
+        for i, w in self._pending:
             w.wait()                 # makes the compute stream wait for the collective; no host sync on nccl
+            if self.done_trace is not None:
+                ev = torch.cuda.Event(enable_timing=True); ev.record()
+                self.done_trace.append((i, ev))
         self._pending = []
 
     def reduce_sum(self, t):

@@ -169,10 +169,9 @@ def _level(name):
     return int(name.split("_")[1][0])
 
 
-def build_plan(opt, number_channels, number_classes, n, h, w, training, want_grad, L, gamma_ok=True):
-    """opt: EngineOptions; L: the C library binding (shape predicates only -- no device work); gamma_ok: no BatchNorm gamma is exactly 0
-    (BatchNorm-apply on load divides by it)."""
-    pl = StepPlan(n, h, w, bool(training), bool(want_grad), opt.key() + (bool(gamma_ok),))
+def build_plan(opt, number_channels, number_classes, n, h, w, training, want_grad, L):
+    """opt: EngineOptions; L: the C library binding (shape predicates only -- no device work)."""
+    pl = StepPlan(n, h, w, bool(training), bool(want_grad), opt.key())
     bf = opt.compute_dtype == "bf16"
     train = bool(training)
     two_gib = 2 ** 31
@@ -272,7 +271,7 @@ def build_plan(opt, number_channels, number_classes, n, h, w, training, want_gra
     # ---- BatchNorm-apply on load (fp32 fused Winograd route): producer -> consumer pairs whose intermediate is never materialised ---------
     def can_defer(a, b):
         pb = pl.layer[b]
-        return (opt.bn_on_load and not bf and opt.wgrad_route == "fused" and pb.fwd == "winograd" and pb.wgrad == "winograd" and gamma_ok
+        return (opt.bn_on_load and not bf and opt.wgrad_route == "fused" and pb.fwd == "winograd" and pb.wgrad == "winograd"
                 and pl.layer[a].y == F32)
     for lvl in (1, 2, 3, 4):
         for a, b in (("conv_%da" % lvl, "conv_%db" % lvl), ("dec_%da" % lvl, "dec_%db" % lvl), ("up_%d" % lvl, "dec_%da" % lvl)):

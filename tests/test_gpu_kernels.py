@@ -1076,6 +1076,47 @@ def test_winograd_batchnorm_apply_on_load_matches_two_passes(hip, shape):
         assert np.abs(dw.cpu().numpy() - dw64).max() < 3e-5 * sw
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 18, 34, 64, 128), (1, 8, 8, 256, 256)])
+def test_winograd_batchnorm_apply_on_load_with_vanishing_scales(hip, shape):
+    # Dead / pruned channels: BatchNorm scale s = gamma / sqrt(var + eps) of magnitude 0, 1e-38, 1e-30, 1e-6, 1e-4, 1e-2 (both signs) on
+    # half of the input channels, shift = O(1): the padding value -t / s is then up to 1e30 in magnitude.  The folded forward must still
+    # match the fp64 oracle evaluated with the TRUE scales (0 included) at the usual bound, borders and corners included, and so must the
+    # fold-corrected weight gradient (csrc/winograd.hip, "Conditioning").
+    n, h, w, ci, co = shape
+    g = torch.Generator(device=DEV).manual_seed(h * w + ci + 1)
+    ldx = ci + 4
+    r = torch.relu(torch.randn(n, h, w, ldx, device=DEV, generator=g))
+    sc = (torch.rand(ci, device=DEV, generator=g) + 0.5) * (torch.randint(0, 2, (ci,), device=DEV, generator=g).float() * 2 - 1)
+    tiny = [0.0, -0.0, 1e-38, -1e-38, 1e-30, -1e-30, 1e-6, -1e-6, 1e-4, -1e-4, 1e-2, -1e-2]
+    for j in range(0, ci, 2):
+        sc[j] = tiny[(j // 2) % len(tiny)]
+    sh = torch.randn(ci, device=DEV, generator=g) * 3 + 2.0
+    wt = torch.randn(3, 3, ci, co, device=DEV, generator=g) * 0.05; b = torch.randn(co, device=DEV, generator=g)
+    Uf = torch.empty(16 * ci * co, device=DEV); bf = torch.empty(co, device=DEV); pad = torch.empty(ci + 8, device=DEV)
+    nbf = hip.unet_winograd_weight_fold_workspace(ci, co); wsf = ws_bytes(nbf)
+    hip.unet_winograd_weight_fold(P(wt), P(b), P(sc), P(sh), P(Uf), P(bf), P(pad), ci, co, P(wsf), nbf, ST())
+    out = torch.empty(n, h, w, co, device=DEV)
+    hip.unet_conv3x3_fwd_winograd_fused(P(r), ldx, P(pad), P(Uf), P(bf), P(out), co, n, h, w, ci, co, 1, None, 0, ST())
+    assert torch.isfinite(pad).all() and pad.abs().max().item() <= 1.0001e30 * max(1.0, sh.abs().max().item())
+    assert torch.isfinite(Uf).all() and torch.isfinite(out).all()
+    yref = (sc.double() * r.double()[..., :ci] + sh.double()).cpu().numpy()
+    ref = on.relu_fwd(on.conv_same_fwd(yref.transpose(0, 3, 1, 2), wt.double().cpu().numpy(), b.double().cpu().numpy())).transpose(0, 2, 3, 1)
+    scale_ = np.abs(ref).max()
+    err = np.abs(out.cpu().numpy() - ref)
+    border = np.ones((h, w), bool); border[1:-1, 1:-1] = False
+    assert err.max() < 3e-5 * scale_ and err[:, border].max() < 3e-5 * scale_, (err.max() / scale_, err[:, border].max() / scale_)
+    dz = torch.randn(n, h, w, co, device=DEV, generator=g)
+    if hip.unet_winograd_wgrad_fused_supported(n, h, w, ci, co) == 1:
+        nbw = hip.unet_conv3x3_wgrad_winograd_fused_workspace(n, h, w, ci, co, 0); wsw = ws_bytes(nbw)
+        dw = torch.empty(3, 3, ci, co, device=DEV)
+        hip.unet_conv3x3_wgrad_winograd_fused(P(r), ldx, P(dz), co, P(dw), n, h, w, ci, co, 0, P(wsw), nbw, ST())
+        total = dz.sum((0, 1, 2)).contiguous()
+        nb8 = hip.unet_conv3x3_wgrad_fold_fix_workspace(co); ws8 = ws_bytes(nb8)
+        hip.unet_conv3x3_wgrad_fold_fix(P(dw), P(sc), P(sh), P(dz), co, P(total), n, h, w, ci, co, P(ws8), nb8, ST())
+        _, dw64, _ = on.conv_same_bwd(yref.transpose(0, 3, 1, 2), wt.double().cpu().numpy(), dz.double().cpu().numpy().transpose(0, 3, 1, 2))
+        assert np.abs(dw.cpu().numpy() - dw64).max() < 3e-5 * np.abs(dw64).max()
+
+
 @pytest.mark.parametrize("shape", [(8, 512, 512, 64, 64), (8, 256, 256, 128, 128), (3, 200, 328, 64, 128), (2, 520, 300, 64, 64), (8, 512, 512, 128, 64)])
 def test_conv3x3_bf16_persistent_kernels_equal_the_per_tile_kernels_at_full_size(hip, shape):
     # The persistent kernels (bf16-stored input, output and saved activation: LDS-DMA patch staging, a workgroup walks tiles t, t + grid,

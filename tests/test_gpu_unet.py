@@ -514,6 +514,67 @@ def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
     assert worst[0] < tol, sorted(errs.items(), key=lambda t: -t[1])[:6]
 
 
+def _dead_channel_case(seed, n, c, k, hw):
+    """make_case with dead / pruned channels in EVERY layer: |gamma| in {0, 1e-6, 1e-4, 1e-2} (both signs) on every third channel,
+    beta = O(1), moving statistics far from the batch statistics"""
+    img, lab, prm, masks = make_case(seed, n, c, k, hw)
+    rng = np.random.default_rng(seed + 1)
+    tiny = np.array([0.0, 1e-6, -1e-4, 1e-2, -1e-6, 1e-4, -1e-2], np.float32)
+    for key in prm:
+        if key.endswith("gamma"):
+            g = prm[key].copy()
+            g[::3] = tiny[np.arange(len(g[::3])) % len(tiny)]
+            prm[key] = g
+        if key.endswith("beta"):
+            prm[key] = rng.normal(0, 1.0, prm[key].shape).astype(np.float32)
+        if key.endswith("moving_mean"):
+            prm[key] = rng.normal(2.0, 1.0, prm[key].shape).astype(np.float32)
+        if key.endswith("moving_var"):
+            prm[key] = rng.uniform(0.05, 4.0, prm[key].shape).astype(np.float32)
+    return img, lab, prm, masks
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, 2, 32), (1, 3, 4, 64), (2, 1, 2, (48, 80))])
+@pytest.mark.parametrize("on_load", [True, False])
+def test_dead_channels_keep_parity_on_both_batchnorm_routes(cfg, on_load):
+    # BatchNorm-apply on load (13 layers of the fp32 route) folds scale and shift into the consumer's weights and a per-channel padding
+    # value -shift / scale: checked here in the regime where that value is huge or undefined -- gamma exactly 0 and |gamma| down to 1e-6
+    # with beta = O(1) in every layer -- against the fp64 oracle at the usual bounds: eval-mode softmax 2e-5 with identical arg-max mask
+    # (moving statistics far from the batch's), training loss 1e-5, every gradient 1e-4 given the device run's branch decisions.  The
+    # two-pass route (on_load=False) runs the same case: both routes are the product, neither is a fallback for the other any more.
+    n, c, k, hw = cfg
+    img, lab, prm, masks = _dead_channel_case(97, n, c, k, hw)
+    model = pkg("model")
+    net = model.UNet(k, n, c)
+    e = net.engine
+    e.opt.bn_on_load = on_load
+    e.load_parameters(prm)
+    ref = on.OracleUNet(k, n, c, params=prm, dtype=np.float64)
+    sm = net.get_keras_model()(img)
+    hh, ww = hw if isinstance(hw, tuple) else (hw, hw)
+    odd = (hh // 16) % 2 or (ww // 16) % 2              # an odd bottleneck tile takes the implicit-GEMM kernels: bott_a is then materialised
+    assert sum(p.defer_y for p in e.pl.layer.values()) == ((12 if odd else 13) if on_load else 0)
+    sm_ref, _ = ref.forward(img, training=False)
+    assert np.abs(sm - sm_ref).max() < 2e-5
+    ok, undecided, differ = argmax_agreement(sm, sm_ref)
+    assert ok and differ == 0, (undecided, differ)
+    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+    e.backward()
+    torch.cuda.synchronize()
+    relu = {name: (e.saved[name][1].float().permute(0, 3, 1, 2) > 0).cpu().numpy() for name, kind, _, _ in e.layers if kind != "deconv"}
+    pidx = {"pool_%d" % l: e.idx[l].permute(0, 3, 1, 2).cpu().numpy().astype(np.int64) for l in (1, 2, 3, 4)}
+    loss_ref, _, g_ref, _, _ = ref.loss_and_grads(img, lab, masks, relu_masks=relu, pool_idx=pidx)
+    assert abs(e.loss_buf[0].item() - loss_ref) < 1e-5 * abs(loss_ref)
+    g_hip = e.export_gradients()
+    errs = grad_errors(g_hip, g_ref)
+    for l in (1, 2, 3, 4):
+        errs.pop("up_%d/bias" % l)
+    worst = max((v, key) for key, v in errs.items())
+    hh, ww = hw if isinstance(hw, tuple) else (hw, hw)
+    tol = 5e-4 if n * (hh // 16) * (ww // 16) <= 4 else 1e-4
+    assert worst[0] < tol, sorted(errs.items(), key=lambda t: -t[1])[:6]
+
+
 def test_clipped_probability_cross_entropy_mode_matches_oracle():
     # Contract.ce_from_softmax_logits = False (the other (K) reading of Keras' CategoricalCrossentropy(from_logits=False)):
     # engine.ce_clip_eps = 1e-7 against the oracle with the same switch -- loss and gradients, same tolerances as the default
