@@ -46,3 +46,19 @@ for h, c in [(512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)]:
     print("bf16 %4d^2 x %4d ch (%5.0f MB)  apply %6.3f ms %5.2f TB/s | bwd (reduce+apply) %6.3f ms %5.2f TB/s"
           % (h, c, byts / 1e6, t1, 2 * byts / t1 / 1e9, t2, 5 * byts / t2 / 1e9), flush=True)
 print("TOTAL bf16 apply %.2f ms  bwd %.2f ms" % tuple(tot))
+# the form 16 of 23 layers take in the mixed-precision step: sums from a data-gradient epilogue (finalize + ONE apply pass), all bf16
+tot = 0.0
+for h, c in [(512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)]:
+    npx = B * h * h
+    r = torch.randn(B, h, h, c, device="cuda").to(torch.bfloat16); dy = torch.randn(B, h, h, c, device="cuda").to(torch.bfloat16)
+    dz = torch.empty_like(r)
+    g = torch.ones(c, device="cuda"); mean, invstd, dg, db, dbias = [torch.rand(c, device="cuda") for _ in range(5)]
+    rows = 64
+    part = torch.rand((c // 64) * rows * 128, device="cuda")
+    nb = L.unet_bn_workspace(npx, c); ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
+    t2 = timeit(lambda: L.unet_bn_bwd_any(P(dy), c, None, 0, None, B, h, h, P(r), c, P(g), P(mean), P(invstd), c, 1, P(dz), c, 1, P(dg), P(db), P(dbias),
+                                          P(part), rows, P(ws), nb, ST(), 1, 1, 0))
+    byts = npx * c * 2.0
+    tot += t2
+    print("bf16 %4d^2 x %4d ch  bwd from partial sums (finalize + apply + colsum) %6.3f ms %5.2f TB/s" % (h, c, t2, 3 * byts / t2 / 1e9), flush=True)
+print("TOTAL bf16 bwd-from-partials %.2f ms" % tot)

@@ -1,0 +1,34 @@
+"""What-if timing of the mixed-precision training step: the step time with one kernel family replaced by a no-op (results are wrong -- this
+only measures how much of the step's critical path the family holds once the two streams overlap).  usage: step_whatif.py [bf16|fp32]"""
+import os, sys, time, importlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+model = importlib.import_module("semantic-segmentation-unet_amd.model")
+c, k = (3, 4) if dtype == "bf16" else (1, 2)
+net = model.UNet(k, 8, c, seed=0, compute_dtype=dtype)
+L = net.engine.L
+g = torch.Generator().manual_seed(0)
+img = torch.randn(8, c, 512, 512, generator=g).cuda()
+lab = torch.nn.functional.one_hot(torch.randint(0, k, (8, 512, 512), generator=g), k).to(torch.int32).cuda()
+def run(steps=20):
+    for _ in range(4): net.train_step((img, lab, None, None))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): net.train_step((img, lab, None, None))
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / steps * 1e3
+base = run()
+print("baseline %.3f ms" % base, flush=True)
+fams = {"bf16": ["unet_conv3x3_wgrad_bf16", "unet_conv3x3_dgrad_bf16", "unet_conv3x3_fwd_bf16", "unet_bn_bwd_any", "unet_bn_apply_any",
+                 "unet_convT2x2_wgrad_bf16", "unet_convT2x2_dgrad_bf16", "unet_convT2x2_fwd_bf16", "unet_bn_train_finalize_partials",
+                 "unet_conv3x3_wgrad_direct", "unet_conv3x3_fwd_direct_stats", "unet_conv1x1_wgrad", "unet_conv1x1_dgrad", "unet_conv1x1_fwd",
+                 "unet_bf16_pack_weights_batch", "unet_adam_keras"],
+        "fp32": ["unet_conv3x3_wgrad_winograd_fused", "unet_conv3x3_dgrad_winograd_fused", "unet_conv3x3_fwd_winograd_fused", "unet_bn_bwd_from_partials",
+                 "unet_bn_bwd_pooled", "unet_bn_bwd", "unet_bn_apply", "unet_bn_apply_maxpool", "unet_convT2x2_wgrad", "unet_convT2x2_dgrad",
+                 "unet_convT2x2_fwd_stream_stats", "unet_winograd_weight_fold", "unet_conv3x3_wgrad_fold_fix", "unet_winograd_weight_transform_batch"]}[dtype]
+for name in fams:
+    orig = getattr(L, name)
+    setattr(L, name, lambda *a: 0)
+    t = run()
+    setattr(L, name, orig)
+    print("without %-40s %.3f ms  (%+.3f)" % (name, t, t - base), flush=True)

@@ -11,6 +11,8 @@
 
 namespace {
 
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
 template <int VEC> __device__ __forceinline__ void vload(float (&v)[VEC], const float* p) {
     if constexpr (VEC == 8) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(p), u = *reinterpret_cast<const f32x4*>(p + 4);
@@ -452,6 +454,121 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
 }
 
+// backward pass 2 with dy, r AND dz stored as bf16 (the mixed-precision training step: every wide layer), 8 channels = 16 bytes per lane.
+// Same arithmetic, same order of additions as bn_bwd_apply_kernel<8> -- dz is bit-identical and the per-lane sums are formed over the same
+// groups of four pixels -- but the loaded words stay PACKED until they are used: 8 pixels in flight cost 64 registers instead of the 128
+// unpacked floats (+ the fp32-storage code path) of the generic kernel, which sits at 200 VGPRs = 2 waves per SIMD and streams at
+// 3.8 TB/s; this one keeps 4+ waves per SIMD.
+__device__ __forceinline__ void bwd16_pixel(const uint4& g, const uint4& v, const float (&A)[8], const float (&Bc)[8], const float (&K)[8],
+                                            int relu, float (&sum)[8], uint4& o) {
+    const unsigned gw[4] = {g.x, g.y, g.z, g.w}, vw[4] = {v.x, v.y, v.z, v.w};
+    unsigned ow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v0 = bf_lo(vw[j]), v1 = bf_hi(vw[j]);
+        float d0 = fmaf(A[2 * j], bf_lo(gw[j]), fmaf(Bc[2 * j], v0, K[2 * j]));
+        float d1 = fmaf(A[2 * j + 1], bf_hi(gw[j]), fmaf(Bc[2 * j + 1], v1, K[2 * j + 1]));
+        if (relu && !(v0 > 0.f)) d0 = 0.f;
+        if (relu && !(v1 > 0.f)) d1 = 0.f;
+        sum[2 * j] += d0; sum[2 * j + 1] += d1;
+        ow[j] = bn_pack2(d0, d1);
+    }
+    o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+
+// Addressing: buffer loads / stores with the lane's (pixel lane, channel group) part as the one per-lane offset register and the pixel
+// step in the SCALAR offset -- 64-bit per-load addresses would cost 2 registers for each of the 24 accesses in flight.
+__global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const uint16_t* __restrict__ dy, int lddy, const uint16_t* __restrict__ r,
+        int ldr, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+        const float* __restrict__ dgamma, const float* __restrict__ dbeta, long P, int C, int tpp, long ppb, int relu,
+        uint16_t* __restrict__ dz, int lddz, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double sRd[];
+    constexpr int VEC = 8;
+    const Lay l = make_lay<VEC>(C, tpp);
+    const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P) p1 = P;
+    double acc[1][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = 0.0;
+    if (l.active) {
+        float A[VEC], Bc[VEC], K[VEC];
+        {
+            float mu[VEC], is[VEC], ga[VEC], dg[VEC], db[VEC];
+            vload<VEC>(mu, mean + l.c0); vload<VEC>(is, invstd + l.c0); vload<VEC>(ga, gamma + l.c0);
+            vload<VEC>(dg, dgamma + l.c0); vload<VEC>(db, dbeta + l.c0);
+            const float invP = 1.0f / (float)P;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float a = ga[e] * is[e], c1 = db[e] * invP, c2 = dg[e] * invP;
+                A[e] = a; Bc[e] = -(a * (c2 * is[e])); K[e] = a * (c2 * is[e] * mu[e] - c1);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t sy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((size_t)P * lddy * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)r, 0, (int)((size_t)P * ldr * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t sz = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (int)((size_t)P * lddz * 2), 0x00020000);
+        const int vy = (l.pl * lddy + l.c0) * 2, vr = (l.pl * ldr + l.c0) * 2, vz = (l.pl * lddz + l.c0) * 2;
+        const int st = l.npl;
+        long base = p0;                                           // uniform: pixel of pixel-lane 0 in this step; the lane's pixel = base + l.pl
+        // main loop: 8 steps while EVERY pixel lane of the block is inside the range (uniform trip count, scalar offsets)
+        for (; base + (st - 1) + 7L * st < p1; base += 8L * st) {
+            i32x4v g[8], v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                g[u] = __builtin_amdgcn_raw_buffer_load_b128(sy, vy, (int)((base + (long)u * st) * lddy * 2), 0);
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(sr, vr, (int)((base + (long)u * st) * ldr * 2), 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                        // sums over groups of four pixels, as the generic kernel forms them
+                float sum4[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sum4[e] = 0.f;
+#pragma unroll
+                for (int u = 4 * h; u < 4 * h + 4; ++u) {
+                    uint4 o;
+                    bwd16_pixel(make_uint4(g[u][0], g[u][1], g[u][2], g[u][3]), make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]), A, Bc, K, relu, sum4, o);
+                    const i32x4v ov = {(int)o.x, (int)o.y, (int)o.z, (int)o.w};
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, sz, vz, (int)((base + (long)u * st) * lddz * 2), 0);
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[0][e] += (double)sum4[e];
+            }
+        }
+        // the end of the range: per lane, groups of four and then single pixels (the same grouping as the generic kernel's)
+        const uint16_t* dyc = dy + l.c0; const uint16_t* rc = r + l.c0; uint16_t* dzc = dz + l.c0;
+        long pix = base + l.pl;
+        for (; pix + 3L * st < p1; pix += 4L * st) {
+            uint4 g[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = *reinterpret_cast<const uint4*>(dyc + (size_t)(pix + (long)u * st) * lddy);
+                v[u] = *reinterpret_cast<const uint4*>(rc + (size_t)(pix + (long)u * st) * ldr);
+            }
+            float sum4[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum4[e] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint4 o;
+                bwd16_pixel(g[u], v[u], A, Bc, K, relu, sum4, o);
+                *reinterpret_cast<uint4*>(dzc + (size_t)(pix + (long)u * st) * lddz) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[0][e] += (double)sum4[e];
+        }
+        for (; pix < p1; pix += st) {
+            const uint4 g = *reinterpret_cast<const uint4*>(dyc + (size_t)pix * lddy), v = *reinterpret_cast<const uint4*>(rc + (size_t)pix * ldr);
+            float s1[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s1[e] = 0.f;
+            uint4 o;
+            bwd16_pixel(g, v, A, Bc, K, relu, s1, o);
+            *reinterpret_cast<uint4*>(dzc + (size_t)pix * lddz) = o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[0][e] += (double)s1[e];
+        }
+    }
+    block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
+}
+
 // ---- the two backward passes for a layer whose output also went through MaxPool2D(2) (PoolGrad): a lane owns one POOLED pixel
 // (and its channel group) per step -- it loads the pooled gradient and the first-max indices once and walks the 2x2 window, instead
 // of every one of the four window pixels fetching them again through the cache (the per-pixel form ran at 2.1-2.6 TB/s).
@@ -561,6 +678,126 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const float* __r
     block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
 }
 
+// The two pooled passes with dy, r, the pooled gradient AND dz stored as bf16 (encoder levels 1-3 of the mixed-precision step): packed
+// registers and buffer addressing as in bn_bwd_apply16_kernel; same arithmetic and the same order of additions as the generic
+// window-per-lane kernels above (which sit at 138-146 VGPRs, 3 waves per SIMD, ~3.8 TB/s).
+struct Pool16 { i32x4v g[4], v[4], pd; unsigned ixlo, ixhi; };
+
+__device__ __forceinline__ void pool16_load(Pool16& w, const __amdgpu_buffer_rsrc_t& sy, const __amdgpu_buffer_rsrc_t& sr,
+                                            const __amdgpu_buffer_rsrc_t& sp, const uint8_t* __restrict__ idx, long op, int c0, int C,
+                                            int lddy, int ldr, int ldp, int H, int W) {
+    const int W2 = W >> 1, H2 = H >> 1;
+    long t = op; const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const long n = t / H2;
+    w.pd = __builtin_amdgcn_raw_buffer_load_b128(sp, (int)((op * ldp + c0) * 2), 0, 0);
+    const uint2 ix = *reinterpret_cast<const uint2*>(idx + (size_t)op * C + c0);
+    w.ixlo = ix.x; w.ixhi = ix.y;
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+        const long pix = (n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1);
+        w.g[pos] = __builtin_amdgcn_raw_buffer_load_b128(sy, (int)((pix * lddy + c0) * 2), 0, 0);
+        w.v[pos] = __builtin_amdgcn_raw_buffer_load_b128(sr, (int)((pix * ldr + c0) * 2), 0, 0);
+    }
+}
+__device__ __forceinline__ float bf_elem(const i32x4v& q, int e) { const unsigned wd = (unsigned)q[e >> 1]; return (e & 1) ? bf_hi(wd) : bf_lo(wd); }
+__device__ __forceinline__ int pool16_winner(const Pool16& w, int e) { return (int)(((e < 4 ? w.ixlo : w.ixhi) >> (8 * (e & 3))) & 0xffu); }
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool16_kernel(const uint16_t* __restrict__ dy, int lddy, const uint16_t* __restrict__ r,
+        int ldr, const float* __restrict__ mean, long P, long P2, int C, int tpp, long ppb, double* __restrict__ part, PoolGrad pg) {
+    extern __shared__ __attribute__((aligned(16))) double sRd[];
+    constexpr int VEC = 8;
+    const Lay l = make_lay<VEC>(C, tpp);
+    const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P2) p1 = P2;
+    double acc[2][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { acc[0][e] = 0.0; acc[1][e] = 0.0; }
+    if (l.active) {
+        float mu[VEC]; vload<VEC>(mu, mean + l.c0);
+        const __amdgpu_buffer_rsrc_t sy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((size_t)P * lddy * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)r, 0, (int)((size_t)P * ldr * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc((void*)pg.pdy, 0, (int)((size_t)P2 * pg.ldp * 2), 0x00020000);
+        for (long op = p0 + l.pl; op < p1; op += l.npl) {
+            Pool16 w;
+            pool16_load(w, sy, sr, sp, pg.idx, op, l.c0, C, lddy, ldr, pg.ldp, pg.H, pg.W);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int win = pool16_winner(w, e);
+                const float pd = bf_elem(w.pd, e);
+                float g[4];
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) { g[pos] = bf_elem(w.g[pos], e); if (win == pos) g[pos] += pd; }
+                const float s0 = (g[0] + g[1]) + (g[2] + g[3]);
+                float s1 = g[0] * (bf_elem(w.v[0], e) - mu[e]);
+                s1 = fmaf(g[1], bf_elem(w.v[1], e) - mu[e], s1); s1 = fmaf(g[2], bf_elem(w.v[2], e) - mu[e], s1); s1 = fmaf(g[3], bf_elem(w.v[3], e) - mu[e], s1);
+                acc[0][e] += (double)s0; acc[1][e] += (double)s1;
+            }
+        }
+    }
+    block_combine<VEC, 2>(acc, l, C, part, gridDim.x, sRd);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool16_kernel(const uint16_t* __restrict__ dy, int lddy, const uint16_t* __restrict__ r,
+        int ldr, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+        const float* __restrict__ dgamma, const float* __restrict__ dbeta, long P, long P2, int C, int tpp, long ppb, int relu,
+        uint16_t* __restrict__ dz, int lddz, double* __restrict__ part, PoolGrad pg) {
+    extern __shared__ __attribute__((aligned(16))) double sRd[];
+    constexpr int VEC = 8;
+    const Lay l = make_lay<VEC>(C, tpp);
+    const long p0 = (long)blockIdx.x * ppb; long p1 = p0 + ppb; if (p1 > P2) p1 = P2;
+    const int H2 = pg.H >> 1, W2 = pg.W >> 1;
+    double acc[1][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = 0.0;
+    if (l.active) {
+        float A[VEC], Bc[VEC], K[VEC];
+        {
+            float mu[VEC], is[VEC], ga[VEC], dg[VEC], db[VEC];
+            vload<VEC>(mu, mean + l.c0); vload<VEC>(is, invstd + l.c0); vload<VEC>(ga, gamma + l.c0);
+            vload<VEC>(dg, dgamma + l.c0); vload<VEC>(db, dbeta + l.c0);
+            const float invP = 1.0f / (float)P;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float a = ga[e] * is[e], c1 = db[e] * invP, c2 = dg[e] * invP;
+                A[e] = a; Bc[e] = -(a * (c2 * is[e])); K[e] = a * (c2 * is[e] * mu[e] - c1);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t sy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((size_t)P * lddy * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)r, 0, (int)((size_t)P * ldr * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc((void*)pg.pdy, 0, (int)((size_t)P2 * pg.ldp * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t sz = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (int)((size_t)P * lddz * 2), 0x00020000);
+        for (long op = p0 + l.pl; op < p1; op += l.npl) {
+            Pool16 w;
+            pool16_load(w, sy, sr, sp, pg.idx, op, l.c0, C, lddy, ldr, pg.ldp, pg.H, pg.W);
+            long t = op; const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const long n = t / H2;
+            float sum4[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum4[e] = 0.f;
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                const long pix = (n * pg.H + 2 * oy + (pos >> 1)) * pg.W + 2 * ox + (pos & 1);
+                i32x4v ov;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float d[2];
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const int e = 2 * j + k2;
+                        const float ge = bf_elem(w.g[pos], e) + (pool16_winner(w, e) == pos ? bf_elem(w.pd, e) : 0.f);
+                        const float ve = bf_elem(w.v[pos], e);
+                        float dd = fmaf(A[e], ge, fmaf(Bc[e], ve, K[e]));
+                        if (relu && !(ve > 0.f)) dd = 0.f;
+                        d[k2] = dd; sum4[e] += dd;
+                    }
+                    ov[j] = (int)bn_pack2(d[0], d[1]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(ov, sz, (int)((pix * lddz + l.c0) * 2), 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[0][e] += (double)sum4[e];
+        }
+    }
+    block_combine<VEC, 1>(acc, l, C, part, gridDim.x, sRd);
+}
+
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* out) {
     __shared__ double sh[4];
     const int c = blockIdx.x;
@@ -611,6 +848,12 @@ template <class K> int resident_grid(K kernel, size_t smem) {
 }
 template <int VEC> int reduce_grid(size_t smem) { static int g = 0; if (!g) g = resident_grid(bn_bwd_reduce_kernel<VEC>, smem); return g; }
 template <int VEC> int apply_grid(size_t smem) { static int g = 0; if (!g) g = resident_grid(bn_bwd_apply_kernel<VEC>, smem); return g; }
+int pool16_grid(int which, size_t smem) {
+    static int g[2] = {0, 0};
+    if (!g[which]) g[which] = which ? resident_grid(bn_bwd_apply_pool16_kernel, smem) : resident_grid(bn_bwd_reduce_pool16_kernel, smem);
+    return g[which];
+}
+int apply16_grid(size_t smem) { static int g = 0; if (!g) g = resident_grid(bn_bwd_apply16_kernel, smem); return g; }
 
 // BatchNorm apply (+ 2x2 max pool when pooled != null) for any storage mix; picks the lane layout
 int launch_bn_apply(const float* r, int ldr, int r16, const float* scale, const float* shift, float* y, int ldy, int y16,
@@ -735,11 +978,27 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
         if (nb_r > nb) nb_r = (int)nb;
         if (nb_a > nb) nb_a = (int)nb;
     }
+    // all four tensors of a pooled layer stored as bf16 (and below 2 GiB: 32-bit buffer offsets): the packed-register kernels, on grids
+    // of their own resident size
+    const size_t ldmax = (size_t)(lddy > ldr ? (lddy > lddz ? lddy : lddz) : (ldr > lddz ? ldr : lddz));
+    const bool small16 = (size_t)P * ldmax * 2 < ((size_t)1 << 31);
+    const bool pool16 = pooled_form && pl.vec == 8 && dt == 7 && pg.p16 && small16 && pg.ldp % 8 == 0;
+    if (pool16) {
+        const long npl = 256 / pl.tpp;
+        long nb = (Pw + npl * 4 - 1) / (npl * 4); if (nb < 1) nb = 1;
+        nb_r = pl.nblk; nb_a = pl.nblk;
+        const int cr = pool16_grid(0, pl.smem2), ca = pool16_grid(1, pl.smem1);
+        if (nb_r > cr) nb_r = cr;
+        if (nb_a > ca) nb_a = ca;
+        if (nb_r > nb) nb_r = (int)nb;
+        if (nb_a > nb) nb_a = (int)nb;
+    }
     const long ppb_r = (Pw + nb_r - 1) / nb_r, ppb_a = (Pw + nb_a - 1) / nb_a;
     if (part_sums) {
         bn_bwd_finalize_partials_kernel<<<C, 256, 0, st>>>(part_sums, rows, C, mean, invstd, dgamma, dbeta);
     } else {
-        if (pooled_form && pl.vec == 8) bn_bwd_reduce_pool_kernel<8><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, Pw, C, pl.tpp, ppb_r, part, pg, dt);
+        if (pool16) bn_bwd_reduce_pool16_kernel<<<nb_r, 256, pl.smem2, st>>>((const uint16_t*)dy, lddy, (const uint16_t*)r, ldr, mean, P, Pw, C, pl.tpp, ppb_r, part, pg);
+        else if (pooled_form && pl.vec == 8) bn_bwd_reduce_pool_kernel<8><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, Pw, C, pl.tpp, ppb_r, part, pg, dt);
         else if (pooled_form)      bn_bwd_reduce_pool_kernel<4><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, Pw, C, pl.tpp, ppb_r, part, pg, dt);
         else if (pl.vec == 8) bn_bwd_reduce_kernel<8><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, ppb_r, part, pg, dt);
         else if (pl.vec == 4) bn_bwd_reduce_kernel<4><<<nb_r, 256, pl.smem2, st>>>(dy, lddy, r, ldr, mean, invstd, P, C, pl.tpp, ppb_r, part, pg, dt);
@@ -749,6 +1008,16 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     }
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     double* part2 = part + (size_t)2 * MAX_BLOCKS * C;
+    if (pool16) {
+        bn_bwd_apply_pool16_kernel<<<nb_a, 256, pl.smem1, st>>>((const uint16_t*)dy, lddy, (const uint16_t*)r, ldr, gamma, mean, invstd, dgamma, dbeta,
+                                                                P, Pw, C, pl.tpp, ppb_a, relu, (uint16_t*)dz, lddz, part2, pg);
+    } else if (dt == 7 && pl.vec == 8 && !pg.pdy && small16) {
+        // dy, r and dz all stored as bf16: the packed-register kernel, on a grid of its own resident size
+        int nb16 = pl.nblk; const int c16 = apply16_grid(pl.smem1); if (nb16 > c16) nb16 = c16;
+        bn_bwd_apply16_kernel<<<nb16, 256, pl.smem1, st>>>((const uint16_t*)dy, lddy, (const uint16_t*)r, ldr, gamma, mean, invstd, dgamma, dbeta,
+                                                           P, C, pl.tpp, (P + nb16 - 1) / nb16, relu, (uint16_t*)dz, lddz, part2);
+        nb_a = nb16;
+    } else
     if (pooled_form && pl.vec == 8) bn_bwd_apply_pool_kernel<8><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, Pw, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
     else if (pooled_form)      bn_bwd_apply_pool_kernel<4><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, Pw, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
     else if (pl.vec == 8) bn_bwd_apply_kernel<8><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
