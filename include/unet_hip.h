@@ -28,8 +28,8 @@ extern "C" {
 #define UNET_ENOSPC (-2)
 
 /* Bumped whenever an exported signature changes; a loader must refuse a library whose unet_hip_abi_version() differs
- * (2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
-#define UNET_HIP_ABI_VERSION 2
+ * (3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
+#define UNET_HIP_ABI_VERSION 3
 int unet_hip_abi_version(void);
 
 /* ---- Conv2D(3x3, 'same', relu) of UNet._conv_layer, UNet/model.py:28-35 (18 instances, :88-134) ------------------ */
@@ -209,11 +209,16 @@ int unet_bn_bwd(const float* dy, int lddy, const float* r, int ldr, const float*
 int unet_bn_bwd_pooled(const float* dy_skip, int lddy, const float* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
                        const float* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
                        float* dz, int lddz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, void* stream);
-/* all three forms in one call (pooled_dy/idx nullable, part_sums nullable), dz optionally stored as bf16 (dz_bf16 != 0) */
+/* all three forms in one call (pooled_dy/idx nullable, part_sums nullable), dz optionally stored as bf16 (dz_bf16 != 0).
+ * host_bias_rows (HOST pointer, nullable): when given, the bias gradient sum(dz) is not finalized here (dbias may be NULL): its
+ * per-block partial sums stay in `ws`, *host_bias_rows receives their row count, and unet_bn_bwd_bias(ws, rows, C, dbias, stream)
+ * finishes it -- on any stream ordered behind this call, typically beside the layer's weight gradient: nothing on the critical chain
+ * BatchNorm backward -> data gradient needs the bias gradient.  `ws` must not be reused until then. */
 int unet_bn_bwd_any(const void* dy, int lddy, const void* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
                     const void* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
                     void* dz, int lddz, int dz_bf16, float* dgamma, float* dbeta, float* dbias, const float* part_sums, int rows,
-                    void* ws, size_t ws_bytes, void* stream, int r_bf16, int dy_bf16, int pooled_dy_bf16);
+                    void* ws, size_t ws_bytes, void* stream, int r_bf16, int dy_bf16, int pooled_dy_bf16, int* host_bias_rows);
+int unet_bn_bwd_bias(const void* ws, int rows, int C, float* dbias, void* stream);
 /* BatchNorm apply (+ the 2x2 max pool when pooled / idx are given) with the conv output it reads (r_bf16) and / or what it writes
  * (y_bf16: y and pooled) stored as bf16 */
 int unet_bn_apply_any(const void* r, int ldr, int r_bf16, const float* scale, const float* shift, void* y, int ldy, int y_bf16,

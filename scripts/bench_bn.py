@@ -40,7 +40,7 @@ for h, c in [(512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)]:
     nb = L.unet_bn_workspace(npx, c); ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
     t1 = timeit(lambda: L.unet_bn_apply_any(P(r), c, 1, P(scale), P(shift), P(y), c, 1, None, 0, None, B, h, h, c, ST()))
     t2 = timeit(lambda: L.unet_bn_bwd_any(P(dy), c, None, 0, None, B, h, h, P(r), c, P(g), P(mean), P(invstd), c, 1, P(dz), c, 1, P(dg), P(db), P(dbias),
-                                          None, 0, P(ws), nb, ST(), 1, 1, 0))
+                                          None, 0, P(ws), nb, ST(), 1, 1, 0, None))
     byts = npx * c * 2.0
     tot[0] += t1; tot[1] += t2
     print("bf16 %4d^2 x %4d ch (%5.0f MB)  apply %6.3f ms %5.2f TB/s | bwd (reduce+apply) %6.3f ms %5.2f TB/s"
@@ -57,7 +57,7 @@ for h, c in [(512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)]:
     part = torch.rand((c // 64) * rows * 128, device="cuda")
     nb = L.unet_bn_workspace(npx, c); ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
     t2 = timeit(lambda: L.unet_bn_bwd_any(P(dy), c, None, 0, None, B, h, h, P(r), c, P(g), P(mean), P(invstd), c, 1, P(dz), c, 1, P(dg), P(db), P(dbias),
-                                          P(part), rows, P(ws), nb, ST(), 1, 1, 0))
+                                          P(part), rows, P(ws), nb, ST(), 1, 1, 0, None))
     byts = npx * c * 2.0
     tot += t2
     print("bf16 %4d^2 x %4d ch  bwd from partial sums (finalize + apply + colsum) %6.3f ms %5.2f TB/s" % (h, c, t2, 3 * byts / t2 / 1e9), flush=True)

@@ -476,8 +476,10 @@ __device__ __forceinline__ void bwd16_pixel(const uint4& g, const uint4& v, cons
     o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
-// Addressing: buffer loads / stores with the lane's (pixel lane, channel group) part as the one per-lane offset register and the pixel
-// step in the SCALAR offset -- 64-bit per-load addresses would cost 2 registers for each of the 24 accesses in flight.
+// Addressing: buffer loads / stores with 32-bit per-lane offsets (the lane's part + a uniform step, one add per access) -- 64-bit
+// per-access addresses would cost 2 registers for each of the 24 accesses in flight.  (The uniform part went into the instruction's SCALAR
+// offset at first: a few stores per launch then landed wrong at full size -- 0.05 % of the elements, sums intact -- in a pattern that
+// pointed at the scalar-offset path and was not understood further; the end-to-end training test on the reference's tiles caught it.)
 __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const uint16_t* __restrict__ dy, int lddy, const uint16_t* __restrict__ r,
         int ldr, const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
         const float* __restrict__ dgamma, const float* __restrict__ dbeta, long P, int C, int tpp, long ppb, int relu,
@@ -513,8 +515,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const uint16_t* __r
             i32x4v g[8], v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                g[u] = __builtin_amdgcn_raw_buffer_load_b128(sy, vy, (int)((base + (long)u * st) * lddy * 2), 0);
-                v[u] = __builtin_amdgcn_raw_buffer_load_b128(sr, vr, (int)((base + (long)u * st) * ldr * 2), 0);
+                g[u] = __builtin_amdgcn_raw_buffer_load_b128(sy, vy + (int)((base + (long)u * st) * lddy * 2), 0, 0);
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(sr, vr + (int)((base + (long)u * st) * ldr * 2), 0, 0);
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                        // sums over groups of four pixels, as the generic kernel forms them
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const uint16_t* __r
                     uint4 o;
                     bwd16_pixel(make_uint4(g[u][0], g[u][1], g[u][2], g[u][3]), make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]), A, Bc, K, relu, sum4, o);
                     const i32x4v ov = {(int)o.x, (int)o.y, (int)o.z, (int)o.w};
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, sz, vz, (int)((base + (long)u * st) * lddz * 2), 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, sz, vz + (int)((base + (long)u * st) * lddz * 2), 0, 0);
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[0][e] += (double)sum4[e];
@@ -949,9 +951,9 @@ extern "C" int unet_bn_apply_maxpool(const float* r, int ldr, const float* scale
 
 static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
         const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta, float* dbias,
-        const float* part_sums, int rows, PoolGrad pg, void* ws, size_t ws_bytes, void* stream, int dt = 0) {
+        const float* part_sums, int rows, PoolGrad pg, void* ws, size_t ws_bytes, void* stream, int dt = 0, int* host_bias_rows = nullptr) {
     // dt: bit 0 = dz stored as bf16, bit 1 = r stored as bf16, bit 2 = dy stored as bf16 (leading dimensions in elements)
-    UNET_CHECK_ARG(dy && r && gamma && mean && invstd && dz && dgamma && dbeta && dbias && ws && P > 0 && C > 0);
+    UNET_CHECK_ARG(dy && r && gamma && mean && invstd && dz && dgamma && dbeta && (dbias || host_bias_rows) && ws && P > 0 && C > 0);
     UNET_CHECK_ARG(lddy >= C && ldr >= C && lddz >= C);
     Plan pl;
     const bool al = unet_aligned16(dy) && unet_aligned16(r) && unet_aligned16(dz) && unet_aligned16(gamma) && unet_aligned16(mean) &&
@@ -1024,6 +1026,7 @@ static int bn_bwd_launch(const float* dy, int lddy, const float* r, int ldr, con
     else if (pl.vec == 4) bn_bwd_apply_kernel<4><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, dt);
     else                  bn_bwd_apply_kernel<1><<<nb_a, 256, pl.smem1, st>>>(dy, lddy, r, ldr, gamma, mean, invstd, dgamma, dbeta, P, C, pl.tpp, ppb_a, relu, dz, lddz, part2, pg, 0);
     rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    if (host_bias_rows) { *host_bias_rows = nb_a; return UNET_OK; }      // the caller finishes the bias gradient (unet_bn_bwd_bias), off the critical chain
     colsum_finalize_kernel<<<C, 256, 0, st>>>(part2, nb_a, C, dbias);
     return UNET_LAUNCH_STATUS();
 }
@@ -1061,13 +1064,22 @@ extern "C" int unet_bn_bwd_from_partials(const float* dy, int lddy, const float*
 extern "C" int unet_bn_bwd_any(const void* dy, int lddy, const void* pooled_dy, int ldp, const uint8_t* idx, int N, int H, int W,
         const void* r, int ldr, const float* gamma, const float* mean, const float* invstd, int C, int relu,
         void* dz, int lddz, int dz_bf16, float* dgamma, float* dbeta, float* dbias, const float* part_sums, int rows,
-        void* ws, size_t ws_bytes, void* stream, int r_bf16, int dy_bf16, int pooled_dy_bf16) {
+        void* ws, size_t ws_bytes, void* stream, int r_bf16, int dy_bf16, int pooled_dy_bf16, int* host_bias_rows) {
     UNET_CHECK_ARG(N > 0 && H > 0 && W > 0 && (pooled_dy == nullptr) == (idx == nullptr));
     UNET_CHECK_ARG(!pooled_dy || (H % 2 == 0 && W % 2 == 0 && ldp >= C));
     UNET_CHECK_ARG(!part_sums || (rows > 0 && C % 64 == 0));
     const PoolGrad pg = pooled_dy ? PoolGrad{(const float*)pooled_dy, ldp, idx, H, W, C, pooled_dy_bf16 ? 1 : 0} : PoolGrad{nullptr, 0, nullptr, 0, 0, 0, 0};
     return bn_bwd_launch((const float*)dy, lddy, (const float*)r, ldr, gamma, mean, invstd, (long)N * H * W, C, relu, (float*)dz, lddz, dgamma, dbeta, dbias,
-                         part_sums, part_sums ? rows : 0, pg, ws, ws_bytes, stream, (dz_bf16 ? 1 : 0) | (r_bf16 ? 2 : 0) | (dy_bf16 ? 4 : 0));
+                         part_sums, part_sums ? rows : 0, pg, ws, ws_bytes, stream, (dz_bf16 ? 1 : 0) | (r_bf16 ? 2 : 0) | (dy_bf16 ? 4 : 0), host_bias_rows);
+}
+
+// The bias gradient sum(dz) of a unet_bn_bwd_any call that was given host_bias_rows: `ws` is that call's workspace (untouched since),
+// `rows` the value it returned.  Only the optimizer / the gradient exchange need it, so a caller runs this beside the layer's weight
+// gradient instead of in front of its data gradient.
+extern "C" int unet_bn_bwd_bias(const void* ws, int rows, int C, float* dbias, void* stream) {
+    UNET_CHECK_ARG(ws && dbias && rows > 0 && rows <= MAX_BLOCKS && C > 0);
+    colsum_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>((const double*)ws + (size_t)2 * MAX_BLOCKS * C, rows, C, dbias);
+    return UNET_LAUNCH_STATUS();
 }
 
 // BatchNorm apply (+ optional 2x2 max pool: pooled / idx non-null) with either side stored as bf16: r_bf16 (the conv output it

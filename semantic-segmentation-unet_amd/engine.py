@@ -553,50 +553,28 @@ class Engine:
         dz = self._buf("dz16_" + name, tuple(r.shape), torch.bfloat16) if dz16 else self._buf("dz_" + name, tuple(r.shape))
         pre = self.bnbwd_part.pop(name, None) if not eval_mode else None
         assert (pre is not None) == (lp.sums_from_dgrad and not eval_mode), name
-        if dz16 or (not eval_mode and (dy.dtype == torch.bfloat16 or r.dtype == torch.bfloat16)):
-            # one entry point for the three forms (plain / pooled / sums from the consumer's data gradient), any of dy / r / dz stored as bf16
+        bias_rows = None
+        if eval_mode:
+            L.unet_bn_eval_bwd(_p(dy), _ld(dy), _p(r), _ld(r), _p(self.coef[name][0]), _p(dz), cout, P, cout, 0 if kind == "deconv" else 1, st)
+        else:
+            # one entry point for the three forms (plain / pooled / sums from the consumer's data gradient: no reduction pass), any of dy /
+            # r / dz stored as bf16.  The bias gradient sum(dz) is left as per-block partials in the layer's own workspace and finished beside
+            # the weight gradient (unet_bn_bwd_bias below): nothing on the chain BatchNorm backward -> data gradient needs it.
             part_ptr, rows = None, 0
             if pre is not None:
                 part, rows, c0 = pre
                 part_ptr = ctypes.c_void_p(part.data_ptr() + (c0 // 64) * rows * 128 * 4)
-            pdy, pidx = pool_grad if (pool_grad is not None and pre is None) else (None, None)
+            pdy, pidx = pool_grad if pool_grad is not None else (None, None)
             assert not (pool_grad is not None and pre is not None)
             nb = L.unet_bn_workspace(P, cout)
-            ws = self._workspace(nb)
+            bnws = self._buf("bnws_" + name, (int(nb) + 256,), torch.uint8)
+            bias_rows = ctypes.c_int(0)
             self._timed("bn_bwd", (1 if pre is not None else 2) * self._nb(dy, r, pdy, pidx if pdy is not None else None) + self._nb(dz), L.unet_bn_bwd_any,
                         _p(dy), _ld(dy), _p(pdy), _ld(pdy) if pdy is not None else 0, _p(pidx), n, ho, wo, _p(r), _ld(r),
                         _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), cout, 0 if kind == "deconv" else 1, _p(dz), cout, int(dz.dtype == torch.bfloat16),
-                        _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]), _p(self.g[name + "/bias"]), part_ptr, rows,
-                        _p(ws), nb, st, int(r.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16),
-                        int(pdy is not None and pdy.dtype == torch.bfloat16))
-        elif eval_mode:
-            L.unet_bn_eval_bwd(_p(dy), _ld(dy), _p(r), _ld(r), _p(self.coef[name][0]), _p(dz), cout, P, cout, 0 if kind == "deconv" else 1, st)
-        elif pre is not None:
-            # sum(dy), sum(dy*r) already came out of the consumer layer's data-gradient kernel: no reduction pass
-            part, rows, c0 = pre
-            nb = L.unet_bn_workspace(P, cout)
-            ws = self._workspace(nb)
-            self._timed("bn_bwd", self._nb(dy, r, dz), L.unet_bn_bwd_from_partials,
-                        _p(dy), _ld(dy), _p(r), _ld(r), _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
-                        0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
-                        _p(self.g[name + "/bias"]), ctypes.c_void_p(part.data_ptr() + (c0 // 64) * rows * 128 * 4), rows,
-                        _p(ws), nb, st)
-        elif pool_grad is not None:
-            # dy = skip gradient + un-pooled gradient of the level below, formed inside the BatchNorm-backward kernels
-            pdy, pidx = pool_grad
-            nb = L.unet_bn_workspace(P, cout)
-            ws = self._workspace(nb)
-            self._timed("bn_bwd", 2 * self._nb(dy, r, pdy, pidx) + self._nb(dz), L.unet_bn_bwd_pooled,
-                        _p(dy), _ld(dy), _p(pdy), _ld(pdy), _p(pidx), n, ho, wo, _p(r), _ld(r), _p(self.p[name + "/gamma"]),
-                        _p(s[0]), _p(s[1]), cout, 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
-                        _p(self.g[name + "/bias"]), _p(ws), nb, st)
-        else:
-            nb = L.unet_bn_workspace(P, cout)
-            ws = self._workspace(nb)
-            self._timed("bn_bwd", 2 * self._nb(dy, r) + self._nb(dz), L.unet_bn_bwd,
-                        _p(dy), _ld(dy), _p(r), _ld(r), _p(self.p[name + "/gamma"]), _p(s[0]), _p(s[1]), P, cout,
-                        0 if kind == "deconv" else 1, _p(dz), cout, _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]),
-                        _p(self.g[name + "/bias"]), _p(ws), nb, st)
+                        _p(self.g[name + "/gamma"]), _p(self.g[name + "/beta"]), None, part_ptr, rows,
+                        _p(bnws), nb, st, int(r.dtype == torch.bfloat16), int(dy.dtype == torch.bfloat16),
+                        int(pdy is not None and pdy.dtype == torch.bfloat16), ctypes.byref(bias_rows))
         w_, dw = self.p[name + "/kernel"], self.g[name + "/kernel"]
         hi, wi = x.shape[1], x.shape[2]
         dx = None
@@ -606,6 +584,7 @@ class Engine:
         def wgrad():
             sd = overlap
             st2 = self._stream()
+            L.unet_bn_bwd_bias(_p(bnws), bias_rows.value, cout, _p(self.g[name + "/bias"]), st2)
             if lp.wgrad == "convt_bf16":
                 nb2 = L.unet_convT2x2_wgrad_bf16_workspace(n, hi, wi, cin, cout)
                 L.unet_convT2x2_wgrad_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),

@@ -791,7 +791,7 @@ def test_bf16_stored_operands_bit_identical(hip):
     gr = [torch.empty(co, device=DEV) for _ in range(6)]
     hip.unet_bn_bwd(P(dy), co, P(r), co, P(gm), P(mean), P(invstd), n * h * w, co, 1, P(zf_), co, P(gr[0]), P(gr[1]), P(gr[2]), P(wsb), nbb, ST())
     hip.unet_bn_bwd_any(P(dy), co, None, 0, None, n, h, w, P(r), co, P(gm), P(mean), P(invstd), co, 1, P(zh), co, 1,
-                        P(gr[3]), P(gr[4]), P(gr[5]), None, 0, P(wsb), nbb, ST(), 0, 0, 0)
+                        P(gr[3]), P(gr[4]), P(gr[5]), None, 0, P(wsb), nbb, ST(), 0, 0, 0, None)
     assert torch.equal(zf_.to(torch.bfloat16), zh)
     assert all(torch.equal(gr[i], gr[i + 3]) for i in range(3))
 
@@ -977,7 +977,16 @@ def test_batchnorm_kernels_on_bf16_stored_tensors(hip, shape, mix):
             hip.unet_bn_bwd(P(dy32), ld, P(r32), ld, P(gm), P(mean), P(invstd), n * h * w, c, 1, P(z_ref), ld, P(gr[0]), P(gr[1]), P(gr[2]), P(wsb), nbb, ST())
         hip.unet_bn_bwd_any(P(dd), ld, P(pp) if pooled else None, ld if pooled else 0, P(ix_ref) if pooled else None, n, h, w, P(rr), ld,
                             P(gm), P(mean), P(invstd), c, 1, P(z), ld, int(o16f), P(gr[3]), P(gr[4]), P(gr[5]), None, 0, P(wsb), nbb, ST(),
-                            int(r16f), int(dy16f), int(dy16f))
+                            int(r16f), int(dy16f), int(dy16f), None)
+        # the deferred form of the bias gradient: same call with host_bias_rows, finished by unet_bn_bwd_bias -> the same bits
+        import ctypes as _ct
+        rows_ = _ct.c_int(0); gb = torch.empty_like(gr[5]); z2 = torch.empty_like(z)
+        hip.unet_bn_bwd_any(P(dd), ld, P(pp) if pooled else None, ld if pooled else 0, P(ix_ref) if pooled else None, n, h, w, P(rr), ld,
+                            P(gm), P(mean), P(invstd), c, 1, P(z2), ld, int(o16f), P(gr[3]), P(gr[4]), None, None, 0, P(wsb), nbb, ST(),
+                            int(r16f), int(dy16f), int(dy16f), _ct.byref(rows_))
+        assert rows_.value > 0
+        hip.unet_bn_bwd_bias(P(wsb), rows_.value, c, P(gb), ST())
+        assert torch.equal(gb, gr[5])
         for i in range(3):
             assert (gr[i] - gr[i + 3]).abs().max().item() <= 2e-6 * gr[i].abs().max().item() + 1e-7, (pooled, i)
         zr = z_ref[..., :c]
@@ -1074,6 +1083,47 @@ def test_winograd_batchnorm_apply_on_load_matches_two_passes(hip, shape):
         sw = np.abs(dw64).max()
         assert np.abs(dw_ref.cpu().numpy() - dw64).max() < 3e-5 * sw
         assert np.abs(dw.cpu().numpy() - dw64).max() < 3e-5 * sw
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 256, 64), (8, 512, 512, 64), (4, 256, 256, 128), (3, 200, 328, 64)])
+@pytest.mark.parametrize("pooled", [False, True])
+def test_bn_bwd_packed_bf16_kernels_equal_the_generic_kernels_at_full_size(hip, shape, pooled):
+    # The mixed-precision step's BatchNorm backward on all-bf16 tensors runs packed-register kernels (bn_bwd_apply16 / pool16); the same
+    # values with dy stored as fp32 take the generic kernels.  dz must be bit-identical and every sum equal to rounding -- at the sizes of
+    # the training step: multi-iteration block loops, 1024-block grids (a first version of the packed kernel was right at the small
+    # test shapes and stored 0.05 % of the elements wrong at these; only the 500-step training test on the reference's tiles noticed).
+    n, h, w, c = shape
+    g = torch.Generator(device=DEV).manual_seed(c + h)
+    bf = torch.bfloat16
+    r = torch.relu(torch.randn(n, h, w, c, device=DEV, generator=g)).to(bf); dy = torch.randn(n, h, w, c, device=DEV, generator=g).to(bf)
+    pdy = torch.randn(n, h // 2, w // 2, c, device=DEV, generator=g).to(bf)
+    idx = torch.randint(0, 4, (n, h // 2, w // 2, c), device=DEV, generator=g, dtype=torch.uint8)
+    gm = torch.rand(c, device=DEV, generator=g) + 0.5; mean = torch.rand(c, device=DEV, generator=g); inv = torch.rand(c, device=DEV, generator=g) + 0.5
+    nb = hip.unet_bn_workspace(n * h * w, c); ws = ws_bytes(nb)
+    outs = []
+    for dy16 in (1, 0):
+        d = dy if dy16 else dy.float()
+        pp = pdy if dy16 else pdy.float()
+        dz = torch.zeros(n, h, w, c, device=DEV, dtype=bf)
+        gr = [torch.empty(c, device=DEV) for _ in range(3)]
+        hip.unet_bn_bwd_any(P(d), c, P(pp) if pooled else None, c if pooled else 0, P(idx) if pooled else None, n, h, w, P(r), c, P(gm), P(mean), P(inv),
+                            c, 1, P(dz), c, 1, P(gr[0]), P(gr[1]), P(gr[2]), None, 0, P(ws), nb, ST(), 1, dy16, dy16, None)
+        outs.append((dz, gr))
+    (za, ga), (zb, gb) = outs
+    assert torch.equal(za, zb)
+    for i in range(3):
+        assert (ga[i] - gb[i]).abs().max().item() <= 2e-6 * gb[i].abs().max().item() + 1e-6, i
+    # and against the formula itself (torch, from the device's own dgamma / dbeta): at most the odd rounding that falls the other way
+    dyt = dy.float()
+    if pooled:
+        up = torch.zeros(n, h, w, c, device=DEV)
+        for pos in range(4):
+            up[:, pos >> 1::2, pos & 1::2, :] = torch.where(idx == pos, pdy.float(), torch.zeros_like(pdy.float()))
+        dyt = dyt + up
+    a = gm * inv; c1 = ga[1] / (n * h * w); c2 = ga[0] / (n * h * w)
+    ref = a * dyt + (-(a * (c2 * inv))) * r.float() + a * (c2 * inv * mean - c1)
+    ref = torch.where(r.float() > 0, ref, torch.zeros_like(ref))
+    assert int(((za.float() - ref).abs() > 2.0 ** -7 * ref.abs() + 1e-3).sum().item()) == 0
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 18, 34, 64, 128), (1, 8, 8, 256, 256)])
