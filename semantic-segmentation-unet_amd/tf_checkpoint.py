@@ -40,15 +40,72 @@ MASK_DELTA = 0xa282ead8
 
 
 # ----------------------------------------------------------------------------------------------------------- crc32c / varints
+# CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) comes from the native library when it loads (hardware-speed: the data shard is
+# 124 MB); on a machine without the HIP build -- inspecting or converting a checkpoint elsewhere -- the numpy table-driven form below
+# takes over (slicing-by-8 tables, a Python loop over 8-byte words: a few MB/s -- instant for an index, about half a minute for the
+# data shard; `verify=False` skips it on reads), so this module needs nothing but numpy.
+_TABLES = None
+
+
+def _crc_tables():
+    global _TABLES
+    if _TABLES is None:
+        t = np.zeros((8, 256), np.uint32)
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+            t[0, i] = c
+        for k in range(1, 8):
+            t[k] = (t[k - 1] >> np.uint32(8)) ^ t[0][t[k - 1] & np.uint32(0xFF)]
+        _TABLES = t
+    return _TABLES
+
+
+def _crc32c_numpy(buf, init=0):
+    """CRC-32C of a bytes-like / uint8 array, continuing from `init` (same convention as the native unet_crc32c_extend)."""
+    t = _crc_tables()
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf.reshape(-1).view(np.uint8)
+    crc = (~init) & 0xFFFFFFFF
+    n = len(a)
+    i = 0
+    t0 = [int(v) for v in t[0]]
+    if n >= 64:
+        # the CRC of a long message is a sequential recurrence; process it 8 bytes at a time with the slicing-by-8 tables
+        m = (n // 8) * 8
+        words = a[:m].reshape(-1, 8)
+        tl = [tt.astype(np.uint64) for tt in t]
+        c = np.uint64(crc)
+        for w in words:                                   # (python-level loop over 8-byte words: fine for indexes, slow but correct for shards)
+            lo = (int(w[0]) | int(w[1]) << 8 | int(w[2]) << 16 | int(w[3]) << 24) ^ int(c)
+            c = (int(tl[7][lo & 0xFF]) ^ int(tl[6][(lo >> 8) & 0xFF]) ^ int(tl[5][(lo >> 16) & 0xFF]) ^ int(tl[4][(lo >> 24) & 0xFF])
+                 ^ int(tl[3][int(w[4])]) ^ int(tl[2][int(w[5])]) ^ int(tl[1][int(w[6])]) ^ int(tl[0][int(w[7])]))
+        crc = int(c)
+        i = m
+    for b in a[i:]:
+        crc = t0[(crc ^ int(b)) & 0xFF] ^ (crc >> 8)
+    return (~crc) & 0xFFFFFFFF
+
+
+def _native():
+    """the native CRC routine, or None where the HIP library cannot be loaded (no GPU toolchain / stale build)"""
+    try:
+        return _lib.lib().unet_crc32c_extend
+    except Exception:                                     # noqa: BLE001 -- any load failure means "use the fallback"
+        return None
+
+
 def crc32c(data, init=0):
     b = bytes(data)
-    return int(_lib.lib().unet_crc32c_extend(init, b, len(b)))
+    f = _native()
+    return int(f(init, b, len(b))) if f is not None else _crc32c_numpy(b, init)
 
 
 def crc32c_array(arr, init=0):
     """CRC of a C-contiguous numpy array without copying it."""
     a = np.ascontiguousarray(arr)
-    return int(_lib.lib().unet_crc32c_extend(init, a.ctypes.data, a.nbytes))
+    f = _native()
+    return int(f(init, a.ctypes.data, a.nbytes)) if f is not None else _crc32c_numpy(a, init)
 
 
 def mask_crc(c):

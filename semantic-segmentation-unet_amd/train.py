@@ -151,6 +151,20 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
         if rank == 0:
             writers = (_Scalars(os.path.join(output_folder, "tensorboard-" + stamp, "train")),
                        _Scalars(os.path.join(output_folder, "tensorboard-" + stamp, "test")))
+
+        def check_labels():
+            """The reference's reader raises IndexError on the first tile with a class id >= number_classes (UNet/imagereader.py:302-312).
+            The device feed only COUNTS such pixels (no host sync per batch), so the counter is polled every LABEL_CHECK_EVERY steps and
+            before anything is written; with several replicas the verdict is all-reduced (MAX) so that every rank raises on the same
+            step instead of one raising and the others waiting in the next collective."""
+            bad = sum(f.out_of_range_labels() for f in feeds if hasattr(f, "out_of_range_labels"))
+            if world > 1:
+                t = torch.tensor([float(bad)], device=dev_)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                bad = int(t.item())
+            if bad > 0:
+                raise IndexError("Number of classes specified differs from number of observed classes in data")
+
         epoch = 0
         while True:
             say("---- Epoch: {} ----".format(epoch))
@@ -174,6 +188,8 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
                     writers[0].scalar("accuracy", train_acc_metric.result(), epoch * train_epoch_size + step)
                 train_loss_metric.reset_states(); train_acc_metric.reset_states()
                 step += 1
+                if step % LABEL_CHECK_EVERY == 0:
+                    check_labels()
             epoch_test_loss = []
             step = 0
             while step <= test_epoch_size:
@@ -183,9 +199,7 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
                 epoch_test_loss.append(loss_value.numpy())
                 step += 1
             test_loss.append(float(np.mean(epoch_test_loss)))
-            for f in feeds:                                       # the reference's reader raises IndexError for a class id >= number_classes
-                if hasattr(f, "out_of_range_labels") and f.out_of_range_labels() > 0:          # (UNet/imagereader.py:302-312)
-                    raise IndexError("Number of classes specified differs from number of observed classes in data")
+            check_labels()                                         # before the csv / checkpoint of this epoch are written
             say("Test Epoch: {}: Loss = {} Accuracy = {}".format(epoch, test_loss_metric.result(), test_acc_metric.result()))
             if writers:
                 writers[1].scalar("loss", test_loss_metric.result(), (epoch + 1) * train_epoch_size)

@@ -137,6 +137,25 @@ def test_bundle_roundtrip_dtypes_strings_and_checksums(tfc, tmp_path):
     assert "model/a/.ATTRIBUTES/VARIABLE_VALUE" in tfc.read_bundle(stem, keys=lambda k: k.startswith("model/a"))
 
 
+def test_checkpoints_are_readable_and_writable_without_the_hip_library(tfc, tmp_path, monkeypatch):
+    # Inspecting / converting a checkpoint on a machine without the gfx950 build: the CRC falls back to the numpy table form.  Same
+    # checksums as the native routine (RFC 3720 vectors, random data, continuation), and a bundle written with one is read by the other.
+    assert tfc._crc32c_numpy(bytes(32)) == 0x8A9136AA and tfc._crc32c_numpy(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert tfc._crc32c_numpy(bytes(range(32))) == 0x46DD794E and tfc._crc32c_numpy(b"123456789") == 0xE3069283
+    r = np.random.default_rng(0).integers(0, 256, 30011, dtype=np.uint8)
+    assert tfc._crc32c_numpy(r) == tfc.crc32c_array(r) == tfc._crc32c_numpy(r[4097:], tfc._crc32c_numpy(r[:4097]))
+    t = {"model/a/.ATTRIBUTES/VARIABLE_VALUE": np.random.default_rng(1).standard_normal((3, 3, 4, 8)).astype(np.float32),
+         "_CHECKPOINTABLE_OBJECT_GRAPH": b"graph" * 9}
+    native_stem, fallback_stem = str(tmp_path / "n" / "ckpt"), str(tmp_path / "f" / "ckpt")
+    tfc.write_bundle(native_stem, t)
+    monkeypatch.setattr(tfc, "_native", lambda: None)                  # "the library cannot be loaded"
+    tfc.write_bundle(fallback_stem, t)
+    for ext in (".index", ".data-00000-of-00001"):
+        assert open(native_stem + ext, "rb").read() == open(fallback_stem + ext, "rb").read()
+    b = tfc.read_bundle(native_stem)
+    assert np.array_equal(b["model/a/.ATTRIBUTES/VARIABLE_VALUE"], t["model/a/.ATTRIBUTES/VARIABLE_VALUE"])
+
+
 def test_unet_variable_naming_and_object_graph(tfc):
     eng = pkg("engine")
     layers = eng.layer_table(1, 2)
