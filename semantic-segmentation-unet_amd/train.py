@@ -16,6 +16,7 @@ import json
 import os
 import time
 
+LABEL_CHECK_EVERY = 16          # train steps between polls of the device-side out-of-range-label counter (one 4-byte read)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before HIP initialises: RCCL needs dmabuf IPC on this platform
 
 import numpy as np
