@@ -46,15 +46,16 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything i
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, chip table (dense, spec)
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table: ~2.5 PF dense bf16 (spec)
+TRAFFIC_TAG = "r03"                  # profiles/<tag>_*_pmc_traffic.json of the current round
 WINOGRAD_MULT_RATIO = 2.25           # F(2x2,3x3): 36 direct multiplies per tile and channel pair -> 16
 
 FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16?, offline PMC traffic file)
-    "conv3x3_fwd_winograd_fused": ("wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "r02d_wino_fwd_pmc_traffic.json"),
-    "conv3x3_dgrad_winograd_fused": ("wino_fused_stream_kernel / _bnstats (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "r02d_wino_dgrad_pmc_traffic.json"),
-    "conv3x3_wgrad_winograd_fused": ("wino_wgrad_fused_kernel (3x3 conv weight gradient, Winograd F(2x2,3x3), reduce over tiles on v_mfma_f32_32x32x2_f32)", True, False, "r02d_wino_wgrad_pmc_traffic.json"),
-    "conv3x3_fwd_bf16": ("conv_bf16_stream_stats_kernel_{128,64} (3x3 conv forward + BatchNorm sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_fwd_pmc_traffic.json"),
-    "conv3x3_dgrad_bf16": ("conv_bf16_stream_bnbwd_kernel_{128,64} (3x3 conv data gradient + producer BatchNorm-backward sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "r02d_bf16_dgrad_pmc_traffic.json"),
-    "conv3x3_wgrad_bf16": ("wgrad_bf16_dma_kernel (3x3 conv weight gradient, pixel contraction on v_mfma_f32_32x32x16_bf16, LDS-DMA staging)", False, True, "r02d_bf16_wgrad_pmc_traffic.json"),
+    "conv3x3_fwd_winograd_fused": ("wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "wino_fwd_pmc_traffic.json"),
+    "conv3x3_dgrad_winograd_fused": ("wino_fused_stream_kernel / _bnstats (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "wino_dgrad_pmc_traffic.json"),
+    "conv3x3_wgrad_winograd_fused": ("wino_wgrad_fused_kernel (3x3 conv weight gradient, Winograd F(2x2,3x3), reduce over tiles on v_mfma_f32_32x32x2_f32)", True, False, "wino_wgrad_pmc_traffic.json"),
+    "conv3x3_fwd_bf16": ("conv_bf16_stream_stats_kernel_{128,64} (3x3 conv forward + BatchNorm sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "bf16_fwd_pmc_traffic.json"),
+    "conv3x3_dgrad_bf16": ("conv_bf16_stream_bnbwd_kernel_{128,64} (3x3 conv data gradient + producer BatchNorm-backward sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "bf16_dgrad_pmc_traffic.json"),
+    "conv3x3_wgrad_bf16": ("wgrad_bf16_dma_kernel (3x3 conv weight gradient, pixel contraction on v_mfma_f32_32x32x16_bf16, LDS-DMA staging)", False, True, "bf16_wgrad_pmc_traffic.json"),
 }
 
 
@@ -262,15 +263,21 @@ def roofline_of(kernels, workload_key):
          "launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"], "ms_per_step": v["ms_per_step"],
          "timing": "HIP events on the launch stream, sampled timed steps, single-stream backward (exclusive)",
          "traffic": None, "traffic_source": None}
-    tf = os.path.join(ROOT, "profiles", tfile)
-    if os.path.exists(tf):
+    # offline PMC passes of this round (scripts/collect_profiles.sh): config 2 / 4 files and the config-5 ones; the file must be FOR this workload
+    for tname in (TRAFFIC_TAG + "_" + tfile, TRAFFIC_TAG + "_config5_" + tfile):
+        tf = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tf):
+            continue
         t = json.load(open(tf))
         if t.get("workload") == workload_key and t.get("launches_per_step") == v["launches_per_step"]:
             r["traffic"] = round(t["hbm_bytes_per_launch"])
             ff = t.get("fetch_size_factor", 2.0)
             r["traffic_source"] = "offline PMC (profiles/%s; FETCH_SIZE x%g%s + WRITE_SIZE, separate passes)" % (
-                tfile, ff, " gfx950 correction" if ff == 2.0 else " (calibrated for this kernel's 16-byte gathers, see the file)")
+                tname, ff, " gfx950 correction" if ff == 2.0 else " (calibrated for this kernel's 16-byte gathers; the x2 reading is in the file)")
             r["algorithmic_bytes_per_launch"] = round(t["algorithmic_bytes_per_launch"])
+            if "hbm_bytes_per_launch_fetch_x2" in t:
+                r["traffic_fetch_x2"] = round(t["hbm_bytes_per_launch_fetch_x2"])
+            break
     return r
 
 

@@ -2,7 +2,10 @@
 # Collect the round's judged profiles on the GPU box:  scripts/collect_profiles.sh <tag>   (run from the repo root under gpurun)
 #   gpurun_out/<tag>_bench_{f32,bf16}_kernel_stats.txt            rocprofv3 --kernel-trace --stats of bench.py (two-stream backward)
 #   gpurun_out/<tag>_bench_{f32,bf16}_exclusive_kernel_stats.txt  the same with --no-overlap (every duration exclusive)
-#   gpurun_out/<tag>_{wino,bf16}_{fwd,dgrad,wgrad}_pmc_traffic.json   FETCH_SIZE / WRITE_SIZE in two separate --pmc passes
+#   gpurun_out/<tag>_{wino,bf16}_{fwd,dgrad,wgrad}_pmc_traffic.json   FETCH_SIZE / WRITE_SIZE in two separate --pmc passes (config 2 / config 4)
+#   gpurun_out/<tag>_config5_wino_{fwd,dgrad,wgrad}_pmc_traffic.json  the same at BASELINE config 5's per-GPU workload (1024x1024x3, 6 classes, batch 2)
+#   gpurun_out/<tag>_layer_table_{f32,bf16}.txt                    per-layer ms / executed TFLOP/s / mfma_busy of the 3x3 families inside the step
+#   gpurun_out/<tag>_overlap_standin.txt                           stand-in collective under the backward pass (scripts/overlap_probe.py)
 # Only --kernel-trace / --stats / --pmc are used (never combined with other trace domains); python3 itself follows `--`.
 set -e
 tag=$1; root=$(pwd); out=$root/gpurun_out; mkdir -p $out
@@ -41,4 +44,29 @@ python3 scripts/pmc_traffic.py $ff $fw wino_wgrad_fused_kernel 17 "512x512x1/2 c
 python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_stats_kernel,conv_bf16_stats_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 1 > $out/${tag}_bf16_fwd_pmc_traffic.json
 python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_bnbwd_kernel,conv_bf16_bnbwd_kernel,conv_bf16_stream_kernel_,conv_bf16_kernel_ 17 "512x512x3/4 classes/batch 8/bf16" $A16 1 > $out/${tag}_bf16_dgrad_pmc_traffic.json
 python3 scripts/pmc_traffic.py $bf $bw ::wgrad_bf16_dma_kernel,::wgrad_bf16_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 > $out/${tag}_bf16_wgrad_pmc_traffic.json
+# BASELINE config 5 (1024x1024x3, 6 classes, batch 2): same pixel count per step as config 2, so the same algorithmic bytes for the 17 layers
+C5="--size 1024 --channels 3 --classes 6 --batch 2"
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_c5_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_c5_$c -- python3 $root/bench.py $C5 --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-kernel-events --no-overlap > /tmp/pmc_c5_$c.log 2>&1
+  echo "pmc config5 $c done"
+done
+cf=$(find /tmp/pmc_c5_FETCH_SIZE -name "*counter_collection.csv" | head -1); cw=$(find /tmp/pmc_c5_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+cd $root
+python3 scripts/pmc_traffic.py $cf $cw wino_fused_stream_stats_kernel 17 "1024x1024x3/6 classes/batch 2/f32" $A32 > $out/${tag}_config5_wino_fwd_pmc_traffic.json
+python3 scripts/pmc_traffic.py $cf $cw wino_fused_stream_bnbwd_kernel,wino_fused_stream_kernel 17 "1024x1024x3/6 classes/batch 2/f32" $A32 > $out/${tag}_config5_wino_dgrad_pmc_traffic.json
+python3 scripts/pmc_traffic.py $cf $cw wino_wgrad_fused_kernel 17 "1024x1024x3/6 classes/batch 2/f32" $A32 > $out/${tag}_config5_wino_wgrad_pmc_traffic.json
+# per-layer table (ms, executed TFLOP/s, mfma_busy) of the three families inside one single-stream step, both precisions
+cd /tmp
+for d in f32 bf16; do
+  extra=""; ck="1 2"; if [ $d = bf16 ]; then extra=$BF; ck="3 4"; fi
+  rm -rf /tmp/pmc_busy_$d
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc_busy_$d -- python3 $root/bench.py $extra --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-kernel-events --no-overlap > /tmp/pmc_busy_$d.log 2>&1
+  bb=$(find /tmp/pmc_busy_$d -name "*counter_collection.csv" | head -1)
+  (cd $root && python3 scripts/layer_table.py $bb $d $ck > $out/${tag}_layer_table_$d.txt)
+  echo "layer table $d done"
+done
+cd $root
+python3 scripts/overlap_probe.py 2>/dev/null | grep wgrad_workgroups > $out/${tag}_overlap_standin.txt
 echo collected

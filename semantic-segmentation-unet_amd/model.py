@@ -116,7 +116,8 @@ class UNet:
         self.optimizer = _Optimizer(learning_rate)
         self.parallel = None         # set by parallel.DataParallel
 
-    # -- reference UNet/model.py:81-83 (tf.train.Checkpoint -> this build's own format, see checkpoint.py)
+    # -- reference UNet/model.py:81-83: tf.train.Checkpoint's own files (TensorBundle ckpt.index + ckpt.data-*, object-graph keys;
+    #    checkpoint.py / tf_checkpoint.py); round-1 .npz files still load
     def load_checkpoint(self, checkpoint_filepath):
         from .checkpoint import load_checkpoint
         load_checkpoint(self, checkpoint_filepath)
