@@ -666,6 +666,8 @@ int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, fl
     a.tby = (H + 15) / 16; a.tbx = (W + 31) / 32; a.n_px = N * a.tby * a.tbx;
     a.x_bytes = (unsigned)((size_t)N * H * W * ldx * (in16 ? 2 : 4));
     // 128-channel tiles halve the input traffic; 64-channel tiles when they would leave compute units idle
+    // (64-channel tiles for the K = 64 layers with 128 outputs -- two workgroups per CU hiding each other's epilogue -- were A/B-tested:
+    // 64->128 @256^2 forward 0.111 -> 0.107 ms, 64->128 @512^2 data gradient + sums 0.401 -> 0.421 ms: no gain, wide tiles stay)
     const bool wide = Cout % 128 == 0 && (long)a.n_px * (Cout / 128) >= conv_bf16_cus();
     a.n_co = Cout / (wide ? 128 : 64);
     const int mode = stats ? stats->mode : 0;

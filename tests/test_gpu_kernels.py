@@ -883,6 +883,44 @@ def test_convT2x2_bf16_wgrad_matches_oracle_on_rounded_operands(hip, shape):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("shape", [(8, 32, 32, 1024, 512), (8, 64, 64, 512, 256), (8, 128, 128, 256, 128), (8, 256, 256, 128, 64), (3, 100, 164, 128, 64)])
+def test_convT2x2_bf16_kernels_at_full_size_dma_staging_equals_register_staging(hip, shape):
+    # The four up-sampling layers of BASELINE config 4 at their real sizes (the oracle is too slow there): a bf16-stored operand takes the
+    # LDS-DMA staged kernels, the same values stored as fp32 the register-staged ones -- forward (+ BatchNorm sums), data gradient (+ the
+    # producer's backward sums) and weight gradient must be BIT-IDENTICAL between the two, with bf16-stored outputs as the step uses them.
+    # (Multi-tile persistent walks, thousands of partial rows, the 128- and 64-column kernels, one ragged shape.)
+    n, h, w, ci, co = shape
+    g = torch.Generator(device=DEV).manual_seed(ci + h)
+    bf = torch.bfloat16
+    x16 = torch.randn(n, h, w, ci, device=DEV, generator=g).to(bf); x32 = x16.float()
+    dz16 = (torch.randn(n, 2 * h, 2 * w, co, device=DEV, generator=g) * 0.1).to(bf); dz32 = dz16.float()
+    r16 = torch.relu(torch.randn(n, h, w, ci, device=DEV, generator=g)).to(bf)
+    wt = torch.randn(2, 2, co, ci, device=DEV, generator=g) / float(np.sqrt(ci)); b = torch.randn(co, device=DEV, generator=g)
+    nb = hip.unet_convT2x2_bf16_packed_bytes(ci, co); wp, wpd = ws_bytes(nb), ws_bytes(nb)
+    hip.unet_convT2x2_bf16_pack_weights(P(wt), P(wp), ci, co, 0, ST()); hip.unet_convT2x2_bf16_pack_weights(P(wt), P(wpd), ci, co, 1, ST())
+    rows = hip.unet_convT2x2_bf16_stats_rows(n, h, w, ci, co, 0); rows2 = hip.unet_convT2x2_bf16_stats_rows(n, h, w, ci, co, 1)
+    outs = []
+    for xin, xf, dzin, zf in ((x16, 1, dz16, 1), (x32, 0, dz32, 0)):
+        z = torch.empty(n, 2 * h, 2 * w, co, device=DEV, dtype=bf); part = torch.zeros((co // 64) * rows * 128, device=DEV)
+        hip.unet_convT2x2_fwd_bf16(P(xin), ci, xf, P(wp), P(b), P(z), co, 1, n, h, w, ci, co, P(part), part.numel() * 4, ST())
+        dx = torch.empty(n, h, w, ci, device=DEV, dtype=bf); part2 = torch.zeros((ci // 64) * rows2 * 128, device=DEV)
+        hip.unet_convT2x2_dgrad_bf16(P(dzin), co, zf, P(wpd), P(dx), ci, 1, n, h, w, ci, co, P(r16), ci, 1, P(part2), part2.numel() * 4, ST())
+        dxp = torch.empty(n, h, w, ci, device=DEV, dtype=bf)
+        hip.unet_convT2x2_dgrad_bf16(P(dzin), co, zf, P(wpd), P(dxp), ci, 1, n, h, w, ci, co, None, 0, 0, None, 0, ST())
+        nbw = hip.unet_convT2x2_wgrad_bf16_workspace(n, h, w, ci, co); wsw = ws_bytes(nbw); dw = torch.zeros(2, 2, co, ci, device=DEV)
+        hip.unet_convT2x2_wgrad_bf16(P(xin), ci, xf, P(dzin), co, zf, P(dw), n, h, w, ci, co, P(wsw), nbw, ST())
+        torch.cuda.synchronize()
+        outs.append((z, part, dx, part2, dxp, dw))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+    z, part, dx, part2, dxp, dw = outs[0]
+    assert torch.equal(dx, dxp) and torch.isfinite(dw).all() and dw.abs().max().item() > 0
+    # the fused sums are the sums of what was computed: forward against the stored (rounded) output, loosely; linearity of the forward
+    s1 = part.view(co // 64, rows, 64, 2).double().sum(1).view(co, 2)[:, 0]
+    ref1 = z.double().sum((0, 1, 2))
+    assert (s1 - ref1).abs().max().item() < 5e-3 * z.double().abs().sum((0, 1, 2)).max().item()
+
+
 def test_bf16_pack_weights_batch_matches_single_packs(hip):
     # one launch for every layer's operands == the per-layer pack kernels, bit for bit (3x3 and transposed-conv jobs mixed)
     g = torch.Generator(device=DEV); g.manual_seed(9)
