@@ -1,3 +1,6 @@
+"""bf16 weight-gradient kernel per layer shape.  Ablations are COMPILE-TIME now: build a variant with
+    scripts/build_variant.sh wgabl1 conv_bf16.hip "-DUNET_CB_ABLATE=1"      (1 = no MFMA stream, 2 = no staging, 4 = no LDS writes, 8 = no barrier)
+and run this script with UNET_HIP_LIB=semantic-segmentation-unet_amd/csrc/libunet_hip_wgabl1.so (results are wrong, timing only)."""
 import ctypes, os, sys, importlib
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -19,4 +22,4 @@ for name, h, ci, co in [("1b", 512, 64, 64), ("2b", 256, 128, 128), ("3b", 128, 
     nbw = L.unet_conv3x3_wgrad_bf16_workspace(B, h, h, ci, co); wsw = torch.empty(nbw + 256, dtype=torch.uint8, device="cuda")
     tw = timeit(lambda: L.unet_conv3x3_wgrad_bf16(P(x), ci, 1, P(dz), co, 1, P(dw), B, h, h, ci, co, P(wsw), nbw, ST()))
     fl = 2.0 * 9 * B * h * h * ci * co
-    print("%-7s ablate=%s wgrad %6.3f ms (%5.0f TF) ws %5.1f MB" % (name, os.environ.get("UNET_WGRAD_BF16_ABLATE", "0"), tw, fl / tw / 1e9, nbw / 1e6), flush=True)
+    print("%-7s lib=%s wgrad %6.3f ms (%5.0f TF) ws %5.1f MB" % (name, os.path.basename(os.environ.get("UNET_HIP_LIB", "default")), tw, fl / tw / 1e9, nbw / 1e6), flush=True)
