@@ -16,8 +16,10 @@ from . import unet_numpy as on
 
 
 class TorchUNet:
+    device = torch.device("cpu")          # (class default: objects assembled without __init__ in tests stay on the CPU)
+
     def __init__(self, number_classes, global_batch_size, number_channels, learning_rate=3e-4, label_smoothing=0,
-                 params=None, seed=0, dtype=torch.float32, contract=None):
+                 params=None, seed=0, dtype=torch.float32, contract=None, device="cpu"):
         self.number_classes = number_classes
         self.global_batch_size = global_batch_size
         self.number_channels = number_channels
@@ -25,9 +27,12 @@ class TorchUNet:
         self.label_smoothing = label_smoothing
         self.contract = contract or on.Contract()
         self.dtype = dtype
+        # device: "cpu" (the oracle proper, and bench.py's cpu_baseline) or "cuda": the same restatement on torch's own GPU kernels, used
+        # ONLY by tests as an independent implementation at sizes the CPU cannot reach (BASELINE config 2 at full size and batch)
+        self.device = torch.device(device)
         self.layers = on.layer_table(number_channels, number_classes)
         src = params if params is not None else on.init_params(number_channels, number_classes, seed)
-        self.params = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in src.items()}
+        self.params = {k: torch.tensor(np.asarray(v), dtype=dtype).to(self.device) for k, v in src.items()}
         self.trainable = on.trainable_names(number_channels, number_classes)
         for k in self.trainable:
             self.params[k].requires_grad_(True)
@@ -55,7 +60,7 @@ class TorchUNet:
         return (r - mu[None, :, None, None]) * (g * inv)[None, :, None, None] + bt[None, :, None, None]
 
     def forward(self, images, training=False, dropout_masks=None):
-        x = torch.as_tensor(np.asarray(images) if not torch.is_tensor(images) else images).to(self.dtype)
+        x = torch.as_tensor(np.asarray(images) if not torch.is_tensor(images) else images).to(self.dtype).to(self.device)
         L = {n: k for n, k, _, _ in self.layers}
         st = {}
         f = lambda name, t: self._block(name, L[name], t, training, st)
@@ -64,7 +69,7 @@ class TorchUNet:
         def drop(t, key):
             if not training:
                 return t
-            return t * torch.as_tensor(np.asarray(dropout_masks[key])).to(self.dtype) * scale
+            return t * torch.as_tensor(np.asarray(dropout_masks[key])).to(self.dtype).to(self.device) * scale
 
         s1 = f("conv_1b", f("conv_1a", x)); p1 = F.max_pool2d(s1, 2)
         s2 = f("conv_2b", f("conv_2a", p1)); p2 = F.max_pool2d(s2, 2)
@@ -79,7 +84,7 @@ class TorchUNet:
         return torch.softmax(logits, dim=-1), logits, st
 
     def loss(self, logits, labels):
-        y = torch.as_tensor(np.asarray(labels) if not torch.is_tensor(labels) else labels).to(self.dtype)
+        y = torch.as_tensor(np.asarray(labels) if not torch.is_tensor(labels) else labels).to(self.dtype).to(self.device)
         if self.label_smoothing:
             y = y * (1.0 - self.label_smoothing) + self.label_smoothing / y.shape[-1]
         if self.contract.ce_from_softmax_logits:
@@ -125,25 +130,25 @@ class TorchUNet:
     def predict_mask(self, images):
         with torch.no_grad():
             softmax, _, _ = self.forward(images, False)
-        return np.argmax(softmax.numpy(), axis=-1).astype(np.int32)
+        return np.argmax(softmax.cpu().numpy(), axis=-1).astype(np.int32)
 
     def input_gradient_eval(self, images, dprob):
         """d sum(dprob * softmax) / d image with the graph in eval mode (autograd)."""
-        x = torch.as_tensor(np.asarray(images)).to(self.dtype).requires_grad_(True)
+        x = torch.as_tensor(np.asarray(images)).to(self.dtype).to(self.device).requires_grad_(True)
         softmax, _, _ = self.forward(x, False)
-        (softmax * torch.as_tensor(np.asarray(dprob)).to(self.dtype)).sum().backward()
-        return x.grad.detach().numpy()
+        (softmax * torch.as_tensor(np.asarray(dprob)).to(self.dtype).to(self.device)).sum().backward()
+        return x.grad.detach().cpu().numpy()
 
     def estimate_radius(self, img):
         """UNet.estimate_radius (reference UNet/model.py:165-202) on a given probe image [1,C,N,N]."""
-        x = torch.as_tensor(np.asarray(img)).to(self.dtype).requires_grad_(True)
+        x = torch.as_tensor(np.asarray(img)).to(self.dtype).to(self.device).requires_grad_(True)
         mid = int(x.shape[2] / 2)
         softmax, _, _ = self.forward(x, False)
         msk = softmax.detach().clone()
         msk[0, mid, mid, :] = 1.0 - msk[0, mid, mid, :]
         loss = (msk - softmax).abs().mean(-1)                      # MeanAbsoluteError(reduction=NONE): [1,H,W]
         loss.sum().backward()                                      # tape.gradient of a non-scalar sums it
-        g = np.abs(x.grad[0].numpy())
+        g = np.abs(x.grad[0].cpu().numpy())
         g = np.average(g, axis=0) if g.shape[0] > 1 else g[0]
         vec = np.maximum(np.max(g, axis=0), np.max(g, axis=1))
         idx = np.nonzero(vec > 1e-8)[0]
@@ -153,4 +158,4 @@ class TorchUNet:
         return int(on.SIZE_FACTOR * np.ceil(float(erf) / on.SIZE_FACTOR))
 
     def numpy_params(self):
-        return {k: v.detach().numpy().copy() for k, v in self.params.items()}
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.params.items()}

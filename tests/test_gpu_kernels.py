@@ -915,10 +915,23 @@ def test_convT2x2_bf16_kernels_at_full_size_dma_staging_equals_register_staging(
         assert torch.equal(a, b_)
     z, part, dx, part2, dxp, dw = outs[0]
     assert torch.equal(dx, dxp) and torch.isfinite(dw).all() and dw.abs().max().item() > 0
-    # the fused sums are the sums of what was computed: forward against the stored (rounded) output, loosely; linearity of the forward
-    s1 = part.view(co // 64, rows, 64, 2).double().sum(1).view(co, 2)[:, 0]
-    ref1 = z.double().sum((0, 1, 2))
-    assert (s1 - ref1).abs().max().item() < 5e-3 * z.double().abs().sum((0, 1, 2)).max().item()
+    # ... and against an independent implementation at this size: torch's own transposed convolution, its input gradient (a stride-2
+    # convolution) and its weight gradient, on the same bf16-valued operands
+    wq = wt.to(bf).float().permute(3, 2, 0, 1).contiguous()                              # [ci][co][a][b] = W[a][b][co][ci]
+    F = torch.nn.functional
+    zref = F.conv_transpose2d(x32.permute(0, 3, 1, 2), wq, b, stride=2).permute(0, 2, 3, 1)
+    assert bool(((z.float() - zref).abs() <= 2.0 ** -7 * zref.abs() + 2e-5 * zref.abs().max()).all())
+    pv = part.view(co // 64, rows, 64, 2).double().sum(1).view(co, 2)
+    s1, s2 = zref.double().sum((0, 1, 2)), (zref.double() ** 2).sum((0, 1, 2))
+    assert (pv[:, 0] - s1).abs().max().item() < 1e-4 * zref.double().abs().sum((0, 1, 2)).max().item() and (pv[:, 1] - s2).abs().max().item() < 1e-4 * s2.abs().max().item()
+    dxref = F.conv2d(dz32.permute(0, 3, 1, 2), wq, stride=2).permute(0, 2, 3, 1)
+    assert bool(((dx.float() - dxref).abs() <= 2.0 ** -7 * dxref.abs() + 2e-5 * dxref.abs().max()).all())
+    pv2 = part2.view(ci // 64, rows2, 64, 2).double().sum(1).view(ci, 2)
+    t1, t2 = dxref.double().sum((0, 1, 2)), (dxref.double() * r16.double()).sum((0, 1, 2))
+    tol = 1e-4 * dxref.double().abs().sum((0, 1, 2)).max().item()
+    assert (pv2[:, 0] - t1).abs().max().item() < tol and (pv2[:, 1] - t2).abs().max().item() < tol
+    dwref = torch.nn.grad.conv2d_weight(dz32.permute(0, 3, 1, 2).contiguous(), (ci, co, 2, 2), x32.permute(0, 3, 1, 2).contiguous(), stride=2).permute(2, 3, 1, 0)
+    assert (dw - dwref).abs().max().item() < 1e-4 * dwref.abs().max().item()
 
 
 def test_bf16_pack_weights_batch_matches_single_packs(hip):
@@ -1231,6 +1244,18 @@ def test_conv3x3_bf16_persistent_kernels_equal_the_per_tile_kernels_at_full_size
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1]) and torch.equal(parts[0], parts[1]), stats
         assert outs[0].float().abs().max().item() > 0.1
+        if stats:
+            # ... and against an INDEPENDENT implementation at this size (both kernel forms share one epilogue): torch's own fp32 convolution
+            # of the same bf16-valued operands.  Output: equal but for roundings that fall the other way; fused sums: those of the fp32 values.
+            ref = torch.relu(torch.nn.functional.conv2d(x32.permute(0, 3, 1, 2), wt.to(bf).float().permute(3, 2, 0, 1).contiguous(), b, padding=1)).permute(0, 2, 3, 1)
+            got = outs[0].float()
+            d = (got - ref).abs()
+            assert bool((d <= 2.0 ** -7 * ref.abs() + 2e-5 * ref.abs().max()).all())
+            assert (got != ref.to(bf).float()).float().mean().item() < 0.02
+            pv = parts[0].view(co // 64, rows, 64, 2).double().sum(1).view(co, 2)
+            s1, s2 = ref.double().sum((0, 1, 2)), (ref.double() ** 2).sum((0, 1, 2))
+            assert (pv[:, 0] - s1).abs().max().item() < 1e-4 * s1.abs().max().item() and (pv[:, 1] - s2).abs().max().item() < 1e-4 * s2.abs().max().item()
+            del ref, got, d
     # data gradient (+ the producer's BatchNorm-backward sums): dz as bf16 (persistent) vs fp32 (per tile), dx and r_prev bf16 in both
     dz16 = (torch.randn(n, h, w, co, device=DEV, generator=g) * 0.1).to(bf); dz32 = dz16.float()
     rp = torch.randn(n, h, w, ci, device=DEV, generator=g).to(bf)
@@ -1245,6 +1270,18 @@ def test_conv3x3_bf16_persistent_kernels_equal_the_per_tile_kernels_at_full_size
             outs.append(dx); parts.append(part)
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1]) and torch.equal(parts[0], parts[1]), stats
+        if stats:
+            # independent check at this size: the input gradient of torch's convolution for the same operands; the producer's backward sums
+            # sum(dx), sum(dx * r) are those of the UNROUNDED data gradient against the stored saved activation
+            ref = torch.nn.functional.conv_transpose2d(dz32.permute(0, 3, 1, 2), wt.to(bf).float().permute(3, 2, 0, 1).contiguous(), padding=1).permute(0, 2, 3, 1)
+            got = outs[0].float()
+            d = (got - ref).abs()
+            assert bool((d <= 2.0 ** -7 * ref.abs() + 2e-5 * ref.abs().max()).all())
+            pv = parts[0].view(ci // 64, rows2, 64, 2).double().sum(1).view(ci, 2)
+            t1, t2 = ref.double().sum((0, 1, 2)), (ref.double() * rp.double()).sum((0, 1, 2))
+            tol1 = 1e-4 * ref.double().abs().sum((0, 1, 2)).max().item()
+            assert (pv[:, 0] - t1).abs().max().item() < tol1 and (pv[:, 1] - t2).abs().max().item() < tol1
+            del ref, got, d
 
 
 @pytest.mark.parametrize("shape", [(2, 20, 40, 128, 64, 0), (1, 7, 33, 64, 128, 8), (3, 9, 20, 64, 64, 24), (8, 512, 512, 64, 64, 0), (8, 64, 64, 512, 512, 0),
@@ -1266,3 +1303,7 @@ def test_conv3x3_bf16_wgrad_dma_staging_equals_register_staging(hip, shape):
     torch.cuda.synchronize()
     assert torch.equal(dwa, dwb)
     assert dwa.abs().max().item() > 0 and torch.isfinite(dwa).all()
+    if pad == 0 and n * h * w >= 8 * 32 * 32:
+        # full-size layers: against an independent implementation (torch's own weight gradient of the same bf16-valued operands)
+        ref = torch.nn.grad.conv2d_weight(x32.permute(0, 3, 1, 2).contiguous(), (co, ci, 3, 3), z32.permute(0, 3, 1, 2).contiguous(), padding=1).permute(2, 3, 1, 0)
+        assert (dwa - ref).abs().max().item() < 1e-4 * ref.abs().max().item(), ((dwa - ref).abs().max().item(), ref.abs().max().item())

@@ -623,6 +623,37 @@ def test_full_size_tile_matches_torch_restatement():
     assert errs["logits/kernel"] < 5e-5 and errs["dec_1b/gamma"] < 5e-5, errs
 
 
+def test_config2_full_size_batch8_matches_the_torch_restatement_run_on_the_gpu():
+    # BASELINE config 2 exactly -- 512x512x1, 2 classes, batch 8 -- against the oracle's torch restatement evaluated with torch's OWN
+    # GPU kernels (fp32): an independent implementation at the one size the CPU oracle cannot reach in a test (it sees one full-size image in
+    # test_full_size_tile_matches_torch_restatement).  Eval-mode softmax + arg-max mask, training loss, every gradient tensor.  Both sides
+    # are fp32 here, so the bounds are those of an fp32 evaluation of the oracle against its own fp64 (see grad_errors): softmax 1e-4,
+    # loss 2e-5, gradients 5e-2 with the tensors nearest the loss at 1e-3.
+    n, c, k, hw = 8, 1, 2, 512
+    img, lab, prm, masks = make_case(71, n, c, k, hw)
+    model = pkg("model")
+    net = model.UNet(k, n, c)
+    net.engine.load_parameters(prm)
+    ref = ot.TorchUNet(k, n, c, params=prm, dtype=torch.float32, device="cuda")
+    sm = net.get_keras_model()(img)
+    with torch.no_grad():
+        sm_ref = ref.forward(img, False)[0].cpu().numpy()
+    assert np.abs(sm - sm_ref).max() < 1e-4
+    ok, undecided, differ = argmax_agreement(sm, sm_ref, margin=2e-4)
+    assert ok and undecided < 1e-3 * sm.shape[0] * hw * hw, (undecided, differ)
+    e = net.engine
+    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+    e.backward()
+    loss_ref, _, g_ref, _ = ref.loss_and_grads(img, lab, masks)
+    assert abs(e.loss_buf[0].item() - float(loss_ref)) < 2e-5 * abs(float(loss_ref))
+    errs = grad_errors(e.export_gradients(), {k2: v.cpu().numpy() for k2, v in g_ref.items()})
+    for l in (1, 2, 3, 4):
+        errs.pop("up_%d/bias" % l)
+    worst = max((v, key) for key, v in errs.items())
+    assert worst[0] < 5e-2, sorted(errs.items(), key=lambda t: -t[1])[:6]
+    assert errs["logits/kernel"] < 1e-3 and errs["dec_1b/gamma"] < 1e-3 and errs["dec_1b/kernel"] < 1e-3, errs
+
+
 def test_two_replicas_compose_to_the_global_batch_step():
     # Data-parallel semantics on the real engine without a second GPU: two HIP engines stand for two replicas of a global batch of 2
     # (one image each, per-replica BatchNorm, own dropout masks, loss / G -- reference UNet/model.py:204-235 under MirroredStrategy);
