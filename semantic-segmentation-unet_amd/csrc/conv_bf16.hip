@@ -847,174 +847,6 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
             asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(t * 64) : "memory");
         }
     };
-    // compute step s from LDS: 4 groups (output row yy, k-step ks) x 9 taps; A fragments three ahead, the next group's B at the group start
-    auto compute = [&](int s) {
-        unsigned xb[4], zb[2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xb[r] = a_lane + (unsigned)(((2 * s + r) % XR) * kWgXRow);
-        zb[0] = b_lane + (unsigned)(((s % (ZR / 2)) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
-        // One asm block per step (generated: 80 transposing reads, 36 MFMAs, counted waits; LDS operations retire in order).  The
-        // fragments live in fixed registers v[88:111] -- A buffers four deep, B two -- because a 128-bit MFMA operand has to be
-        // assembled from two 64-bit reads: as separate asm statements that took compiler copies plus s_nop padding in front of
-        // every MFMA (57 cycles per MFMA measured); inside one block nothing can be scheduled between a read and its use.
-        asm volatile(
-            "ds_read_b64_tr_b16 v[104:105], %13 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[106:107], %13 offset:256\n\t"
-            "ds_read_b64_tr_b16 v[88:89], %9 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[90:91], %9 offset:256\n\t"
-            "ds_read_b64_tr_b16 v[92:93], %9 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[94:95], %9 offset:320\n\t"
-            "ds_read_b64_tr_b16 v[96:97], %9 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[98:99], %9 offset:384\n\t"
-            "ds_read_b64_tr_b16 v[108:109], %13 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[110:111], %13 offset:1280\n\t"
-            "ds_read_b64_tr_b16 v[100:101], %10 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[102:103], %10 offset:256\n\t"
-            "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %0, v[88:91], v[104:107], %0\n\t"
-            "ds_read_b64_tr_b16 v[88:89], %10 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[90:91], %10 offset:320\n\t"
-            "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %1, v[92:95], v[104:107], %1\n\t"
-            "ds_read_b64_tr_b16 v[92:93], %10 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[94:95], %10 offset:384\n\t"
-            "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %2, v[96:99], v[104:107], %2\n\t"
-            "ds_read_b64_tr_b16 v[96:97], %11 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[98:99], %11 offset:256\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %3, v[100:103], v[104:107], %3\n\t"
-            "ds_read_b64_tr_b16 v[100:101], %11 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[102:103], %11 offset:320\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %4, v[88:91], v[104:107], %4\n\t"
-            "ds_read_b64_tr_b16 v[88:89], %11 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[90:91], %11 offset:384\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %5, v[92:95], v[104:107], %5\n\t"
-            "ds_read_b64_tr_b16 v[92:93], %9 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[94:95], %9 offset:1280\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %6, v[96:99], v[104:107], %6\n\t"
-            "ds_read_b64_tr_b16 v[96:97], %9 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[98:99], %9 offset:1344\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %7, v[100:103], v[104:107], %7\n\t"
-            "ds_read_b64_tr_b16 v[100:101], %9 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[102:103], %9 offset:1408\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %8, v[88:91], v[104:107], %8\n\t"
-            "ds_read_b64_tr_b16 v[104:105], %14 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[106:107], %14 offset:256\n\t"
-            "ds_read_b64_tr_b16 v[88:89], %10 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[90:91], %10 offset:1280\n\t"
-            "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %0, v[92:95], v[108:111], %0\n\t"
-            "ds_read_b64_tr_b16 v[92:93], %10 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[94:95], %10 offset:1344\n\t"
-            "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %1, v[96:99], v[108:111], %1\n\t"
-            "ds_read_b64_tr_b16 v[96:97], %10 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[98:99], %10 offset:1408\n\t"
-            "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %2, v[100:103], v[108:111], %2\n\t"
-            "ds_read_b64_tr_b16 v[100:101], %11 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[102:103], %11 offset:1280\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %3, v[88:91], v[108:111], %3\n\t"
-            "ds_read_b64_tr_b16 v[88:89], %11 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[90:91], %11 offset:1344\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %4, v[92:95], v[108:111], %4\n\t"
-            "ds_read_b64_tr_b16 v[92:93], %11 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[94:95], %11 offset:1408\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %5, v[96:99], v[108:111], %5\n\t"
-            "ds_read_b64_tr_b16 v[96:97], %10 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[98:99], %10 offset:256\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %6, v[100:103], v[108:111], %6\n\t"
-            "ds_read_b64_tr_b16 v[100:101], %10 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[102:103], %10 offset:320\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %7, v[88:91], v[108:111], %7\n\t"
-            "ds_read_b64_tr_b16 v[88:89], %10 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[90:91], %10 offset:384\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %8, v[92:95], v[108:111], %8\n\t"
-            "ds_read_b64_tr_b16 v[108:109], %14 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[110:111], %14 offset:1280\n\t"
-            "ds_read_b64_tr_b16 v[92:93], %11 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[94:95], %11 offset:256\n\t"
-            "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %0, v[96:99], v[104:107], %0\n\t"
-            "ds_read_b64_tr_b16 v[96:97], %11 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[98:99], %11 offset:320\n\t"
-            "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %1, v[100:103], v[104:107], %1\n\t"
-            "ds_read_b64_tr_b16 v[100:101], %11 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[102:103], %11 offset:384\n\t"
-            "s_waitcnt lgkmcnt(8)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %2, v[88:91], v[104:107], %2\n\t"
-            "ds_read_b64_tr_b16 v[88:89], %12 offset:0\n\t"
-            "ds_read_b64_tr_b16 v[90:91], %12 offset:256\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %3, v[92:95], v[104:107], %3\n\t"
-            "ds_read_b64_tr_b16 v[92:93], %12 offset:64\n\t"
-            "ds_read_b64_tr_b16 v[94:95], %12 offset:320\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %4, v[96:99], v[104:107], %4\n\t"
-            "ds_read_b64_tr_b16 v[96:97], %12 offset:128\n\t"
-            "ds_read_b64_tr_b16 v[98:99], %12 offset:384\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %5, v[100:103], v[104:107], %5\n\t"
-            "ds_read_b64_tr_b16 v[100:101], %10 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[102:103], %10 offset:1280\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %6, v[88:91], v[104:107], %6\n\t"
-            "ds_read_b64_tr_b16 v[88:89], %10 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[90:91], %10 offset:1344\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %7, v[92:95], v[104:107], %7\n\t"
-            "ds_read_b64_tr_b16 v[92:93], %10 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[94:95], %10 offset:1408\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %8, v[96:99], v[104:107], %8\n\t"
-            "ds_read_b64_tr_b16 v[96:97], %11 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[98:99], %11 offset:1280\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %0, v[100:103], v[108:111], %0\n\t"
-            "ds_read_b64_tr_b16 v[100:101], %11 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[102:103], %11 offset:1344\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %1, v[88:91], v[108:111], %1\n\t"
-            "ds_read_b64_tr_b16 v[88:89], %11 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[90:91], %11 offset:1408\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %2, v[92:95], v[108:111], %2\n\t"
-            "ds_read_b64_tr_b16 v[92:93], %12 offset:1024\n\t"
-            "ds_read_b64_tr_b16 v[94:95], %12 offset:1280\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %3, v[96:99], v[108:111], %3\n\t"
-            "ds_read_b64_tr_b16 v[96:97], %12 offset:1088\n\t"
-            "ds_read_b64_tr_b16 v[98:99], %12 offset:1344\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %4, v[100:103], v[108:111], %4\n\t"
-            "ds_read_b64_tr_b16 v[100:101], %12 offset:1152\n\t"
-            "ds_read_b64_tr_b16 v[102:103], %12 offset:1408\n\t"
-            "s_waitcnt lgkmcnt(6)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %5, v[88:91], v[108:111], %5\n\t"
-            "s_waitcnt lgkmcnt(4)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %6, v[92:95], v[108:111], %6\n\t"
-            "s_waitcnt lgkmcnt(2)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %7, v[96:99], v[108:111], %7\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_mfma_f32_32x32x16_bf16 %8, v[100:103], v[108:111], %8\n\t"
-            : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+v"(acc[8])
-            : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(zb[0]), "v"(zb[1])
-            : "memory", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111");
-    };
-
     // DMA form: a row slot (2 groups x 36 pixels x 64 B = 288 16-byte pieces) is filled by five wave-instructions; piece 64 k + lane =
     // (group, pixel, 16-byte quarter of the pixel's 32 channels) -- the LDS image is a copy of memory
     constexpr int NI = 5;
@@ -1027,6 +859,149 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
             dgrp[k] = P / 144; const int rem = P % 144; dpix[k] = rem >> 2; dj[k] = rem & 3;
         }
     }
+    // compute step s from LDS: 4 groups (output row yy, k-step ks) x 9 taps; A fragments three ahead, the next group's B at the group start
+    auto compute = [&](int s) {
+        unsigned xb[4], zb[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xb[r] = a_lane + (unsigned)(((2 * s + r) % XR) * kWgXRow);
+        zb[0] = b_lane + (unsigned)(((s % (ZR / 2)) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
+        // One asm block per step, generated by scripts/gen_wgrad_bf16_step.py: 56 transposing reads, 36 MFMAs, counted waits (LDS operations
+        // retire in order).  Input row r of the step serves tap a = r of output row 0 AND tap a = r - 1 of output row 1, so each of the 24
+        // A fragments (4 rows x 3 column shifts x 2 k-steps) is read ONCE and feeds both MFMAs (round 2 read 36: one per MFMA -- 1 KB of
+        // fragment reads per MFMA and wave is the LDS's whole rate at a busy matrix pipe); both dz rows of a k-step are live together.
+        // The fragments live in fixed registers v[80:111] -- an A ring of four, the four B fragments of the step -- because a 128-bit
+        // MFMA operand has to be assembled from two 64-bit reads: as separate asm statements that took compiler copies plus s_nop
+        // padding in front of every MFMA (57 cycles per MFMA measured); inside one block nothing can be scheduled between a read and its use.
+        // Measured (round 3, same box, 13 layers): the shared A fragments are worth 1-3 %; placing the five DMA instructions of pass s + 3
+        // INSIDE this block (one per seven MFMAs, `--dma` of the generator) instead of in front of it changed nothing (2.128 vs 2.128 ms,
+        // 2.150 vs 2.142 ms over the layers) although the no-DMA ablation is 20 % faster: what the ablation removes is the WAIT for the
+        // rows (vmcnt), i.e. the L2 / fabric delivery rate of a 64 x 64 tile's 288 flop per staged byte, not the issue slots.
+        asm volatile(
+            "ds_read_b64_tr_b16 v[96:97], %[z0] offset:0\n\t"
+            "ds_read_b64_tr_b16 v[98:99], %[z0] offset:256\n\t"
+            "ds_read_b64_tr_b16 v[80:81], %[x0] offset:0\n\t"
+            "ds_read_b64_tr_b16 v[82:83], %[x0] offset:256\n\t"
+            "ds_read_b64_tr_b16 v[84:85], %[x0] offset:64\n\t"
+            "ds_read_b64_tr_b16 v[86:87], %[x0] offset:320\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %[x0] offset:128\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %[x0] offset:384\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c0], v[80:83], v[96:99], %[c0]\n\t"
+            "ds_read_b64_tr_b16 v[100:101], %[z1] offset:0\n\t"
+            "ds_read_b64_tr_b16 v[102:103], %[z1] offset:256\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %[x1] offset:0\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %[x1] offset:256\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c1], v[84:87], v[96:99], %[c1]\n\t"
+            "ds_read_b64_tr_b16 v[80:81], %[x1] offset:64\n\t"
+            "ds_read_b64_tr_b16 v[82:83], %[x1] offset:320\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c2], v[88:91], v[96:99], %[c2]\n\t"
+            "ds_read_b64_tr_b16 v[84:85], %[x1] offset:128\n\t"
+            "ds_read_b64_tr_b16 v[86:87], %[x1] offset:384\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c3], v[92:95], v[96:99], %[c3]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c0], v[92:95], v[100:103], %[c0]\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %[x2] offset:0\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %[x2] offset:256\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c4], v[80:83], v[96:99], %[c4]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c1], v[80:83], v[100:103], %[c1]\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %[x2] offset:64\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %[x2] offset:320\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c5], v[84:87], v[96:99], %[c5]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c2], v[84:87], v[100:103], %[c2]\n\t"
+            "ds_read_b64_tr_b16 v[80:81], %[x2] offset:128\n\t"
+            "ds_read_b64_tr_b16 v[82:83], %[x2] offset:384\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c6], v[88:91], v[96:99], %[c6]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c3], v[88:91], v[100:103], %[c3]\n\t"
+            "ds_read_b64_tr_b16 v[84:85], %[x3] offset:0\n\t"
+            "ds_read_b64_tr_b16 v[86:87], %[x3] offset:256\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c7], v[92:95], v[96:99], %[c7]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c4], v[92:95], v[100:103], %[c4]\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %[x3] offset:64\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %[x3] offset:320\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c8], v[80:83], v[96:99], %[c8]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c5], v[80:83], v[100:103], %[c5]\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %[x3] offset:128\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %[x3] offset:384\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c6], v[84:87], v[100:103], %[c6]\n\t"
+            "ds_read_b64_tr_b16 v[104:105], %[z0] offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[106:107], %[z0] offset:1280\n\t"
+            "ds_read_b64_tr_b16 v[80:81], %[x0] offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[82:83], %[x0] offset:1280\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c7], v[88:91], v[100:103], %[c7]\n\t"
+            "ds_read_b64_tr_b16 v[84:85], %[x0] offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[86:87], %[x0] offset:1344\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c8], v[92:95], v[100:103], %[c8]\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %[x0] offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %[x0] offset:1408\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c0], v[80:83], v[104:107], %[c0]\n\t"
+            "ds_read_b64_tr_b16 v[108:109], %[z1] offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[110:111], %[z1] offset:1280\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %[x1] offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %[x1] offset:1280\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c1], v[84:87], v[104:107], %[c1]\n\t"
+            "ds_read_b64_tr_b16 v[80:81], %[x1] offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[82:83], %[x1] offset:1344\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c2], v[88:91], v[104:107], %[c2]\n\t"
+            "ds_read_b64_tr_b16 v[84:85], %[x1] offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[86:87], %[x1] offset:1408\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c3], v[92:95], v[104:107], %[c3]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c0], v[92:95], v[108:111], %[c0]\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %[x2] offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %[x2] offset:1280\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c4], v[80:83], v[104:107], %[c4]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c1], v[80:83], v[108:111], %[c1]\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %[x2] offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %[x2] offset:1344\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c5], v[84:87], v[104:107], %[c5]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c2], v[84:87], v[108:111], %[c2]\n\t"
+            "ds_read_b64_tr_b16 v[80:81], %[x2] offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[82:83], %[x2] offset:1408\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c6], v[88:91], v[104:107], %[c6]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c3], v[88:91], v[108:111], %[c3]\n\t"
+            "ds_read_b64_tr_b16 v[84:85], %[x3] offset:1024\n\t"
+            "ds_read_b64_tr_b16 v[86:87], %[x3] offset:1280\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c7], v[92:95], v[104:107], %[c7]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c4], v[92:95], v[108:111], %[c4]\n\t"
+            "ds_read_b64_tr_b16 v[88:89], %[x3] offset:1088\n\t"
+            "ds_read_b64_tr_b16 v[90:91], %[x3] offset:1344\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c8], v[80:83], v[104:107], %[c8]\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c5], v[80:83], v[108:111], %[c5]\n\t"
+            "ds_read_b64_tr_b16 v[92:93], %[x3] offset:1152\n\t"
+            "ds_read_b64_tr_b16 v[94:95], %[x3] offset:1408\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c6], v[84:87], v[108:111], %[c6]\n\t"
+            "s_waitcnt lgkmcnt(2)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c7], v[88:91], v[108:111], %[c7]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mfma_f32_32x32x16_bf16 %[c8], v[92:95], v[108:111], %[c8]\n\t"
+            : [c0] "+a"(acc[0]), [c1] "+a"(acc[1]), [c2] "+a"(acc[2]), [c3] "+a"(acc[3]), [c4] "+a"(acc[4]), [c5] "+a"(acc[5]), [c6] "+a"(acc[6]), [c7] "+a"(acc[7]),
+              [c8] "+v"(acc[8])
+            : [x0] "v"(xb[0]), [x1] "v"(xb[1]), [x2] "v"(xb[2]), [x3] "v"(xb[3]), [z0] "v"(zb[0]), [z1] "v"(zb[1])
+            : "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99",
+              "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111");
+    };
+
     auto dma_issue = [&](int j) {
         const int row = is_x ? y0 - 1 + 2 * j + rho : y0 + 2 * (j - 1) + rho;
         const bool rok = is_x ? (row >= 0 && row < p.H) : (row >= y0 && row < y_end);
