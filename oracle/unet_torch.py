@@ -40,14 +40,24 @@ class TorchUNet:
         self.adam_v = {k: torch.zeros_like(self.params[k]) for k in self.trainable}
         self.iterations = 0
 
-    def _block(self, name, kind, x, training, stats):
+    def _block(self, name, kind, x, training, stats, relu_masks=None):
         P = self.params
         w, b = P[name + "/kernel"], P[name + "/bias"]
         if kind == "deconv":
             r = F.conv_transpose2d(x, w.permute(3, 2, 0, 1), b, stride=2)
         else:
             k = w.shape[0]
-            r = F.relu(F.conv2d(x, w.permute(3, 2, 0, 1), b, padding=(k - 1) // 2))
+            z = F.conv2d(x, w.permute(3, 2, 0, 1), b, padding=(k - 1) // 2)
+            if relu_masks is not None and name in relu_masks:
+                # the ReLU decision of a device run imposed (NCHW bool): the network is piecewise linear and fp32 rounding flips decisions
+                # of pre-activations at rounding level; `imposed_flips[name]` = largest |z| among the overridden decisions relative to
+                # max |z| of the layer, for the caller to bound
+                m = torch.as_tensor(np.asarray(relu_masks[name])).to(self.device)
+                flipped = (z.detach() > 0) != m
+                self.imposed_flips[name] = float(z.detach().abs()[flipped].max() / z.detach().abs().max()) if bool(flipped.any()) else 0.0
+                r = z * m.to(self.dtype)
+            else:
+                r = F.relu(z)
         g, bt = P[name + "/gamma"], P[name + "/beta"]
         eps = self.contract.bn_eps
         if training:
@@ -59,11 +69,12 @@ class TorchUNet:
         inv = torch.rsqrt(var + eps)
         return (r - mu[None, :, None, None]) * (g * inv)[None, :, None, None] + bt[None, :, None, None]
 
-    def forward(self, images, training=False, dropout_masks=None):
+    def forward(self, images, training=False, dropout_masks=None, relu_masks=None):
         x = torch.as_tensor(np.asarray(images) if not torch.is_tensor(images) else images).to(self.dtype).to(self.device)
         L = {n: k for n, k, _, _ in self.layers}
         st = {}
-        f = lambda name, t: self._block(name, L[name], t, training, st)
+        self.imposed_flips = {}
+        f = lambda name, t: self._block(name, L[name], t, training, st, relu_masks)
         scale = 1.0 / (1.0 - self.contract.dropout_rate)
 
         def drop(t, key):
@@ -98,8 +109,8 @@ class TorchUNet:
             ell = -(y * torch.log(q)).sum(-1)
         return (ell.sum(0) / self.global_batch_size).mean()
 
-    def loss_and_grads(self, images, labels, dropout_masks):
-        softmax, logits, st = self.forward(images, True, dropout_masks)
+    def loss_and_grads(self, images, labels, dropout_masks, relu_masks=None):
+        softmax, logits, st = self.forward(images, True, dropout_masks, relu_masks)
         loss = self.loss(logits, labels)
         grads = torch.autograd.grad(loss, [self.params[k] for k in self.trainable])
         return loss.detach(), softmax.detach(), dict(zip(self.trainable, grads)), st

@@ -527,6 +527,273 @@ __global__ __launch_bounds__(256) void conv1x1_narrow_wgrad_kernel(const float* 
     }
 }
 
+// ---- first 3x3 layer (Cin = 1..4 -> 64) on the fp32 matrix cores ----------------------------------------------------------------------
+// The stencil kernels above keep 9 * Cin weight quads in registers (108 VGPRs at Cin = 3: two waves per SIMD) and gather their 3 x 6 x Cin
+// window with one conditional scalar load per value: at Cin = 3 and a bf16 output (268 MB written at 8 x 512^2) the forward ran 0.19 ms and the
+// weight gradient 0.19 ms against 0.06 ms of HBM time -- latency-bound at that occupancy.  Here the contraction (K = 9 * Cin, padded to an
+// even number) runs on v_mfma_f32_32x32x2_f32 with fp32 operands (the layer is outside the bf16 contract: its input is the image):
+//   forward   D[pixel][co] : A = window values gathered straight from global memory (the image is L2-resident: 25 MB), one dword per lane and
+//             k-step, zeros outside the image through the buffer range check; B = the whole filter in 2 * K/2 registers per lane;
+//   wgrad     D[k][co]     : the contraction runs over pixels, two per MFMA; A = window value k of the two pixels, B = their dz rows.
+// No LDS in the loops, every wave walks 32-pixel row segments on its own.  Output channel of MFMA column j, accumulator c = 2 j + c,
+// so a lane's pair of results is one 4-byte (bf16) or 8-byte (fp32) store and a row of 32 lanes writes the pixel's whole 64-channel row.
+#ifndef UNET_FIRST_ABLATE
+#define UNET_FIRST_ABLATE 0      /* diagnostic builds (scripts/build_variant.sh; results wrong): 1 no stores, 2 no MFMAs, 4 no window loads, 8 no statistics */
+#endif
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef int first_rsrc_t __attribute__((ext_vector_type(4)));
+// The window / dz loads of these kernels are asm volatile with hand-counted waits: written as builtins the compiler SANK each prefetch down to
+// its consumer (the loads of the next segment landed right in front of that segment's MFMAs, one vmcnt wait per MFMA pair: matrix pipe 46 %
+// busy, 0.11-0.12 ms per launch).  Loads, stores and DMA count together in issue order, so "all but the N youngest" is exact.
+__device__ __forceinline__ first_rsrc_t first_rsrc(const void* p, size_t bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    return first_rsrc_t{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)(unsigned)bytes, 0x00020000};
+}
+__device__ __forceinline__ void first_ld32(float& dst, int voff, first_rsrc_t r) {
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(r) : "memory");
+}
+__device__ __forceinline__ void first_ld32u(unsigned& dst, int voff, first_rsrc_t r) {
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(r) : "memory");
+}
+// (the pair's part of the address as the instruction's immediate offset, < 4096: no vector instruction per load)
+#define FIRST_LD32_IMM(dst, voff, r, imm) asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(dst) : "v"(voff), "s"(r), "n"(imm) : "memory")
+template <int N> __device__ __forceinline__ void first_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int CIN> struct FirstGeom {
+    static constexpr int K = 9 * CIN, S = (K + 1) / 2;
+    // window element k = tap * CIN + ci (the HWIO order of the filter): row offset da, column offset db, channel ci
+    static __device__ __forceinline__ int da(int k) { return k / (3 * CIN) - 1; }
+    static __device__ __forceinline__ int db(int k) { return (k / CIN) % 3 - 1; }
+    static __device__ __forceinline__ int ci(int k) { return k % CIN; }
+};
+
+template <int CIN, int OUT16>
+__global__ __launch_bounds__(256) void conv3x3_first_mfma_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+        const float* __restrict__ bias, void* __restrict__ out, int ldo, int N, int H, int W, int relu, float* __restrict__ stat_part) {
+    typedef FirstGeom<CIN> G;
+    constexpr int K = G::K, S = G::S;
+    __shared__ float sStat[4 * 64 * 2 * 2];
+    const int lane = threadIdx.x & 63, j = lane & 31, lh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float wr[S][2];
+    int koff[S];
+    unsigned top = 0, bot = 0, left = 0, right = 0, pad = 0;          // bit s: window element k = 2 s + lh of this lane looks up / down / left / right / is padding
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int k = 2 * s + lh;
+        const bool real = k < K;
+        const int kk = real ? k : 0;
+        wr[s][0] = real ? w[kk * 64 + 2 * j] : 0.f; wr[s][1] = real ? w[kk * 64 + 2 * j + 1] : 0.f;
+        koff[s] = ((G::da(kk) * W + G::db(kk)) * ldx + G::ci(kk)) * 4;
+        top |= (unsigned)(G::da(kk) < 0) << s; bot |= (unsigned)(G::da(kk) > 0) << s;
+        left |= (unsigned)(G::db(kk) < 0) << s; right |= (unsigned)(G::db(kk) > 0) << s; pad |= (unsigned)(!real) << s;
+    }
+    const float b0 = bias ? bias[2 * j] : 0.f, b1 = bias ? bias[2 * j + 1] : 0.f;
+    const float lo = relu ? 0.f : -__builtin_inff();
+    const first_rsrc_t srd_x = first_rsrc(x, (size_t)N * H * W * ldx * 4);
+    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)N * H * W * ldo * (OUT16 ? 2 : 4)), 0x00020000);
+    const int SW = (W + 31) >> 5;
+    const int nseg = N * H * SW, stride = (int)gridDim.x * 4;
+    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
+    float a[2][S];
+    auto gather = [&](float (&dst)[S], int seg) {
+        const int sx = seg % SW, row = seg / SW, y = row % H;            // row = n * H + y
+        const int px = 32 * sx + j;
+        unsigned bad = pad | (y == 0 ? top : 0u) | (y == H - 1 ? bot : 0u) | (px == 0 ? left : 0u) | (px + 1 >= W ? right : 0u) | (px >= W ? ~0u : 0u);
+        const int base = (row * W + px) * ldx * 4;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (UNET_FIRST_ABLATE & 4) dst[s] = __builtin_bit_cast(float, base + koff[s] + (int)((bad >> s) & 1));
+            else first_ld32(dst[s], ((bad >> s) & 1) ? (int)0x80000000 : base + koff[s], srd_x);
+    };
+    // One segment: the NEXT segment's window loads are issued first (into the other buffer), then the MFMAs and the epilogue of this one.
+    // Measured at 8 x 512^2 x 3 -> 64 with a bf16 output (ms per launch): 0.045 without MFMAs and stores, 0.105 with the MFMAs, 0.117 with
+    // both -- the parts ADD UP whatever the arrangement: the epilogue placed between the MFMA pairs out of a second accumulator set (clean
+    // interleave in the ISA, two waves per SIMD) ran the same 0.118 as this form with three waves per SIMD.  v_mfma_f32_32x32x2_f32 runs on the
+    // vector ALUs' fp32 multipliers (its rate IS the packed-fp32 vector rate), so vector instructions do not hide behind it as they do behind
+    // the bf16 matrix instructions; the lever left is fewer vector instructions (~15 per stored pixel pair today).
+    // Vector-memory operations younger than `cur`'s loads at the wait: the previous segment's 16 stores (none before the first) and the next
+    // segment's S loads (none for the last).
+    const int pstep = ldo * (OUT16 ? 2 : 4);
+    auto step = [&](float (&cur)[S], float (&nxt)[S], int seg, bool first) {
+        const bool more = seg + stride < nseg;
+        if (more) gather(nxt, seg + stride);
+        if (first) { if (more) first_wait<S>(); else first_wait<0>(); }
+        else       { if (more) first_wait<S + 16>(); else first_wait<16>(); }
+#pragma unroll
+        for (int s = 0; s < S; ++s) asm volatile("" : "+v"(cur[s]));       // (the MFMAs below read `cur` after the wait)
+        const f32x16 zero = {};
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (UNET_FIRST_ABLATE & 2) { acc0[s & 15] += cur[s] * wr[s][0]; acc1[s & 15] += cur[s] * wr[s][1]; continue; }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], wr[s][0], s == 0 ? zero : acc0, 0, 0, 0);   // (starts from the constant 0: no 32 register writes)
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], wr[s][1], s == 0 ? zero : acc1, 0, 0, 0);
+        }
+        const int sx = seg % SW, row = seg / SW;
+        const int px0 = 32 * sx + 4 * lh;
+        const int obase = ((row * W + px0) * ldo + 2 * j) * (OUT16 ? 2 : 4);
+        const int wrem = W - px0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int dp = (e & 3) + 8 * (e >> 2);
+            const bool ok = dp < wrem;
+            const float v0 = fmaxf(acc0[e] + b0, lo), v1 = fmaxf(acc1[e] + b1, lo);
+            const float m0 = ok ? v0 : 0.f, m1 = ok ? v1 : 0.f;
+            if (!(UNET_FIRST_ABLATE & 8)) { st1[0] += m0; st2[0] += m0 * m0; st1[1] += m1; st2[1] += m1 * m1; }    // (sums of the fp32 values, before any rounding of the stored tensor)
+            else { st1[0] += m0; }
+            if ((UNET_FIRST_ABLATE & 1) && st1[0] != 1.2345e38f) continue;
+            const int vo = ok ? obase + dp * pstep : (int)0x80000000;
+            if constexpr (OUT16) {
+                unsigned h;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(v0), "v"(v1));
+                __builtin_amdgcn_raw_buffer_store_b32(h, srd_o, vo, 0, 0);
+            } else {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 o; o[0] = __builtin_bit_cast(unsigned, v0); o[1] = __builtin_bit_cast(unsigned, v1);
+                __builtin_amdgcn_raw_buffer_store_b64(o, srd_o, vo, 0, 0);
+            }
+        }
+    };
+    int seg = (int)blockIdx.x * 4 + wv;
+    if (seg < nseg) gather(a[0], seg);
+    bool first = true;
+    while (seg < nseg) {
+        step(a[0], a[1], seg, first); seg += stride; first = false;
+        if (seg >= nseg) break;
+        step(a[1], a[0], seg, false); seg += stride;
+    }
+    if (stat_part) {            // one row of partials per block, layout of unet_bn_train_finalize_partials: [C/64][rows][64][2]; fixed order
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { st1[c] += __shfl_xor(st1[c], 32); st2[c] += __shfl_xor(st2[c], 32); }
+        if (lh == 0) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { sStat[(wv * 64 + 2 * j + c) * 2] = st1[c]; sStat[(wv * 64 + 2 * j + c) * 2 + 1] = st2[c]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) t += sStat[l * 128 + threadIdx.x];
+            stat_part[(size_t)blockIdx.x * 128 + threadIdx.x] = t;
+        }
+    }
+}
+
+// weight gradient (dz stored as bf16): dw[k][co] = sum over pixels of window value k of the pixel x dz[pixel][co]; partials per block ->
+// sum_partials_kernel
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_first_mfma_wgrad_kernel(const float* __restrict__ x, int ldx, const void* __restrict__ dz, int lddz,
+        float* __restrict__ part, int N, int H, int W) {
+    typedef FirstGeom<CIN> G;
+    constexpr int K = G::K;
+    static_assert(K <= 32, "window elements are MFMA rows");
+    __shared__ float sAcc[4][2][16][64];
+    const int lane = threadIdx.x & 63, j = lane & 31, lh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // A operand: MFMA row i = lane & 31 = window element k, reduce index lane >> 5 = which of the two pixels
+    const bool real = j < K;
+    const int kk = real ? j : 0;
+    const int da = G::da(kk), db = G::db(kk);
+    const int koff = ((da * W + db + lh) * ldx + G::ci(kk)) * 4;
+    const first_rsrc_t srd_x = first_rsrc(x, (size_t)N * H * W * ldx * 4);
+    const first_rsrc_t srd_z = first_rsrc(dz, (size_t)N * H * W * lddz * 2);
+    const int SW = (W + 31) >> 5;
+    const int nseg = N * H * SW, stride = (int)gridDim.x * 4;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    struct Raw { float a[16]; unsigned z[16]; };
+    auto issue = [&](Raw& r, int seg) {
+        const int sx = seg % SW, row = seg / SW, y = row % H;
+        const bool rowok = real && (unsigned)(y + da) < (unsigned)H;
+        const int x0 = 32 * sx;
+        const int abase = (row * W + x0) * ldx * 4 + koff;
+        const int zbase = ((row * W + x0 + lh) * lddz + 2 * j) * 2;
+        if (x0 + 32 <= W && ldx == CIN && lddz == 64) {
+            // whole segment inside the row, dense tensors: only the first and the last pair can look past the row's ends, and the pair's
+            // part of every address is an instruction immediate (the fp32 matrix instructions run on the vector ALUs' multipliers: vector
+            // instructions do not hide behind them -- per-load address arithmetic was 190 of this loop's 230 vector instructions per segment)
+            const int va = rowok ? abase : (int)0x80000000;
+            const int va0 = (rowok && x0 + lh + db >= 0) ? abase : (int)0x80000000, va15 = (rowok && x0 + 30 + lh + db < W) ? abase : (int)0x80000000;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                FIRST_LD32_IMM(r.a[t], t == 0 ? va0 : t == 15 ? va15 : va, srd_x, 2 * t * CIN * 4);
+                FIRST_LD32_IMM(r.z[t], zbase, srd_z, t * 256);
+            }
+            return;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int col = x0 + 2 * t + lh;                          // this lane's pixel of pair t
+            const bool aok = rowok && (unsigned)(col + db) < (unsigned)W;
+            first_ld32(r.a[t], aok ? abase + 2 * t * ldx * 4 : (int)0x80000000, srd_x);
+            const int zo = col < W ? zbase + 2 * t * lddz * 2 : (int)0x80000000;
+            first_ld32u(r.z[t], zo, srd_z);
+        }
+    };
+    // one segment: the NEXT segment's 32 loads go out first, then this one's 32 MFMAs
+    auto step = [&](Raw& cur, Raw& nxt, int seg) {
+        if (seg + stride < nseg) { issue(nxt, seg + stride); first_wait<32>(); } else first_wait<0>();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) asm volatile("" : "+v"(cur.a[t]), "+v"(cur.z[t]));   // (the MFMAs below read `cur` after the wait)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const unsigned h = cur.z[t];                              // channels 2 j (low half) and 2 j + 1 of the pixel
+            const float z0 = __builtin_bit_cast(float, h << 16), z1 = __builtin_bit_cast(float, h & 0xffff0000u);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t], z0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t], z1, acc1, 0, 0, 0);
+        }
+    };
+    Raw r0, r1;
+    int seg = (int)blockIdx.x * 4 + wv;
+    if (seg < nseg) issue(r0, seg);
+    while (seg < nseg) {
+        step(r0, r1, seg); seg += stride;
+        if (seg >= nseg) break;
+        step(r1, r0, seg); seg += stride;
+    }
+    // the four waves in a fixed order; accumulator e of column j = dw[k = (e & 3) + 8 (e >> 2) + 4 lh][co = 2 j + c]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { sAcc[wv][lh][e][2 * j] = acc0[e]; sAcc[wv][lh][e][2 * j + 1] = acc1[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * 64; i += 256) {
+        const int k = i >> 6, co = i & 63;
+        const int h = (k >> 2) & 1, e = (k & 3) + 4 * (k >> 3);
+        part[(size_t)blockIdx.x * K * 64 + i] = (sAcc[0][h][e][co] + sAcc[1][h][e][co]) + (sAcc[2][h][e][co] + sAcc[3][h][e][co]);
+    }
+}
+
+// the matrix-core forms serve Cout = 64 with tensors below 2 GiB (32-bit buffer offsets)
+static bool first_mfma_shape(int N, int H, int W, int Cin, int Cout) {       // (sizes at the tightest leading dimensions: what the row-count query can know)
+#ifdef UNET_FIRST_STENCIL        /* diagnostic builds (scripts/build_variant.sh): the stencil kernels everywhere */
+    return false;
+#endif
+    return Cin >= 1 && Cin <= 4 && Cout == 64 && (size_t)N * H * W * 64 * 4 < ((size_t)1 << 31);
+}
+static bool first_mfma_fits(int N, int H, int W, int ldx, int ld64, int es64) {
+    return (size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * ld64 * es64 < ((size_t)1 << 31);
+}
+// one resident wave of workgroups (register-limited: 3-5 per CU), each wave of which walks its share of the segments: a grid of 1024
+// on 768 slots ran two rounds, the second a third full (0.123 ms instead of ~0.09 at 8 x 512^2 x 3)
+template <int CIN> static int first_fwd_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int per_cu = 0, dev = 0; hipDeviceProp_t pr;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_first_mfma_fwd_kernel<CIN, 1>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        (void)hipGetDevice(&dev);
+        const int cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        slots = per_cu * cus;
+    }
+    return slots;
+}
+static int first_fwd_blocks(int N, int H, int W, int Cin) {
+    const long seg = (long)N * H * ((W + 31) / 32);
+    const int slots = Cin == 1 ? first_fwd_slots<1>() : Cin == 2 ? first_fwd_slots<2>() : Cin == 3 ? first_fwd_slots<3>() : first_fwd_slots<4>();
+    long b = (seg + 3) / 4; if (b > slots) b = slots; if (b < 1) b = 1;
+    return (int)b;
+}
+
 }  // namespace
 
 static int direct_fwd_launch(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
@@ -540,6 +807,18 @@ static int direct_fwd_launch(const float* x, int ldx, const float* w, const floa
     const size_t smem = (size_t)9 * CI_CHUNK * Cout * sizeof(float);
     UNET_CHECK_ARG(smem <= 64 * 1024);
     long blocks = (P + ppb - 1) / ppb; if (blocks > 4096) blocks = 4096;
+    if (first_mfma_shape(N, H, W, Cin, Cout) && !(first_mfma_fits(N, H, W, ldx, ldo, out_bf16 ? 2 : 4) && ldo % 2 == 0) && stat_part)
+        return UNET_EINVAL;                                            // (the row count promised by unet_conv3x3_fwd_direct_stats_rows is the matrix-core kernel's)
+    if (first_mfma_shape(N, H, W, Cin, Cout) && first_mfma_fits(N, H, W, ldx, ldo, out_bf16 ? 2 : 4) && ldo % 2 == 0) {
+        const int b1 = first_fwd_blocks(N, H, W, Cin);
+        hipStream_t st = (hipStream_t)stream;
+        if (stat_part && stat_bytes < (size_t)b1 * 128 * sizeof(float)) return UNET_ENOSPC;
+#define UNET_FIRST(CI) do { if (out_bf16) conv3x3_first_mfma_fwd_kernel<CI, 1><<<b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, relu, stat_part); \
+                            else          conv3x3_first_mfma_fwd_kernel<CI, 0><<<b1, 256, 0, st>>>(x, ldx, w, bias, out, ldo, N, H, W, relu, stat_part); } while (0)
+        if (Cin == 1) UNET_FIRST(1); else if (Cin == 2) UNET_FIRST(2); else if (Cin == 3) UNET_FIRST(3); else UNET_FIRST(4);
+#undef UNET_FIRST
+        return UNET_LAUNCH_STATUS();
+    }
     if (Cin <= 4 && W % 4 == 0 && unet_aligned16(w)) {
         long b1 = (P / 4 + ppb - 1) / ppb; if (b1 > 4096) b1 = 4096;
         hipStream_t st = (hipStream_t)stream;
@@ -567,6 +846,7 @@ extern "C" int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, 
 
 // rows of BatchNorm partial sums the strip kernel would write per 64-channel block (0: the generic kernel would run)
 extern "C" int unet_conv3x3_fwd_direct_stats_rows(int N, int H, int W, int Cin, int Cout) {
+    if (N > 0 && H > 0 && W > 0 && first_mfma_shape(N, H, W, Cin, Cout)) return first_fwd_blocks(N, H, W, Cin);
     if (N <= 0 || H <= 0 || W <= 0 || Cin < 1 || Cin > 4 || W % 4 != 0 || Cout % 64 != 0 || Cout > 1024) return 0;
     const int ppb = 256 / (Cout / 4);
     long b1 = ((long)N * H * W / 4 + ppb - 1) / ppb; if (b1 > 4096) b1 = 4096;
@@ -601,6 +881,13 @@ extern "C" int unet_conv3x3_wgrad_direct(const float* xin, int ldx, const void* 
     const size_t smem = (size_t)(256 / tpp) * 9 * Cout * sizeof(float);
     UNET_CHECK_ARG(smem <= 64 * 1024);
     hipStream_t st = (hipStream_t)stream;
+    if (dz_bf16 && first_mfma_shape(N, H, W, Cin, Cout) && 9 * Cin <= 32 && first_mfma_fits(N, H, W, ldx, lddz, 2) && lddz % 2 == 0) {
+        // (9 * Cin window elements are the 32 MFMA rows: Cin <= 3; the workspace holds `blocks` partial filters either way.  With an fp32 dz
+        // the stencil kernels below are at the tensor's HBM time already -- 0.120 ms for 537 MB at 8 x 512^2 against 0.136 here)
+        if (Cin == 1)      conv3x3_first_mfma_wgrad_kernel<1><<<blocks, 256, 0, st>>>(xin, ldx, dzv, lddz, (float*)ws, N, H, W);
+        else if (Cin == 2) conv3x3_first_mfma_wgrad_kernel<2><<<blocks, 256, 0, st>>>(xin, ldx, dzv, lddz, (float*)ws, N, H, W);
+        else               conv3x3_first_mfma_wgrad_kernel<3><<<blocks, 256, 0, st>>>(xin, ldx, dzv, lddz, (float*)ws, N, H, W);
+    } else
     if (Cin >= 2 && Cin <= 4 && W % 4 == 0) {                       // every block range is whole 4-pixel strips (ppb % 4 == 0, P % 4 == 0)
 #define UNET_WG(CI) do { if (dz_bf16) conv3x3_direct_wgrad_multi_kernel<CI, 1><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb); \
                          else         conv3x3_direct_wgrad_multi_kernel<CI, 0><<<blocks, 256, smem, st>>>(xin, ldx, dz, lddz, (float*)ws, N, H, W, Cout, ppb); } while (0)

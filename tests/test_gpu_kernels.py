@@ -171,9 +171,10 @@ def test_convT2x2_fwd_stream_matches_igemm_and_oracle(hip, shape):
         assert relerr(from_nhwc(out), z_ref) < 2e-5
 
 
-@pytest.mark.parametrize("cin,w", [(1, 21), (3, 21), (1, 24), (2, 24), (3, 24), (4, 24), (5, 24)])
+@pytest.mark.parametrize("cin,w", [(1, 21), (3, 21), (1, 24), (2, 24), (3, 24), (4, 24), (5, 24), (1, 70), (3, 96), (4, 33)])
 def test_first_layer_direct_conv(hip, cin, w):
-    # w % 4 == 0 with cin <= 4 takes the strip kernels (4 pixels per thread, weights in registers), the rest the generic ones
+    # cin <= 4 with 64 output channels takes the matrix-core kernels (32-pixel row segments: widths below, at and across a segment; odd
+    # widths), cin = 5 the generic ones
     n, h, co = 2, 18, 64
     rng = np.random.default_rng(cin)
     x = rng.standard_normal((n, cin, h, w)); wt = rng.standard_normal((3, 3, cin, co)); b = rng.standard_normal(co)
@@ -196,12 +197,17 @@ def test_first_layer_direct_conv(hip, cin, w):
     dw = torch.empty(3, 3, cin, co, device=DEV)
     hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dzd), co, 0, P(dw), n, h, w, cin, co, P(ws), nb, ST())
     assert relerr(dw.cpu().numpy().astype(np.float64), dw_ref) < 1e-5
-    # dz stored as bf16: the same (bf16-representable) values as a bf16 and as an fp32 tensor give the same bits
+    # dz stored as bf16: the same (bf16-representable) values as a bf16 and as an fp32 tensor give the same gradient (the bf16 tensor takes
+    # the matrix-core kernel for cin <= 3, the fp32 one the stencil kernels: same products, another summation order), both the oracle's
     dz16 = dzd.to(torch.bfloat16); dz32 = dz16.float()
     dwa, dwb = torch.empty_like(dw), torch.empty_like(dw)
     hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dz16), co, 1, P(dwa), n, h, w, cin, co, P(ws), nb, ST())
     hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dz32), co, 0, P(dwb), n, h, w, cin, co, P(ws), nb, ST())
-    assert torch.equal(dwa, dwb)
+    _, dw16_ref, _ = on.conv_same_bwd(x, wt, from_nhwc(dz32))
+    assert relerr(dwa.cpu().numpy().astype(np.float64), dw16_ref) < 1e-5 and relerr(dwb.cpu().numpy().astype(np.float64), dw16_ref) < 1e-5
+    dwa2 = torch.empty_like(dw)                                    # and bit-reproducible from call to call
+    hip.unet_conv3x3_wgrad_direct(P(xd), cin, P(dz16), co, 1, P(dwa2), n, h, w, cin, co, P(ws), nb, ST())
+    assert torch.equal(dwa, dwa2)
     rows = hip.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, co)
     if rows > 0:
         # + BatchNorm sums, output stored as fp32 or bf16: the bf16 tensor is the fp32 one rounded (nearest even), the sums identical

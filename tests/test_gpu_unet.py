@@ -176,6 +176,7 @@ def test_unet_matches_torch_restatement_at_128():
     g = e.export_gradients()
     errs = grad_errors(g, {k2: v.numpy() for k2, v in g_ref.items()})
     worst = max((v, key) for key, v in errs.items())
+    print("ERRS", {k2: float("%.3g" % v) for k2, v in sorted(errs.items())})
     assert worst[0] < 5e-2, worst
     assert errs["logits/kernel"] < 5e-5 and errs["dec_1b/gamma"] < 5e-5, errs
 
@@ -615,7 +616,14 @@ def test_full_size_tile_matches_torch_restatement():
     e = net.engine
     e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
     e.backward()
-    loss_ref, _, g_ref, _ = ref.loss_and_grads(img, lab, masks)
+    # The tight tensors see two ReLU layers between themselves and the loss (dec_1b, logits): the reference takes the device run's decisions
+    # there.  fp32 evaluation error reaches 5e-5 (max) at the last layers of a 512^2 tile, so one to five of the 524 288 class-map
+    # pre-activations sit close enough to zero to flip, and ONE flip at a pixel with a large loss gradient moves these sums by 1e-4 (seen when
+    # the first layer's kernel, and with it the rounding pattern downstream, changed: 3e-7 -> 1.6e-4).  The imposed decisions may differ from
+    # the reference's own only at pre-activations of that size (the rule of test_gradients_match_oracle_given_the_same_branch_decisions).
+    relu = {name: (e.saved[name][1].float().permute(0, 3, 1, 2) > 0).cpu().numpy() for name in ("dec_1b", "logits")}
+    loss_ref, _, g_ref, _ = ref.loss_and_grads(img, lab, masks, relu_masks=relu)
+    assert max(ref.imposed_flips.values()) < 1e-4, ref.imposed_flips
     assert abs(e.loss_buf[0].item() - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
     errs = grad_errors(e.export_gradients(), {k2: v.numpy() for k2, v in g_ref.items()})
     worst = max((v, key) for key, v in errs.items())
