@@ -24,6 +24,9 @@
 #ifndef UNET_CB_ABLATE
 #define UNET_CB_ABLATE 0        /* diagnostic builds (scripts/build_variant.sh): see conv_bf16_body */
 #endif
+#ifndef UNET_CBS_ABLATE
+#define UNET_CBS_ABLATE 0       /* diagnostic builds of the persistent kernels (results wrong): 1 no DMA, 2 no MFMA stream, 4 no epilogue, 8 no patch DMA, 16 no weight DMA */
+#endif
 
 namespace {
 
@@ -479,6 +482,12 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
 // + epilogue arithmetic 0.208, + stores 0.230: with one workgroup per CU the epilogue (700 VALU instructions and 64 4-byte-per-lane
 // stores per wave and tile) is serial with the matrix pipe, while a second resident workgroup hides most of it -- latency was not the
 // limiter, so the extra stages bought nothing.
+// Round 3 repeated the question for the 128-channel tiles (one workgroup per CU) with ablation builds (UNET_CBS_ABLATE) and one counter pass;
+// 1024->512 @64^2 forward + sums, ms per launch: MFMA stream alone 0.162 (matrix pipe 78 % busy at 2.07 GHz), + epilogue 0.167, + DMA instead
+// 0.209, everything 0.219 (66 % busy at 1.98 GHz); the DMA alone 0.099.  So the DMA costs 0.047 although it would fit under the MFMA stream twice.
+// A THREE-stage patch ring (patch of chunk q + 2 and weights of chunk q + 1 issued during chunk q, counted vmcnt wait that leaves the
+// patch pieces in flight, 136 KB of LDS) passed every test and ran the same 0.222 ms: the loss is not the latency of the patch DMA.  What is
+// left unexplained sits between the weight DMA, the LDS it shares with 54 fragment reads per chunk and wave, and the clock (-4 % with DMA on).
 __device__ __attribute__((aligned(256))) uint16_t g_zero_page_b[4096 + 64];       // zero source that out-of-image patch pixels walk over (per channel)
 
 template <int NCO, int STATS>
@@ -561,9 +570,10 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
                                              (lds_void_b*)(smem + stage * STAGE + kXP + (wv + 4 * k) * 1024), 16, 0, 0);
     };
     auto fill = [&](const Src& s, int chunk, int stage, int g) {    // this wave's share of a chunk's DMA, spread over the MFMA groups
-        if (g < KX) issue_x1(s, chunk, stage, g);
-        if (2 * g < KW) issue_w1(s, chunk, stage, 2 * g);
-        if (2 * g + 1 < KW) issue_w1(s, chunk, stage, 2 * g + 1);
+        if (UNET_CBS_ABLATE & 1) return;
+        if (g < KX && !(UNET_CBS_ABLATE & 8)) issue_x1(s, chunk, stage, g);
+        if (2 * g < KW && !(UNET_CBS_ABLATE & 16)) issue_w1(s, chunk, stage, 2 * g);
+        if (2 * g + 1 < KW && !(UNET_CBS_ABLATE & 16)) issue_w1(s, chunk, stage, 2 * g + 1);
     };
 
     const int G = (int)gridDim.x;
@@ -586,18 +596,20 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
         for (int c = 0; c < nchunks; c += 2) {                       // Cin % 32 == 0: an even number of chunks, chunk c lives in stage c & 1
-            cb_compute<NCO, 0, STAGE, 1>(acc, a_base, b_base, [&](int g) { fill(sf, c + 1, 1, g); }, asel, amask);
+            if (UNET_CBS_ABLATE & 2) { for (int g = 0; g < 18; ++g) fill(sf, c + 1, 1, g); }
+            else cb_compute<NCO, 0, STAGE, 1>(acc, a_base, b_base, [&](int g) { fill(sf, c + 1, 1, g); }, asel, amask);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             int cn = c + 2;
             if (cn == nchunks) {                                     // the stream continues with chunk 0 of the workgroup's next tile
                 cn = 0;                                              // (after the last tile: chunk 0 of this one again -- valid memory, never read)
                 if (logical + G < total) { nxt = tile_at(logical + G); sf = sources(nxt); }
             }
-            cb_compute<NCO, 1, STAGE, 1>(acc, a_base, b_base, [&](int g) { fill(sf, cn, 0, g); }, asel, amask);
+            if (UNET_CBS_ABLATE & 2) { for (int g = 0; g < 18; ++g) fill(sf, cn, 0, g); }
+            else cb_compute<NCO, 1, STAGE, 1>(acc, a_base, b_base, [&](int g) { fill(sf, cn, 0, g); }, asel, amask);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        cb_epilogue<NCO, STATS, 1>(p, acc, cur.img, cur.ty0, cur.tx0, cur.co0, cur.t % p.n_px, red, tid, wv, li, lh);
+        if (!(UNET_CBS_ABLATE & 4)) cb_epilogue<NCO, STATS, 1>(p, acc, cur.img, cur.ty0, cur.tx0, cur.co0, cur.t % p.n_px, red, tid, wv, li, lh);
         cur = nxt;
     }
 }
@@ -668,7 +680,10 @@ int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, fl
     // 128-channel tiles halve the input traffic; 64-channel tiles when they would leave compute units idle
     // (64-channel tiles for the K = 64 layers with 128 outputs -- two workgroups per CU hiding each other's epilogue -- were A/B-tested:
     // 64->128 @256^2 forward 0.111 -> 0.107 ms, 64->128 @512^2 data gradient + sums 0.401 -> 0.421 ms: no gain, wide tiles stay)
-    const bool wide = Cout % 128 == 0 && (long)a.n_px * (Cout / 128) >= conv_bf16_cus();
+#ifndef UNET_CB_NARROW_MAX
+#define UNET_CB_NARROW_MAX 0     /* diagnostic builds: 64-channel tiles (two workgroups per CU) for every layer with Cout <= this */
+#endif
+    const bool wide = Cout % 128 == 0 && (long)a.n_px * (Cout / 128) >= conv_bf16_cus() && Cout > UNET_CB_NARROW_MAX;
     a.n_co = Cout / (wide ? 128 : 64);
     const int mode = stats ? stats->mode : 0;
     if (mode) {
