@@ -17,6 +17,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define UNET_CHECK_ARG(cond) do { if (!(cond)) return UNET_EINVAL; } while (0)
 #define UNET_LAUNCH_STATUS() ((int)hipGetLastError())
 
+// Streaming stores (nt policy) for kernels that only write a tensor larger than the caches.  UNET_NT is the compile-time set of kernel families
+// that use them (bits below; scripts/build_variant_all.sh varies it).  Measured, round 3: the class-map input gradient alone (268 MB bf16 written,
+// launched back to back) 0.099 -> 0.066 ms; inside the training step (same box, ms per step, bf16 / fp32): none 12.71 / 44.22, FIRST 12.65 / 44.11,
+// BN 12.68 / 44.40, BN16 12.64 / 44.13, CONV16 12.62 / 44.19, all four 12.67 / 44.46 against a repeat of none at 12.67 / 44.31 -- only the
+// write-only kernels gain anything that survives the noise, so only they stream.
+#ifndef UNET_NT
+#define UNET_NT 1
+#endif
+#define UNET_NT_FIRST 1       /* first layer forward, class-map input gradient */
+#define UNET_NT_BN 2          /* BatchNorm apply / backward-apply (generic kernels) */
+#define UNET_NT_BN16 4        /* packed bf16 BatchNorm backward kernels */
+#define UNET_NT_CONV16 8      /* bf16 3x3 / transposed conv epilogues */
+#define UNET_NT_AUX(bit) ((UNET_NT & (bit)) ? 2 : 0)             /* cache-policy operand of the raw buffer stores: bit 1 = nt */
+typedef unsigned unet_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned unet_u32x2 __attribute__((ext_vector_type(2)));
+template <int BIT, class T> __device__ __forceinline__ void unet_store(T* p, T v) {
+    if constexpr ((UNET_NT & BIT) != 0) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 static inline bool unet_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int unet_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

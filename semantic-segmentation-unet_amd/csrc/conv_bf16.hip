@@ -272,8 +272,8 @@ __device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)
                     hvec_t h;
 #pragma unroll
                     for (int c = 0; c < NCO; c += 2) h[c >> 1] = cb_pack2(v[c], v[c + 1]);
-                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b64(h, srd_o, ovoff, 0, 0);
-                    else                    __builtin_amdgcn_raw_buffer_store_b32(h[0], srd_o, ovoff, 0, 0);
+                    if constexpr (NCO == 4) __builtin_amdgcn_raw_buffer_store_b64(h, srd_o, ovoff, 0, UNET_NT_AUX(UNET_NT_CONV16));
+                    else                    __builtin_amdgcn_raw_buffer_store_b32(h[0], srd_o, ovoff, 0, UNET_NT_AUX(UNET_NT_CONV16));
                 } else {
                     ovec_t ov;
 #pragma unroll
@@ -1454,7 +1454,7 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
                     const float send = lpar ? vv[e] : vv[e + 1];
                     const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
                     const unsigned pk = lpar ? cb_pack2(recv, vv[e + 1]) : cb_pack2(vv[e], recv);
-                    __builtin_amdgcn_raw_buffer_store_b32(pk, srd_o, ovoff[e], so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(pk, srd_o, ovoff[e], so, UNET_NT_AUX(UNET_NT_CONV16));
                 }
             } else {
 #pragma unroll

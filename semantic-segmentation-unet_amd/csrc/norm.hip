@@ -46,8 +46,8 @@ template <int VEC> __device__ __forceinline__ void vload_dt(float (&v)[VEC], con
 template <int VEC> __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
     if constexpr (VEC == 8) {
         f32x4 t = {v[0], v[1], v[2], v[3]}, u = {v[4], v[5], v[6], v[7]};
-        *reinterpret_cast<f32x4*>(p) = t; *reinterpret_cast<f32x4*>(p + 4) = u;
-    } else if constexpr (VEC == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
+        unet_store<UNET_NT_BN>(reinterpret_cast<f32x4*>(p), t); unet_store<UNET_NT_BN>(reinterpret_cast<f32x4*>(p + 4), u);
+    } else if constexpr (VEC == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; unet_store<UNET_NT_BN>(reinterpret_cast<f32x4*>(p), t); }
     else *p = v[0];
 }
 
@@ -58,12 +58,12 @@ __device__ __forceinline__ unsigned bn_pack2(float lo, float hi) { unsigned r; a
 template <int VEC> __device__ __forceinline__ void vstore_dt(float* base, size_t idx, const float (&v)[VEC], int out16) {
     if constexpr (VEC == 8) {
         if (out16) {
-            uint4 t; t.x = bn_pack2(v[0], v[1]); t.y = bn_pack2(v[2], v[3]); t.z = bn_pack2(v[4], v[5]); t.w = bn_pack2(v[6], v[7]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + idx) = t; return;
+            const unet_u32x4 t = {bn_pack2(v[0], v[1]), bn_pack2(v[2], v[3]), bn_pack2(v[4], v[5]), bn_pack2(v[6], v[7])};
+            unet_store<UNET_NT_BN>(reinterpret_cast<unet_u32x4*>(reinterpret_cast<uint16_t*>(base) + idx), t); return;
         }
     }
     if constexpr (VEC == 4) {
-        if (out16) { uint2 t; t.x = bn_pack2(v[0], v[1]); t.y = bn_pack2(v[2], v[3]); *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + idx) = t; return; }
+        if (out16) { const unet_u32x2 t = {bn_pack2(v[0], v[1]), bn_pack2(v[2], v[3])}; unet_store<UNET_NT_BN>(reinterpret_cast<unet_u32x2*>(reinterpret_cast<uint16_t*>(base) + idx), t); return; }
     }
     vstore<VEC>(base + idx, v);
 }
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const uint16_t* __r
                     uint4 o;
                     bwd16_pixel(make_uint4(g[u][0], g[u][1], g[u][2], g[u][3]), make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]), A, Bc, K, relu, sum4, o);
                     const i32x4v ov = {(int)o.x, (int)o.y, (int)o.z, (int)o.w};
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, sz, vz + (int)((base + (long)u * st) * lddz * 2), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, sz, vz + (int)((base + (long)u * st) * lddz * 2), 0, UNET_NT_AUX(UNET_NT_BN16));
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[0][e] += (double)sum4[e];
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool16_kernel(const uint16_t
                     }
                     ov[j] = (int)bn_pack2(d[0], d[1]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(ov, sz, (int)((pix * lddz + l.c0) * 2), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ov, sz, (int)((pix * lddz + l.c0) * 2), 0, UNET_NT_AUX(UNET_NT_BN16));
             }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[0][e] += (double)sum4[e];
