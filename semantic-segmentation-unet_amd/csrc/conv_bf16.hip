@@ -25,7 +25,7 @@
 #define UNET_CB_ABLATE 0        /* diagnostic builds (scripts/build_variant.sh): see conv_bf16_body */
 #endif
 #ifndef UNET_CBS_ABLATE
-#define UNET_CBS_ABLATE 0       /* diagnostic builds of the persistent kernels (results wrong): 1 no DMA, 2 no MFMA stream, 4 no epilogue, 8 no patch DMA, 16 no weight DMA */
+#define UNET_CBS_ABLATE 0       /* diagnostic builds of the persistent kernels (results wrong): 1 no DMA, 2 no MFMA stream, 4 no epilogue, 8 no patch DMA, 16 no weight DMA, 32 patch DMA from contiguous memory */
 #endif
 
 namespace {
@@ -488,6 +488,9 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
 // A THREE-stage patch ring (patch of chunk q + 2 and weights of chunk q + 1 issued during chunk q, counted vmcnt wait that leaves the
 // patch pieces in flight, 136 KB of LDS) passed every test and ran the same 0.222 ms: the loss is not the latency of the patch DMA.  What is
 // left unexplained sits between the weight DMA, the LDS it shares with 54 fragment reads per chunk and wave, and the clock (-4 % with DMA on).
+// Two more suspects cleared the same day: the patch pieces read from one CONTIGUOUS 20 KB block per chunk instead of 32 bytes per pixel row
+// (UNET_CBS_ABLATE bit 32) cost the same, so it is not the scattered source; one DMA instruction per MFMA group instead of three in groups
+// 0..4 is worth 1-3 % (kept: see fill), so it is not mainly back-to-back issue either.
 __device__ __attribute__((aligned(256))) uint16_t g_zero_page_b[4096 + 64];       // zero source that out-of-image patch pixels walk over (per channel)
 
 template <int NCO, int STATS>
@@ -546,6 +549,8 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
             const bool ok = pp < 18 * kPW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             s.x[k] = ok ? reinterpret_cast<const char*>(p.x) + (((size_t)(c.img * p.H + gy) * p.W + gx) * p.ldx) * 2 + h * 16
                         : reinterpret_cast<const char*>(g_zero_page_b) + h * 16;
+            // (diagnostic: the same byte count from a CONTIGUOUS 20 KB block per tile and chunk -- wrong data, isolates the cost of the 32-byte pieces)
+            if (UNET_CBS_ABLATE & 32) s.x[k] = reinterpret_cast<const char*>(p.x) + ((size_t)(c.t % p.n_px) * 20480 * (p.Cin / 16) + (size_t)id * 1024 + lane * 16) % ((size_t)p.x_bytes - 65536);
         }
         s.w = reinterpret_cast<const char*>(p.wp) + (size_t)c.co0 * 16;
         return s;
@@ -561,8 +566,10 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
     }
     auto issue_x1 = [&](const Src& s, int chunk, int stage, int k) {
         const int id = wv + 4 * k;
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s.x[k] + (size_t)chunk * 32),
-                                         (lds_void_b*)(smem + stage * STAGE + id * 1024), 16, 0, 0);
+        const char* src = s.x[k] + (size_t)chunk * 32;
+        if (UNET_CBS_ABLATE & 32)
+            src = reinterpret_cast<const char*>(p.x) + ((size_t)(s.x[k] - reinterpret_cast<const char*>(p.x)) + (size_t)chunk * 20480) % ((size_t)p.x_bytes - 65536);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void_b*)(smem + stage * STAGE + id * 1024), 16, 0, 0);
     };
     auto issue_w1 = [&](const Src& s, int chunk, int stage, int k) {
         if (NPIECE % 4 == 0 || wv + 4 * k < NPIECE)
@@ -571,9 +578,11 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
     };
     auto fill = [&](const Src& s, int chunk, int stage, int g) {    // this wave's share of a chunk's DMA, spread over the MFMA groups
         if (UNET_CBS_ABLATE & 1) return;
-        if (g < KX && !(UNET_CBS_ABLATE & 8)) issue_x1(s, chunk, stage, g);
-        if (2 * g < KW && !(UNET_CBS_ABLATE & 16)) issue_w1(s, chunk, stage, 2 * g);
-        if (2 * g + 1 < KW && !(UNET_CBS_ABLATE & 16)) issue_w1(s, chunk, stage, 2 * g + 1);
+        // ONE piece per MFMA group: a global_load_lds costs the issuing wave ~15 cycles behind an MFMA but ~64 directly behind another one (3.1);
+        // three per group (patch + two weight pieces in groups 0..4) made the patch pieces 3.5 x as expensive as the weight pieces per instruction
+        static_assert(KW + KX <= 18, "one DMA instruction per MFMA group");
+        if (g < KW) { if (!(UNET_CBS_ABLATE & 16)) issue_w1(s, chunk, stage, g); }
+        else if (g - KW < KX) { if (!(UNET_CBS_ABLATE & 8)) issue_x1(s, chunk, stage, g - KW); }
     };
 
     const int G = (int)gridDim.x;
