@@ -70,11 +70,11 @@ HBM_FAMILY = {   # engine profile key -> description; `work` of these launches i
     "dropout": "dropout_kernel (in place, mask from a counter hash)",
     "softmax_ce": "softmax_ce_kernel (softmax + cross-entropy + d logits, K classes)",
     "adam": "adam_keras_kernel (flat buffers: theta, g, m, v -> theta, m, v)",
-    "first_layer_fwd": "conv3x3_direct_*_stats (first layer, Cin = image channels: VALU stencil + BatchNorm sums)",
-    "first_layer_wgrad": "conv3x3_wgrad_direct (first layer weight gradient)",
-    "classmap_fwd": "conv1x1_narrow_fwd8_kernel (class map 64 -> K)",
-    "classmap_dgrad": "conv1x1_narrow_dgrad_kernel",
-    "classmap_wgrad": "conv1x1_narrow_wgrad_kernel",
+    "first_layer_fwd": "conv3x3_first_mfma_fwd_kernel (first layer, Cin = image channels -> 64: window gathered from global memory, v_mfma_f32_32x32x2_f32, + BatchNorm sums)",
+    "first_layer_wgrad": "first layer weight gradient (conv3x3_first_mfma_wgrad_kernel with a bf16 dz, the stencil kernel with an fp32 one)",
+    "classmap_fwd": "classmap64_fwd_kernel (class map 64 -> K, a channel octet per lane)",
+    "classmap_dgrad": "classmap64_dgrad_kernel (bf16 input gradient) / conv1x1_narrow_dgrad_kernel (fp32)",
+    "classmap_wgrad": "classmap64_wgrad_kernel",
 }
 
 
