@@ -224,6 +224,57 @@ def test_first_layer_direct_conv(hip, cin, w):
         assert relerr(sums[:, 0], zr.sum(0)) < 1e-5 and relerr(sums[:, 1], (zr * zr).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("cin,k,n", [(1, 2, 8), (3, 4, 8)])
+def test_first_layer_and_class_map_at_full_size_match_torch_convolutions(hip, cin, k, n):
+    # The two ends of the network at BASELINE's tile size (8 x 512^2), bf16-stored 64-channel tensors as the mixed-precision step has them,
+    # against torch's own fp64 convolutions: the matrix-core first layer (forward + BatchNorm sums + weight gradient, hand-counted waits:
+    # a wait one count too lenient shows here as a handful of wrong or irreproducible elements) and the octet-per-lane class-map kernels.
+    h = w = 512
+    g = torch.Generator(device=DEV).manual_seed(100 + cin)
+    x = torch.randn(n, h, w, cin, device=DEV, generator=g); wt = torch.randn(3, 3, cin, 64, device=DEV, generator=g) * 0.3; b = torch.randn(64, device=DEV, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wt.double().permute(3, 2, 0, 1), b.double(), padding=1)).permute(0, 2, 3, 1)
+    rows = hip.unet_conv3x3_fwd_direct_stats_rows(n, h, w, cin, 64)
+    outs = []
+    for rep in range(2):
+        o = torch.zeros(n, h, w, 64, device=DEV, dtype=torch.bfloat16); part = torch.zeros(rows * 128, device=DEV)
+        hip.unet_conv3x3_fwd_direct_stats(P(x), cin, P(wt), P(b), P(o), 64, 1, n, h, w, cin, 64, 1, P(part), part.numel() * 4, ST())
+        outs.append((o, part))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    o32 = torch.zeros(n, h, w, 64, device=DEV); part32 = torch.zeros(rows * 128, device=DEV)
+    hip.unet_conv3x3_fwd_direct_stats(P(x), cin, P(wt), P(b), P(o32), 64, 0, n, h, w, cin, 64, 1, P(part32), part32.numel() * 4, ST())
+    assert float((o32.double() - ref).abs().max()) < 2e-5 and torch.equal(o32.to(torch.bfloat16), outs[0][0]) and torch.equal(part32, outs[0][1])
+    sums = outs[0][1].view(rows, 64, 2).double().sum(0)
+    rs = torch.stack([ref.reshape(-1, 64).sum(0), (ref * ref).reshape(-1, 64).sum(0)], 1)
+    assert float(((sums - rs).abs() / rs.abs()).max()) < 2e-6
+    dz = torch.randn(n, h, w, 64, device=DEV, generator=g).to(torch.bfloat16)
+    nb = hip.unet_conv3x3_wgrad_direct_workspace(n, h, w, cin, 64); ws = ws_bytes(nb)
+    dws = []
+    for rep in range(2):
+        dw = torch.empty(3, 3, cin, 64, device=DEV)
+        hip.unet_conv3x3_wgrad_direct(P(x), cin, P(dz), 64, 1, P(dw), n, h, w, cin, 64, P(ws), nb, ST())
+        dws.append(dw)
+    xp = torch.nn.functional.pad(x.double().permute(0, 3, 1, 2), (1, 1, 1, 1)); dzn = dz.double().permute(0, 3, 1, 2)
+    dref = torch.stack([torch.stack([torch.einsum("ncyx,nkyx->ck", xp[:, :, a:a + h, bb:bb + w], dzn) for bb in range(3)]) for a in range(3)])
+    assert torch.equal(dws[0], dws[1]) and float((dws[0].double() - dref).norm() / dref.norm()) < 2e-6
+    # class map on the bf16 64-channel tensor
+    pix = n * h * w
+    y = torch.randn(n, h, w, 64, device=DEV, generator=g).to(torch.bfloat16); wk = torch.randn(64, k, device=DEV, generator=g) * 0.2; bk = torch.randn(k, device=DEV, generator=g)
+    z = torch.empty(n, h, w, k, device=DEV)
+    hip.unet_conv1x1_fwd(P(y), 64, 1, P(wk), P(bk), P(z), k, pix, 64, k, 1, ST())
+    zref = torch.relu(y.double().reshape(-1, 64) @ wk.double() + bk.double()).reshape(n, h, w, k)
+    assert float((z.double() - zref).abs().max()) < 2e-5
+    dzk = torch.randn(n, h, w, k, device=DEV, generator=g)
+    dx = torch.empty(n, h, w, 64, device=DEV, dtype=torch.bfloat16)
+    hip.unet_conv1x1_dgrad(P(dzk), k, P(wk), P(dx), 64, 1, pix, 64, k, ST())
+    dxref = (dzk.double().reshape(-1, k) @ wk.double().t()).reshape(n, h, w, 64)
+    assert float((dx.double() - dxref).abs().max()) < 2.0 ** -8 * float(dxref.abs().max())          # bf16 storage: half an ulp of the largest element
+    nb2 = hip.unet_conv1x1_wgrad_workspace(pix, 64, k); ws2 = ws_bytes(nb2)
+    dwk = torch.empty(64, k, device=DEV)
+    hip.unet_conv1x1_wgrad(P(y), 64, 1, P(dzk), k, P(dwk), pix, 64, k, P(ws2), nb2, ST())
+    dwref = y.double().reshape(-1, 64).t() @ dzk.double().reshape(-1, k)
+    assert float((dwk.double() - dwref).norm() / dwref.norm()) < 2e-6
+
+
 @pytest.mark.parametrize("k", [2, 6, 11])
 def test_conv1x1_class_map(hip, k):
     n, h, w, ci = 2, 9, 13, 64
