@@ -117,10 +117,12 @@ int unet_conv3x3_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_conv3x3_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_conv3x3_wgrad_bf16(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
                             int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-/* first layer (Cin = number_channels, UNet/model.py:88): VALU stencil, any Cin, Cout/4 a power of two <= 256 */
+/* first layer (Cin = number_channels, UNet/model.py:88): any Cin, Cout/4 a power of two <= 256; Cin <= 4 with Cout == 64 runs on the fp32
+ * matrix cores (window gathered from global memory), the rest as a VALU stencil */
 int unet_conv3x3_fwd_direct(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                             int N, int H, int W, int Cin, int Cout, int relu, void* stream);
-/* + BatchNorm sums of the output from the strip kernel (Cin <= 4, W % 4 == 0, Cout % 64 == 0): rows > 0 when it applies */
+/* + BatchNorm sums of the output in the same kernel (Cin <= 4 and Cout == 64, or Cin <= 4, W % 4 == 0, Cout % 64 == 0): rows of partial
+ * sums it writes per 64-channel block, 0 when no such kernel applies */
 int unet_conv3x3_fwd_direct_stats_rows(int N, int H, int W, int Cin, int Cout);
 /* out_bf16: the output tensor is stored as bf16 (ldo in elements; the sums are those of the fp32 values) */
 int unet_conv3x3_fwd_direct_stats(const float* x, int ldx, const float* w, const float* bias, void* out, int ldo, int out_bf16,
