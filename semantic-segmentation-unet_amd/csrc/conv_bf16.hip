@@ -511,6 +511,11 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
 // A THREE-stage patch ring (patch of chunk q + 2 and weights of chunk q + 1 issued during chunk q, counted vmcnt wait that leaves the
 // patch pieces in flight, 136 KB of LDS) passed every test and ran the same 0.222 ms: the loss is not the latency of the patch DMA.  What is
 // left unexplained sits between the weight DMA, the LDS it shares with 54 fragment reads per chunk and wave, and the clock (-4 % with DMA on).
+// The 128-channel tile on EIGHT waves (waves 0-3 output channels 0-63, waves 4-7 channels 64-127, 128 accumulator registers each, patch and
+// weights staged once for both: two waves per SIMD without the doubled patch traffic of two 64-channel workgroups) was built, passed the kernel
+// tests and measured against this form on every layer: 64->128 @256^2 forward -10 %, 128->128 -3 %, 128->64 @512^2 data gradient -6 %, every layer
+// with >= 256 reduce channels +0-2 %: about -0.06 ms per step for three more kernels -- removed.  It fits the counter finding below: these
+// kernels are short of power, not of latency cover.
 // Two more suspects cleared the same day: the patch pieces read from one CONTIGUOUS 20 KB block per chunk instead of 32 bytes per pixel row
 // (UNET_CBS_ABLATE bit 32) cost the same, so it is not the scattered source; one DMA instruction per MFMA group instead of three in groups
 // 0..4 is worth 1-3 % (kept: see fill), so it is not mainly back-to-back issue either.
