@@ -24,8 +24,8 @@ template <int B16> __device__ __forceinline__ void st_quad(float* base, size_t e
         uint2 h;
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h.x) : "v"(v[0]), "v"(v[1]));
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h.y) : "v"(v[2]), "v"(v[3]));
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem) = h;
-    } else *reinterpret_cast<f32x4*>(base + elem) = v;
+        unet_store<UNET_NT_FIRST>(reinterpret_cast<unet_u32x2*>(reinterpret_cast<uint16_t*>(base) + elem), unet_u32x2{h.x, h.y});
+    } else unet_store<UNET_NT_FIRST>(reinterpret_cast<f32x4*>(base + elem), v);          // (st_quad's users only write: first layer, class-map input gradient)
 }
 
 // ---- 3x3 'same' conv, small Cin, forward ---------------------------------------------------------------------
