@@ -17,13 +17,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define UNET_CHECK_ARG(cond) do { if (!(cond)) return UNET_EINVAL; } while (0)
 #define UNET_LAUNCH_STATUS() ((int)hipGetLastError())
 
-// Streaming stores (nt policy) for kernels that only write a tensor larger than the caches.  UNET_NT is the compile-time set of kernel families
-// that use them (bits below; scripts/build_variant_all.sh varies it).  Measured, round 3: the class-map input gradient alone (268 MB bf16 written,
-// launched back to back) 0.099 -> 0.066 ms; inside the training step (same box, ms per step, bf16 / fp32): none 12.71 / 44.22, FIRST 12.65 / 44.11,
-// BN 12.68 / 44.40, BN16 12.64 / 44.13, CONV16 12.62 / 44.19, all four 12.67 / 44.46 against a repeat of none at 12.67 / 44.31 -- only the
-// write-only kernels gain anything that survives the noise, so only they stream.
+// Streaming stores (nt policy).  UNET_NT is the compile-time set of kernel families that use them (bits below; scripts/build_variant_all.sh
+// varies it).  Measured, round 3: write-only kernels launched back to back gain a third (class-map input gradient, 268 MB bf16: 0.099 -> 0.066 ms;
+// fp32: 0.144 -> 0.117).  Inside the training step (same box, alternating runs of 60 steps, ms per bf16 step): FIRST only 13.03 / 13.09 / 13.07,
+// FIRST + CONV16 12.98 / 13.00 / 12.99, + BN16 13.02 / 13.00 / 13.00; a first pass had BN (generic BatchNorm kernels) at +-0.  So the write-only
+// kernels and the bf16 conv epilogues stream; the BatchNorm passes, whose output the next kernel reads back at once, do not.
 #ifndef UNET_NT
-#define UNET_NT 1
+#define UNET_NT 9
 #endif
 #define UNET_NT_FIRST 1       /* first layer forward, class-map input gradient */
 #define UNET_NT_BN 2          /* BatchNorm apply / backward-apply (generic kernels) */
