@@ -21,7 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // varies it).  Measured, round 3: write-only kernels launched back to back gain a third (class-map input gradient, 268 MB bf16: 0.099 -> 0.066 ms;
 // fp32: 0.144 -> 0.117).  Inside the training step (same box, alternating runs of 60 steps, ms per bf16 step): FIRST only 13.03 / 13.09 / 13.07,
 // FIRST + CONV16 12.98 / 13.00 / 12.99, + BN16 13.02 / 13.00 / 13.00; a first pass had BN (generic BatchNorm kernels) at +-0.  So the write-only
-// kernels and the bf16 conv epilogues stream; the BatchNorm passes, whose output the next kernel reads back at once, do not.
+// kernels and the bf16 conv epilogues stream; the BatchNorm passes, whose output the next kernel reads back at once, do not.  The fp32 step
+// loses with streaming outputs: fused Winograd forward / data gradient 44.05 -> 45.2 ms, transposed-conv forward 44.05 -> 44.3 (three
+// alternating runs each) -- their consumers (BatchNorm-apply on load, the next layer) find the tensor in the Infinity Cache today.
 #ifndef UNET_NT
 #define UNET_NT 9
 #endif
