@@ -515,8 +515,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const uint16_t* __r
             i32x4v g[8], v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                g[u] = __builtin_amdgcn_raw_buffer_load_b128(sy, vy + (int)((base + (long)u * st) * lddy * 2), 0, 0);
-                v[u] = __builtin_amdgcn_raw_buffer_load_b128(sr, vr + (int)((base + (long)u * st) * ldr * 2), 0, 0);
+                g[u] = __builtin_amdgcn_raw_buffer_load_b128(sy, vy + (int)((base + (long)u * st) * lddy * 2), 0, UNET_NT_AUX(UNET_NT_LDBN16));
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(sr, vr + (int)((base + (long)u * st) * ldr * 2), 0, UNET_NT_AUX(UNET_NT_LDBN16));
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                        // sums over groups of four pixels, as the generic kernel forms them
@@ -685,6 +685,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const float* __r
 // window-per-lane kernels above (which sit at 138-146 VGPRs, 3 waves per SIMD, ~3.8 TB/s).
 struct Pool16 { i32x4v g[4], v[4], pd; unsigned ixlo, ixhi; };
 
+template <int LAST>               // LAST: the apply pass, which reads dy and r for the last time (streaming policy, common.h)
 __device__ __forceinline__ void pool16_load(Pool16& w, const __amdgpu_buffer_rsrc_t& sy, const __amdgpu_buffer_rsrc_t& sr,
                                             const __amdgpu_buffer_rsrc_t& sp, const uint8_t* __restrict__ idx, long op, int c0, int C,
                                             int lddy, int ldr, int ldp, int H, int W) {
@@ -696,8 +697,8 @@ __device__ __forceinline__ void pool16_load(Pool16& w, const __amdgpu_buffer_rsr
 #pragma unroll
     for (int pos = 0; pos < 4; ++pos) {
         const long pix = (n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1);
-        w.g[pos] = __builtin_amdgcn_raw_buffer_load_b128(sy, (int)((pix * lddy + c0) * 2), 0, 0);
-        w.v[pos] = __builtin_amdgcn_raw_buffer_load_b128(sr, (int)((pix * ldr + c0) * 2), 0, 0);
+        w.g[pos] = __builtin_amdgcn_raw_buffer_load_b128(sy, (int)((pix * lddy + c0) * 2), 0, LAST ? UNET_NT_AUX(UNET_NT_LDBN16) : 0);
+        w.v[pos] = __builtin_amdgcn_raw_buffer_load_b128(sr, (int)((pix * ldr + c0) * 2), 0, LAST ? UNET_NT_AUX(UNET_NT_LDBN16) : 0);
     }
 }
 __device__ __forceinline__ float bf_elem(const i32x4v& q, int e) { const unsigned wd = (unsigned)q[e >> 1]; return (e & 1) ? bf_hi(wd) : bf_lo(wd); }
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool16_kernel(const uint16_
         const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc((void*)pg.pdy, 0, (int)((size_t)P2 * pg.ldp * 2), 0x00020000);
         for (long op = p0 + l.pl; op < p1; op += l.npl) {
             Pool16 w;
-            pool16_load(w, sy, sr, sp, pg.idx, op, l.c0, C, lddy, ldr, pg.ldp, pg.H, pg.W);
+            pool16_load<0>(w, sy, sr, sp, pg.idx, op, l.c0, C, lddy, ldr, pg.ldp, pg.H, pg.W);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const int win = pool16_winner(w, e);
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool16_kernel(const uint16_t
         const __amdgpu_buffer_rsrc_t sz = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (int)((size_t)P * lddz * 2), 0x00020000);
         for (long op = p0 + l.pl; op < p1; op += l.npl) {
             Pool16 w;
-            pool16_load(w, sy, sr, sp, pg.idx, op, l.c0, C, lddy, ldr, pg.ldp, pg.H, pg.W);
+            pool16_load<1>(w, sy, sr, sp, pg.idx, op, l.c0, C, lddy, ldr, pg.ldp, pg.H, pg.W);
             long t = op; const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const long n = t / H2;
             float sum4[VEC];
 #pragma unroll
