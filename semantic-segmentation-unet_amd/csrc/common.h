@@ -29,13 +29,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // step.  The same in the generic kernels of the fp32 step LOSES (44.07 -> 44.27, 44.09 -> 44.18, 44.12 -> 44.26): there r is read again by the
 // consumer layer's weight gradient (BatchNorm-apply on load), so it is not a last use; not kept.
 #ifndef UNET_NT
-#define UNET_NT 73
+#define UNET_NT 201
 #endif
 #define UNET_NT_FIRST 1       /* first layer forward, class-map input gradient */
 #define UNET_NT_BN 2          /* BatchNorm apply / backward-apply (generic kernels) */
 #define UNET_NT_BN16 4        /* packed bf16 BatchNorm backward kernels */
 #define UNET_NT_CONV16 8      /* bf16 3x3 / transposed conv epilogues */
 #define UNET_NT_LDBN16 64     /* last-use LOADS of dy and r in the packed bf16 BatchNorm backward apply kernels */
+#define UNET_NT_LDAPPLY 128   /* the conv output r read by BatchNorm apply: its next reader is the backward pass (12.74/12.78/12.77 -> 12.71/12.74/12.71 ms
+                               * per bf16 step, fp32 unchanged within 0.05) */
 #define UNET_NT_AUX(bit) ((UNET_NT & (bit)) ? 2 : 0)             /* cache-policy operand of the raw buffer stores: bit 1 = nt */
 typedef unsigned unet_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned unet_u32x2 __attribute__((ext_vector_type(2)));

@@ -12,12 +12,16 @@
 namespace {
 
 typedef int i32x4v __attribute__((ext_vector_type(4)));
+constexpr int kApplyNT = (UNET_NT & UNET_NT_LDAPPLY) != 0;
 
-template <int VEC> __device__ __forceinline__ void vload(float (&v)[VEC], const float* p) {
+template <class T, int NT> __device__ __forceinline__ T bn_ld(const T* p) {
+    if constexpr (NT != 0) return __builtin_nontemporal_load(p); else return *p;
+}
+template <int VEC, int NT = 0> __device__ __forceinline__ void vload(float (&v)[VEC], const float* p) {
     if constexpr (VEC == 8) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p), u = *reinterpret_cast<const f32x4*>(p + 4);
+        const f32x4 t = bn_ld<f32x4, NT>(reinterpret_cast<const f32x4*>(p)), u = bn_ld<f32x4, NT>(reinterpret_cast<const f32x4*>(p + 4));
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; v[4] = u[0]; v[5] = u[1]; v[6] = u[2]; v[7] = u[3];
-    } else if constexpr (VEC == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    } else if constexpr (VEC == 4) { const f32x4 t = bn_ld<f32x4, NT>(reinterpret_cast<const f32x4*>(p)); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
     else v[0] = *p;
 }
 __device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
@@ -25,23 +29,23 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(f
 // load from an fp32 tensor or (in16, VEC >= 4) from a bf16 tensor of the same logical layout (element index idx).  VEC == 8 is the
 // 16-byte-per-lane form for bf16 tensors (8 channels per lane; an fp32 tensor is then two 16-byte loads): 8-byte accesses run at
 // 0.54-0.70 of the 16-byte rate on this memory system, which is what held the bf16-storage mode back in round 1
-template <int VEC> __device__ __forceinline__ void vload_dt(float (&v)[VEC], const float* base, size_t idx, int in16) {
+template <int VEC, int NT = 0> __device__ __forceinline__ void vload_dt(float (&v)[VEC], const float* base, size_t idx, int in16) {
     if constexpr (VEC == 8) {
         if (in16) {
-            const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + idx);
-            v[0] = bf_lo(t.x); v[1] = bf_hi(t.x); v[2] = bf_lo(t.y); v[3] = bf_hi(t.y);
-            v[4] = bf_lo(t.z); v[5] = bf_hi(t.z); v[6] = bf_lo(t.w); v[7] = bf_hi(t.w);
+            const unet_u32x4 t = bn_ld<unet_u32x4, NT>(reinterpret_cast<const unet_u32x4*>(reinterpret_cast<const uint16_t*>(base) + idx));
+            v[0] = bf_lo(t[0]); v[1] = bf_hi(t[0]); v[2] = bf_lo(t[1]); v[3] = bf_hi(t[1]);
+            v[4] = bf_lo(t[2]); v[5] = bf_hi(t[2]); v[6] = bf_lo(t[3]); v[7] = bf_hi(t[3]);
             return;
         }
     }
     if constexpr (VEC == 4) {
         if (in16) {
-            const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
-            v[0] = bf_lo(t.x); v[1] = bf_hi(t.x); v[2] = bf_lo(t.y); v[3] = bf_hi(t.y);
+            const unet_u32x2 t = bn_ld<unet_u32x2, NT>(reinterpret_cast<const unet_u32x2*>(reinterpret_cast<const uint16_t*>(base) + idx));
+            v[0] = bf_lo(t[0]); v[1] = bf_hi(t[0]); v[2] = bf_lo(t[1]); v[3] = bf_hi(t[1]);
             return;
         }
     }
-    vload<VEC>(v, base + idx);
+    vload<VEC, NT>(v, base + idx);
 }
 template <int VEC> __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
     if constexpr (VEC == 8) {
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     for (; pix + 3 * S < P; pix += 4 * S) {
         float v[4][VEC];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vload_dt<VEC>(v[u], r, (size_t)(pix + u * S) * ldr + l.c0, out16 & 2);
+        for (int u = 0; u < 4; ++u) vload_dt<VEC, kApplyNT>(v[u], r, (size_t)(pix + u * S) * ldr + l.c0, out16 & 2);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
     for (; pix < P; pix += S) {
         float v[VEC];
-        vload_dt<VEC>(v, r, (size_t)pix * ldr + l.c0, out16 & 2);
+        vload_dt<VEC, kApplyNT>(v, r, (size_t)pix * ldr + l.c0, out16 & 2);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[e] = fmaf(a[e], v[e], b[e]);
         vstore_dt<VEC>(y, (size_t)pix * ldy + l.c0, v, out16 & 1);
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
             const size_t pix = (size_t)((long)n * H + 2 * oy + (pos >> 1)) * W + 2 * ox + (pos & 1);
-            vload_dt<VEC>(v[pos], r, pix * ldr + l.c0, out16 & 2);
+            vload_dt<VEC, kApplyNT>(v[pos], r, pix * ldr + l.c0, out16 & 2);
         }
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
