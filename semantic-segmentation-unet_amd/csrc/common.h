@@ -28,6 +28,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // write -- read next by the data- and weight-gradient kernels -- keeps the cache: 12.84 -> 12.70 / 12.84 -> 12.77 / 12.83 -> 12.69 ms per bf16
 // step.  The same in the generic kernels of the fp32 step LOSES (44.07 -> 44.27, 44.09 -> 44.18, 44.12 -> 44.26): there r is read again by the
 // consumer layer's weight gradient (BatchNorm-apply on load), so it is not a last use; not kept.
+// LDS-DMA SOURCES with the streaming policy (diagnostic build, same A/B): the conv patch 12.78 -> 14.05 ms, the weight gradient's input rows
+// -> 13.08, its dz rows -> 13.05: every staged tensor is re-read inside its kernel by the other channel tiles and wants the L2; not kept.
 #ifndef UNET_NT
 #define UNET_NT 201
 #endif
