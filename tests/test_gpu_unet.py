@@ -472,7 +472,8 @@ def test_bf16_operand_beyond_2gib_falls_back_to_fp32_kernels():
 
 @pytest.mark.parametrize("cfg", [(2, 1, 2, 32, "fp32"), (2, 3, 4, 64, "fp32"), (1, 1, 2, 128, "fp32"),
                                  (3, 1, 2, (48, 80), "fp32"), (1, 3, 6, (16, 176), "fp32"),             # non-square tiles, odd batch
-                                 (1, 2, 11, 32, "fp32"), (5, 4, 3, 32, "fp32")])                        # other channel / class counts
+                                 (1, 2, 11, 32, "fp32"), (5, 4, 3, 32, "fp32"),                        # other channel / class counts
+                                 (2, 5, 3, 32, "fp32")])                                               # five image channels: the generic first-layer kernels, separate statistics pass
 def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
     # End-to-end gradients at 1e-4 instead of 5e-2.  The network is piecewise linear: its gradient is discontinuous only in the
     # branch decisions (ReLU masks, max-pool winners), and fp32 rounding flips a few of those for pre-activations within ~1e-7
