@@ -23,12 +23,15 @@ fams = {"bf16": ["unet_conv3x3_wgrad_bf16", "unet_conv3x3_dgrad_bf16", "unet_con
                  "unet_convT2x2_wgrad_bf16", "unet_convT2x2_dgrad_bf16", "unet_convT2x2_fwd_bf16", "unet_bn_train_finalize_partials",
                  "unet_conv3x3_wgrad_direct", "unet_conv3x3_fwd_direct_stats", "unet_conv1x1_wgrad", "unet_conv1x1_dgrad", "unet_conv1x1_fwd",
                  "unet_bf16_pack_weights_batch", "unet_adam_keras"],
-        "fp32": ["unet_conv3x3_wgrad_winograd_fused", "unet_conv3x3_dgrad_winograd_fused", "unet_conv3x3_fwd_winograd_fused", "unet_bn_bwd_from_partials",
-                 "unet_bn_bwd_pooled", "unet_bn_bwd", "unet_bn_apply", "unet_bn_apply_maxpool", "unet_convT2x2_wgrad", "unet_convT2x2_dgrad",
+        "fp32": ["unet_conv3x3_wgrad_winograd_fused", "unet_conv3x3_dgrad_winograd_fused", "unet_conv3x3_fwd_winograd_fused", "unet_bn_bwd_any",
+                 "unet_bn_apply", "unet_bn_apply_maxpool", "unet_bn_train_finalize_partials", "unet_convT2x2_wgrad", "unet_convT2x2_dgrad",
                  "unet_convT2x2_fwd_stream_stats", "unet_winograd_weight_fold", "unet_conv3x3_wgrad_fold_fix", "unet_winograd_weight_transform_batch"]}[dtype]
+# a family's no-op takes its dependants along: the BatchNorm backward leaves the bias gradient's partial rows to unet_bn_bwd_bias
+together = {"unet_bn_bwd_any": ["unet_bn_bwd_bias"]}
 for name in fams:
-    orig = getattr(L, name)
-    setattr(L, name, lambda *a: 0)
+    names = [name] + together.get(name, [])
+    origs = [getattr(L, n) for n in names]
+    for n in names: setattr(L, n, lambda *a: 0)
     t = run()
-    setattr(L, name, orig)
+    for n, o in zip(names, origs): setattr(L, n, o)
     print("without %-40s %.3f ms  (%+.3f)" % (name, t, t - base), flush=True)

@@ -1235,57 +1235,63 @@ __device__ __forceinline__ float fold_scale(float sc, float sh) {
     return fabsf(sc) < smin ? copysignf(smin, sc) : sc;
 }
 
+// One launch: a workgroup owns kFoldCo output channels and ALL input-channel groups, so the folded bias (a sum over the input channels)
+// is finished inside it -- thread = (output channel, one of 64 lanes over the 8-channel groups), fixed-order double sums.  (Round 3: the
+// separate bias kernel was one of three tiny launches between two persistent convolutions, each worth 25 us of chain in the fp32 step.)
+constexpr int kFoldCo = 4, kFoldLanes = 256 / kFoldCo;
 __global__ __launch_bounds__(256) void wino_weight_fold_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-        const float* __restrict__ shift, float* __restrict__ uf, float* __restrict__ part, float* __restrict__ pad, int Ci, int Co) {
+        const float* __restrict__ shift, const float* __restrict__ bias, float* __restrict__ uf, float* __restrict__ bias_out,
+        float* __restrict__ pad, int Ci, int Co) {
+    __shared__ double sPart[kFoldLanes][kFoldCo];
     const size_t plane = (size_t)Ci * Co;
-    const long items = (long)(Ci >> 3) * Co;
-    const long it = (long)blockIdx.x * 256 + threadIdx.x;
-    if (it >= items) return;
-    const int c8 = (int)(it / Co), co = (int)(it % Co);
-    float t[16][8];
-    float tsum = 0.f;
+    const int col = threadIdx.x % kFoldCo, gl = threadIdx.x / kFoldCo;
+    const int co = blockIdx.x * kFoldCo + col;
+    const bool live = co < Co;
+    double bsum = 0.0;
+    for (int c8 = gl; c8 < (Ci >> 3) && live; c8 += kFoldLanes) {
+        float t[16][8];
+        float tsum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int ci = 8 * c8 + e;
-        const float sh = shift[ci], sc = fold_scale(scale[ci], sh);
-        float g[3][3], gs = 0.f;
+        for (int e = 0; e < 8; ++e) {
+            const int ci = 8 * c8 + e;
+            const float sh = shift[ci], sc = fold_scale(scale[ci], sh);
+            float g[3][3], gs = 0.f;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) { const float v = w[((size_t)(a * 3 + b) * Ci + ci) * Co + co]; gs += v; g[a][b] = sc * v; }
-        tsum = fmaf(sh, gs, tsum);
-        float s[4][3];
+                for (int b = 0; b < 3; ++b) { const float v = w[((size_t)(a * 3 + b) * Ci + ci) * Co + co]; gs += v; g[a][b] = sc * v; }
+            tsum = fmaf(sh, gs, tsum);
+            float s[4][3];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            s[0][b] = g[0][b];
-            s[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-            s[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-            s[3][b] = g[2][b];
+            for (int b = 0; b < 3; ++b) {
+                s[0][b] = g[0][b];
+                s[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+                s[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+                s[3][b] = g[2][b];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                t[4 * r + 0][e] = s[r][0]; t[4 * r + 1][e] = 0.5f * (s[r][0] + s[r][1] + s[r][2]);
+                t[4 * r + 2][e] = 0.5f * (s[r][0] - s[r][1] + s[r][2]); t[4 * r + 3][e] = s[r][2];
+            }
+            if (co == 0) pad[ci] = -sh / sc;
         }
+        const size_t offf = ((size_t)c8 * Co + co) * 8;                                   // [k/8][n=co][k%8]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            t[4 * r + 0][e] = s[r][0]; t[4 * r + 1][e] = 0.5f * (s[r][0] + s[r][1] + s[r][2]);
-            t[4 * r + 2][e] = 0.5f * (s[r][0] - s[r][1] + s[r][2]); t[4 * r + 3][e] = s[r][2];
+        for (int xi = 0; xi < 16; ++xi) {
+            float* o = uf + (size_t)xi * plane + offf;
+            *reinterpret_cast<f32x4*>(o) = f32x4{t[xi][0], t[xi][1], t[xi][2], t[xi][3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{t[xi][4], t[xi][5], t[xi][6], t[xi][7]};
         }
-        if (co == 0) pad[ci] = -sh / sc;
+        bsum += (double)tsum;                                           // shift term of this 8-channel group
     }
-    const size_t offf = ((size_t)c8 * Co + co) * 8;                                   // [k/8][n=co][k%8]
+    sPart[gl][col] = bsum;
+    __syncthreads();
+    if (gl == 0 && live) {
+        double sacc = 0.0;
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) {
-        float* o = uf + (size_t)xi * plane + offf;
-        *reinterpret_cast<f32x4*>(o) = f32x4{t[xi][0], t[xi][1], t[xi][2], t[xi][3]};
-        *reinterpret_cast<f32x4*>(o + 4) = f32x4{t[xi][4], t[xi][5], t[xi][6], t[xi][7]};
-    }
-    part[(size_t)c8 * Co + co] = tsum;                                  // shift term of this 8-channel group, summed in fixed order below
-}
-
-__global__ __launch_bounds__(256) void wino_fold_bias_kernel(const float* __restrict__ part, int rows, const float* __restrict__ bias,
-                                                             float* __restrict__ bias_out, float* __restrict__ pad, int Ci, int Co) {
-    const int co = blockIdx.x * 256 + threadIdx.x;
-    if (co < Co) {
-        double s = 0.0;
-        for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * Co + co];
-        bias_out[co] = (float)((double)(bias ? bias[co] : 0.f) + s);
+        for (int l = 0; l < kFoldLanes; ++l) sacc += sPart[l][col];
+        bias_out[co] = (float)((double)(bias ? bias[co] : 0.f) + sacc);
     }
     if (blockIdx.x == 0 && threadIdx.x < 8) pad[Ci + threadIdx.x] = 0.f;             // the 8 floats the halo pointers may walk past the end
 }
@@ -1515,11 +1521,8 @@ extern "C" int unet_winograd_weight_fold(const float* w, const float* bias, cons
                                          float* pad, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(w && scale && shift && Uc && bias_out && pad && ws && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 4 == 0 && unet_aligned16(Uc));
     if (ws_bytes < unet_winograd_weight_fold_workspace(Cin, Cout)) return UNET_ENOSPC;
-    const long items = (long)(Cin / 8) * Cout;
-    hipStream_t st = (hipStream_t)stream;
-    wino_weight_fold_kernel<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(w, scale, shift, Uc, (float*)ws, pad, Cin, Cout);
-    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    wino_fold_bias_kernel<<<(unsigned)((Cout + 255) / 256), 256, 0, st>>>((const float*)ws, Cin / 8, bias, bias_out, pad, Cin, Cout);
+    (void)ws;                                                          // (round 3: the bias is finished inside the fold kernel; the workspace is unused)
+    wino_weight_fold_kernel<<<(unsigned)((Cout + kFoldCo - 1) / kFoldCo), 256, 0, (hipStream_t)stream>>>(w, scale, shift, bias, Uc, bias_out, pad, Cin, Cout);
     return UNET_LAUNCH_STATUS();
 }
 
