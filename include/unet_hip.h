@@ -28,8 +28,8 @@ extern "C" {
 #define UNET_ENOSPC (-2)
 
 /* Bumped whenever an exported signature changes; a loader must refuse a library whose unet_hip_abi_version() differs
- * (3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
-#define UNET_HIP_ABI_VERSION 3
+ * (4: round 4 -- the BF16x6 Winograd route: unet_*_x6; 3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
+#define UNET_HIP_ABI_VERSION 4
 int unet_hip_abi_version(void);
 
 /* ---- Conv2D(3x3, 'same', relu) of UNet._conv_layer, UNet/model.py:28-35 (18 instances, :88-134) ------------------ */
@@ -85,6 +85,27 @@ int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, const float* dz
 size_t unet_conv3x3_wgrad_fold_fix_workspace(int Cout);
 int unet_conv3x3_wgrad_fold_fix(float* dw, const float* scale, const float* shift, const float* dz, int lddz, const float* total,
                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* ---- the same Winograd F(2x2,3x3) layers with the 16 point products on the BF16 matrix pipe at fp32 grade ("BF16x6") ---------------
+ * A second route to the fp32 result of UNet._conv_layer (UNet/model.py:28-35), beside unet_conv3x3_*_winograd_fused: every fp32 operand of a
+ * Winograd-domain product is split EXACTLY into three bf16 pieces (h + m + l), the six piece products hh, hm, mh, hl, lh, mm are exact
+ * and accumulate in fp32 (v_mfma_f32_32x32x16_bf16); the three dropped products are below 2^-24 of the product, i.e. one fp32 multiply's
+ * rounding, so the error against an fp64 evaluation equals that of the fp32 matrix instruction (tests/test_gpu_x6.py asserts <= 1.25 x).
+ * The transforms stay fp32.  Shapes: H, W even, reduce channels % 32 == 0 and >= 64, output channels % 64 == 0 (unet_winograd_x6_supported).
+ * Weight operands (16 * 3 * Cin * Cout bf16 = unet_winograd_x6_weight_bytes): _x6(w, mode 0 forward / 1 data gradient), every layer and
+ * direction in one launch with _x6_batch (jobs: njobs x 6 int64 = { w, U6, Cin | Cout << 32, first_block, mode, 0 }, first_block = running
+ * sum of ceil(Cin * Cout / 2048)), or _fold_x6 = unet_winograd_weight_fold for this route.  The two conv entry points take the arguments of
+ * unet_conv3x3_fwd_winograd_fused / unet_conv3x3_dgrad_winograd_fused with U6 in place of Uc; stat_part rows are the same function. */
+int unet_winograd_x6_supported(int N, int H, int W, int K, int Nout);
+size_t unet_winograd_x6_weight_bytes(int Cin, int Cout);
+int unet_winograd_weight_transform_x6(const float* w, void* U6, int Cin, int Cout, int mode, void* stream);
+int unet_winograd_weight_transform_x6_batch(const void* jobs, int njobs, int total_blocks, void* stream);
+int unet_winograd_weight_fold_x6(const float* w, const float* bias, const float* scale, const float* shift, void* U6, float* bias_out,
+                                 float* pad, int Cin, int Cout, void* stream);
+int unet_conv3x3_fwd_winograd_x6(const float* x, int ldx, const float* pad, const void* U6, const float* bias, float* out, int ldo,
+                                 int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream);
+int unet_conv3x3_dgrad_winograd_x6(const float* dz, int lddz, const void* U6d, float* dx, int lddx,
+                                   int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+                                   float* stat_part, size_t stat_bytes, void* stream);
 /* ---- bf16 matrix-core 3x3 convolution (BASELINE config 4: bf16 forward/backward, fp32 master weights; the reference keeps
  * its mixed-precision policy commented out, UNet/train.py:52-54) ------------------------------------------------------
  * Operands rounded to bf16 (nearest-even), exact products, fp32 accumulation.

@@ -1,0 +1,18 @@
+"""One BF16x6 forward + one native forward launch per shape (for rocprofv3 counter passes): python scripts/x6_one.py"""
+import ctypes, importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+L = importlib.import_module("semantic-segmentation-unet_amd._lib").lib()
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+for shape in [(8, 64, 64, 512, 512), (8, 512, 512, 64, 64)]:
+    n, h, w, ci, co = shape
+    x = torch.randn(n, h, w, ci, device="cuda"); wt = torch.randn(3, 3, ci, co, device="cuda") / float(np.sqrt(9 * ci))
+    u = torch.empty(L.unet_winograd_x6_weight_bytes(ci, co), dtype=torch.uint8, device="cuda")
+    L.unet_winograd_weight_transform_x6(P(wt), P(u), ci, co, 0, ST())
+    uc = torch.empty(16 * ci * co, device="cuda"); L.unet_winograd_weight_transform(P(wt), P(uc), ci, co, 2, ST())
+    y = torch.empty(n, h, w, co, device="cuda")
+    for _ in range(3):
+        L.unet_conv3x3_fwd_winograd_x6(P(x), ci, None, P(u), None, P(y), co, n, h, w, ci, co, 1, None, 0, ST())
+        L.unet_conv3x3_fwd_winograd_fused(P(x), ci, None, P(uc), None, P(y), co, n, h, w, ci, co, 1, None, 0, ST())
+    torch.cuda.synchronize()

@@ -1,0 +1,23 @@
+"""Diagnostic: s_memtime phases of the BF16x6 forward kernel's units (build: scripts/build_variant.sh x6tl winograd_x6.hip "-DUNET_X6_ABLATE=8";
+run with UNET_HIP_LIB=.../libunet_hip_x6tl.so).  Prints, per unit of workgroup 0 / wave 0: operand wait, MFMA stream, DMA/LDS wait, barrier."""
+import ctypes, importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+L = importlib.import_module("semantic-segmentation-unet_amd._lib").lib()
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+for shape in [(8, 64, 64, 512, 512), (8, 512, 512, 64, 64), (8, 32, 32, 1024, 1024), (8, 256, 256, 128, 128)]:
+    n, h, w, ci, co = shape
+    x = torch.randn(n, h, w, ci, device="cuda"); wt = torch.randn(3, 3, ci, co, device="cuda") / float(np.sqrt(9 * ci))
+    u = torch.empty(L.unet_winograd_x6_weight_bytes(ci, co), dtype=torch.uint8, device="cuda")
+    L.unet_winograd_weight_transform_x6(P(wt), P(u), ci, co, 0, ST())
+    y = torch.empty(n, h, w, co, device="cuda")
+    for _ in range(3):
+        L.unet_conv3x3_fwd_winograd_x6(P(x), ci, None, P(u), None, P(y), co, n, h, w, ci, co, 1, None, 0, ST())
+    torch.cuda.synchronize()
+    out = (ctypes.c_longlong * 8)()
+    L.cdll.unet_debug_x6_timeline(out)
+    t = list(out)
+    units = max(t[4], 1)
+    print("%-26s units %5d: operand wait %6.0f | stream %6.0f | vm/lgkm wait %6.0f | barrier %6.0f  (cycles per unit); tile total/unit %6.0f" % (
+        str(shape), units, t[0] / units, t[1] / units, t[2] / units, t[3] / units, t[5] / units), flush=True)

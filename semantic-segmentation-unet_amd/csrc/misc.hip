@@ -408,4 +408,4 @@ extern "C" int unet_conv3x3_dgrad_direct(const float* dz, int lddz, const float*
     return UNET_LAUNCH_STATUS();
 }
 
-extern "C" int unet_hip_abi_version(void) { return 3; }       // == UNET_HIP_ABI_VERSION of include/unet_hip.h
+extern "C" int unet_hip_abi_version(void) { return 4; }       // == UNET_HIP_ABI_VERSION of include/unet_hip.h
