@@ -43,13 +43,15 @@ __device__ long long g_x6_timeline[8];
 typedef int x6_i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned x6_u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kX6DB = 24 * 1024;                  // one D chunk buffer: 324 pixel slots x 64 B in 24 1-KB DMA pieces (21 used + 3 dummies)
+constexpr int kX6DB = 21 * 1024;                  // one D chunk buffer: 324 pixel slots x 64 B in 21 1-KB DMA pieces (the last one a quarter used)
 constexpr int kX6IB = 24 * 1024;                  // one V or U unit image
 constexpr int kX6Blk = 2048;                      // one (point, piece) block: 64 rows x 32 B
-constexpr int kX6V = 2 * kX6DB, kX6U = kX6V + 2 * kX6IB, kX6Smem = kX6U + 2 * kX6IB;      // 147456 B
+// LDS map: D0 D1 (21 KB each) | V0 U0 | V1 U1 | 16 KB spare.  The epilogue's exchange region X = V1 U1 spare (64 KB): idle at a tile's end (the last unit's parity is 1).
+constexpr int kX6V = 2 * kX6DB, kX6U = kX6V + kX6IB, kX6Par = 2 * kX6IB, kX6X = kX6V + kX6Par, kX6Smem = kX6X + 64 * 1024;      // 154 KB
 constexpr int kX6RowB = 18 * 64;                  // bytes between patch rows in D
 
 #define X6_RD128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
+#define X6_WR2(base, o0, o1, v0, v1) asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(base), "v"(v0), "v"(v1), "n"(o0), "n"(o1) : "memory")
 #define X6_WR64(base, off, val) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(val), "n"(off) : "memory")
 #define X6_MFMA(accv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(accv) : "v"(av), "v"(bv) : "memory")
 // LDS-DMA of one 1-KB piece (16 B per lane) to LDS byte address `ldsaddr` (wave-uniform): M0 carries the LDS address.  Written as asm so
@@ -140,95 +142,112 @@ template <int R2, int C> __device__ __forceinline__ void x6_row_stage(f32x4 (&dd
 }
 #define X6_TIE_DD(d) "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
 
-// One unit: the 24 MFMAs of point row R of a chunk with D parity DP (V / U buffers R & 1), and everything that runs in their shadow.
-//   S0 / S1: the two sets of 8 row registers; set (R & 1) holds the row stage of unit g+1 (consumed here), the other one takes the raw
-//            rows of unit g+2 and ends as its row stage;
-//   us: source of U(g+1) for this wave's first block (uniform), uoff[j]: the lane's byte offset of its piece j from there;
-//   dptr: this lane's running sources of its six D pieces -- the two issued in this unit (R != 1) advance by one chunk, or jump to the next
-//         tile's patch (dnxt) when `dswitch` says this was the tile's last chunk (uniform).
-// LDS instructions retire in order; the lgkmcnt immediates count the LDS instructions issued behind the one waited for.
+// ---- the unit, by role ------------------------------------------------------------------------------------------------------------------
+// MFMA role of unit (chunk parity DP, point row R): 24 MFMAs into the wave's accumulators 4 (R >> 1) + p from V / U buffers R & 1, and this
+// wave's DMA duty: six pieces of U(g+1) and (R != 2) two D pieces.
+// Operand pieces are prefetched one by one, three MFMAs ahead of their first use, so that about seven 16-byte fragments are live instead of
+// two whole points' twelve (the kernel runs two waves per SIMD: 128 vector registers).  Products of a point in the order
+//   (h,h) (h,m) (m,h) (m,m) (h,l) (l,h)            [weights piece, data piece]
+// introduce u_h v_h | v_m | u_m | - | v_l | u_l; the pieces are read in exactly that order of need:
+//   before the unit: u_h v_h v_m u_m of point 0;  behind MFMA k of point p:  k=1: v_l(p)  k=2: u_l(p)  k=3: u_h v_h(p+1)  k=4: v_m(p+1)  k=5: u_m(p+1)
+// LDS reads are this role's only LDS instructions and retire in order: every lgkmcnt below = the reads issued behind the piece waited for.
+//   us: source of U(g+1) for this wave's first block (uniform), ublk: bytes between its pieces, u_lane: the lane's byte offset in a piece;
+//   da / db: the lane's sources of the two D pieces issued here.
+#define X6_RDU(dst, PT, PC) X6_RD128(dst, b_base, (PT * 3 + PC) * kX6Blk)
+#define X6_RDV(dst, PT, PC) X6_RD128(dst, a_base, (PT * 3 + PC) * kX6Blk)
 template <int R, int DP, bool FIRST>
-__device__ __forceinline__ void x6_unit(f32x16 (&acc)[16], f32x4 (&S0)[8], f32x4 (&S1)[8], X6Frag (&fr)[2], X6Split& sp,
-                                        unsigned a_base, unsigned b_base, const unsigned (&d_base)[4], unsigned v_base,
-                                        const char* us, const unsigned (&uoff)[6], const float* (&dptr)[6], const float* (&dnxt)[6], bool dswitch,
-                                        unsigned lds_w, long long (&tl)[6]) {
+__device__ __forceinline__ void x6_mfma_role(f32x16 (&acc)[8], unsigned a_base0, unsigned b_base0,
+                                             const char* us, size_t ublk, unsigned u_lane, const float* da, const float* db, bool has_db, unsigned lds_w) {
     constexpr int P = R & 1, PN = P ^ 1;
-#if (UNET_X6_ABLATE & 8)
-    long long q0, q1, q2, q3;
-    X6_STAMP(q0);
-#endif
-    constexpr int R2 = (R + 2) & 3, DPR = DP ^ (R >= 2 ? 1 : 0);
-    // D pieces issued here: R = 2: chunk c+2 pieces 0,1 (wave's j = 0,1); R = 3: pieces j = 2,3; R = 0: chunk c+1, j = 4,5; R = 1: none
-    constexpr int ND = R == 1 ? 0 : 2;
-    constexpr int DJ = R == 2 ? 0 : R == 3 ? 2 : 4;
-    constexpr int DPW = R == 0 ? (DP ^ 1) : DP;                       // buffer of that chunk
-    f32x4 (&tt)[8] = P ? S1 : S0;
-    f32x4 (&dd)[8] = P ? S0 : S1;
-    asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_FRAG(fr[0]));        // point 0's operands (issued by the caller side of the barrier)
-    X6_STAMP(q1);
+    // D pieces issued by the MFMA group of this unit: R = 3: chunk c+2, pieces wq, wq+4; R = 0: chunk c+1, pieces wq+8, wq+12;
+    // R = 1: chunk c+1, pieces wq+16, wq+20; R = 2: none
+    constexpr int ND = R == 2 ? 0 : 2;
+    constexpr int DPC = R == 3 ? 0 : R == 0 ? 8 : 16;                 // first piece of the pair, before the wave's own wq
+    constexpr int DPW = R == 3 ? DP : (DP ^ 1);                       // buffer of that chunk
+    const unsigned a_base = a_base0 + P * kX6Par, b_base = b_base0 + P * kX6Par;
+    x6_i32x4 uh[2], vh[2], vm[2], um[2], vl[2], ul[2];               // [point parity]
+    X6_RDU(uh[0], 0, 0); X6_RDV(vh[0], 0, 0); X6_RDV(vm[0], 0, 1); X6_RDU(um[0], 0, 1);
 #pragma unroll
-    for (int n = 0; n < 24; ++n) {
-        const int p = n / 6, k = n % 6;
-        X6Frag& f = fr[p & 1];
-        if (k == 0 && p > 0) asm volatile("s_waitcnt lgkmcnt(3)" : X6_TIE_FRAG(f));       // behind its reads: the previous point's 3 V writes
-        // piece products, small to large: (m,m) (l,h) (h,l) (m,h) (h,m) (h,h);  u = weights (rows = channels), v = data (columns = tiles)
-        const int ui = k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 0 : k == 3 ? 1 : 0;
-        const int vi = k == 0 ? 1 : k == 1 ? 0 : k == 2 ? 2 : k == 3 ? 0 : k == 4 ? 1 : 0;
-#if !(UNET_X6_ABLATE & 32)       /* diagnostics: 32 = no MFMAs (results wrong) */
-        if (FIRST && k == 0) X6_MFMA0(acc[4 * R + p], f.u[ui], f.v[vi]);
-        else X6_MFMA(acc[4 * R + p], f.u[ui], f.v[vi]);
+    for (int p = 0; p < 4; ++p) {
+        const int e = p & 1, o = e ^ 1;
+        f32x16& A = acc[4 * (R >> 1) + p];
+        // (h,h)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(uh[e]), "+v"(vh[e]));
+#if !(UNET_X6_ABLATE & 32)
+        if (FIRST) X6_MFMA0(A, uh[e], vh[e]); else X6_MFMA(A, uh[e], vh[e]);
 #endif
-        // ---- in the shadow of MFMA n
-        if (k == 0 && p < 3 && !(UNET_X6_ABLATE & 128)) {        // operands of the next point
-            if (p == 0) x6_read_ops<P, 1>(fr[1], a_base, b_base);
-            if (p == 1) x6_read_ops<P, 2>(fr[0], a_base, b_base);
-            if (p == 2) x6_read_ops<P, 3>(fr[1], a_base, b_base);
-        }
-        if (n >= 1 && n <= 4 && !(UNET_X6_ABLATE & 512)) {       // raw rows of unit g+2, two reads per gap
-            if (n == 1) x6_read_rows<R2, DPR, 0>(dd, d_base);
-            if (n == 2) x6_read_rows<R2, DPR, 1>(dd, d_base);
-            if (n == 3) x6_read_rows<R2, DPR, 2>(dd, d_base);
-            if (n == 4) x6_read_rows<R2, DPR, 3>(dd, d_base);
-        }
-        if ((n & 1) == 0 && n < 12 && !(UNET_X6_ABLATE & 64))    // U(g+1): one DMA every second MFMA (the vector-memory issue path is busy ~64 cycles per DMA)
-            X6_DMA_S(uoff[n >> 1], us, lds_w, kX6U + PN * kX6IB + (n >> 1) * 4096);
-        if (ND && n == 12 && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ], lds_w, DPW * kX6DB + DJ * 4096);
-        if (ND && n == 14 && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ + 1], lds_w, DPW * kX6DB + (DJ + 1) * 4096);
-        if (ND && n == 17) {                                     // (a light gap) the two pointers move on
-            if (dswitch) { dptr[DJ] = dnxt[DJ]; dptr[DJ + 1] = dnxt[DJ + 1]; }
-            else { dptr[DJ] += 16; dptr[DJ + 1] += 16; }
-            X6_PIN("+v"(dptr[DJ]), "+v"(dptr[DJ + 1]));
-        }
-        if (k < 5) {                                             // column stage + split of point p of unit g+1
-            if (p == 0) { if (k == 0) x6_split_step<0, 0>(sp, tt); if (k == 1) x6_split_step<1, 0>(sp, tt); if (k == 2) x6_split_step<2, 0>(sp, tt); if (k == 3) x6_split_step<3, 0>(sp, tt); if (k == 4) x6_split_step<4, 0>(sp, tt); }
-            if (p == 1) { if (k == 0) x6_split_step<0, 1>(sp, tt); if (k == 1) x6_split_step<1, 1>(sp, tt); if (k == 2) x6_split_step<2, 1>(sp, tt); if (k == 3) x6_split_step<3, 1>(sp, tt); if (k == 4) x6_split_step<4, 1>(sp, tt); }
-            if (p == 2) { if (k == 0) x6_split_step<0, 2>(sp, tt); if (k == 1) x6_split_step<1, 2>(sp, tt); if (k == 2) x6_split_step<2, 2>(sp, tt); if (k == 3) x6_split_step<3, 2>(sp, tt); if (k == 4) x6_split_step<4, 2>(sp, tt); }
-            if (p == 3) { if (k == 0) x6_split_step<0, 3>(sp, tt); if (k == 1) x6_split_step<1, 3>(sp, tt); if (k == 2) x6_split_step<2, 3>(sp, tt); if (k == 3) x6_split_step<3, 3>(sp, tt); if (k == 4) x6_split_step<4, 3>(sp, tt); }
-            if (k == 4 && !(UNET_X6_ABLATE & 256)) {
-                if (p == 0) x6_write_v<PN, 0>(sp, v_base);
-                if (p == 1) x6_write_v<PN, 1>(sp, v_base);
-                if (p == 2) x6_write_v<PN, 2>(sp, v_base);
-                if (p == 3) x6_write_v<PN, 3>(sp, v_base);
-            }
-        } else {                                                 // row stage of unit g+2, one patch column per point
-            if (p == 0) { asm volatile("s_waitcnt lgkmcnt(3)" : X6_TIE_DD(dd)); x6_row_stage<R2, 0>(dd); }      // behind the row reads: point 0's V writes
-            if (p == 1) x6_row_stage<R2, 1>(dd);
-            if (p == 2) x6_row_stage<R2, 2>(dd);
-            if (p == 3) x6_row_stage<R2, 3>(dd);
-        }
+        if (p == 0) X6_RDV(vl[e], 0, 2); if (p == 1) X6_RDV(vl[e], 1, 2); if (p == 2) X6_RDV(vl[e], 2, 2); if (p == 3) X6_RDV(vl[e], 3, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // (h,m)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vm[e]));
+#if !(UNET_X6_ABLATE & 32)
+        X6_MFMA(A, uh[e], vm[e]);
+#endif
+        if (p == 0) X6_RDU(ul[e], 0, 2); if (p == 1) X6_RDU(ul[e], 1, 2); if (p == 2) X6_RDU(ul[e], 2, 2); if (p == 3) X6_RDU(ul[e], 3, 2);
+        if (p < 3 && !(UNET_X6_ABLATE & 64)) X6_DMA_S(u_lane, us + (size_t)(2 * p) * ublk, lds_w, kX6U + PN * kX6Par + (2 * p) * 4096);      // U(g+1) pieces 0, 2, 4
+        __builtin_amdgcn_sched_barrier(0);
+        // (m,h)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(um[e]));
+#if !(UNET_X6_ABLATE & 32)
+        X6_MFMA(A, um[e], vh[e]);
+#endif
+        if (p == 0) { X6_RDU(uh[o], 1, 0); X6_RDV(vh[o], 1, 0); }
+        if (p == 1) { X6_RDU(uh[o], 2, 0); X6_RDV(vh[o], 2, 0); }
+        if (p == 2) { X6_RDU(uh[o], 3, 0); X6_RDV(vh[o], 3, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        // (m,m)
+#if !(UNET_X6_ABLATE & 32)
+        X6_MFMA(A, um[e], vm[e]);
+#endif
+        if (p == 0) X6_RDV(vm[o], 1, 1); if (p == 1) X6_RDV(vm[o], 2, 1); if (p == 2) X6_RDV(vm[o], 3, 1);
+        if (p < 3 && !(UNET_X6_ABLATE & 64)) X6_DMA_S(u_lane, us + (size_t)(2 * p + 1) * ublk, lds_w, kX6U + PN * kX6Par + (2 * p + 1) * 4096);   // pieces 1, 3, 5
+        if (p == 3 && ND && !(UNET_X6_ABLATE & 64)) X6_DMA_V(da, lds_w, DPW * kX6DB + DPC * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        // (h,l): behind v_l: u_l, then the next point's u_h, v_h, v_m
+        if (p < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vl[e])); else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(vl[e]));
+#if !(UNET_X6_ABLATE & 32)
+        X6_MFMA(A, uh[e], vl[e]);
+#endif
+        if (p == 0) X6_RDU(um[o], 1, 1); if (p == 1) X6_RDU(um[o], 2, 1); if (p == 2) X6_RDU(um[o], 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // (l,h): behind u_l: the next point's u_h, v_h, v_m, u_m
+        if (p < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ul[e])); else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ul[e]));
+#if !(UNET_X6_ABLATE & 32)
+        X6_MFMA(A, ul[e], vh[e]);
+#endif
+        if (p == 3 && ND && !(UNET_X6_ABLATE & 64) && (R != 1 || has_db)) X6_DMA_V(db, lds_w, DPW * kX6DB + (DPC + 4) * 1024);      // (pieces 21..23 do not exist)
         __builtin_amdgcn_sched_barrier(0);
     }
-    X6_STAMP(q2);
-#if (UNET_X6_ABLATE & 8)
-    if (ND) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    X6_STAMP(q3);
-    asm volatile("s_barrier" ::: "memory");
-    { long long q4; X6_STAMP(q4); tl[0] += q1 - q0; tl[1] += q2 - q1; tl[2] += q3 - q2; tl[3] += q4 - q3; tl[4] += 1; }
-#else
-    if (ND) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-    x6_read_ops<PN, 0>(fr[0], a_base, b_base);                   // point 0 of the next unit
+    // leave this unit's D pieces in flight (they are needed a unit later at the earliest; the wave's next wait is a vmcnt(0))
+    if (ND && (R != 1 || has_db)) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    else if (ND) asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Transform role: raw rows of point row R1 from D buffer DPR -> row stage -> column stage + split -> V image PN (the unit the SAME wave
+// group multiplies next).  Lane = (tile, channel quad).  Plain code: its vector instructions run beside the partner wave's MFMAs.
+template <int R1, int DPR, int PN>
+__device__ __forceinline__ void x6_transform_role(const unsigned (&d_base)[4], unsigned v_base0) {
+    const unsigned v_base = v_base0 + PN * kX6Par;
+    f32x4 dd[8];
+    x6_read_rows<R1, DPR, 0>(dd, d_base); x6_read_rows<R1, DPR, 1>(dd, d_base); x6_read_rows<R1, DPR, 2>(dd, d_base); x6_read_rows<R1, DPR, 3>(dd, d_base);
+    asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_DD(dd));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dd[c] = X6Rows<R1>::ADD ? dd[c] + dd[4 + c] : dd[c] - dd[4 + c];
+    x6_u32x2 lprev;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 vv = j == 0 ? dd[0] - dd[2] : j == 1 ? dd[1] + dd[2] : j == 2 ? dd[2] - dd[1] : dd[1] - dd[3];
+        float a[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = vv[e] - x6_trunc(vv[e]); b[e] = a[e] - x6_trunc(a[e]); }
+        // (h, m) of a point are 2048 bytes = 4 x 512 apart: one ds_write2st64_b64; the l pieces of two points share one
+        X6_WR2(v_base, (j * 3 + 0) * 4, (j * 3 + 1) * 4, (x6_u32x2{x6_hi2(vv[0], vv[1]), x6_hi2(vv[2], vv[3])}), (x6_u32x2{x6_hi2(a[0], a[1]), x6_hi2(a[2], a[3])}));
+        const x6_u32x2 lcur = x6_u32x2{x6_hi2(b[0], b[1]), x6_hi2(b[2], b[3])};
+        if (j & 1) X6_WR2(v_base, ((j - 1) * 3 + 2) * 4, (j * 3 + 2) * 4, lprev, lcur);
+        lprev = lcur;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 struct X6Args {
@@ -236,33 +255,154 @@ struct X6Args {
     const uint16_t* U6;          // [K/16][unit 4][point 4][piece 3][Nout][16] bf16
 };
 
+// ---- epilogue of the wave pair ------------------------------------------------------------------------------------------------------------
+// SIMD partners (mi, ni, ph = 0 / 1) hold point rows {0, 2} / {1, 3} of the same [32 channels x 32 tiles] block.  The output transform
+// A^T m A is linear in the rows: each partner applies it to its own two rows (partial row stage rr0 = A + sB B, rr1 = sA A - B with
+// (sA, sB) = (0, 1) / (1, 0), then the column stage), hands the two channel quads it does not finish to the other one through LDS
+// (8 KB per wave, 64 KB in the buffers that are idle at a tile's end), adds what it receives and finishes its own two quads: bias, ReLU,
+// BatchNorm sums, stores.  Channel quad g = accumulator elements 4g..4g+3 = channels n0 + 32 ni + 8 g + 4 lh + {0..3}; ph keeps g = 2 ph, 2 ph + 1.
+template <int G> __device__ __forceinline__ void x6_partial_quad(const f32x16 (&acc)[8], float sA, float sB, f32x4 (&y)[4]) {
+    f32x2 yy[2][2][2];                            // [out row][out col][channel pair]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x2 rr[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // explicit accumulator reads (element extraction left to the compiler round-trips whole accumulators through VGPRs)
+            float a0, a1, b0, b1;
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(a0) : "a"(acc[j][4 * G + 2 * h]));
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(a1) : "a"(acc[j][4 * G + 2 * h + 1]));
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(b0) : "a"(acc[4 + j][4 * G + 2 * h]));
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(b1) : "a"(acc[4 + j][4 * G + 2 * h + 1]));
+            rr[0][j] = f32x2{fmaf(sB, b0, a0), fmaf(sB, b1, a1)};
+            rr[1][j] = f32x2{fmaf(sA, a0, -b0), fmaf(sA, a1, -b1)};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            yy[i][0][h] = rr[i][0] + (rr[i][1] + rr[i][2]);
+            yy[i][1][h] = (rr[i][1] - rr[i][2]) - rr[i][3];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) y[2 * i + j] = f32x4{yy[i][j][0].x, yy[i][j][0].y, yy[i][j][1].x, yy[i][j][1].y};
+}
+#define X6_WR128_RT(base, off, val) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "v"(val), "n"(off) : "memory")
+
+// ONE code path for both partners: the ph = 1 wave reads its weight rows rotated by 16 (x6_stream_body), so in BOTH waves accumulator
+// elements 0..7 (quads 0, 1) are the channels the wave finishes itself -- 32 ni + 16 ph + 8 q + 4 lh + {0..3} -- and elements 8..15 the
+// ones it hands to its partner.
 template <int STATS>
-__device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
+__device__ __forceinline__ void x6_pair_epilogue(const f32x16 (&acc)[8], const WinoFusedArgs& p, int img, int by, int bx, int n0, int mi, int ni,
+                                                 int ph, int wq, int li, int lh, unsigned xbase, f32x2 (&s1)[4], f32x2 (&s2)[4]) {
+    const int kq0 = 2 * ph;                        // kept channel quads (of the wave pair's 32 channels): kq0, kq0 + 1
+    const float sA = ph ? 1.f : 0.f, sB = ph ? 0.f : 1.f;
+    const unsigned xw = xbase + (unsigned)((wq * 2 + ph) * 8192), xr = xbase + (unsigned)((wq * 2 + (ph ^ 1)) * 8192);
+    const int lt = 32 * mi + li;
+    const int ty = 8 * by + (lt >> 3), tx = 8 * bx + (lt & 7);
+    const bool ok = ty < (p.H >> 1) && tx < (p.W >> 1);
+    float* o = p.out + ((size_t)(img * p.H + 2 * ty) * p.W + 2 * tx) * p.ldo + n0 + 32 * ni + 4 * lh + 8 * kq0;
+    const size_t rowstride = (size_t)p.W * p.ldo;
+    {
+        f32x4 y[4];
+        x6_partial_quad<2>(acc, sA, sB, y);
+#pragma unroll
+        for (int px = 0; px < 4; ++px) X6_WR128_RT(xw, px * 1024, y[px]);
+        x6_partial_quad<3>(acc, sA, sB, y);
+#pragma unroll
+        for (int px = 0; px < 4; ++px) X6_WR128_RT(xw, (4 + px) * 1024, y[px]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    const bool rok = STATS == 2 && ok && n0 >= p.bn_c0 && n0 < p.bn_c1;
+    const float* r = STATS == 2 ? p.bn_r + ((size_t)(img * p.H + 2 * ty) * p.W + 2 * tx) * p.bn_ldr + (n0 - p.bn_c0) + 32 * ni + 4 * lh + 8 * kq0 : nullptr;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                   // one kept quad at a time: partner's half from LDS, own half from the accumulators
+        f32x4 yp[4], rv[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) X6_RD128(yp[px], xr, (4 * q + px) * 1024);
+        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * ni + 4 * lh + 8 * (kq0 + q));
+        if (STATS == 2) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                rv[px] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (rok) rv[px] = *reinterpret_cast<const f32x4*>(r + ((size_t)(px >> 1) * p.W + (px & 1)) * p.bn_ldr + 8 * q);
+            }
+        }
+        f32x4 yk[4];
+        if (q == 0) x6_partial_quad<0>(acc, sA, sB, yk); else x6_partial_quad<1>(acc, sA, sB, yk);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yp[0]), "+v"(yp[1]), "+v"(yp[2]), "+v"(yp[3]));
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            f32x4 v = (yk[px] + yp[px]) + bias4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+            if (ok) {
+                *reinterpret_cast<f32x4*>(o + (size_t)(px >> 1) * rowstride + (size_t)(px & 1) * p.ldo + 8 * q) = v;
+                if (STATS == 1) {
+                    s1[2 * q] += f32x2{v[0], v[1]}; s1[2 * q + 1] += f32x2{v[2], v[3]};
+                    s2[2 * q] += f32x2{v[0] * v[0], v[1] * v[1]}; s2[2 * q + 1] += f32x2{v[2] * v[2], v[3] * v[3]};
+                }
+                if (STATS == 2) {
+                    s1[2 * q] += f32x2{v[0], v[1]}; s1[2 * q + 1] += f32x2{v[2], v[3]};
+                    s2[2 * q] += f32x2{v[0] * rv[px][0], v[1] * rv[px][1]}; s2[2 * q + 1] += f32x2{v[2] * rv[px][2], v[3] * rv[px][3]};
+                }
+            }
+        }
+    }
+    asm volatile("s_barrier" ::: "memory");        // every partner read is done: the exchange buffers are the next unit's V / U images
+}
+
+// per-lane running sums -> the wave's 16 channels of its row of partials; layout as wf_write_stats: stat_part[tn][row][64 channels][2]
+__device__ __forceinline__ void x6_write_stats(const WinoFusedArgs& p, int t0, int rows_per_tn, int mi, int ni, int ph, int li, int lh,
+                                               f32x2 (&s1)[4], f32x2 (&s2)[4]) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[4 * i] = s1[i].x; v[4 * i + 1] = s1[i].y; v[4 * i + 2] = s2[i].x; v[4 * i + 3] = s2[i].y; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) v[i] += __shfl_xor(v[i], m, 32);
+    if (li != 0) return;
+    const int tn = t0 % p.nt, row = 2 * (t0 / p.nt) + mi;
+    float* o = p.stat_part + ((size_t)tn * rows_per_tn + row) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                       // pair i = 2 q + h -> channels 32 ni + 8 (2 ph + q) + 4 lh + 2 h + {0, 1}
+        const int ch = 32 * ni + 8 * (2 * ph + (i >> 1)) + 4 * lh + 2 * (i & 1);
+        o[2 * ch] = v[4 * i]; o[2 * ch + 1] = v[4 * i + 2]; o[2 * ch + 2] = v[4 * i + 1]; o[2 * ch + 3] = v[4 * i + 3];
+    }
+}
+
+// The body of one wave group.  PH (waves 4 PH .. 4 PH + 3) is a template parameter: the two groups run different straight-line code
+// (with the role chosen by a branch around the accumulator-modifying statements the compiler copied accumulator tuples through scratch).
+template <int STATS, int PH>
+__device__ __forceinline__ void x6_group_body(const X6Args& q, int ntiles, char* smem) {
     const WinoFusedArgs& p = q.f;
-    __shared__ __attribute__((aligned(1024))) char smem[kX6Smem];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mi = wv & 1, ni = wv >> 1;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int ph = PH;
+    const int wq = w8 & 3;                                      // SIMD partners are waves wq and wq + 4
+    const int mi = wq & 1, ni = wq >> 1;
     const int li = lane & 31, lh = lane >> 5;
     const int nchunks = p.K / 16;
 
-    // ---- DMA duty.  U: piece wv + 4 j of a unit image = block (wv >> 1) + 2 j, rows 32 (wv & 1) + lane / 2, 16-byte slot lane & 1
-    //      (source-side swizzle: slot ^ bit 3 of the row).  D: piece wv + 4 j = pixel slots 16 (wv + 4 j) + lane / 4, channel quad lane & 3.
-    const int urow = 32 * (wv & 1) + (lane >> 1);
+    // ---- DMA duty (in the MFMA role).  U: piece wq + 4 j of a unit image = block (wq >> 1) + 2 j, rows 32 (wq & 1) + lane / 2, 16-byte slot
+    //      lane & 1 (source-side swizzle: slot ^ bit 3 of the row).  D: piece = pixel slots 16 piece + lane / 4, channel quad lane & 3; group
+    //      ph = 0 owns pieces wq + 8, wq + 12, group ph = 1 pieces wq, wq + 4, wq + 16, wq + 20 (21..23 are dummies beyond the patch).
+    const int urow = 32 * (wq & 1) + (lane >> 1);
     const unsigned u_lane = (unsigned)(urow * 32 + 16 * ((lane & 1) ^ ((urow >> 3) & 1)));
-    unsigned uoff[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) uoff[j] = u_lane + (unsigned)j * 2u * (unsigned)p.Nout * 32u;      // blocks b and b + 2 are 2 N rows apart
+    const size_t ublk = (size_t)2 * p.Nout * 32;                                      // blocks b and b + 2 are 2 N rows apart
     const size_t ustep = (size_t)12 * p.Nout * 32;                                    // bytes between units
-    int ppy[6], ppx[6], poff[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int s = 16 * (wv + 4 * j) + (lane >> 2);
-        const int py = s / 18, px = x6_col_of(s % 18);
-        ppy[j] = s < 324 ? py : (1 << 20);                                            // past the patch: never inside the image
-        ppx[j] = px;
-        poff[j] = (py * p.W + px) * p.ldx + 4 * (lane & 3);
-    }
+    auto piece_geom = [&](int piece, int& py_, int& px_, int& off_) {
+        const int s_ = 16 * piece + (lane >> 2);
+        const int py = s_ / 18, px = x6_col_of(s_ % 18);
+        py_ = s_ < 324 ? py : (1 << 20);                                              // past the patch: never inside the image
+        px_ = px;
+        off_ = (py * p.W + px) * p.ldx + 4 * (lane & 3);
+    };
+    auto slot_piece = [&](int j) { return ph ? (j < 2 ? wq + 4 * j : wq + 16 + 4 * (j - 2)) : wq + 8 + 4 * (j & 1); };
     struct TileCoord { int tn, bx, by, img; };
     auto decode = [&](int t) { TileCoord c; c.tn = t % p.nt; t /= p.nt; c.bx = t % p.tbx; t /= p.tbx; c.by = t % p.tby; c.img = t / p.tby; return c; };
     const TileCoord dstep = decode((int)gridDim.x);
@@ -274,81 +414,79 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         return c;
     };
     const float* const padsrc = p.pad ? p.pad : g_zero_page_f;
-    auto tile_sources = [&](const TileCoord& c, const float* (&dp)[6], const char*& ub0) {
+    auto pixel_src = [&](const TileCoord& c, int py, int px, int off) {
         const int gy0 = 16 * c.by - 1, gx0 = 16 * c.bx - 1;
         const float* xb = p.x + ((long long)(c.img * p.H + gy0) * p.W + gx0) * p.ldx;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const bool ok = (unsigned)(gy0 + ppy[j]) < (unsigned)p.H && (unsigned)(gx0 + ppx[j]) < (unsigned)p.W;
-            dp[j] = ok ? xb + poff[j] : padsrc + 4 * (lane & 3);
-        }
-        ub0 = reinterpret_cast<const char*>(q.U6) + ((size_t)(wv >> 1) * p.Nout + (size_t)c.tn * 64) * 32;
+        const bool ok = (unsigned)(gy0 + py) < (unsigned)p.H && (unsigned)(gx0 + px) < (unsigned)p.W;
+        return ok ? xb + off : padsrc + 4 * (lane & 3);
     };
+    auto slot_src = [&](const TileCoord& c, int j) { int py, px, off; piece_geom(slot_piece(j), py, px, off); return pixel_src(c, py, px, off); };
+    auto u_source = [&](const TileCoord& c) { return reinterpret_cast<const char*>(q.U6) + ((size_t)(wq >> 1) * p.Nout + (size_t)c.tn * 64) * 32; };
 
     // ---- LDS byte addresses
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_f*)smem;
-    const int arow = 32 * mi + li, brow = 32 * ni + li;
-    const unsigned a_base = lds0 + kX6V + (unsigned)(arow * 32 + 16 * (lh ^ ((arow >> 3) & 1)));
-    const unsigned b_base = lds0 + kX6U + (unsigned)(brow * 32 + 16 * (lh ^ ((brow >> 3) & 1)));
-    const int t_lt = 16 * wv + (lane >> 2), t_q = lane & 3;                      // transform duty: (tile, channel quad)
+    const int arow = 32 * mi + li;
+    const int t_lt = 16 * wq + (lane >> 2), t_q = lane & 3;                      // transform duty: (tile, channel quad)
+    const unsigned a_base = lds0 + kX6V + (unsigned)(arow * 32 + 16 * (lh ^ ((arow >> 3) & 1)));          // parity 0; parity 1 is kX6Par further
+    // (the ph = 1 partner takes its 32 weight rows rotated by 16: see x6_pair_epilogue)
+    const int brow_r = 32 * ni + ((li + 16 * ph) & 31);
+    const unsigned b_base = lds0 + kX6U + (unsigned)(brow_r * 32 + 16 * (lh ^ ((brow_r >> 3) & 1)));
+    const unsigned v_base = lds0 + kX6V + (unsigned)(t_lt * 32 + 16 * ((t_q >> 1) ^ ((t_lt >> 3) & 1)) + 8 * (t_q & 1));
     unsigned d_base[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         d_base[c] = lds0 + (unsigned)(((2 * (t_lt >> 3)) * 18 + x6_slot_of(2 * (t_lt & 7) + c)) * 64 + 16 * t_q);
-    const unsigned v_base = lds0 + kX6V + (unsigned)(t_lt * 32 + 16 * ((t_q >> 1) ^ ((t_lt >> 3) & 1)) + 8 * (t_q & 1));
-    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wv * 1024));       // this wave's first piece, as an M0 value
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wq * 1024));       // this wave's first piece, as an M0 value
 
-    f32x16 acc[16];
-    f32x4 S0[8], S1[8];
-    X6Frag fr[2];
-    X6Split sp;
-    const float* dptr[6]; const float* dnxt[6]; const char* ucur; const char* unxt;
+    f32x16 acc[8];
+    const float* dptr[4]; const char* ucur; const char* unxt;
     int t = blockIdx.x;
     if ((gridDim.x & 7) == 0 && (p.nt & 7) != 0) t = (t & 7) * (int)(gridDim.x >> 3) + (t >> 3);       // XCD-aware renumbering, as winograd.hip
     const int t_first = t;
-    f32x2 s1[8], s2[8];
+    f32x2 s1[4], s2[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s1[i] = f32x2{0.f, 0.f}; s2[i] = f32x2{0.f, 0.f}; }
+    for (int i = 0; i < 4; ++i) { s1[i] = f32x2{0.f, 0.f}; s2[i] = f32x2{0.f, 0.f}; }
     TileCoord tc = decode(t);
-    tile_sources(tc, dptr, ucur);
-
-    // ---- prologue of the workgroup's first tile: D(0), D(1) pieces 0..3, U(unit 0) -> LDS; V(unit 0) by a full transform; row stage of unit 1
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        X6_DMA_V(dptr[j], lds_w, j * 4096);
-        if (j < 4) X6_DMA_V(dptr[j] + 16, lds_w, kX6DB + j * 4096);
-        X6_DMA_S(uoff[j], ucur, lds_w, kX6U + j * 4096);
-        dptr[j] += j < 4 ? 32 : 16;                              // next issue: chunk 2 (pieces 0..3), chunk 1 (pieces 4, 5)
+    for (int j = 0; j < 4; ++j) dptr[j] = slot_src(tc, j);
+    ucur = u_source(tc);
+
+    // ---- prologue of the workgroup's first tile: D(0) (all eight waves, three pieces each), D(1) pieces 0..7 (group 1), U(unit 0) (group 0)
+    //      -> LDS; then group 0 transforms unit 0
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int py, px, off;
+        piece_geom(w8 + 8 * j, py, px, off);
+        if (w8 + 8 * j < 21) X6_DMA_V(pixel_src(tc, py, px, off), lds_w + ph * 4096, 8 * j * 1024);  // piece w8 + 8 j = wq + 4 ph + 8 j
+    }
+    if (ph) {
+        X6_DMA_V(dptr[0] + 16, lds_w, kX6DB); X6_DMA_V(dptr[1] + 16, lds_w, kX6DB + 4096);
+        dptr[0] += 32; dptr[1] += 32; dptr[2] += 16; dptr[3] += 16;           // next: chunk 2 (pieces 0..7), chunk 1 (pieces 16..23)
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) X6_DMA_S(u_lane, ucur + (size_t)j * ublk, lds_w, kX6U + j * 4096);
+        dptr[0] += 16; dptr[1] += 16;                                         // next: chunk 1 (pieces 8..15)
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    x6_read_rows<0, 0, 0>(S1, d_base); x6_read_rows<0, 0, 1>(S1, d_base); x6_read_rows<0, 0, 2>(S1, d_base); x6_read_rows<0, 0, 3>(S1, d_base);
-    x6_read_rows<1, 0, 0>(S0, d_base); x6_read_rows<1, 0, 1>(S0, d_base); x6_read_rows<1, 0, 2>(S0, d_base); x6_read_rows<1, 0, 3>(S0, d_base);
-    asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_DD(S1));
-    asm volatile("" : X6_TIE_DD(S0));
-    x6_row_stage<0, 0>(S1); x6_row_stage<0, 1>(S1); x6_row_stage<0, 2>(S1); x6_row_stage<0, 3>(S1);
-    x6_row_stage<1, 0>(S0); x6_row_stage<1, 1>(S0); x6_row_stage<1, 2>(S0); x6_row_stage<1, 3>(S0);
-    x6_split_step<0, 0>(sp, S1); x6_split_step<1, 0>(sp, S1); x6_split_step<2, 0>(sp, S1); x6_split_step<3, 0>(sp, S1); x6_split_step<4, 0>(sp, S1); x6_write_v<0, 0>(sp, v_base);
-    x6_split_step<0, 1>(sp, S1); x6_split_step<1, 1>(sp, S1); x6_split_step<2, 1>(sp, S1); x6_split_step<3, 1>(sp, S1); x6_split_step<4, 1>(sp, S1); x6_write_v<0, 1>(sp, v_base);
-    x6_split_step<0, 2>(sp, S1); x6_split_step<1, 2>(sp, S1); x6_split_step<2, 2>(sp, S1); x6_split_step<3, 2>(sp, S1); x6_split_step<4, 2>(sp, S1); x6_write_v<0, 2>(sp, v_base);
-    x6_split_step<0, 3>(sp, S1); x6_split_step<1, 3>(sp, S1); x6_split_step<2, 3>(sp, S1); x6_split_step<3, 3>(sp, S1); x6_split_step<4, 3>(sp, S1); x6_write_v<0, 3>(sp, v_base);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    x6_read_ops<0, 0>(fr[0], a_base, b_base);
+    if (ph == 0) x6_transform_role<0, 0, 0>(d_base, v_base);
+    else asm volatile("s_barrier" ::: "memory");
 
-    long long tl[6] = {0, 0, 0, 0, 0, 0};
     for (; t < ntiles; t += gridDim.x) {
-#if (UNET_X6_ABLATE & 8)
-        long long e0; X6_STAMP(e0);
-#endif
         const TileCoord tcn = t + (int)gridDim.x < ntiles ? advance(tc) : tc;            // the last tile prefetches itself again
-        tile_sources(tcn, dnxt, unxt);
-        f32x4 bias4[4];
-        wf_load_bias(p, tc.tn * 64, ni, lh, bias4);
-        // U(g + 1) of unit g = 4 c + R, continuing into the next tile.  D pieces: unit R = 0 issues chunk c + 1 (the tile's last one when
-        // c = nchunks - 2), R = 2, 3 issue chunk c + 2 (the last one when c = nchunks - 3); behind the last chunk the pointers jump to the next tile
+        unxt = u_source(tcn);
+        // the D pointers of the slots a unit issued move on behind it: one chunk further, or to the next tile's patch behind the tile's last chunk
+        auto advance_slots = [&](int s0, bool last) {
+            if (last) { dptr[s0] = slot_src(tcn, s0); dptr[s0 + 1] = slot_src(tcn, s0 + 1); }
+            else { dptr[s0] += 16; dptr[s0 + 1] += 16; }
+        };
+        // U(g + 1) of unit g = 4 c + R, continuing into the next tile.  D pieces: the unit R = 3 issues chunk c + 2 (the tile's last one when
+        // c = nchunks - 3), R = 0, 1 issue chunk c + 1 (the last one when c = nchunks - 2); behind the last chunk the pointers jump to the next tile
 #define X6_US(c, R) ((4 * (c) + (R) + 1 < 4 * nchunks) ? ucur + (size_t)(4 * (c) + (R) + 1) * ustep : unxt)
-#define X6_UNIT(R, DP, FIRST, c) \
-        x6_unit<R, DP, FIRST>(acc, S0, S1, fr, sp, a_base, b_base, d_base, v_base, X6_US(c, R), uoff, dptr, dnxt, \
-                              (R) == 0 ? (c) == nchunks - 2 : (c) == nchunks - 3, lds_w, tl)
+#define X6_UNIT(R, DP, FIRST, c) do { \
+        if constexpr (PH == ((R) & 1)) { \
+            x6_mfma_role<R, DP, FIRST>(acc, a_base, b_base, X6_US(c, R), ublk, u_lane, dptr[(R) == 1 ? 2 : 0], dptr[(R) == 1 ? 3 : 1], wq == 0, lds_w); \
+            if ((R) != 2) advance_slots((R) == 1 ? 2 : 0, (R) == 3 ? (c) == nchunks - 3 : (c) == nchunks - 2); \
+        } else x6_transform_role<((R) + 1) & 3, (DP) ^ ((R) == 3 ? 1 : 0), ((R) & 1) ^ 1>(d_base, v_base); } while (0)
         X6_UNIT(0, 0, true, 0); X6_UNIT(1, 0, true, 0); X6_UNIT(2, 0, true, 0); X6_UNIT(3, 0, true, 0);
         X6_UNIT(0, 1, false, 1); X6_UNIT(1, 1, false, 1); X6_UNIT(2, 1, false, 1); X6_UNIT(3, 1, false, 1);
         for (int c = 2; c < nchunks; c += 2) {
@@ -357,26 +495,22 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         }
 #undef X6_UNIT
 #undef X6_US
-        asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_FRAG(fr[0]));           // the next unit's first operands have landed before anything below may move them
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMAs are invisible to the compiler's hazard recogniser
-        f32x4 rv[4][4];
-        if (STATS == 2) wf_load_r(p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, rv);
-        wf_epilogue<STATS>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, bias4, s1, s2, rv);
+        x6_pair_epilogue<STATS>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, ph, wq, li, lh, lds0 + kX6X + (unsigned)lane * 16, s1, s2);
         ucur = unxt; tc = tcn;
-#if (UNET_X6_ABLATE & 8)
-        { long long e1; X6_STAMP(e1); tl[5] += e1 - e0; }
-#endif
     }
-#if (UNET_X6_ABLATE & 8)
-    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 6; ++i) g_x6_timeline[i] = tl[i];
-#endif
-    // retire the prefetches of the tile that never runs (LDS reads into fr[0], DMAs) before the wave ends
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : X6_TIE_FRAG(fr[0]) :: "memory");
-    if (STATS) wf_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), mi, ni, li, lh, s1, s2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // retire the prefetches of the tile that never runs
+    if (STATS) x6_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), mi, ni, ph, li, lh, s1, s2);
 }
-__global__ __launch_bounds__(256, 1) void wino_x6_stream_kernel(X6Args q, int ntiles) { x6_stream_body<0>(q, ntiles); }
-__global__ __launch_bounds__(256, 1) void wino_x6_stream_stats_kernel(X6Args q, int ntiles) { x6_stream_body<1>(q, ntiles); }
-__global__ __launch_bounds__(256, 1) void wino_x6_stream_bnbwd_kernel(X6Args q, int ntiles) { x6_stream_body<2>(q, ntiles); }
+template <int STATS>
+__device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
+    __shared__ __attribute__((aligned(1024))) char smem[kX6Smem];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) x6_group_body<STATS, 0>(q, ntiles, smem);
+    else x6_group_body<STATS, 1>(q, ntiles, smem);
+}
+__global__ __launch_bounds__(512, 2) void wino_x6_stream_kernel(X6Args q, int ntiles) { x6_stream_body<0>(q, ntiles); }
+__global__ __launch_bounds__(512, 2) void wino_x6_stream_stats_kernel(X6Args q, int ntiles) { x6_stream_body<1>(q, ntiles); }
+__global__ __launch_bounds__(512, 2) void wino_x6_stream_bnbwd_kernel(X6Args q, int ntiles) { x6_stream_body<2>(q, ntiles); }
 
 // ---- weight operands: G g G^T in fp32 (as winograd.hip), then the exact three-piece split, in the kernel's unit layout -----------------
 //   U6[((((k/16) * 4 + r) * 4 + j) * 3 + piece) * N + n) * 16 + k % 16],   point xi = 4 r + j
@@ -519,10 +653,10 @@ int run_wino_x6(const float* x, int ldx, const uint16_t* U6, const float* bias, 
     const dim3 grid((unsigned)(blocks < cus ? blocks : cus));
     if (bb) {
         a.bn_r = bb->r; a.bn_ldr = bb->ldr; a.bn_c0 = bb->c0; a.bn_c1 = bb->c1;
-        wino_x6_stream_bnbwd_kernel<<<grid, 256, 0, st>>>(q, (int)blocks);
+        wino_x6_stream_bnbwd_kernel<<<grid, 512, 0, st>>>(q, (int)blocks);
     }
-    else if (stat_part) wino_x6_stream_stats_kernel<<<grid, 256, 0, st>>>(q, (int)blocks);
-    else                wino_x6_stream_kernel<<<grid, 256, 0, st>>>(q, (int)blocks);
+    else if (stat_part) wino_x6_stream_stats_kernel<<<grid, 512, 0, st>>>(q, (int)blocks);
+    else                wino_x6_stream_kernel<<<grid, 512, 0, st>>>(q, (int)blocks);
     return UNET_LAUNCH_STATUS();
 }
 
