@@ -34,7 +34,8 @@
 namespace {
 
 #if (UNET_X6_ABLATE & 8)
-__device__ long long g_x6_timeline[8];
+__device__ long long g_x6_timeline[16];
+__device__ __forceinline__ void x6_tl_add(int i, long long v) { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) g_x6_timeline[i] += v; }
 #define X6_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
 #else
 #define X6_STAMP(t)
@@ -143,29 +144,25 @@ template <int R2, int C> __device__ __forceinline__ void x6_row_stage(f32x4 (&dd
 #define X6_TIE_DD(d) "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
 
 // ---- the unit, by role ------------------------------------------------------------------------------------------------------------------
-// MFMA role of unit (chunk parity DP, point row R): 24 MFMAs into the wave's accumulators 4 (R >> 1) + p from V / U buffers R & 1, and this
-// wave's DMA duty: six pieces of U(g+1) and (R != 2) two D pieces.
+// MFMA role of unit with point row R: 24 MFMAs into the wave's accumulators 4 (R >> 1) + p from V / U buffers R & 1.  Nothing else: the
+// DMAs and the transform run in the partner group (x6_transform_role), on the same SIMDs.
 // Operand pieces are prefetched one by one, three MFMAs ahead of their first use, so that about seven 16-byte fragments are live instead of
 // two whole points' twelve (the kernel runs two waves per SIMD: 128 vector registers).  Products of a point in the order
 //   (h,h) (h,m) (m,h) (m,m) (h,l) (l,h)            [weights piece, data piece]
 // introduce u_h v_h | v_m | u_m | - | v_l | u_l; the pieces are read in exactly that order of need:
 //   before the unit: u_h v_h v_m u_m of point 0;  behind MFMA k of point p:  k=1: v_l(p)  k=2: u_l(p)  k=3: u_h v_h(p+1)  k=4: v_m(p+1)  k=5: u_m(p+1)
 // LDS reads are this role's only LDS instructions and retire in order: every lgkmcnt below = the reads issued behind the piece waited for.
-//   us: source of U(g+1) for this wave's first block (uniform), ublk: bytes between its pieces, u_lane: the lane's byte offset in a piece;
-//   da / db: the lane's sources of the two D pieces issued here.
 #define X6_RDU(dst, PT, PC) X6_RD128(dst, b_base, (PT * 3 + PC) * kX6Blk)
 #define X6_RDV(dst, PT, PC) X6_RD128(dst, a_base, (PT * 3 + PC) * kX6Blk)
-template <int R, int DP, bool FIRST>
-__device__ __forceinline__ void x6_mfma_role(f32x16 (&acc)[8], unsigned a_base0, unsigned b_base0,
-                                             const char* us, size_t ublk, unsigned u_lane, const float* da, const float* db, bool has_db, unsigned lds_w) {
-    constexpr int P = R & 1, PN = P ^ 1;
-    // D pieces issued by the MFMA group of this unit: R = 3: chunk c+2, pieces wq, wq+4; R = 0: chunk c+1, pieces wq+8, wq+12;
-    // R = 1: chunk c+1, pieces wq+16, wq+20; R = 2: none
-    constexpr int ND = R == 2 ? 0 : 2;
-    constexpr int DPC = R == 3 ? 0 : R == 0 ? 8 : 16;                 // first piece of the pair, before the wave's own wq
-    constexpr int DPW = R == 3 ? DP : (DP ^ 1);                       // buffer of that chunk
+template <int R, bool FIRST>
+__device__ __forceinline__ void x6_mfma_role(f32x16 (&acc)[8], unsigned a_base0, unsigned b_base0) {
+    constexpr int P = R & 1;
     const unsigned a_base = a_base0 + P * kX6Par, b_base = b_base0 + P * kX6Par;
     x6_i32x4 uh[2], vh[2], vm[2], um[2], vl[2], ul[2];               // [point parity]
+#if (UNET_X6_ABLATE & 8)
+    long long q0, q1, q2;
+    X6_STAMP(q0);
+#endif
     X6_RDU(uh[0], 0, 0); X6_RDV(vh[0], 0, 0); X6_RDV(vm[0], 0, 1); X6_RDU(um[0], 0, 1);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -184,7 +181,6 @@ __device__ __forceinline__ void x6_mfma_role(f32x16 (&acc)[8], unsigned a_base0,
         X6_MFMA(A, uh[e], vm[e]);
 #endif
         if (p == 0) X6_RDU(ul[e], 0, 2); if (p == 1) X6_RDU(ul[e], 1, 2); if (p == 2) X6_RDU(ul[e], 2, 2); if (p == 3) X6_RDU(ul[e], 3, 2);
-        if (p < 3 && !(UNET_X6_ABLATE & 64)) X6_DMA_S(u_lane, us + (size_t)(2 * p) * ublk, lds_w, kX6U + PN * kX6Par + (2 * p) * 4096);      // U(g+1) pieces 0, 2, 4
         __builtin_amdgcn_sched_barrier(0);
         // (m,h)
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(um[e]));
@@ -200,8 +196,6 @@ __device__ __forceinline__ void x6_mfma_role(f32x16 (&acc)[8], unsigned a_base0,
         X6_MFMA(A, um[e], vm[e]);
 #endif
         if (p == 0) X6_RDV(vm[o], 1, 1); if (p == 1) X6_RDV(vm[o], 2, 1); if (p == 2) X6_RDV(vm[o], 3, 1);
-        if (p < 3 && !(UNET_X6_ABLATE & 64)) X6_DMA_S(u_lane, us + (size_t)(2 * p + 1) * ublk, lds_w, kX6U + PN * kX6Par + (2 * p + 1) * 4096);   // pieces 1, 3, 5
-        if (p == 3 && ND && !(UNET_X6_ABLATE & 64)) X6_DMA_V(da, lds_w, DPW * kX6DB + DPC * 1024);
         __builtin_amdgcn_sched_barrier(0);
         // (h,l): behind v_l: u_l, then the next point's u_h, v_h, v_m
         if (p < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vl[e])); else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(vl[e]));
@@ -215,39 +209,102 @@ __device__ __forceinline__ void x6_mfma_role(f32x16 (&acc)[8], unsigned a_base0,
 #if !(UNET_X6_ABLATE & 32)
         X6_MFMA(A, ul[e], vh[e]);
 #endif
-        if (p == 3 && ND && !(UNET_X6_ABLATE & 64) && (R != 1 || has_db)) X6_DMA_V(db, lds_w, DPW * kX6DB + (DPC + 4) * 1024);      // (pieces 21..23 do not exist)
         __builtin_amdgcn_sched_barrier(0);
     }
-    // leave this unit's D pieces in flight (they are needed a unit later at the earliest; the wave's next wait is a vmcnt(0))
-    if (ND && (R != 1 || has_db)) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-    else if (ND) asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#if (UNET_X6_ABLATE & 8)
+    X6_STAMP(q1);
+#endif
+    asm volatile("s_barrier" ::: "memory");
+#if (UNET_X6_ABLATE & 8)
+    X6_STAMP(q2);
+    x6_tl_add(4 * P + 0, q1 - q0); x6_tl_add(4 * P + 1, q2 - q1); x6_tl_add(8, 1);
+#endif
 }
 
-// Transform role: raw rows of point row R1 from D buffer DPR -> row stage -> column stage + split -> V image PN (the unit the SAME wave
-// group multiplies next).  Lane = (tile, channel quad).  Plain code: its vector instructions run beside the partner wave's MFMAs.
-template <int R1, int DPR, int PN>
-__device__ __forceinline__ void x6_transform_role(const unsigned (&d_base)[4], unsigned v_base0) {
-    const unsigned v_base = v_base0 + PN * kX6Par;
-    f32x4 dd[8];
-    x6_read_rows<R1, DPR, 0>(dd, d_base); x6_read_rows<R1, DPR, 1>(dd, d_base); x6_read_rows<R1, DPR, 2>(dd, d_base); x6_read_rows<R1, DPR, 3>(dd, d_base);
+// Transform role of the group that multiplies NEXT (ph = (R + 1) & 1), during unit (chunk parity DP, point row R):
+//   1. this wave's DMA duty, first thing, so that every piece has the whole unit to land: six pieces of U(g+1) and, by R, two D pieces --
+//      R = 2: chunk c+2, pieces wq, wq+4 (slots 0, 1 of group 1); R = 3: chunk c+2, pieces wq+8, wq+12 (slots 0, 1 of group 0);
+//      R = 0: chunk c+1, pieces wq+16, wq+20 (slots 2, 3 of group 1; 21..23 do not exist); R = 1: none;
+//   2. the raw rows of point row R+1 -- already in `dd`, read at the end of this wave's previous transform unit -- through row stage,
+//      column stage and split into the V image of unit g+1 (lane = (tile, channel quad));
+//   3. unless `tile_end`, the raw rows of this wave's NEXT transform unit (point row R+3 of chunk c + (R >= 1)) into dd.
+// Plain code: its vector instructions run beside the partner wave's MFMAs.
+//   us: source of U(g+1) for this wave's first block (uniform), ublk: bytes between its pieces, u_lane: the lane's byte offset in a piece;
+//   da / db: the lane's sources of the two D pieces (R != 1); has_db: piece wq + 20 exists (wq == 0).
+template <int R3, int DPR> __device__ __forceinline__ void x6_prefetch_rows(f32x4 (&dd)[8], const unsigned (&d_base)[4]) {
+    x6_read_rows<R3, DPR, 0>(dd, d_base); x6_read_rows<R3, DPR, 1>(dd, d_base); x6_read_rows<R3, DPR, 2>(dd, d_base); x6_read_rows<R3, DPR, 3>(dd, d_base);
+}
+// rows (point row R1) in dd -> V image at v_base: row stage, column stage, split, 6 ds_write2st64_b64
+// `slot(i)`, i = 0..7, is called at eight evenly spaced points of the instruction stream (the caller's DMA issues: back to back each one
+// would stall the wave for the ~64 cycles the previous one holds the vector-memory issue path).
+template <int R1, class Slot> __device__ __forceinline__ void x6_rows_to_v(f32x4 (&dd)[8], unsigned v_base, Slot&& slot) {
+    slot(0);
     asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_DD(dd));
 #pragma unroll
     for (int c = 0; c < 4; ++c) dd[c] = X6Rows<R1>::ADD ? dd[c] + dd[4 + c] : dd[c] - dd[4 + c];
+    X6_PIN("+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]), "+v"(dd[3]));
     x6_u32x2 lprev;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const f32x4 vv = j == 0 ? dd[0] - dd[2] : j == 1 ? dd[1] + dd[2] : j == 2 ? dd[2] - dd[1] : dd[1] - dd[3];
+        slot(2 * j + 1);
+        f32x4 vv = j == 0 ? dd[0] - dd[2] : j == 1 ? dd[1] + dd[2] : j == 2 ? dd[2] - dd[1] : dd[1] - dd[3];
+        X6_PIN("+v"(vv));
+        if (j < 3) slot(2 * j + 2);
         float a[4], b[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] = vv[e] - x6_trunc(vv[e]); b[e] = a[e] - x6_trunc(a[e]); }
+        for (int e = 0; e < 4; ++e) {
+#if (UNET_X6_ABLATE & 16)
+            a[e] = vv[e]; b[e] = vv[e];
+#else
+            a[e] = vv[e] - x6_trunc(vv[e]); b[e] = a[e] - x6_trunc(a[e]);
+#endif
+        }
         // (h, m) of a point are 2048 bytes = 4 x 512 apart: one ds_write2st64_b64; the l pieces of two points share one
-        X6_WR2(v_base, (j * 3 + 0) * 4, (j * 3 + 1) * 4, (x6_u32x2{x6_hi2(vv[0], vv[1]), x6_hi2(vv[2], vv[3])}), (x6_u32x2{x6_hi2(a[0], a[1]), x6_hi2(a[2], a[3])}));
         const x6_u32x2 lcur = x6_u32x2{x6_hi2(b[0], b[1]), x6_hi2(b[2], b[3])};
+#if !(UNET_X6_ABLATE & 256)
+        X6_WR2(v_base, (j * 3 + 0) * 4, (j * 3 + 1) * 4, (x6_u32x2{x6_hi2(vv[0], vv[1]), x6_hi2(vv[2], vv[3])}), (x6_u32x2{x6_hi2(a[0], a[1]), x6_hi2(a[2], a[3])}));
         if (j & 1) X6_WR2(v_base, ((j - 1) * 3 + 2) * 4, (j * 3 + 2) * 4, lprev, lcur);
+#else
+        asm volatile("" :: "v"(lcur), "v"(lprev), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+#endif
         lprev = lcur;
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <int R, int DP>
+__device__ __forceinline__ void x6_transform_role(f32x4 (&dd)[8], const unsigned (&d_base)[4], unsigned v_base0, const char* us, size_t ublk,
+                                                  unsigned u_lane, const float* da, const float* db, bool has_db, unsigned lds_w, bool tile_end) {
+    constexpr int PN = (R & 1) ^ 1, R1 = (R + 1) & 3, R3 = (R + 3) & 3;
+    constexpr int ND = R == 1 ? 0 : 2;
+    constexpr int DPC = R == 2 ? 0 : R == 3 ? 8 : 16;                 // first piece of the pair, before the wave's own wq
+    constexpr int DPW = R == 0 ? (DP ^ 1) : DP;                       // buffer of that chunk
+    constexpr int DP3 = DP ^ (R >= 1 ? 1 : 0);                        // buffer of the rows prefetched here
+#if (UNET_X6_ABLATE & 8)
+    long long q0, q1, q2;
+    X6_STAMP(q0);
+#endif
+    auto dma = [&](int i) {
+        if (UNET_X6_ABLATE & 64) return;
+        if (i == 0) X6_DMA_S(u_lane, us, lds_w, kX6U + PN * kX6Par);
+        if (i == 1) X6_DMA_S(u_lane, us + ublk, lds_w, kX6U + PN * kX6Par + 4096);
+        if (i == 2) X6_DMA_S(u_lane, us + 2 * ublk, lds_w, kX6U + PN * kX6Par + 2 * 4096);
+        if (i == 3) X6_DMA_S(u_lane, us + 3 * ublk, lds_w, kX6U + PN * kX6Par + 3 * 4096);
+        if (i == 4) X6_DMA_S(u_lane, us + 4 * ublk, lds_w, kX6U + PN * kX6Par + 4 * 4096);
+        if (i == 5) X6_DMA_S(u_lane, us + 5 * ublk, lds_w, kX6U + PN * kX6Par + 5 * 4096);
+        if (i == 6 && ND) X6_DMA_V(da, lds_w, DPW * kX6DB + DPC * 1024);
+        if (i == 7 && ND && (R != 0 || has_db)) X6_DMA_V(db, lds_w, DPW * kX6DB + (DPC + 4) * 1024);
+    };
+    x6_rows_to_v<R1>(dd, v_base0 + PN * kX6Par, dma);
+    if (!tile_end) x6_prefetch_rows<R3, DP3>(dd, d_base);
+#if (UNET_X6_ABLATE & 8)
+    X6_STAMP(q1);
+#endif
+    // the V writes are done once at most the eight row reads behind them are outstanding
+    if (!tile_end) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if (UNET_X6_ABLATE & 8)
+    X6_STAMP(q2);
+    x6_tl_add(4 * PN + 2, q1 - q0); x6_tl_add(4 * PN + 3, q2 - q1);
+#endif
 }
 
 struct X6Args {
@@ -451,25 +508,29 @@ __device__ __forceinline__ void x6_group_body(const X6Args& q, int ntiles, char*
     for (int j = 0; j < 4; ++j) dptr[j] = slot_src(tc, j);
     ucur = u_source(tc);
 
-    // ---- prologue of the workgroup's first tile: D(0) (all eight waves, three pieces each), D(1) pieces 0..7 (group 1), U(unit 0) (group 0)
-    //      -> LDS; then group 0 transforms unit 0
+    // ---- prologue of the workgroup's first tile: D(0) (all eight waves, three pieces each), D(1) pieces 0..15 (both groups' slots 0, 1),
+    //      U(unit 0) (group 0) -> LDS; group 0 transforms unit 0; every wave reads the raw rows of its first transform unit
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         int py, px, off;
         piece_geom(w8 + 8 * j, py, px, off);
         if (w8 + 8 * j < 21) X6_DMA_V(pixel_src(tc, py, px, off), lds_w + ph * 4096, 8 * j * 1024);  // piece w8 + 8 j = wq + 4 ph + 8 j
     }
-    if (ph) {
-        X6_DMA_V(dptr[0] + 16, lds_w, kX6DB); X6_DMA_V(dptr[1] + 16, lds_w, kX6DB + 4096);
-        dptr[0] += 32; dptr[1] += 32; dptr[2] += 16; dptr[3] += 16;           // next: chunk 2 (pieces 0..7), chunk 1 (pieces 16..23)
-    } else {
+    X6_DMA_V(dptr[0] + 16, lds_w + (ph ? 0 : 8192), kX6DB); X6_DMA_V(dptr[1] + 16, lds_w + (ph ? 0 : 8192), kX6DB + 4096);
+    dptr[0] += 32; dptr[1] += 32;                                             // next: chunk 2
+    if (ph) { dptr[2] += 16; dptr[3] += 16; }                                 // next: chunk 1 (pieces 16..20)
+    else {
 #pragma unroll
         for (int j = 0; j < 6; ++j) X6_DMA_S(u_lane, ucur + (size_t)j * ublk, lds_w, kX6U + j * 4096);
-        dptr[0] += 16; dptr[1] += 16;                                         // next: chunk 1 (pieces 8..15)
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (ph == 0) x6_transform_role<0, 0, 0>(d_base, v_base);
-    else asm volatile("s_barrier" ::: "memory");
+    f32x4 dd[8];
+    if (ph == 0) {
+        x6_prefetch_rows<0, 0>(dd, d_base);
+        x6_rows_to_v<0>(dd, v_base, [](int) {});
+        x6_prefetch_rows<2, 0>(dd, d_base);                                   // group 0's first transform unit is (0, 1): point row 2
+    } else x6_prefetch_rows<1, 0>(dd, d_base);                                // group 1's is (0, 0): point row 1
+    asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
 
     for (; t < ntiles; t += gridDim.x) {
         const TileCoord tcn = t + (int)gridDim.x < ntiles ? advance(tc) : tc;            // the last tile prefetches itself again
@@ -479,14 +540,16 @@ __device__ __forceinline__ void x6_group_body(const X6Args& q, int ntiles, char*
             if (last) { dptr[s0] = slot_src(tcn, s0); dptr[s0 + 1] = slot_src(tcn, s0 + 1); }
             else { dptr[s0] += 16; dptr[s0 + 1] += 16; }
         };
-        // U(g + 1) of unit g = 4 c + R, continuing into the next tile.  D pieces: the unit R = 3 issues chunk c + 2 (the tile's last one when
-        // c = nchunks - 3), R = 0, 1 issue chunk c + 1 (the last one when c = nchunks - 2); behind the last chunk the pointers jump to the next tile
+        // U(g + 1) of unit g = 4 c + R, continuing into the next tile.  D pieces: the units R = 2, 3 issue chunk c + 2 (the tile's last one when
+        // c = nchunks - 3), R = 0 issues chunk c + 1 (the last one when c = nchunks - 2); behind the last chunk the pointers jump to the next tile
 #define X6_US(c, R) ((4 * (c) + (R) + 1 < 4 * nchunks) ? ucur + (size_t)(4 * (c) + (R) + 1) * ustep : unxt)
 #define X6_UNIT(R, DP, FIRST, c) do { \
-        if constexpr (PH == ((R) & 1)) { \
-            x6_mfma_role<R, DP, FIRST>(acc, a_base, b_base, X6_US(c, R), ublk, u_lane, dptr[(R) == 1 ? 2 : 0], dptr[(R) == 1 ? 3 : 1], wq == 0, lds_w); \
-            if ((R) != 2) advance_slots((R) == 1 ? 2 : 0, (R) == 3 ? (c) == nchunks - 3 : (c) == nchunks - 2); \
-        } else x6_transform_role<((R) + 1) & 3, (DP) ^ ((R) == 3 ? 1 : 0), ((R) & 1) ^ 1>(d_base, v_base); } while (0)
+        if constexpr (PH == ((R) & 1)) x6_mfma_role<R, FIRST>(acc, a_base, b_base); \
+        else { \
+            x6_transform_role<R, DP>(dd, d_base, v_base, X6_US(c, R), ublk, u_lane, dptr[(R) == 0 ? 2 : 0], dptr[(R) == 0 ? 3 : 1], wq == 0, lds_w, \
+                                     (R) >= 2 && (c) == nchunks - 1); \
+            if ((R) != 1) advance_slots((R) == 0 ? 2 : 0, (R) == 0 ? (c) == nchunks - 2 : (c) == nchunks - 3); \
+        } } while (0)
         X6_UNIT(0, 0, true, 0); X6_UNIT(1, 0, true, 0); X6_UNIT(2, 0, true, 0); X6_UNIT(3, 0, true, 0);
         X6_UNIT(0, 1, false, 1); X6_UNIT(1, 1, false, 1); X6_UNIT(2, 1, false, 1); X6_UNIT(3, 1, false, 1);
         for (int c = 2; c < nchunks; c += 2) {
@@ -497,6 +560,8 @@ __device__ __forceinline__ void x6_group_body(const X6Args& q, int ntiles, char*
 #undef X6_US
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMAs are invisible to the compiler's hazard recogniser
         x6_pair_epilogue<STATS>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, ph, wq, li, lh, lds0 + kX6X + (unsigned)lane * 16, s1, s2);
+        // the raw rows of this wave's first transform unit of the next tile (its D(0) landed before the tile's last chunk ended)
+        if (ph == 0) x6_prefetch_rows<2, 0>(dd, d_base); else x6_prefetch_rows<1, 0>(dd, d_base);
         ucur = unxt; tc = tcn;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // retire the prefetches of the tile that never runs
@@ -663,7 +728,7 @@ int run_wino_x6(const float* x, int ldx, const uint16_t* U6, const float* bias, 
 }  // namespace
 
 #if (UNET_X6_ABLATE & 8)
-extern "C" int unet_debug_x6_timeline(long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x6_timeline), 64); }
+extern "C" int unet_debug_x6_timeline(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_x6_timeline), 128); }
 #endif
 
 // 1 when the BF16x6 kernels take the layer: H, W even, reduce channels K a multiple of 32 (>= 64), output channels a multiple of 64.
