@@ -86,19 +86,18 @@ __device__ __forceinline__ unsigned x6_hi2(float lo, float hi) {       // { bf16
 }
 __device__ __forceinline__ float x6_trunc(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
 
-// Column stage + split of point J (column J of the unit's row of points) in five steps of 5-6 vector instructions; tt[c] = the row-stage
-// result of patch column c (4 channels).  V[.][0] = t0 - t2, [1] = t1 + t2, [2] = t2 - t1, [3] = t1 - t3.
+// Column stage + split of one point in five steps of 5-6 vector instructions; tt[c] = the row-stage result of the wave's patch column c
+// (4 channels).  The four points of a unit's row: V[.][0] = t0 - t2, [1] = t1 + t2, [2] = t2 - t1, [3] = t1 - t3.
 // X6_PIN: an empty volatile asm over a step's inputs / results.  Instruction selection orders pure arithmetic freely between the volatile
 // MFMAs (sched_barrier only binds the machine scheduler); tied to a volatile statement on both sides a step stays in its gap.
 #define X6_PIN(...) asm volatile("" : __VA_ARGS__)
-template <int K, int J> __device__ __forceinline__ void x6_split_step(X6Split& s, f32x4 (&tt)[8]) {
-#if (UNET_X6_ABLATE & 16)        /* diagnostics: no column stage / split (results wrong) */
-    return;
+template <int K, int TA, int TB, bool ADD> __device__ __forceinline__ void x6_split_step(X6Split& s, f32x4 (&tt)[6]) {
+#if (UNET_X6_ABLATE & 16)
+    if (K) return;
 #endif
     if constexpr (K == 0) {
-        constexpr int TA = J == 0 ? 0 : J == 2 ? 2 : 1, TB = J == 0 ? 2 : J == 1 ? 2 : J == 2 ? 1 : 3;
         X6_PIN("+v"(tt[TA]), "+v"(tt[TB]));
-        const f32x4 vv = J == 1 ? tt[TA] + tt[TB] : tt[TA] - tt[TB];
+        const f32x4 vv = ADD ? tt[TA] + tt[TB] : tt[TA] - tt[TB];
         s.v[0] = vv[0]; s.v[1] = vv[1]; s.v[2] = vv[2]; s.v[3] = vv[3];
         s.h[0] = x6_hi2(s.v[0], s.v[1]);
         X6_PIN("+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.h[0]));
@@ -117,193 +116,137 @@ template <int K, int J> __device__ __forceinline__ void x6_split_step(X6Split& s
     } else {
         s.b[2] = s.a[2] - x6_trunc(s.a[2]); s.b[3] = s.a[3] - x6_trunc(s.a[3]);
         s.l[0] = x6_hi2(s.b[0], s.b[1]); s.l[1] = x6_hi2(s.b[2], s.b[3]);
+        X6_PIN("+v"(s.l[0]), "+v"(s.l[1]));
     }
 }
-// the three pieces of point J -> V image PAR (3 ds_write_b64)
-template <int PAR, int J> __device__ __forceinline__ void x6_write_v(const X6Split& s, unsigned v_base) {
-    X6_WR64(v_base, PAR * kX6IB + (J * 3 + 0) * kX6Blk, (x6_u32x2{s.h[0], s.h[1]}));
-    X6_WR64(v_base, PAR * kX6IB + (J * 3 + 1) * kX6Blk, (x6_u32x2{s.m[0], s.m[1]}));
-    X6_WR64(v_base, PAR * kX6IB + (J * 3 + 2) * kX6Blk, (x6_u32x2{s.l[0], s.l[1]}));
+// the wave's two points: J0 = 2 PH, J0 + 1; local patch columns 0..2 = global PH .. PH + 2
+template <int K, int Q, int PH> __device__ __forceinline__ void x6_point_step(X6Split& s, f32x4 (&tt)[6]) {
+    constexpr int J = 2 * PH + Q;
+    constexpr int GA = J == 0 ? 0 : J == 2 ? 2 : 1, GB = J == 0 ? 2 : J == 1 ? 2 : J == 2 ? 1 : 3;      // global columns: tA -/+ tB
+    x6_split_step<K, GA - PH, GB - PH, J == 1>(s, tt);
 }
 
-// raw rows of the unit with point row R2 from D buffer DPR -> dd[0..3] (row ra), dd[4..7] (row rb); tt = ra -/+ rb:
-//   R2 = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
+// raw rows of the unit with point row R2: rows ra, rb of the patch; tt = ra -/+ rb:   R2 = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
 template <int R2> struct X6Rows {
     static constexpr int RA = R2 == 0 ? 0 : R2 == 2 ? 2 : 1, RB = R2 == 0 ? 2 : R2 == 1 ? 2 : R2 == 2 ? 1 : 3;
     static constexpr bool ADD = R2 == 1;
 };
-template <int R2, int DPR, int C> __device__ __forceinline__ void x6_read_rows(f32x4 (&dd)[8], const unsigned (&d_base)[4]) {
-    X6_RD128(dd[C], d_base[C], DPR * kX6DB + X6Rows<R2>::RA * kX6RowB);
-    X6_RD128(dd[4 + C], d_base[C], DPR * kX6DB + X6Rows<R2>::RB * kX6RowB);
-}
-template <int R2, int C> __device__ __forceinline__ void x6_row_stage(f32x4 (&dd)[8]) {
-    X6_PIN("+v"(dd[C]), "+v"(dd[4 + C]));
-    dd[C] = X6Rows<R2>::ADD ? dd[C] + dd[4 + C] : dd[C] - dd[4 + C];
-    X6_PIN("+v"(dd[C]));
-}
-#define X6_TIE_DD(d) "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
-
-// ---- the unit, by role ------------------------------------------------------------------------------------------------------------------
-// MFMA role of unit with point row R: 24 MFMAs into the wave's accumulators 4 (R >> 1) + p from V / U buffers R & 1.  Nothing else: the
-// DMAs and the transform run in the partner group (x6_transform_role), on the same SIMDs.
-// Operand pieces are prefetched one by one, three MFMAs ahead of their first use, so that about seven 16-byte fragments are live instead of
-// two whole points' twelve (the kernel runs two waves per SIMD: 128 vector registers).  Products of a point in the order
-//   (h,h) (h,m) (m,h) (m,m) (h,l) (l,h)            [weights piece, data piece]
-// introduce u_h v_h | v_m | u_m | - | v_l | u_l; the pieces are read in exactly that order of need:
-//   before the unit: u_h v_h v_m u_m of point 0;  behind MFMA k of point p:  k=1: v_l(p)  k=2: u_l(p)  k=3: u_h v_h(p+1)  k=4: v_m(p+1)  k=5: u_m(p+1)
-// LDS reads are this role's only LDS instructions and retire in order: every lgkmcnt below = the reads issued behind the piece waited for.
-#define X6_RDU(dst, PT, PC) X6_RD128(dst, b_base, (PT * 3 + PC) * kX6Blk)
-#define X6_RDV(dst, PT, PC) X6_RD128(dst, a_base, (PT * 3 + PC) * kX6Blk)
-template <int R, bool FIRST>
-__device__ __forceinline__ void x6_mfma_role(f32x16 (&acc)[8], unsigned a_base0, unsigned b_base0) {
-    constexpr int P = R & 1;
-    const unsigned a_base = a_base0 + P * kX6Par, b_base = b_base0 + P * kX6Par;
-    x6_i32x4 uh[2], vh[2], vm[2], um[2], vl[2], ul[2];               // [point parity]
-#if (UNET_X6_ABLATE & 8)
-    long long q0, q1, q2;
-    X6_STAMP(q0);
-#endif
-    X6_RDU(uh[0], 0, 0); X6_RDV(vh[0], 0, 0); X6_RDV(vm[0], 0, 1); X6_RDU(um[0], 0, 1);
+// the wave's three patch columns of both rows from D buffer DPR: dd[c] (row ra), dd[3 + c] (row rb); six ds_read_b128
+template <int R2, int DPR> __device__ __forceinline__ void x6_read_rows(f32x4 (&dd)[6], const unsigned (&d_base)[3]) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int e = p & 1, o = e ^ 1;
-        f32x16& A = acc[4 * (R >> 1) + p];
-        // (h,h)
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(uh[e]), "+v"(vh[e]));
-#if !(UNET_X6_ABLATE & 32)
-        if (FIRST) X6_MFMA0(A, uh[e], vh[e]); else X6_MFMA(A, uh[e], vh[e]);
-#endif
-        if (p == 0) X6_RDV(vl[e], 0, 2); if (p == 1) X6_RDV(vl[e], 1, 2); if (p == 2) X6_RDV(vl[e], 2, 2); if (p == 3) X6_RDV(vl[e], 3, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        // (h,m)
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vm[e]));
-#if !(UNET_X6_ABLATE & 32)
-        X6_MFMA(A, uh[e], vm[e]);
-#endif
-        if (p == 0) X6_RDU(ul[e], 0, 2); if (p == 1) X6_RDU(ul[e], 1, 2); if (p == 2) X6_RDU(ul[e], 2, 2); if (p == 3) X6_RDU(ul[e], 3, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        // (m,h)
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(um[e]));
-#if !(UNET_X6_ABLATE & 32)
-        X6_MFMA(A, um[e], vh[e]);
-#endif
-        if (p == 0) { X6_RDU(uh[o], 1, 0); X6_RDV(vh[o], 1, 0); }
-        if (p == 1) { X6_RDU(uh[o], 2, 0); X6_RDV(vh[o], 2, 0); }
-        if (p == 2) { X6_RDU(uh[o], 3, 0); X6_RDV(vh[o], 3, 0); }
-        __builtin_amdgcn_sched_barrier(0);
-        // (m,m)
-#if !(UNET_X6_ABLATE & 32)
-        X6_MFMA(A, um[e], vm[e]);
-#endif
-        if (p == 0) X6_RDV(vm[o], 1, 1); if (p == 1) X6_RDV(vm[o], 2, 1); if (p == 2) X6_RDV(vm[o], 3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // (h,l): behind v_l: u_l, then the next point's u_h, v_h, v_m
-        if (p < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vl[e])); else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(vl[e]));
-#if !(UNET_X6_ABLATE & 32)
-        X6_MFMA(A, uh[e], vl[e]);
-#endif
-        if (p == 0) X6_RDU(um[o], 1, 1); if (p == 1) X6_RDU(um[o], 2, 1); if (p == 2) X6_RDU(um[o], 3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // (l,h): behind u_l: the next point's u_h, v_h, v_m, u_m
-        if (p < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ul[e])); else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ul[e]));
-#if !(UNET_X6_ABLATE & 32)
-        X6_MFMA(A, ul[e], vh[e]);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < 3; ++c) {
+        X6_RD128(dd[c], d_base[c], DPR * kX6DB + X6Rows<R2>::RA * kX6RowB);
+        X6_RD128(dd[3 + c], d_base[c], DPR * kX6DB + X6Rows<R2>::RB * kX6RowB);
     }
-#if (UNET_X6_ABLATE & 8)
-    X6_STAMP(q1);
-#endif
+}
+#define X6_TIE_DD(d) "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])
+template <int R2> __device__ __forceinline__ void x6_row_stage(f32x4 (&dd)[6]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dd[c] = X6Rows<R2>::ADD ? dd[c] + dd[3 + c] : dd[c] - dd[3 + c];
+    X6_PIN("+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]));
+}
+
+// ---- one unit of one wave ------------------------------------------------------------------------------------------------------------------
+// Eight waves; SIMD partners (wq, PH = 0 / 1) split every unit's four points (a row of the 4x4 point grid): the wave multiplies points
+// J0 = 2 PH, J0 + 1 into accumulators 2 R + q and transforms those two points' V of the NEXT unit for its 16 tiles x channel quad.  Both
+// partners run the same kind of stream, so one's LDS-write / DMA-issue / wait stalls are the other's issue slots, and the vector work
+// issues from two waves (2 cycles per instruction instead of one wave's 4).
+//   12 MFMAs:  point q:  (h,h) (h,m) (m,h) (m,m) (h,l) (l,h)   [weights piece, data piece]; operand pieces read one by one, >= 3 MFMAs ahead;
+//   transform: raw rows of unit g+1 (6 reads at the top) -> row stage behind the 3rd MFMA -> five split steps per point, one per MFMA ->
+//              three ds_write2st64_b64;   DMA: three pieces of U(g+1), one D piece (R != 2).
+// LDS instructions retire in order: each lgkmcnt = the LDS instructions issued behind the piece waited for.
+#define X6_RDU(dst, J, PC) X6_RD128(dst, b_base, ((J) * 3 + PC) * kX6Blk)
+#define X6_RDV(dst, J, PC) X6_RD128(dst, a_base, ((J) * 3 + PC) * kX6Blk)
+template <int R, int DP, bool FIRST, int PH>
+__device__ __forceinline__ void x6_unit(f32x16 (&acc)[8], unsigned a_base0, unsigned b_base0, const unsigned (&d_base)[3], unsigned v_base0,
+                                        const char* us, size_t ublk, unsigned u_lane, const float* dsrc, bool has_d, unsigned lds_w) {
+    constexpr int P = R & 1, PN = P ^ 1, J0 = 2 * PH;
+    constexpr int R1 = (R + 1) & 3, DPR = DP ^ (R == 3 ? 1 : 0);      // rows of unit g+1
+    // D piece of this unit: R = 3: chunk c+2, piece w8; R = 0: chunk c+1, piece 8 + w8; R = 1: chunk c+1, piece 16 + w8 (w8 < 5); R = 2: none
+    constexpr int DPC = R == 3 ? 0 : R == 0 ? 8 : 16;
+    constexpr int DPW = R == 3 ? DP : (DP ^ 1);
+    const unsigned a_base = a_base0 + P * kX6Par, b_base = b_base0 + P * kX6Par, v_base = v_base0 + PN * kX6Par;
+    x6_i32x4 uh[2], vh[2], vm[2], um[2], vl[2], ul[2];               // [point]
+    f32x4 dd[6];
+    X6Split sp;
+    unsigned lA[2];
+    X6_RDU(uh[0], J0, 0); X6_RDV(vh[0], J0, 0); X6_RDV(vm[0], J0, 1); X6_RDU(um[0], J0, 1);
+    x6_read_rows<R1, DPR>(dd, d_base);
+    f32x16& A0 = acc[2 * R], &A1 = acc[2 * R + 1];
+#define X6_M(A, u, v) X6_MFMA(A, u, v)
+    // ---- point 0
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(uh[0]), "+v"(vh[0]));
+    if (FIRST) X6_MFMA0(A0, uh[0], vh[0]); else X6_M(A0, uh[0], vh[0]);
+    X6_RDV(vl[0], J0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vm[0]));
+    X6_M(A0, uh[0], vm[0]);
+    X6_RDU(ul[0], J0, 2);
+    if (!(UNET_X6_ABLATE & 64)) X6_DMA_S(u_lane, us, lds_w, kX6U + PN * kX6Par);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(um[0]));
+    X6_M(A0, um[0], vh[0]);
+    X6_RDU(uh[1], J0 + 1, 0); X6_RDV(vh[1], J0 + 1, 0);
+    asm volatile("s_waitcnt lgkmcnt(4)" : X6_TIE_DD(dd));                 // the six row reads (behind them: v_l, u_l, u_h', v_h')
+    x6_row_stage<R1>(dd);
+    __builtin_amdgcn_sched_barrier(0);
+    X6_M(A0, um[0], vm[0]);
+    X6_RDV(vm[1], J0 + 1, 1);
+    x6_point_step<0, 0, PH>(sp, dd);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vl[0]));
+    X6_M(A0, uh[0], vl[0]);
+    X6_RDU(um[1], J0 + 1, 1);
+    if (!(UNET_X6_ABLATE & 64)) X6_DMA_S(u_lane, us + ublk, lds_w, kX6U + PN * kX6Par + 8192);
+    x6_point_step<1, 0, PH>(sp, dd);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ul[0]));
+    X6_M(A0, ul[0], vh[0]);
+    x6_point_step<2, 0, PH>(sp, dd);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- point 1
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(uh[1]), "+v"(vh[1]));
+    if (FIRST) X6_MFMA0(A1, uh[1], vh[1]); else X6_M(A1, uh[1], vh[1]);
+    X6_RDV(vl[1], J0 + 1, 2);
+    x6_point_step<3, 0, PH>(sp, dd);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vm[1]));
+    X6_M(A1, uh[1], vm[1]);
+    X6_RDU(ul[1], J0 + 1, 2);
+    x6_point_step<4, 0, PH>(sp, dd);
+    if (!(UNET_X6_ABLATE & 256)) X6_WR2(v_base, (J0 * 3 + 0) * 4, (J0 * 3 + 1) * 4, (x6_u32x2{sp.h[0], sp.h[1]}), (x6_u32x2{sp.m[0], sp.m[1]}));
+    lA[0] = sp.l[0]; lA[1] = sp.l[1];
+    if (!(UNET_X6_ABLATE & 64)) X6_DMA_S(u_lane, us + 2 * ublk, lds_w, kX6U + PN * kX6Par + 2 * 8192);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(um[1]));
+    X6_M(A1, um[1], vh[1]);
+    x6_point_step<0, 1, PH>(sp, dd);
+    __builtin_amdgcn_sched_barrier(0);
+    X6_M(A1, um[1], vm[1]);
+    x6_point_step<1, 1, PH>(sp, dd);
+    if (R != 2 && has_d && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dsrc, lds_w, DPW * kX6DB + DPC * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vl[1]));
+    X6_M(A1, uh[1], vl[1]);
+    x6_point_step<2, 1, PH>(sp, dd);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ul[1]));
+    X6_M(A1, ul[1], vh[1]);
+    x6_point_step<3, 1, PH>(sp, dd);
+    x6_point_step<4, 1, PH>(sp, dd);
+    if (!(UNET_X6_ABLATE & 256)) {
+        X6_WR2(v_base, ((J0 + 1) * 3 + 0) * 4, ((J0 + 1) * 3 + 1) * 4, (x6_u32x2{sp.h[0], sp.h[1]}), (x6_u32x2{sp.m[0], sp.m[1]}));
+        X6_WR2(v_base, (J0 * 3 + 2) * 4, ((J0 + 1) * 3 + 2) * 4, (x6_u32x2{lA[0], lA[1]}), (x6_u32x2{sp.l[0], sp.l[1]}));
+    }
+#undef X6_M
+    // this unit's D piece stays in flight (needed two units later at the earliest)
+#if (UNET_X6_ABLATE & 2048)      /* diagnostics (results wrong): no waits at the end of a unit, barrier only */
     asm volatile("s_barrier" ::: "memory");
-#if (UNET_X6_ABLATE & 8)
-    X6_STAMP(q2);
-    x6_tl_add(4 * P + 0, q1 - q0); x6_tl_add(4 * P + 1, q2 - q1); x6_tl_add(8, 1);
-#endif
-}
-
-// Transform role of the group that multiplies NEXT (ph = (R + 1) & 1), during unit (chunk parity DP, point row R):
-//   1. this wave's DMA duty, first thing, so that every piece has the whole unit to land: six pieces of U(g+1) and, by R, two D pieces --
-//      R = 2: chunk c+2, pieces wq, wq+4 (slots 0, 1 of group 1); R = 3: chunk c+2, pieces wq+8, wq+12 (slots 0, 1 of group 0);
-//      R = 0: chunk c+1, pieces wq+16, wq+20 (slots 2, 3 of group 1; 21..23 do not exist); R = 1: none;
-//   2. the raw rows of point row R+1 -- already in `dd`, read at the end of this wave's previous transform unit -- through row stage,
-//      column stage and split into the V image of unit g+1 (lane = (tile, channel quad));
-//   3. unless `tile_end`, the raw rows of this wave's NEXT transform unit (point row R+3 of chunk c + (R >= 1)) into dd.
-// Plain code: its vector instructions run beside the partner wave's MFMAs.
-//   us: source of U(g+1) for this wave's first block (uniform), ublk: bytes between its pieces, u_lane: the lane's byte offset in a piece;
-//   da / db: the lane's sources of the two D pieces (R != 1); has_db: piece wq + 20 exists (wq == 0).
-template <int R3, int DPR> __device__ __forceinline__ void x6_prefetch_rows(f32x4 (&dd)[8], const unsigned (&d_base)[4]) {
-    x6_read_rows<R3, DPR, 0>(dd, d_base); x6_read_rows<R3, DPR, 1>(dd, d_base); x6_read_rows<R3, DPR, 2>(dd, d_base); x6_read_rows<R3, DPR, 3>(dd, d_base);
-}
-// rows (point row R1) in dd -> V image at v_base: row stage, column stage, split, 6 ds_write2st64_b64
-// `slot(i)`, i = 0..7, is called at eight evenly spaced points of the instruction stream (the caller's DMA issues: back to back each one
-// would stall the wave for the ~64 cycles the previous one holds the vector-memory issue path).
-template <int R1, class Slot> __device__ __forceinline__ void x6_rows_to_v(f32x4 (&dd)[8], unsigned v_base, Slot&& slot) {
-    slot(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_DD(dd));
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dd[c] = X6Rows<R1>::ADD ? dd[c] + dd[4 + c] : dd[c] - dd[4 + c];
-    X6_PIN("+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]), "+v"(dd[3]));
-    x6_u32x2 lprev;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        slot(2 * j + 1);
-        f32x4 vv = j == 0 ? dd[0] - dd[2] : j == 1 ? dd[1] + dd[2] : j == 2 ? dd[2] - dd[1] : dd[1] - dd[3];
-        X6_PIN("+v"(vv));
-        if (j < 3) slot(2 * j + 2);
-        float a[4], b[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#if (UNET_X6_ABLATE & 16)
-            a[e] = vv[e]; b[e] = vv[e];
+#elif (UNET_X6_ABLATE & 4096)    /* diagnostics (results wrong): no barrier either */
+    asm volatile("" ::: "memory");
 #else
-            a[e] = vv[e] - x6_trunc(vv[e]); b[e] = a[e] - x6_trunc(a[e]);
-#endif
-        }
-        // (h, m) of a point are 2048 bytes = 4 x 512 apart: one ds_write2st64_b64; the l pieces of two points share one
-        const x6_u32x2 lcur = x6_u32x2{x6_hi2(b[0], b[1]), x6_hi2(b[2], b[3])};
-#if !(UNET_X6_ABLATE & 256)
-        X6_WR2(v_base, (j * 3 + 0) * 4, (j * 3 + 1) * 4, (x6_u32x2{x6_hi2(vv[0], vv[1]), x6_hi2(vv[2], vv[3])}), (x6_u32x2{x6_hi2(a[0], a[1]), x6_hi2(a[2], a[3])}));
-        if (j & 1) X6_WR2(v_base, ((j - 1) * 3 + 2) * 4, (j * 3 + 2) * 4, lprev, lcur);
-#else
-        asm volatile("" :: "v"(lcur), "v"(lprev), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
-#endif
-        lprev = lcur;
-    }
-}
-template <int R, int DP>
-__device__ __forceinline__ void x6_transform_role(f32x4 (&dd)[8], const unsigned (&d_base)[4], unsigned v_base0, const char* us, size_t ublk,
-                                                  unsigned u_lane, const float* da, const float* db, bool has_db, unsigned lds_w, bool tile_end) {
-    constexpr int PN = (R & 1) ^ 1, R1 = (R + 1) & 3, R3 = (R + 3) & 3;
-    constexpr int ND = R == 1 ? 0 : 2;
-    constexpr int DPC = R == 2 ? 0 : R == 3 ? 8 : 16;                 // first piece of the pair, before the wave's own wq
-    constexpr int DPW = R == 0 ? (DP ^ 1) : DP;                       // buffer of that chunk
-    constexpr int DP3 = DP ^ (R >= 1 ? 1 : 0);                        // buffer of the rows prefetched here
-#if (UNET_X6_ABLATE & 8)
-    long long q0, q1, q2;
-    X6_STAMP(q0);
-#endif
-    auto dma = [&](int i) {
-        if (UNET_X6_ABLATE & 64) return;
-        if (i == 0) X6_DMA_S(u_lane, us, lds_w, kX6U + PN * kX6Par);
-        if (i == 1) X6_DMA_S(u_lane, us + ublk, lds_w, kX6U + PN * kX6Par + 4096);
-        if (i == 2) X6_DMA_S(u_lane, us + 2 * ublk, lds_w, kX6U + PN * kX6Par + 2 * 4096);
-        if (i == 3) X6_DMA_S(u_lane, us + 3 * ublk, lds_w, kX6U + PN * kX6Par + 3 * 4096);
-        if (i == 4) X6_DMA_S(u_lane, us + 4 * ublk, lds_w, kX6U + PN * kX6Par + 4 * 4096);
-        if (i == 5) X6_DMA_S(u_lane, us + 5 * ublk, lds_w, kX6U + PN * kX6Par + 5 * 4096);
-        if (i == 6 && ND) X6_DMA_V(da, lds_w, DPW * kX6DB + DPC * 1024);
-        if (i == 7 && ND && (R != 0 || has_db)) X6_DMA_V(db, lds_w, DPW * kX6DB + (DPC + 4) * 1024);
-    };
-    x6_rows_to_v<R1>(dd, v_base0 + PN * kX6Par, dma);
-    if (!tile_end) x6_prefetch_rows<R3, DP3>(dd, d_base);
-#if (UNET_X6_ABLATE & 8)
-    X6_STAMP(q1);
-#endif
-    // the V writes are done once at most the eight row reads behind them are outstanding
-    if (!tile_end) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(8)\n\ts_barrier" ::: "memory");
+    if (R != 2 && has_d) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if (UNET_X6_ABLATE & 8)
-    X6_STAMP(q2);
-    x6_tl_add(4 * PN + 2, q1 - q0); x6_tl_add(4 * PN + 3, q2 - q1);
 #endif
 }
 
@@ -313,31 +256,36 @@ struct X6Args {
 };
 
 // ---- epilogue of the wave pair ------------------------------------------------------------------------------------------------------------
-// SIMD partners (mi, ni, ph = 0 / 1) hold point rows {0, 2} / {1, 3} of the same [32 channels x 32 tiles] block.  The output transform
-// A^T m A is linear in the rows: each partner applies it to its own two rows (partial row stage rr0 = A + sB B, rr1 = sA A - B with
-// (sA, sB) = (0, 1) / (1, 0), then the column stage), hands the two channel quads it does not finish to the other one through LDS
-// (8 KB per wave, 64 KB in the buffers that are idle at a tile's end), adds what it receives and finishes its own two quads: bias, ReLU,
-// BatchNorm sums, stores.  Channel quad g = accumulator elements 4g..4g+3 = channels n0 + 32 ni + 8 g + 4 lh + {0..3}; ph keeps g = 2 ph, 2 ph + 1.
-template <int G> __device__ __forceinline__ void x6_partial_quad(const f32x16 (&acc)[8], float sA, float sB, f32x4 (&y)[4]) {
+// SIMD partners (mi, ni, PH = 0 / 1) hold point COLUMNS {0, 1} / {2, 3} of the same [32 channels x 32 tiles] block, all four rows.  The
+// output transform's row stage is lane-local; its column stage is linear in the columns, so each partner forms its partial 2x2 output
+//     PH = 0:  y[.][0] = rr0 + rr1,  y[.][1] = rr1          PH = 1:  y[.][0] = rr2,  y[.][1] = -rr2 - rr3
+// hands the two channel quads it does not finish to the other one through LDS (8 KB per wave, 64 KB in the buffers that are idle at a
+// tile's end), adds what it receives and finishes its own two quads: bias, ReLU, BatchNorm sums, stores.  The PH = 1 wave reads its
+// weight rows rotated by 16 (x6_group_body), so in BOTH waves accumulator elements 0..7 (quads 0, 1) are the channels the wave finishes
+// itself -- 32 ni + 16 PH + 8 q + 4 lh + {0..3} -- and elements 8..15 the ones it hands over.
+template <int G, int PH> __device__ __forceinline__ void x6_partial_quad(const f32x16 (&acc)[8], f32x4 (&y)[4]) {
     f32x2 yy[2][2][2];                            // [out row][out col][channel pair]
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        f32x2 rr[2][4];
+        f32x2 rr[2][2];                           // [out row][the wave's column q]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // explicit accumulator reads (element extraction left to the compiler round-trips whole accumulators through VGPRs)
-            float a0, a1, b0, b1;
-            asm("v_accvgpr_read_b32 %0, %1" : "=v"(a0) : "a"(acc[j][4 * G + 2 * h]));
-            asm("v_accvgpr_read_b32 %0, %1" : "=v"(a1) : "a"(acc[j][4 * G + 2 * h + 1]));
-            asm("v_accvgpr_read_b32 %0, %1" : "=v"(b0) : "a"(acc[4 + j][4 * G + 2 * h]));
-            asm("v_accvgpr_read_b32 %0, %1" : "=v"(b1) : "a"(acc[4 + j][4 * G + 2 * h + 1]));
-            rr[0][j] = f32x2{fmaf(sB, b0, a0), fmaf(sB, b1, a1)};
-            rr[1][j] = f32x2{fmaf(sA, a0, -b0), fmaf(sA, a1, -b1)};
+        for (int q = 0; q < 2; ++q) {
+            f32x2 m[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // explicit accumulator reads (element extraction left to the compiler round-trips whole accumulators through VGPRs)
+                float e0, e1;
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(e0) : "a"(acc[2 * i + q][4 * G + 2 * h]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(e1) : "a"(acc[2 * i + q][4 * G + 2 * h + 1]));
+                m[i] = f32x2{e0, e1};
+            }
+            rr[0][q] = m[0] + (m[1] + m[2]);
+            rr[1][q] = (m[1] - m[2]) - m[3];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            yy[i][0][h] = rr[i][0] + (rr[i][1] + rr[i][2]);
-            yy[i][1][h] = (rr[i][1] - rr[i][2]) - rr[i][3];
+            if (PH == 0) { yy[i][0][h] = rr[i][0] + rr[i][1]; yy[i][1][h] = rr[i][1]; }
+            else { yy[i][0][h] = rr[i][0]; yy[i][1][h] = -rr[i][0] - rr[i][1]; }
         }
     }
 #pragma unroll
@@ -347,15 +295,11 @@ template <int G> __device__ __forceinline__ void x6_partial_quad(const f32x16 (&
 }
 #define X6_WR128_RT(base, off, val) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "v"(val), "n"(off) : "memory")
 
-// ONE code path for both partners: the ph = 1 wave reads its weight rows rotated by 16 (x6_stream_body), so in BOTH waves accumulator
-// elements 0..7 (quads 0, 1) are the channels the wave finishes itself -- 32 ni + 16 ph + 8 q + 4 lh + {0..3} -- and elements 8..15 the
-// ones it hands to its partner.
-template <int STATS>
+template <int STATS, int PH>
 __device__ __forceinline__ void x6_pair_epilogue(const f32x16 (&acc)[8], const WinoFusedArgs& p, int img, int by, int bx, int n0, int mi, int ni,
-                                                 int ph, int wq, int li, int lh, unsigned xbase, f32x2 (&s1)[4], f32x2 (&s2)[4]) {
-    const int kq0 = 2 * ph;                        // kept channel quads (of the wave pair's 32 channels): kq0, kq0 + 1
-    const float sA = ph ? 1.f : 0.f, sB = ph ? 0.f : 1.f;
-    const unsigned xw = xbase + (unsigned)((wq * 2 + ph) * 8192), xr = xbase + (unsigned)((wq * 2 + (ph ^ 1)) * 8192);
+                                                 int wq, int li, int lh, unsigned xbase, f32x2 (&s1)[4], f32x2 (&s2)[4]) {
+    constexpr int kq0 = 2 * PH;                    // kept channel quads (of the wave pair's 32 channels): kq0, kq0 + 1
+    const unsigned xw = xbase + (unsigned)((wq * 2 + PH) * 8192), xr = xbase + (unsigned)((wq * 2 + (PH ^ 1)) * 8192);
     const int lt = 32 * mi + li;
     const int ty = 8 * by + (lt >> 3), tx = 8 * bx + (lt & 7);
     const bool ok = ty < (p.H >> 1) && tx < (p.W >> 1);
@@ -363,10 +307,10 @@ __device__ __forceinline__ void x6_pair_epilogue(const f32x16 (&acc)[8], const W
     const size_t rowstride = (size_t)p.W * p.ldo;
     {
         f32x4 y[4];
-        x6_partial_quad<2>(acc, sA, sB, y);
+        x6_partial_quad<2, PH>(acc, y);
 #pragma unroll
         for (int px = 0; px < 4; ++px) X6_WR128_RT(xw, px * 1024, y[px]);
-        x6_partial_quad<3>(acc, sA, sB, y);
+        x6_partial_quad<3, PH>(acc, y);
 #pragma unroll
         for (int px = 0; px < 4; ++px) X6_WR128_RT(xw, (4 + px) * 1024, y[px]);
     }
@@ -389,7 +333,7 @@ __device__ __forceinline__ void x6_pair_epilogue(const f32x16 (&acc)[8], const W
             }
         }
         f32x4 yk[4];
-        if (q == 0) x6_partial_quad<0>(acc, sA, sB, yk); else x6_partial_quad<1>(acc, sA, sB, yk);
+        if (q == 0) x6_partial_quad<0, PH>(acc, yk); else x6_partial_quad<1, PH>(acc, yk);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yp[0]), "+v"(yp[1]), "+v"(yp[2]), "+v"(yp[3]));
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
@@ -432,25 +376,23 @@ __device__ __forceinline__ void x6_write_stats(const WinoFusedArgs& p, int t0, i
     }
 }
 
-// The body of one wave group.  PH (waves 4 PH .. 4 PH + 3) is a template parameter: the two groups run different straight-line code
-// (with the role chosen by a branch around the accumulator-modifying statements the compiler copied accumulator tuples through scratch).
+// The body of one wave group.  PH (waves 4 PH .. 4 PH + 3) is a template parameter: the two groups run different straight-line code.
 template <int STATS, int PH>
 __device__ __forceinline__ void x6_group_body(const X6Args& q, int ntiles, char* smem) {
     const WinoFusedArgs& p = q.f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int ph = PH;
     const int wq = w8 & 3;                                      // SIMD partners are waves wq and wq + 4
     const int mi = wq & 1, ni = wq >> 1;
     const int li = lane & 31, lh = lane >> 5;
     const int nchunks = p.K / 16;
 
-    // ---- DMA duty (in the MFMA role).  U: piece wq + 4 j of a unit image = block (wq >> 1) + 2 j, rows 32 (wq & 1) + lane / 2, 16-byte slot
-    //      lane & 1 (source-side swizzle: slot ^ bit 3 of the row).  D: piece = pixel slots 16 piece + lane / 4, channel quad lane & 3; group
-    //      ph = 0 owns pieces wq + 8, wq + 12, group ph = 1 pieces wq, wq + 4, wq + 16, wq + 20 (21..23 are dummies beyond the patch).
+    // ---- DMA duty.  U: piece w8 + 8 j (j = 0..2) of a unit image = block (wq >> 1) + 2 PH + 4 j, rows 32 (wq & 1) + lane / 2, 16-byte slot
+    //      lane & 1 (source-side swizzle: slot ^ bit 3 of the row).  D: piece = pixel slots 16 piece + lane / 4, channel quad lane & 3; the
+    //      wave owns pieces w8 (issued in units R = 3), 8 + w8 (R = 0) and 16 + w8 (R = 1; exists for w8 < 5).
     const int urow = 32 * (wq & 1) + (lane >> 1);
     const unsigned u_lane = (unsigned)(urow * 32 + 16 * ((lane & 1) ^ ((urow >> 3) & 1)));
-    const size_t ublk = (size_t)2 * p.Nout * 32;                                      // blocks b and b + 2 are 2 N rows apart
+    const size_t ublk = (size_t)4 * p.Nout * 32;                                      // blocks b and b + 4 are 4 N rows apart
     const size_t ustep = (size_t)12 * p.Nout * 32;                                    // bytes between units
     auto piece_geom = [&](int piece, int& py_, int& px_, int& off_) {
         const int s_ = 16 * piece + (lane >> 2);
@@ -459,7 +401,6 @@ __device__ __forceinline__ void x6_group_body(const X6Args& q, int ntiles, char*
         px_ = px;
         off_ = (py * p.W + px) * p.ldx + 4 * (lane & 3);
     };
-    auto slot_piece = [&](int j) { return ph ? (j < 2 ? wq + 4 * j : wq + 16 + 4 * (j - 2)) : wq + 8 + 4 * (j & 1); };
     struct TileCoord { int tn, bx, by, img; };
     auto decode = [&](int t) { TileCoord c; c.tn = t % p.nt; t /= p.nt; c.bx = t % p.tbx; t /= p.tbx; c.by = t % p.tby; c.img = t / p.tby; return c; };
     const TileCoord dstep = decode((int)gridDim.x);
@@ -477,26 +418,27 @@ __device__ __forceinline__ void x6_group_body(const X6Args& q, int ntiles, char*
         const bool ok = (unsigned)(gy0 + py) < (unsigned)p.H && (unsigned)(gx0 + px) < (unsigned)p.W;
         return ok ? xb + off : padsrc + 4 * (lane & 3);
     };
-    auto slot_src = [&](const TileCoord& c, int j) { int py, px, off; piece_geom(slot_piece(j), py, px, off); return pixel_src(c, py, px, off); };
-    auto u_source = [&](const TileCoord& c) { return reinterpret_cast<const char*>(q.U6) + ((size_t)(wq >> 1) * p.Nout + (size_t)c.tn * 64) * 32; };
+    auto slot_src = [&](const TileCoord& c, int j) { int py, px, off; piece_geom(8 * j + w8, py, px, off); return pixel_src(c, py, px, off); };
+    auto u_source = [&](const TileCoord& c) { return reinterpret_cast<const char*>(q.U6) + ((size_t)((wq >> 1) + 2 * PH) * p.Nout + (size_t)c.tn * 64) * 32; };
+    const bool has2 = w8 < 5;                                                         // piece 16 + w8 exists
 
     // ---- LDS byte addresses
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_f*)smem;
     const int arow = 32 * mi + li;
-    const int t_lt = 16 * wq + (lane >> 2), t_q = lane & 3;                      // transform duty: (tile, channel quad)
+    const int t_lt = 16 * wq + (lane >> 2), t_q = lane & 3;                      // transform duty: (tile, channel quad), points 2 PH, 2 PH + 1
     const unsigned a_base = lds0 + kX6V + (unsigned)(arow * 32 + 16 * (lh ^ ((arow >> 3) & 1)));          // parity 0; parity 1 is kX6Par further
-    // (the ph = 1 partner takes its 32 weight rows rotated by 16: see x6_pair_epilogue)
-    const int brow_r = 32 * ni + ((li + 16 * ph) & 31);
+    // (the PH = 1 partner takes its 32 weight rows rotated by 16: see x6_pair_epilogue)
+    const int brow_r = 32 * ni + ((li + 16 * PH) & 31);
     const unsigned b_base = lds0 + kX6U + (unsigned)(brow_r * 32 + 16 * (lh ^ ((brow_r >> 3) & 1)));
     const unsigned v_base = lds0 + kX6V + (unsigned)(t_lt * 32 + 16 * ((t_q >> 1) ^ ((t_lt >> 3) & 1)) + 8 * (t_q & 1));
-    unsigned d_base[4];
+    unsigned d_base[3];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-        d_base[c] = lds0 + (unsigned)(((2 * (t_lt >> 3)) * 18 + x6_slot_of(2 * (t_lt & 7) + c)) * 64 + 16 * t_q);
-    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wq * 1024));       // this wave's first piece, as an M0 value
+    for (int c = 0; c < 3; ++c)
+        d_base[c] = lds0 + (unsigned)(((2 * (t_lt >> 3)) * 18 + x6_slot_of(2 * (t_lt & 7) + PH + c)) * 64 + 16 * t_q);
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + w8 * 1024));       // this wave's first piece, as an M0 value
 
     f32x16 acc[8];
-    const float* dptr[4]; const char* ucur; const char* unxt;
+    const float* dptr[3]; const char* ucur; const char* unxt;
     int t = blockIdx.x;
     if ((gridDim.x & 7) == 0 && (p.nt & 7) != 0) t = (t & 7) * (int)(gridDim.x >> 3) + (t >> 3);       // XCD-aware renumbering, as winograd.hip
     const int t_first = t;
@@ -505,51 +447,48 @@ __device__ __forceinline__ void x6_group_body(const X6Args& q, int ntiles, char*
     for (int i = 0; i < 4; ++i) { s1[i] = f32x2{0.f, 0.f}; s2[i] = f32x2{0.f, 0.f}; }
     TileCoord tc = decode(t);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dptr[j] = slot_src(tc, j);
+    for (int j = 0; j < 3; ++j) dptr[j] = slot_src(tc, j);
     ucur = u_source(tc);
 
-    // ---- prologue of the workgroup's first tile: D(0) (all eight waves, three pieces each), D(1) pieces 0..15 (both groups' slots 0, 1),
-    //      U(unit 0) (group 0) -> LDS; group 0 transforms unit 0; every wave reads the raw rows of its first transform unit
+    // ---- prologue of the workgroup's first tile: D(0) (every piece), D(1) pieces 0..7, U(unit 0) -> LDS; then V(unit 0)
+    X6_DMA_V(dptr[0], lds_w, 0); X6_DMA_V(dptr[1], lds_w, 8192);
+    if (has2) X6_DMA_V(dptr[2], lds_w, 16384);
+    X6_DMA_V(dptr[0] + 16, lds_w, kX6DB);
+    dptr[0] += 32; dptr[1] += 16; dptr[2] += 16;                              // next: chunk 2 (piece w8), chunk 1 (pieces 8 + w8, 16 + w8)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        int py, px, off;
-        piece_geom(w8 + 8 * j, py, px, off);
-        if (w8 + 8 * j < 21) X6_DMA_V(pixel_src(tc, py, px, off), lds_w + ph * 4096, 8 * j * 1024);  // piece w8 + 8 j = wq + 4 ph + 8 j
-    }
-    X6_DMA_V(dptr[0] + 16, lds_w + (ph ? 0 : 8192), kX6DB); X6_DMA_V(dptr[1] + 16, lds_w + (ph ? 0 : 8192), kX6DB + 4096);
-    dptr[0] += 32; dptr[1] += 32;                                             // next: chunk 2
-    if (ph) { dptr[2] += 16; dptr[3] += 16; }                                 // next: chunk 1 (pieces 16..20)
-    else {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) X6_DMA_S(u_lane, ucur + (size_t)j * ublk, lds_w, kX6U + j * 4096);
-    }
+    for (int j = 0; j < 3; ++j) X6_DMA_S(u_lane, ucur + (size_t)j * ublk, lds_w, kX6U + j * 8192);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    f32x4 dd[8];
-    if (ph == 0) {
-        x6_prefetch_rows<0, 0>(dd, d_base);
-        x6_rows_to_v<0>(dd, v_base, [](int) {});
-        x6_prefetch_rows<2, 0>(dd, d_base);                                   // group 0's first transform unit is (0, 1): point row 2
-    } else x6_prefetch_rows<1, 0>(dd, d_base);                                // group 1's is (0, 0): point row 1
-    asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+    {
+        f32x4 dd[6]; X6Split sp; unsigned lA[2];
+        x6_read_rows<0, 0>(dd, d_base);
+        asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_DD(dd));
+        x6_row_stage<0>(dd);
+        x6_point_step<0, 0, PH>(sp, dd); x6_point_step<1, 0, PH>(sp, dd); x6_point_step<2, 0, PH>(sp, dd); x6_point_step<3, 0, PH>(sp, dd); x6_point_step<4, 0, PH>(sp, dd);
+        X6_WR2(v_base, (2 * PH * 3 + 0) * 4, (2 * PH * 3 + 1) * 4, (x6_u32x2{sp.h[0], sp.h[1]}), (x6_u32x2{sp.m[0], sp.m[1]}));
+        lA[0] = sp.l[0]; lA[1] = sp.l[1];
+        x6_point_step<0, 1, PH>(sp, dd); x6_point_step<1, 1, PH>(sp, dd); x6_point_step<2, 1, PH>(sp, dd); x6_point_step<3, 1, PH>(sp, dd); x6_point_step<4, 1, PH>(sp, dd);
+        X6_WR2(v_base, ((2 * PH + 1) * 3 + 0) * 4, ((2 * PH + 1) * 3 + 1) * 4, (x6_u32x2{sp.h[0], sp.h[1]}), (x6_u32x2{sp.m[0], sp.m[1]}));
+        X6_WR2(v_base, (2 * PH * 3 + 2) * 4, ((2 * PH + 1) * 3 + 2) * 4, (x6_u32x2{lA[0], lA[1]}), (x6_u32x2{sp.l[0], sp.l[1]}));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     for (; t < ntiles; t += gridDim.x) {
         const TileCoord tcn = t + (int)gridDim.x < ntiles ? advance(tc) : tc;            // the last tile prefetches itself again
         unxt = u_source(tcn);
-        // the D pointers of the slots a unit issued move on behind it: one chunk further, or to the next tile's patch behind the tile's last chunk
-        auto advance_slots = [&](int s0, bool last) {
-            if (last) { dptr[s0] = slot_src(tcn, s0); dptr[s0 + 1] = slot_src(tcn, s0 + 1); }
-            else { dptr[s0] += 16; dptr[s0 + 1] += 16; }
-        };
-        // U(g + 1) of unit g = 4 c + R, continuing into the next tile.  D pieces: the units R = 2, 3 issue chunk c + 2 (the tile's last one when
-        // c = nchunks - 3), R = 0 issues chunk c + 1 (the last one when c = nchunks - 2); behind the last chunk the pointers jump to the next tile
+        // the D pointer of the slot a unit issued moves on behind it: one chunk further, or to the next tile's patch behind the tile's last chunk
+        auto advance_slot = [&](int s0, bool last) { if (last) dptr[s0] = slot_src(tcn, s0); else dptr[s0] += 16; };
+        // U(g + 1) of unit g = 4 c + R, continuing into the next tile.  D pieces: the unit R = 3 issues chunk c + 2 (the tile's last one when
+        // c = nchunks - 3), R = 0, 1 issue chunk c + 1 (the last one when c = nchunks - 2); behind the last chunk the pointer jumps to the next tile
+#if (UNET_X6_ABLATE & 1024)      /* diagnostics: every U DMA re-reads the first unit's weights (always cache-hot) */
+#define X6_US(c, R) (ucur)
+#else
 #define X6_US(c, R) ((4 * (c) + (R) + 1 < 4 * nchunks) ? ucur + (size_t)(4 * (c) + (R) + 1) * ustep : unxt)
+#endif
 #define X6_UNIT(R, DP, FIRST, c) do { \
-        if constexpr (PH == ((R) & 1)) x6_mfma_role<R, FIRST>(acc, a_base, b_base); \
-        else { \
-            x6_transform_role<R, DP>(dd, d_base, v_base, X6_US(c, R), ublk, u_lane, dptr[(R) == 0 ? 2 : 0], dptr[(R) == 0 ? 3 : 1], wq == 0, lds_w, \
-                                     (R) >= 2 && (c) == nchunks - 1); \
-            if ((R) != 1) advance_slots((R) == 0 ? 2 : 0, (R) == 0 ? (c) == nchunks - 2 : (c) == nchunks - 3); \
-        } } while (0)
+        x6_unit<R, DP, FIRST, PH>(acc, a_base, b_base, d_base, v_base, X6_US(c, R), ublk, u_lane, dptr[(R) == 3 ? 0 : (R) == 0 ? 1 : 2], (R) != 1 || has2, lds_w); \
+        if ((R) == 3) advance_slot(0, (c) == nchunks - 3); \
+        if ((R) == 0) advance_slot(1, (c) == nchunks - 2); \
+        if ((R) == 1) advance_slot(2, (c) == nchunks - 2); } while (0)
         X6_UNIT(0, 0, true, 0); X6_UNIT(1, 0, true, 0); X6_UNIT(2, 0, true, 0); X6_UNIT(3, 0, true, 0);
         X6_UNIT(0, 1, false, 1); X6_UNIT(1, 1, false, 1); X6_UNIT(2, 1, false, 1); X6_UNIT(3, 1, false, 1);
         for (int c = 2; c < nchunks; c += 2) {
@@ -559,13 +498,11 @@ __device__ __forceinline__ void x6_group_body(const X6Args& q, int ntiles, char*
 #undef X6_UNIT
 #undef X6_US
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMAs are invisible to the compiler's hazard recogniser
-        x6_pair_epilogue<STATS>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, ph, wq, li, lh, lds0 + kX6X + (unsigned)lane * 16, s1, s2);
-        // the raw rows of this wave's first transform unit of the next tile (its D(0) landed before the tile's last chunk ended)
-        if (ph == 0) x6_prefetch_rows<2, 0>(dd, d_base); else x6_prefetch_rows<1, 0>(dd, d_base);
+        x6_pair_epilogue<STATS, PH>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, wq, li, lh, lds0 + kX6X + (unsigned)lane * 16, s1, s2);
         ucur = unxt; tc = tcn;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // retire the prefetches of the tile that never runs
-    if (STATS) x6_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), mi, ni, ph, li, lh, s1, s2);
+    if (STATS) x6_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), mi, ni, PH, li, lh, s1, s2);
 }
 template <int STATS>
 __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
