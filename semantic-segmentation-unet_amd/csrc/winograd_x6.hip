@@ -46,11 +46,10 @@ typedef unsigned x6_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kX6DB = 24 * 1024;                  // one D chunk buffer: 324 pixel slots x 64 B in 24 1-KB DMA pieces (21 used + 3 dummies)
 constexpr int kX6IB = 24 * 1024;                  // one V or U unit image
 constexpr int kX6Blk = 2048;                      // one (point, piece) block: 64 rows x 32 B
-constexpr int kX6V = 2 * kX6DB, kX6Smem = kX6V + 2 * kX6IB;      // 96 KB: D0 D1 V0 V1 (the weights never touch the LDS)
+constexpr int kX6V = 2 * kX6DB, kX6U = kX6V + 2 * kX6IB, kX6Smem = kX6U + 2 * kX6IB;      // 147456 B
 constexpr int kX6RowB = 18 * 64;                  // bytes between patch rows in D
 
 #define X6_RD128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
-#define X6_WR2(base, o0, o1, v0, v1) asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(base), "v"(v0), "v"(v1), "n"(o0), "n"(o1) : "memory")
 #define X6_WR64(base, off, val) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(val), "n"(off) : "memory")
 #define X6_MFMA(accv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(accv) : "v"(av), "v"(bv) : "memory")
 // LDS-DMA of one 1-KB piece (16 B per lane) to LDS byte address `ldsaddr` (wave-uniform): M0 carries the LDS address.  Written as asm so
@@ -59,8 +58,6 @@ constexpr int kX6RowB = 18 * 64;                  // bytes between patch rows in
 // (ldsw = the wave's LDS base in ONE scalar register, ldsoff an immediate: the sum is formed in M0 itself)
 #define X6_DMA_S(voff, sbase, ldsw, ldsoff) asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(ldsw), "n"(ldsoff) : "memory", "scc")
 #define X6_DMA_V(vptr, ldsw, ldsoff) asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vptr), "s"(ldsw), "n"(ldsoff) : "memory", "scc")
-// weight fragment straight into registers: 16 B per lane from SGPR base + 32-bit lane offset; asynchronous (vmcnt), tied at its wait
-#define X6_LDU(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory")
 #define X6_MFMA0(accv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(accv) : "v"(av), "v"(bv) : "memory")
 
 // slot of patch column x (0..17) inside a patch row: pixels two apart (the stride between neighbouring tiles) must land on different
@@ -68,17 +65,18 @@ constexpr int kX6RowB = 18 * 64;                  // bytes between patch rows in
 __host__ __device__ constexpr int x6_slot_of(int x) { return x >= 16 ? x : (x & ~7) + ((x & 7) == 0 ? 0 : (x & 7) == 1 ? 1 : (x & 7) == 2 ? 5 : (x & 7) == 3 ? 2 : (x & 7) == 4 ? 6 : (x & 7) == 5 ? 3 : (x & 7) == 6 ? 7 : 4); }
 __host__ __device__ constexpr int x6_col_of(int s) { return s >= 16 ? s : (s & ~7) + ((s & 7) == 0 ? 0 : (s & 7) == 1 ? 1 : (s & 7) == 2 ? 3 : (s & 7) == 3 ? 5 : (s & 7) == 4 ? 7 : (s & 7) == 5 ? 2 : (s & 7) == 6 ? 4 : 6); }
 
-struct X6Frag { x6_i32x4 v[3]; };                 // data operands of one point: pieces h, m, l (LDS)
-struct X6URing { x6_i32x4 u[4][3]; };             // weight operands of four consecutive points: pieces h, m, l (global memory -> registers)
+struct X6Frag { x6_i32x4 u[3], v[3]; };           // MFMA operands of one point: weight pieces (h, m, l), data pieces (h, m, l)
 struct X6Split { float v[4], a[4], b[4]; unsigned h[2], m[2], l[2]; };
 
 // operand reads of point PT of the unit in buffers PAR: 6 ds_read_b128
-template <int PAR, int PT> __device__ __forceinline__ void x6_read_ops(X6Frag& f, unsigned a_base) {
+template <int PAR, int PT> __device__ __forceinline__ void x6_read_ops(X6Frag& f, unsigned a_base, unsigned b_base) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) X6_RD128(f.v[k], a_base, PAR * kX6IB + (PT * 3 + k) * kX6Blk);
+    for (int k = 0; k < 3; ++k) {
+        X6_RD128(f.u[k], b_base, PAR * kX6IB + (PT * 3 + k) * kX6Blk);
+        X6_RD128(f.v[k], a_base, PAR * kX6IB + (PT * 3 + k) * kX6Blk);
+    }
 }
-#define X6_TIE_FRAG(f) "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2])
-#define X6_TIE_U(r, s) "+v"(r.u[s][0]), "+v"(r.u[s][1]), "+v"(r.u[s][2])
+#define X6_TIE_FRAG(f) "+v"(f.u[0]), "+v"(f.u[1]), "+v"(f.u[2]), "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2])
 
 __device__ __forceinline__ unsigned x6_hi2(float lo, float hi) {       // { bf16 bits of lo (truncated) , of hi } packed, lo in the low half
     return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
@@ -119,11 +117,10 @@ template <int K, int J> __device__ __forceinline__ void x6_split_step(X6Split& s
     }
 }
 // the three pieces of point J -> V image PAR (3 ds_write_b64)
-// (h, m) of a point are 2048 B = 4 x 512 apart: one ds_write2st64_b64; the l pieces of points 2 i, 2 i + 1 share one (lprev = the even point's)
-template <int PAR, int J> __device__ __forceinline__ void x6_write_v(const X6Split& s, unsigned v_base, unsigned (&lprev)[2]) {
-    X6_WR2(v_base, PAR * 48 + (J * 3 + 0) * 4, PAR * 48 + (J * 3 + 1) * 4, (x6_u32x2{s.h[0], s.h[1]}), (x6_u32x2{s.m[0], s.m[1]}));
-    if (J & 1) X6_WR2(v_base, PAR * 48 + ((J - 1) * 3 + 2) * 4, PAR * 48 + (J * 3 + 2) * 4, (x6_u32x2{lprev[0], lprev[1]}), (x6_u32x2{s.l[0], s.l[1]}));
-    else { lprev[0] = s.l[0]; lprev[1] = s.l[1]; }
+template <int PAR, int J> __device__ __forceinline__ void x6_write_v(const X6Split& s, unsigned v_base) {
+    X6_WR64(v_base, PAR * kX6IB + (J * 3 + 0) * kX6Blk, (x6_u32x2{s.h[0], s.h[1]}));
+    X6_WR64(v_base, PAR * kX6IB + (J * 3 + 1) * kX6Blk, (x6_u32x2{s.m[0], s.m[1]}));
+    X6_WR64(v_base, PAR * kX6IB + (J * 3 + 2) * kX6Blk, (x6_u32x2{s.l[0], s.l[1]}));
 }
 
 // raw rows of the unit with point row R2 from D buffer DPR -> dd[0..3] (row ra), dd[4..7] (row rb); tt = ra -/+ rb:
@@ -143,69 +140,49 @@ template <int R2, int C> __device__ __forceinline__ void x6_row_stage(f32x4 (&dd
 }
 #define X6_TIE_DD(d) "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
 
-// One unit: the 24 MFMAs of point row R of a chunk with D parity DP (V buffers R & 1), and everything that runs in their shadow.
+// One unit: the 24 MFMAs of point row R of a chunk with D parity DP (V / U buffers R & 1), and everything that runs in their shadow.
 //   S0 / S1: the two sets of 8 row registers; set (R & 1) holds the row stage of unit g+1 (consumed here), the other one takes the raw
 //            rows of unit g+2 and ends as its row stage;
-//   ring:    the weight fragments of four consecutive points, slot = point & 3.  Behind the first MFMA of point p the three fragments of
-//            point p+3 are requested (global_load_dwordx4 from `unext`, which then moves on one point): three points = 18 MFMAs of lead.
-//            `ulast` (uniform): that point was the tile's last one, `unext` jumps to the next tile's weights;
-//   dptr:    this lane's running sources of its six D pieces -- the two issued in this unit (R != 1) advance by one chunk, or jump to
-//            the next tile's patch (next_src(slot)) when `dswitch` says this was the tile's last chunk (uniform).
-// LDS instructions retire in order, so do vector-memory instructions: every lgkmcnt / vmcnt immediate counts what was issued behind the
-// item waited for.  vmcnt before point p: the loads of points p+1, p+2 (6) and the D pieces issued in between (point 2 of a unit).
-template <int R, int DP, bool FIRST, class NextSrc>
-__device__ __forceinline__ void x6_unit(f32x16 (&acc)[16], f32x4 (&S0)[8], f32x4 (&S1)[8], X6Frag (&fr)[2], X6URing& ring, X6Split& sp,
-                                        unsigned a_base, const unsigned (&d_base)[4], unsigned v_base,
-                                        const char*& unext, const char* unxt, int& upoints, size_t pstep, const unsigned (&uoff)[3],
-                                        const float* (&dptr)[6], NextSrc&& next_src, bool dswitch, unsigned lds_w) {
+//   us: source of U(g+1) for this wave's first block (uniform), uoff[j]: the lane's byte offset of its piece j from there;
+//   dptr: this lane's running sources of its six D pieces -- the two issued in this unit (R != 1) advance by one chunk, or jump to the next
+//         tile's patch (dnxt) when `dswitch` says this was the tile's last chunk (uniform).
+// LDS instructions retire in order; the lgkmcnt immediates count the LDS instructions issued behind the one waited for.
+template <int R, int DP, bool FIRST>
+__device__ __forceinline__ void x6_unit(f32x16 (&acc)[16], f32x4 (&S0)[8], f32x4 (&S1)[8], X6Frag (&fr)[2], X6Split& sp,
+                                        unsigned a_base, unsigned b_base, const unsigned (&d_base)[4], unsigned v_base,
+                                        const char* us, const unsigned (&uoff)[6], const float* (&dptr)[6], const float* (&dnxt)[6], bool dswitch,
+                                        unsigned lds_w, long long (&tl)[6]) {
     constexpr int P = R & 1, PN = P ^ 1;
+#if (UNET_X6_ABLATE & 8)
+    long long q0, q1, q2, q3;
+    X6_STAMP(q0);
+#endif
     constexpr int R2 = (R + 2) & 3, DPR = DP ^ (R >= 2 ? 1 : 0);
     // D pieces issued here: R = 2: chunk c+2 pieces 0,1 (wave's j = 0,1); R = 3: pieces j = 2,3; R = 0: chunk c+1, j = 4,5; R = 1: none
     constexpr int ND = R == 1 ? 0 : 2;
-    constexpr int NDPREV = R == 2 ? 0 : 2;                            // D pieces of the previous unit
     constexpr int DJ = R == 2 ? 0 : R == 3 ? 2 : 4;
     constexpr int DPW = R == 0 ? (DP ^ 1) : DP;                       // buffer of that chunk
     f32x4 (&tt)[8] = P ? S1 : S0;
     f32x4 (&dd)[8] = P ? S0 : S1;
-    unsigned lprev[2];
-    asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_FRAG(fr[0]));        // point 0's data operands (issued by the caller side of the barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_FRAG(fr[0]));        // point 0's operands (issued by the caller side of the barrier)
+    X6_STAMP(q1);
 #pragma unroll
     for (int n = 0; n < 24; ++n) {
         const int p = n / 6, k = n % 6;
         X6Frag& f = fr[p & 1];
-        if (k == 0) {
-            // this point's weight fragments: behind them the loads of the next two points, and the D pieces of point 2 (of the previous unit for p = 0)
-            if (p == 0) { if (NDPREV) asm volatile("s_waitcnt vmcnt(8)" : X6_TIE_U(ring, 0)); else asm volatile("s_waitcnt vmcnt(6)" : X6_TIE_U(ring, 0)); }
-            if (p == 1) { if (NDPREV) asm volatile("s_waitcnt vmcnt(8)" : X6_TIE_U(ring, 1)); else asm volatile("s_waitcnt vmcnt(6)" : X6_TIE_U(ring, 1)); }
-            if (p == 2) asm volatile("s_waitcnt vmcnt(6)" : X6_TIE_U(ring, 2));
-            if (p == 3) { if (ND) asm volatile("s_waitcnt vmcnt(8)" : X6_TIE_U(ring, 3)); else asm volatile("s_waitcnt vmcnt(6)" : X6_TIE_U(ring, 3)); }
-            if (p == 1) asm volatile("s_waitcnt lgkmcnt(9)" : X6_TIE_FRAG(f));      // behind its reads: 8 row reads + point 0's V write
-            if (p == 2) asm volatile("s_waitcnt lgkmcnt(2)" : X6_TIE_FRAG(f));      // point 1's two V writes
-            if (p == 3) asm volatile("s_waitcnt lgkmcnt(1)" : X6_TIE_FRAG(f));      // point 2's V write
-        }
+        if (k == 0 && p > 0) asm volatile("s_waitcnt lgkmcnt(3)" : X6_TIE_FRAG(f));       // behind its reads: the previous point's 3 V writes
         // piece products, small to large: (m,m) (l,h) (h,l) (m,h) (h,m) (h,h);  u = weights (rows = channels), v = data (columns = tiles)
         const int ui = k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 0 : k == 3 ? 1 : 0;
         const int vi = k == 0 ? 1 : k == 1 ? 0 : k == 2 ? 2 : k == 3 ? 0 : k == 4 ? 1 : 0;
 #if !(UNET_X6_ABLATE & 32)       /* diagnostics: 32 = no MFMAs (results wrong) */
-        if (FIRST && k == 0) X6_MFMA0(acc[4 * R + p], ring.u[p][ui], f.v[vi]);
-        else X6_MFMA(acc[4 * R + p], ring.u[p][ui], f.v[vi]);
+        if (FIRST && k == 0) X6_MFMA0(acc[4 * R + p], f.u[ui], f.v[vi]);
+        else X6_MFMA(acc[4 * R + p], f.u[ui], f.v[vi]);
 #endif
         // ---- in the shadow of MFMA n
-        if (k == 0 && p < 3 && !(UNET_X6_ABLATE & 128)) {        // data operands of the next point
-            if (p == 0) x6_read_ops<P, 1>(fr[1], a_base);
-            if (p == 1) x6_read_ops<P, 2>(fr[0], a_base);
-            if (p == 2) x6_read_ops<P, 3>(fr[1], a_base);
-        }
-        if (k == 0) {                                            // weights of point p + 3 into the slot of point p - 1 (whose last MFMA has issued)
-            const int sl = (p + 3) & 3;
-            if (!(UNET_X6_ABLATE & 64)) {
-                if (sl == 0) { X6_LDU(ring.u[0][0], uoff[0], unext); X6_LDU(ring.u[0][1], uoff[1], unext); X6_LDU(ring.u[0][2], uoff[2], unext); }
-                if (sl == 1) { X6_LDU(ring.u[1][0], uoff[0], unext); X6_LDU(ring.u[1][1], uoff[1], unext); X6_LDU(ring.u[1][2], uoff[2], unext); }
-                if (sl == 2) { X6_LDU(ring.u[2][0], uoff[0], unext); X6_LDU(ring.u[2][1], uoff[1], unext); X6_LDU(ring.u[2][2], uoff[2], unext); }
-                if (sl == 3) { X6_LDU(ring.u[3][0], uoff[0], unext); X6_LDU(ring.u[3][1], uoff[1], unext); X6_LDU(ring.u[3][2], uoff[2], unext); }
-            }
-            unext += pstep;
-            if (--upoints == 0) { unext = unxt; upoints = 0x7fffffff; }          // (re-armed by the caller at the next tile)
+        if (k == 0 && p < 3 && !(UNET_X6_ABLATE & 128)) {        // operands of the next point
+            if (p == 0) x6_read_ops<P, 1>(fr[1], a_base, b_base);
+            if (p == 1) x6_read_ops<P, 2>(fr[0], a_base, b_base);
+            if (p == 2) x6_read_ops<P, 3>(fr[1], a_base, b_base);
         }
         if (n >= 1 && n <= 4 && !(UNET_X6_ABLATE & 512)) {       // raw rows of unit g+2, two reads per gap
             if (n == 1) x6_read_rows<R2, DPR, 0>(dd, d_base);
@@ -213,10 +190,12 @@ __device__ __forceinline__ void x6_unit(f32x16 (&acc)[16], f32x4 (&S0)[8], f32x4
             if (n == 3) x6_read_rows<R2, DPR, 2>(dd, d_base);
             if (n == 4) x6_read_rows<R2, DPR, 3>(dd, d_base);
         }
-        if (ND && n == 13 && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ], lds_w, DPW * kX6DB + DJ * 4096);          // (point 2, behind its weight loads)
-        if (ND && n == 15 && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ + 1], lds_w, DPW * kX6DB + (DJ + 1) * 4096);
+        if ((n & 1) == 0 && n < 12 && !(UNET_X6_ABLATE & 64))    // U(g+1): one DMA every second MFMA (the vector-memory issue path is busy ~64 cycles per DMA)
+            X6_DMA_S(uoff[n >> 1], us, lds_w, kX6U + PN * kX6IB + (n >> 1) * 4096);
+        if (ND && n == 12 && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ], lds_w, DPW * kX6DB + DJ * 4096);
+        if (ND && n == 14 && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ + 1], lds_w, DPW * kX6DB + (DJ + 1) * 4096);
         if (ND && n == 17) {                                     // (a light gap) the two pointers move on
-            if (dswitch) { dptr[DJ] = next_src(DJ); dptr[DJ + 1] = next_src(DJ + 1); }
+            if (dswitch) { dptr[DJ] = dnxt[DJ]; dptr[DJ + 1] = dnxt[DJ + 1]; }
             else { dptr[DJ] += 16; dptr[DJ + 1] += 16; }
             X6_PIN("+v"(dptr[DJ]), "+v"(dptr[DJ + 1]));
         }
@@ -226,21 +205,30 @@ __device__ __forceinline__ void x6_unit(f32x16 (&acc)[16], f32x4 (&S0)[8], f32x4
             if (p == 2) { if (k == 0) x6_split_step<0, 2>(sp, tt); if (k == 1) x6_split_step<1, 2>(sp, tt); if (k == 2) x6_split_step<2, 2>(sp, tt); if (k == 3) x6_split_step<3, 2>(sp, tt); if (k == 4) x6_split_step<4, 2>(sp, tt); }
             if (p == 3) { if (k == 0) x6_split_step<0, 3>(sp, tt); if (k == 1) x6_split_step<1, 3>(sp, tt); if (k == 2) x6_split_step<2, 3>(sp, tt); if (k == 3) x6_split_step<3, 3>(sp, tt); if (k == 4) x6_split_step<4, 3>(sp, tt); }
             if (k == 4 && !(UNET_X6_ABLATE & 256)) {
-                if (p == 0) x6_write_v<PN, 0>(sp, v_base, lprev);
-                if (p == 1) x6_write_v<PN, 1>(sp, v_base, lprev);
-                if (p == 2) x6_write_v<PN, 2>(sp, v_base, lprev);
-                if (p == 3) x6_write_v<PN, 3>(sp, v_base, lprev);
+                if (p == 0) x6_write_v<PN, 0>(sp, v_base);
+                if (p == 1) x6_write_v<PN, 1>(sp, v_base);
+                if (p == 2) x6_write_v<PN, 2>(sp, v_base);
+                if (p == 3) x6_write_v<PN, 3>(sp, v_base);
             }
         } else {                                                 // row stage of unit g+2, one patch column per point
-            if (p == 0) { asm volatile("s_waitcnt lgkmcnt(1)" : X6_TIE_DD(dd)); x6_row_stage<R2, 0>(dd); }      // behind the row reads: point 0's V write
+            if (p == 0) { asm volatile("s_waitcnt lgkmcnt(3)" : X6_TIE_DD(dd)); x6_row_stage<R2, 0>(dd); }      // behind the row reads: point 0's V writes
             if (p == 1) x6_row_stage<R2, 1>(dd);
             if (p == 2) x6_row_stage<R2, 2>(dd);
             if (p == 3) x6_row_stage<R2, 3>(dd);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (the vector-memory waits sit in front of the points that need the data)
-    x6_read_ops<PN, 0>(fr[0], a_base);                           // point 0 of the next unit
+    X6_STAMP(q2);
+#if (UNET_X6_ABLATE & 8)
+    if (ND) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    X6_STAMP(q3);
+    asm volatile("s_barrier" ::: "memory");
+    { long long q4; X6_STAMP(q4); tl[0] += q1 - q0; tl[1] += q2 - q1; tl[2] += q3 - q2; tl[3] += q4 - q3; tl[4] += 1; }
+#else
+    if (ND) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+    x6_read_ops<PN, 0>(fr[0], a_base, b_base);                   // point 0 of the next unit
 }
 
 struct X6Args {
@@ -260,12 +248,12 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
 
     // ---- DMA duty.  U: piece wv + 4 j of a unit image = block (wv >> 1) + 2 j, rows 32 (wv & 1) + lane / 2, 16-byte slot lane & 1
     //      (source-side swizzle: slot ^ bit 3 of the row).  D: piece wv + 4 j = pixel slots 16 (wv + 4 j) + lane / 4, channel quad lane & 3.
-    // weights: the lane's MFMA fragment of (point, piece) = 16 bytes at U6 + ((point * 3 + piece) * N + n0 + 32 ni + li) * 32 + 16 lh
-    const size_t pstep = (size_t)3 * p.Nout * 32;                                     // bytes between points
-    unsigned uoff[3];
+    const int urow = 32 * (wv & 1) + (lane >> 1);
+    const unsigned u_lane = (unsigned)(urow * 32 + 16 * ((lane & 1) ^ ((urow >> 3) & 1)));
+    unsigned uoff[6];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) uoff[k] = (unsigned)(((size_t)k * p.Nout + 32 * ni + li) * 32 + 16 * lh);
-    const int NP = 16 * nchunks;                                                      // points per tile
+    for (int j = 0; j < 6; ++j) uoff[j] = u_lane + (unsigned)j * 2u * (unsigned)p.Nout * 32u;      // blocks b and b + 2 are 2 N rows apart
+    const size_t ustep = (size_t)12 * p.Nout * 32;                                    // bytes between units
     int ppy[6], ppx[6], poff[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -286,18 +274,22 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         return c;
     };
     const float* const padsrc = p.pad ? p.pad : g_zero_page_f;
-    auto slot_src = [&](const TileCoord& c, int j) {
+    auto tile_sources = [&](const TileCoord& c, const float* (&dp)[6], const char*& ub0) {
         const int gy0 = 16 * c.by - 1, gx0 = 16 * c.bx - 1;
         const float* xb = p.x + ((long long)(c.img * p.H + gy0) * p.W + gx0) * p.ldx;
-        const bool ok = (unsigned)(gy0 + ppy[j]) < (unsigned)p.H && (unsigned)(gx0 + ppx[j]) < (unsigned)p.W;
-        return ok ? xb + poff[j] : padsrc + 4 * (lane & 3);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const bool ok = (unsigned)(gy0 + ppy[j]) < (unsigned)p.H && (unsigned)(gx0 + ppx[j]) < (unsigned)p.W;
+            dp[j] = ok ? xb + poff[j] : padsrc + 4 * (lane & 3);
+        }
+        ub0 = reinterpret_cast<const char*>(q.U6) + ((size_t)(wv >> 1) * p.Nout + (size_t)c.tn * 64) * 32;
     };
-    auto u_source = [&](const TileCoord& c) { return reinterpret_cast<const char*>(q.U6) + (size_t)c.tn * 64 * 32; };
 
     // ---- LDS byte addresses
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_f*)smem;
-    const int arow = 32 * mi + li;
+    const int arow = 32 * mi + li, brow = 32 * ni + li;
     const unsigned a_base = lds0 + kX6V + (unsigned)(arow * 32 + 16 * (lh ^ ((arow >> 3) & 1)));
+    const unsigned b_base = lds0 + kX6U + (unsigned)(brow * 32 + 16 * (lh ^ ((brow >> 3) & 1)));
     const int t_lt = 16 * wv + (lane >> 2), t_q = lane & 3;                      // transform duty: (tile, channel quad)
     unsigned d_base[4];
 #pragma unroll
@@ -309,9 +301,8 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
     f32x16 acc[16];
     f32x4 S0[8], S1[8];
     X6Frag fr[2];
-    X6URing ring;
     X6Split sp;
-    const float* dptr[6]; const char* unext; const char* unxt; int upoints;
+    const float* dptr[6]; const float* dnxt[6]; const char* ucur; const char* unxt;
     int t = blockIdx.x;
     if ((gridDim.x & 7) == 0 && (p.nt & 7) != 0) t = (t & 7) * (int)(gridDim.x >> 3) + (t >> 3);       // XCD-aware renumbering, as winograd.hip
     const int t_first = t;
@@ -319,51 +310,45 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = f32x2{0.f, 0.f}; s2[i] = f32x2{0.f, 0.f}; }
     TileCoord tc = decode(t);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) dptr[j] = slot_src(tc, j);
-    unext = u_source(tc);
+    tile_sources(tc, dptr, ucur);
 
-    // ---- prologue of the workgroup's first tile: D(0), D(1) pieces 0..3 -> LDS; the weights of points 0, 1, 2 -> ring; V(unit 0) by a full
-    //      transform; row stage of unit 1
+    // ---- prologue of the workgroup's first tile: D(0), D(1) pieces 0..3, U(unit 0) -> LDS; V(unit 0) by a full transform; row stage of unit 1
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         X6_DMA_V(dptr[j], lds_w, j * 4096);
         if (j < 4) X6_DMA_V(dptr[j] + 16, lds_w, kX6DB + j * 4096);
+        X6_DMA_S(uoff[j], ucur, lds_w, kX6U + j * 4096);
         dptr[j] += j < 4 ? 32 : 16;                              // next issue: chunk 2 (pieces 0..3), chunk 1 (pieces 4, 5)
     }
-#pragma unroll
-    for (int pt = 0; pt < 3; ++pt) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) X6_LDU(ring.u[pt][k], uoff[k], unext);
-        unext += pstep;
-    }
-    upoints = NP - 3;
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : X6_TIE_U(ring, 0), X6_TIE_U(ring, 1), X6_TIE_U(ring, 2) :: "memory");
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     x6_read_rows<0, 0, 0>(S1, d_base); x6_read_rows<0, 0, 1>(S1, d_base); x6_read_rows<0, 0, 2>(S1, d_base); x6_read_rows<0, 0, 3>(S1, d_base);
     x6_read_rows<1, 0, 0>(S0, d_base); x6_read_rows<1, 0, 1>(S0, d_base); x6_read_rows<1, 0, 2>(S0, d_base); x6_read_rows<1, 0, 3>(S0, d_base);
     asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_DD(S1));
     asm volatile("" : X6_TIE_DD(S0));
     x6_row_stage<0, 0>(S1); x6_row_stage<0, 1>(S1); x6_row_stage<0, 2>(S1); x6_row_stage<0, 3>(S1);
     x6_row_stage<1, 0>(S0); x6_row_stage<1, 1>(S0); x6_row_stage<1, 2>(S0); x6_row_stage<1, 3>(S0);
-    unsigned lpro[2];
-    x6_split_step<0, 0>(sp, S1); x6_split_step<1, 0>(sp, S1); x6_split_step<2, 0>(sp, S1); x6_split_step<3, 0>(sp, S1); x6_split_step<4, 0>(sp, S1); x6_write_v<0, 0>(sp, v_base, lpro);
-    x6_split_step<0, 1>(sp, S1); x6_split_step<1, 1>(sp, S1); x6_split_step<2, 1>(sp, S1); x6_split_step<3, 1>(sp, S1); x6_split_step<4, 1>(sp, S1); x6_write_v<0, 1>(sp, v_base, lpro);
-    x6_split_step<0, 2>(sp, S1); x6_split_step<1, 2>(sp, S1); x6_split_step<2, 2>(sp, S1); x6_split_step<3, 2>(sp, S1); x6_split_step<4, 2>(sp, S1); x6_write_v<0, 2>(sp, v_base, lpro);
-    x6_split_step<0, 3>(sp, S1); x6_split_step<1, 3>(sp, S1); x6_split_step<2, 3>(sp, S1); x6_split_step<3, 3>(sp, S1); x6_split_step<4, 3>(sp, S1); x6_write_v<0, 3>(sp, v_base, lpro);
+    x6_split_step<0, 0>(sp, S1); x6_split_step<1, 0>(sp, S1); x6_split_step<2, 0>(sp, S1); x6_split_step<3, 0>(sp, S1); x6_split_step<4, 0>(sp, S1); x6_write_v<0, 0>(sp, v_base);
+    x6_split_step<0, 1>(sp, S1); x6_split_step<1, 1>(sp, S1); x6_split_step<2, 1>(sp, S1); x6_split_step<3, 1>(sp, S1); x6_split_step<4, 1>(sp, S1); x6_write_v<0, 1>(sp, v_base);
+    x6_split_step<0, 2>(sp, S1); x6_split_step<1, 2>(sp, S1); x6_split_step<2, 2>(sp, S1); x6_split_step<3, 2>(sp, S1); x6_split_step<4, 2>(sp, S1); x6_write_v<0, 2>(sp, v_base);
+    x6_split_step<0, 3>(sp, S1); x6_split_step<1, 3>(sp, S1); x6_split_step<2, 3>(sp, S1); x6_split_step<3, 3>(sp, S1); x6_split_step<4, 3>(sp, S1); x6_write_v<0, 3>(sp, v_base);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    x6_read_ops<0, 0>(fr[0], a_base);
+    x6_read_ops<0, 0>(fr[0], a_base, b_base);
 
+    long long tl[6] = {0, 0, 0, 0, 0, 0};
     for (; t < ntiles; t += gridDim.x) {
+#if (UNET_X6_ABLATE & 8)
+        long long e0; X6_STAMP(e0);
+#endif
         const TileCoord tcn = t + (int)gridDim.x < ntiles ? advance(tc) : tc;            // the last tile prefetches itself again
-        unxt = u_source(tcn);
-        auto next_src = [&](int j) { return slot_src(tcn, j); };
+        tile_sources(tcn, dnxt, unxt);
         f32x4 bias4[4];
         wf_load_bias(p, tc.tn * 64, ni, lh, bias4);
-        // D pieces: unit R = 0 issues chunk c + 1 (the tile's last one when c = nchunks - 2), R = 2, 3 issue chunk c + 2 (the last one when
-        // c = nchunks - 3); behind the last chunk the pointers jump to the next tile.  The weight stream (unext) runs three points ahead.
+        // U(g + 1) of unit g = 4 c + R, continuing into the next tile.  D pieces: unit R = 0 issues chunk c + 1 (the tile's last one when
+        // c = nchunks - 2), R = 2, 3 issue chunk c + 2 (the last one when c = nchunks - 3); behind the last chunk the pointers jump to the next tile
+#define X6_US(c, R) ((4 * (c) + (R) + 1 < 4 * nchunks) ? ucur + (size_t)(4 * (c) + (R) + 1) * ustep : unxt)
 #define X6_UNIT(R, DP, FIRST, c) \
-        x6_unit<R, DP, FIRST>(acc, S0, S1, fr, ring, sp, a_base, d_base, v_base, unext, unxt, upoints, pstep, uoff, dptr, next_src, \
-                              (R) == 0 ? (c) == nchunks - 2 : (c) == nchunks - 3, lds_w)
+        x6_unit<R, DP, FIRST>(acc, S0, S1, fr, sp, a_base, b_base, d_base, v_base, X6_US(c, R), uoff, dptr, dnxt, \
+                              (R) == 0 ? (c) == nchunks - 2 : (c) == nchunks - 3, lds_w, tl)
         X6_UNIT(0, 0, true, 0); X6_UNIT(1, 0, true, 0); X6_UNIT(2, 0, true, 0); X6_UNIT(3, 0, true, 0);
         X6_UNIT(0, 1, false, 1); X6_UNIT(1, 1, false, 1); X6_UNIT(2, 1, false, 1); X6_UNIT(3, 1, false, 1);
         for (int c = 2; c < nchunks; c += 2) {
@@ -371,16 +356,22 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
             X6_UNIT(0, 1, false, c + 1); X6_UNIT(1, 1, false, c + 1); X6_UNIT(2, 1, false, c + 1); X6_UNIT(3, 1, false, c + 1);
         }
 #undef X6_UNIT
-        upoints = NP - 3;                                                      // (the next tile's first three points are on their way)
+#undef X6_US
         asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_FRAG(fr[0]));           // the next unit's first operands have landed before anything below may move them
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMAs are invisible to the compiler's hazard recogniser
         f32x4 rv[4][4];
         if (STATS == 2) wf_load_r(p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, rv);
         wf_epilogue<STATS>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, bias4, s1, s2, rv);
-        tc = tcn;
+        ucur = unxt; tc = tcn;
+#if (UNET_X6_ABLATE & 8)
+        { long long e1; X6_STAMP(e1); tl[5] += e1 - e0; }
+#endif
     }
-    // retire the prefetches of the tile that never runs (LDS reads into fr[0], weight loads, DMAs) before the wave ends
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : X6_TIE_FRAG(fr[0]), X6_TIE_U(ring, 0), X6_TIE_U(ring, 1), X6_TIE_U(ring, 2) :: "memory");
+#if (UNET_X6_ABLATE & 8)
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 6; ++i) g_x6_timeline[i] = tl[i];
+#endif
+    // retire the prefetches of the tile that never runs (LDS reads into fr[0], DMAs) before the wave ends
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : X6_TIE_FRAG(fr[0]) :: "memory");
     if (STATS) wf_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), mi, ni, li, lh, s1, s2);
 }
 __global__ __launch_bounds__(256, 1) void wino_x6_stream_kernel(X6Args q, int ntiles) { x6_stream_body<0>(q, ntiles); }
@@ -537,6 +528,9 @@ int run_wino_x6(const float* x, int ldx, const uint16_t* U6, const float* bias, 
 
 }  // namespace
 
+#if (UNET_X6_ABLATE & 8)
+extern "C" int unet_debug_x6_timeline(long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x6_timeline), 64); }
+#endif
 
 // 1 when the BF16x6 kernels take the layer: H, W even, reduce channels K a multiple of 32 (>= 64), output channels a multiple of 64.
 extern "C" int unet_winograd_x6_supported(int N, int H, int W, int K, int Nout) { return x6_shape_ok(N, H, W, K, Nout) ? 1 : 0; }

@@ -117,6 +117,7 @@ class Engine:
         self._eval_coefs = set()                # (layer, destination) pairs whose eval-mode scale / shift are current
         self.view = {}
         self._fused_U, self._fused_dirty = None, True
+        self._x6_U, self._x6_dirty = None, True
         self._bf16_W, self._bf16_dirty = {}, True
         self.bnbwd_part = {}
         self.init_parameters(seed)
@@ -236,9 +237,32 @@ class Engine:
             self._fused_dirty = False
         return self._fused_U[name]
 
+    def _x6_kernels(self, name):
+        """(U6 forward, U6 data gradient): the layer's Winograd-transformed kernel as three bf16 pieces per value (csrc/winograd_x6.hip), every
+        layer and direction of the BF16x6 route in one batched launch after a parameter change."""
+        if self._x6_U is None:
+            self._x6_U, rows, blk = {}, [], 0
+            for n, kind, cin, cout in self.layers:
+                if kind != "conv3" or cin % 16 or cout % 16:
+                    continue
+                nb = self.L.unet_winograd_x6_weight_bytes(cin, cout)
+                u = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
+                self._x6_U[n] = u
+                for mode in (0, 1):
+                    rows.append([self.p[n + "/kernel"].data_ptr(), u[mode].data_ptr(), cin | (cout << 32), blk, mode, 0])
+                    blk += (cin * cout + 2047) // 2048
+            self._x6_jobs = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+            self._x6_blocks = blk
+            self._x6_dirty = True
+        if self._x6_dirty:
+            self.L.unet_winograd_weight_transform_x6_batch(_p(self._x6_jobs), self._x6_jobs.shape[0], self._x6_blocks, self._stream())
+            self._x6_dirty = False
+        return self._x6_U[name]
+
     def parameters_changed(self):
         """theta was written from outside (broadcast, checkpoint): every cached transform of the kernels is stale."""
         self._fused_dirty = True
+        self._x6_dirty = True
         self._bf16_dirty = True
         self._eval_folded.clear(); self._eval_coefs.clear()
 
@@ -285,8 +309,11 @@ class Engine:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def _fold_buffers(self, name):
+    def _fold_buffers(self, name, x6=False):
         cin, cout = self.cin[name], self.cout[name]
+        if x6:
+            return (self._buf("U6fold_" + name, (self.L.unet_winograd_x6_weight_bytes(cin, cout),), torch.uint8),
+                    self._buf("bfold_" + name, (cout,)), self._buf("pad_" + name, (cin + 8,)))
         return (self._buf("Ufold_" + name, (16 * cin * cout,)), self._buf("bfold_" + name, (cout,)), self._buf("pad_" + name, (cin + 8,)))
 
     def _block_fwd(self, name, x, y_out, training, pool=None, in_view=None, r_out=None, stat_out=None):
@@ -339,23 +366,28 @@ class Engine:
         elif lp.fwd == "winograd":
             rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
             stat_part = part(rows)
+            x6 = lp.fwd_x6
             if in_view is not None:
                 # BatchNorm-apply on load: scaled weight transform, folded bias, per-channel padding value (this step's coefficients)
-                uc, bias_eff, pad = self._fold_buffers(name)
+                uc, bias_eff, pad = self._fold_buffers(name, x6)
                 if training or name not in self._eval_folded:
                     # (inference: the coefficients come from the moving statistics -- constants until the parameters change -- so
                     # the fold of one forward serves every later tile)
-                    nbf = L.unet_winograd_weight_fold_workspace(cin, cout)
-                    L.unet_winograd_weight_fold(_p(w_), _p(b_), _p(in_view[0]), _p(in_view[1]), _p(uc), _p(bias_eff), _p(pad), cin, cout,
-                                                _p(self._workspace(nbf)), nbf, st)
+                    if x6:
+                        L.unet_winograd_weight_fold_x6(_p(w_), _p(b_), _p(in_view[0]), _p(in_view[1]), _p(uc), _p(bias_eff), _p(pad), cin, cout, st)
+                    else:
+                        nbf = L.unet_winograd_weight_fold_workspace(cin, cout)
+                        L.unet_winograd_weight_fold(_p(w_), _p(b_), _p(in_view[0]), _p(in_view[1]), _p(uc), _p(bias_eff), _p(pad), cin, cout,
+                                                    _p(self._workspace(nbf)), nbf, st)
                     if training:
                         self._eval_folded.discard(name)
                     else:
                         self._eval_folded.add(name)
             else:
-                uc, bias_eff, pad = self._fused_kernels(name)[0], b_, None
+                uc, bias_eff, pad = (self._x6_kernels(name)[0] if x6 else self._fused_kernels(name)[0]), b_, None
             # (with stat_part the conv kernel also leaves the BatchNorm sums of its output: one activation read less per layer)
-            self._timed("conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_winograd_fused,
+            self._timed("conv3x3_fwd_winograd_x6" if x6 else "conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout,
+                        L.unet_conv3x3_fwd_winograd_x6 if x6 else L.unet_conv3x3_fwd_winograd_fused,
                         _p(x), _ld(x), _p(pad), _p(uc), _p(bias_eff), _p(r), _ld(r), n, h, w, cin, cout, 1,
                         _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
             fused_stats = (stat_part, rows) if rows > 0 else None
@@ -659,6 +691,10 @@ class Engine:
                 self._timed("conv3x3_dgrad_bf16", fl, L.unet_conv3x3_dgrad_bf16,
                             _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx16), n, ho, wo, cin, cout,
                             _p(r_prev), ldr_prev, r16_prev, c0, c1, _p(part), nbp, st)
+            elif lp.dgrad == "winograd" and lp.dgrad_x6:
+                self._timed("conv3x3_dgrad_winograd_x6", fl, L.unet_conv3x3_dgrad_winograd_x6,
+                            _p(dz), cout, _p(self._x6_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
+                            _p(r_prev), ldr_prev, c0, c1, _p(part), nbp, st)
             elif lp.dgrad == "winograd":
                 self._timed("conv3x3_dgrad_winograd_fused", fl, L.unet_conv3x3_dgrad_winograd_fused,
                             _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
@@ -722,6 +758,7 @@ class Engine:
         """Keras Adam on the flat buffers (reference UNet/model.py:79,223)."""
         self.iterations += 1
         self._fused_dirty = True
+        self._x6_dirty = True
         self._bf16_dirty = True
         self._eval_folded.clear(); self._eval_coefs.clear()
         t = self.iterations

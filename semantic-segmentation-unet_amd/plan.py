@@ -28,6 +28,9 @@ class EngineOptions:
     variables ONCE at construction -- the C library itself reads no environment)."""
     compute_dtype: str = "fp32"       # "fp32": the reference's arithmetic | "bf16": BASELINE config 4 (bf16 contractions, fp32 master weights)
     conv_route: str = "fused"         # 3x3 forward / data gradient: "fused" = fused Winograd F(2x2,3x3) where it applies | "direct" = implicit GEMM
+    fp32_matrix: str = "bf16x6"       # how the fused Winograd forward / data gradient multiply in fp32 mode: "bf16x6" = fp32 operands as three bf16
+    #                                   pieces, six products on the bf16 matrix pipe, fp32 accumulation (fp32-grade; csrc/winograd_x6.hip) where
+    #                                   the shape allows | "native" = v_mfma_f32_32x32x2_f32 everywhere (csrc/winograd.hip)
     wgrad_route: str = "fused"        # 3x3 weight gradient: "fused" Winograd | "direct"
     bn_on_load: bool = True           # fp32 fused route: BatchNorm-apply folded into the consumer's weights (13 layers)
     fuse_bn_stats: bool = True        # BatchNorm sums from conv / data-gradient epilogues instead of reduction passes
@@ -45,6 +48,7 @@ class EngineOptions:
         o.compute_dtype = env.get("UNET_COMPUTE_DTYPE", o.compute_dtype)
         o.conv_route = env.get("UNET_CONV_ROUTE", o.conv_route)
         o.wgrad_route = env.get("UNET_WGRAD_ROUTE", o.wgrad_route)
+        o.fp32_matrix = env.get("UNET_FP32_MATRIX", o.fp32_matrix)
         for name, var in (("bn_on_load", "UNET_BN_ON_LOAD"), ("fuse_bn_stats", "UNET_FUSE_BN_STATS"), ("fuse_pool", "UNET_FUSE_POOL"),
                           ("bf16_storage", "UNET_BF16_STORAGE"), ("bf16_activations", "UNET_BF16_ACTIVATIONS"),
                           ("overlap_wgrad", "UNET_OVERLAP_WGRAD")):
@@ -54,6 +58,8 @@ class EngineOptions:
             o.wgrad_workgroups = int(env["UNET_WGRAD_CUS"])
         if o.compute_dtype not in ("fp32", "bf16"):
             raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
+        if o.fp32_matrix not in ("bf16x6", "native"):
+            raise ValueError("fp32_matrix must be 'bf16x6' or 'native'")
         return o
 
     def key(self):
@@ -93,6 +99,8 @@ class LayerPlan:
     fwd: str = ""                  # conv3: bf16 | winograd | mfma | direct;  deconv: convt_bf16 | convt_stream | convt_igemm;  conv1: conv1x1
     dgrad: str = ""                # same families; "none" = not computed in a training step (first layer)
     wgrad: str = ""
+    fwd_x6: bool = False           # fwd == "winograd": the BF16x6 kernel (fp32-grade products on the bf16 matrix pipe) instead of the fp32-MFMA one
+    dgrad_x6: bool = False         # the same for the data gradient
     x_on_load: bool = False        # the layer reads its producer's conv output through BatchNorm-apply on load (fp32 Winograd route)
     defer_y: bool = False          # ... and this layer's own BatchNorm output is not materialised (its consumer applies it on load)
     r: str = F32                   # storage of the conv output (post-ReLU, pre-BatchNorm)
@@ -121,7 +129,7 @@ class StepPlan:
         rows = ["plan n=%d h=%d w=%d training=%s want_grad=%s" % (self.n, self.h, self.w, self.training, self.want_grad)]
         for p in self.layer.values():
             rows.append("%-8s %-6s %4d->%-4d @%dx%d  fwd=%-12s dgrad=%-11s wgrad=%-10s r=%s y=%s dz=%s dx=%s%s%s%s%s" % (
-                p.name, p.kind, p.cin, p.cout, p.ho, p.wo, p.fwd, p.dgrad, p.wgrad, p.r, p.y, p.dz, p.dx,
+                p.name, p.kind, p.cin, p.cout, p.ho, p.wo, p.fwd + ("/x6" if p.fwd_x6 else ""), p.dgrad + ("/x6" if p.dgrad_x6 else ""), p.wgrad, p.r, p.y, p.dz, p.dx,
                 " on_load" if p.x_on_load else "", " defer_y" if p.defer_y else "", " fwd_stats" if p.fwd_stats else "",
                 " sums<-" + CONSUMER.get(p.name, "?") if p.sums_from_dgrad else ""))
         rows.append("concat/pool storage: " + " ".join("L%d=%s%s" % (l, d, "(fused)" if self.fuse_pool[l] else "") for l, d in self.cat.items()))
@@ -199,6 +207,9 @@ def build_plan(opt, number_channels, number_classes, n, h, w, training, want_gra
                    and L.unet_conv3x3_bf16_supported(n, p.ho, p.wo, p.cout, p.cin) == 1)
             p.fwd = "bf16" if b16 else "winograd" if wino_ok(p) else "mfma" if L.unet_conv3x3_mfma_supported(p.cin, p.cout) else "direct"
             p.dgrad = "bf16" if b16 else "winograd" if wino_ok(p, True) else "mfma" if L.unet_conv3x3_mfma_supported(p.cout, p.cin) else "direct"
+            if opt.fp32_matrix == "bf16x6":
+                p.fwd_x6 = p.fwd == "winograd" and L.unet_winograd_x6_supported(n, p.ho, p.wo, p.cin, p.cout) == 1
+                p.dgrad_x6 = p.dgrad == "winograd" and L.unet_winograd_x6_supported(n, p.ho, p.wo, p.cout, p.cin) == 1
             if bf and small and L.unet_conv3x3_wgrad_bf16_supported(n, p.ho, p.wo, p.cin, p.cout) == 1:
                 p.wgrad = "bf16"
             elif opt.wgrad_route == "fused" and L.unet_winograd_wgrad_fused_supported(n, p.ho, p.wo, p.cin, p.cout) == 1:

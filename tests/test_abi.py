@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     protos = pkg("_lib").parse_header()
     assert set(protos) == names
     lib_mod = pkg("_lib")
-    assert cdll.unet_hip_abi_version() == lib_mod.header_abi_version() == 3
+    assert cdll.unet_hip_abi_version() == lib_mod.header_abi_version() == 4
     assert cdll.unet_conv3x3_mfma_supported(64, 128) == 1 and cdll.unet_conv3x3_mfma_supported(1, 64) == 0
 
 
@@ -71,6 +71,10 @@ def test_step_plan_states_routes_and_storage_at_any_size():
         pl = plan.build_plan(plan.EngineOptions(), c, k, *shp, True, True, L)
         assert sum(p.defer_y for p in pl.layer.values()) == 13 and sum(p.x_on_load for p in pl.layer.values()) == 13
         assert all(p.fwd == p.dgrad == p.wgrad == "winograd" for n, p in pl.layer.items() if p.kind == "conv3" and n != "conv_1a")
+        # ... and their forward / data-gradient products run on the bf16 matrix pipe at fp32 grade (BF16x6) by default, natively on request
+        assert all(p.fwd_x6 and p.dgrad_x6 for n, p in pl.layer.items() if p.kind == "conv3" and n != "conv_1a") and "winograd/x6" in pl.describe()
+        nat = plan.build_plan(plan.EngineOptions(fp32_matrix="native"), c, k, *shp, True, True, L)
+        assert not any(p.fwd_x6 or p.dgrad_x6 for p in nat.layer.values())
         assert not any(v == plan.BF16 for p in pl.layer.values() for v in (p.r, p.y, p.dz, p.dx))
     # a bf16 operand beyond 2 GiB (1024x1024, batch 4: dec_1a's concat input) falls back to the fp32 kernels for that ONE layer
     big = plan.build_plan(plan.EngineOptions(compute_dtype="bf16"), 3, 6, 4, 1024, 1024, True, True, L)

@@ -1,0 +1,39 @@
+"""Per-kernel error budgets of the fp32 contraction kernels (round 4): every kernel family within 4 x of the error it had against torch's
+fp64 convolution when tests/golden/fp32_kernel_errors.json was made -- bounds of 1e-7 .. 1e-6, two orders tighter than the generic 2e-5 of
+tests/test_gpu_kernels.py -- and the BF16x6 Winograd route (csrc/winograd_x6.hip: fp32 operands as three bf16 pieces, six products on the
+bf16 matrix pipe) no worse than 1.25 x the native fp32-MFMA route on the same inputs, including inputs chosen to hurt it."""
+import json
+import os
+
+import pytest
+import torch
+
+import fp32_error_cases as fc
+
+pytestmark = pytest.mark.gpu
+TABLE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp32_kernel_errors.json")))["cases"]
+
+
+@pytest.mark.parametrize("family,shape,seed", fc.CASES, ids=[fc.case_key(*c) for c in fc.CASES])
+def test_fp32_kernel_error_within_4x_of_the_committed_table(hip, family, shape, seed):
+    mx, rms = fc.run_case(hip, family, shape, seed)
+    want = TABLE[fc.case_key(family, shape, seed)]
+    assert mx <= 4.0 * want["max"] and rms <= 4.0 * want["rms"], (mx, rms, want)
+    assert mx < 5e-6                                   # (and in absolute terms: nothing in the table is above 1.5e-6)
+
+
+X6_SHAPES = [(2, 16, 16, 64, 64), (1, 20, 36, 256, 128), (5, 104, 136, 64, 64), (2, 32, 48, 128, 192), (1, 16, 16, 1024, 64)]
+
+
+@pytest.mark.parametrize("kind", ["normal", "raw16", "mixed", "edges"])
+@pytest.mark.parametrize("shape", X6_SHAPES)
+def test_bf16x6_route_is_as_accurate_as_the_fp32_matrix_instruction(hip, shape, kind):
+    # normal: unit-variance activations;  raw16: un-normalised 16-bit pixel values (|x| up to 6.5e4, all positive: the Winograd transform's
+    # differences cancel five digits);  mixed: eight decades of magnitude inside every 16-channel chunk (one MFMA K);  edges: mantissas on
+    # and next to the boundaries of the three bf16 pieces (0x7fff / 0x8000 / 0x8001 patterns) in activations AND weights.
+    # A three-product emulation (hh + hm + mh) fails this by 6 x in rms (profiles/r03_bf16x6_micro.txt).
+    for fam6, famn in (("x6_fwd", "wino_fwd"), ("x6_dgrad", "wino_dgrad")):
+        m6, r6 = fc.run_case(hip, fam6, shape, 7, kind)
+        mn, rn = fc.run_case(hip, famn, shape, 7, kind)
+        assert r6 <= 1.25 * rn and m6 <= 1.5 * mn, (fam6, kind, (m6, r6), (mn, rn))
+        assert r6 < 2e-6 and torch.isfinite(torch.tensor(m6))
