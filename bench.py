@@ -46,10 +46,17 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything i
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, chip table (dense, spec)
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table: ~2.5 PF dense bf16 (spec)
-TRAFFIC_TAG = "r03"                  # profiles/<tag>_*_pmc_traffic.json of the current round
+TRAFFIC_TAG = "r04"                  # profiles/<tag>_*_pmc_traffic.json of the current round
 WINOGRAD_MULT_RATIO = 2.25           # F(2x2,3x3): 36 direct multiplies per tile and channel pair -> 16
 
-FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16?, offline PMC traffic file)
+X6_PRODUCTS = 6                      # BF16x6: six bf16 piece products per fp32-grade product (hh hm mh hl lh mm)
+ARITHMETIC = {"bf16x6": "fp32 operands as 3 bf16 pieces, 6 products, fp32 accumulate (3x3 forward / data gradient: csrc/winograd_x6.hip; "
+                        "weight gradients, transposed convs and everything else: native fp32)",
+              "native": "fp32 (v_mfma_f32_32x32x2_f32 for every contraction)"}
+
+FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16 matrix pipe?, offline PMC traffic file)
+    "conv3x3_fwd_winograd_x6": ("wino_x6_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3), fp32-grade products as 6 x v_mfma_f32_32x32x16_bf16 on three-piece operands)", True, True, "x6_fwd_pmc_traffic.json"),
+    "conv3x3_dgrad_winograd_x6": ("wino_x6_stream_kernel / _bnbwd (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3), fp32-grade products as 6 x v_mfma_f32_32x32x16_bf16)", True, True, "x6_dgrad_pmc_traffic.json"),
     "conv3x3_fwd_winograd_fused": ("wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "wino_fwd_pmc_traffic.json"),
     "conv3x3_dgrad_winograd_fused": ("wino_fused_stream_kernel / _bnstats (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "wino_dgrad_pmc_traffic.json"),
     "conv3x3_wgrad_winograd_fused": ("wino_wgrad_fused_kernel (3x3 conv weight gradient, Winograd F(2x2,3x3), reduce over tiles on v_mfma_f32_32x32x2_f32)", True, False, "wino_wgrad_pmc_traffic.json"),
@@ -180,13 +187,14 @@ def cpu_baseline_bounded(args, budget_s=420):
 
 
 def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype, steps, warmup, no_overlap, kernel_events,
-                 sample_every, barrier):
+                 sample_every, barrier, fp32_matrix="bf16x6"):
     """W warm-up + K timed optimizer steps of one workload -> dict with dt, per-family kernel figures, final loss."""
     import torch
     G = batch * world
     net = model.UNet(classes, G, channels, learning_rate=3e-4, device=dev, seed=0,
                      compute_dtype={"f32": "fp32", "bf16": "bf16"}[dtype])
     net.engine.overlap_wgrad = not no_overlap
+    net.engine.opt.fp32_matrix = fp32_matrix
     if world > 1:
         par = importlib.import_module(PKG + ".parallel")
         net.parallel = par.DataParallel(net.engine)
@@ -238,11 +246,16 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
                 continue
             desc, wino, bf16, _ = FAMILY.get(key, (key, False, False, None))
             eff = fl / (ms * 1e-3) / 1e12
-            ex = eff / WINOGRAD_MULT_RATIO if wino else eff
+            x6 = key.endswith("_x6")
+            grade = eff / WINOGRAD_MULT_RATIO if wino else eff           # fp32-grade multiply-adds actually performed (as FLOP/s)
+            ex = grade * X6_PRODUCTS if x6 else grade                    # matrix-pipe FLOP/s executed (BF16x6: six bf16 products each)
             peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
             kernels[key] = {"launches_per_step": len(evs) // sampled, "ms_per_step": round(ms / sampled, 3),
                             "avg_launch_ms": round(ms / len(evs), 4), "effective_tflops": round(eff, 2),
                             "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4), "exclusive": True}
+            if x6:
+                kernels[key]["fp32_grade_tflops"] = round(grade, 2)
+                kernels[key]["fp32_grade_vs_fp32_mfma_peak"] = round(grade / PEAK_FP32_MFMA_TFLOPS, 4)
     del net
     torch.cuda.empty_cache()
     return {"dt": dt, "kernels": kernels, "final_loss": final_loss, "sampled_steps": sampled, "G": G, "buckets": buckets}
@@ -257,12 +270,17 @@ def roofline_of(kernels, workload_key):
     v = cands[key]
     desc, wino, bf16, tfile = FAMILY[key]
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    x6 = key.endswith("_x6")
     r = {"bound": "mfma", "kernel": desc, "family": key, "achieved": v["executed_tflops"], "peak": peak, "unit": "TFLOP/s",
          "frac": v["executed_frac"], "effective": v["effective_tflops"],
-         "flop_accounting": ("executed = algorithmic / 2.25 (Winograd F(2x2,3x3))" if wino else "executed = algorithmic (implicit GEMM)"),
+         "flop_accounting": ("executed = 6 x algorithmic / 2.25 bf16-MFMA FLOP (Winograd F(2x2,3x3), six piece products per fp32-grade product) against the bf16 peak"
+                             if x6 else "executed = algorithmic / 2.25 (Winograd F(2x2,3x3))" if wino else "executed = algorithmic (implicit GEMM)"),
          "launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"], "ms_per_step": v["ms_per_step"],
          "timing": "HIP events on the launch stream, sampled timed steps, single-stream backward (exclusive)",
          "traffic": None, "traffic_source": None}
+    if x6:
+        r["fp32_grade_tflops"] = v["fp32_grade_tflops"]
+        r["fp32_grade_vs_fp32_mfma_peak"] = v["fp32_grade_vs_fp32_mfma_peak"]
     # offline PMC passes of this round (scripts/collect_profiles.sh): config 2 / 4 files and the config-5 ones; the file must be FOR this workload
     for tname in (TRAFFIC_TAG + "_" + tfile, TRAFFIC_TAG + "_config5_" + tfile):
         tf = os.path.join(ROOT, "profiles", tname)
@@ -293,6 +311,9 @@ def main():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="contraction precision of the 3x3 layers; bf16 = BASELINE config 4 (fp32 master weights, fp32 accumulation)")
+    ap.add_argument("--fp32-matrix", choices=["bf16x6", "native"], default="bf16x6",
+                    help="fp32 mode: how the fused Winograd forward / data gradient multiply -- fp32-grade on the bf16 matrix pipe (three-piece "
+                         "operands, six products; default) or the native fp32 matrix instruction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream in every step (A/B switch)")
@@ -332,7 +353,7 @@ def main():
     model = importlib.import_module(PKG + ".model")
     sample_every = max(2, min(args.sample_every, args.steps)) if args.steps > 1 else 1
     res = run_workload(model, dev, world, rank, args.size, args.channels, args.classes, args.batch, args.dtype, args.steps,
-                       args.warmup, args.no_overlap, not args.no_kernel_events, sample_every, barrier)
+                       args.warmup, args.no_overlap, not args.no_kernel_events, sample_every, barrier, args.fp32_matrix)
     dt = res["dt"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -357,15 +378,18 @@ def main():
 
     extras = []
     if world == 1 and not args.no_extra and (args.size, args.channels, args.classes, args.batch, args.dtype) == (512, 1, 2, 8, "f32"):
-        for (size, ch, kc, b, dty, label) in ((512, 3, 4, 8, "bf16", "BASELINE config 4 per-GPU workload"),
-                                              (1024, 3, 6, 2, "f32", "BASELINE config 5 per-GPU workload")):
+        other = "native" if args.fp32_matrix == "bf16x6" else "bf16x6"
+        for (size, ch, kc, b, dty, label, fm) in ((512, 3, 4, 8, "bf16", "BASELINE config 4 per-GPU workload", args.fp32_matrix),
+                                                  (1024, 3, 6, 2, "f32", "BASELINE config 5 per-GPU workload", args.fp32_matrix),
+                                                  (512, 1, 2, 8, "f32", "BASELINE config 2 on the OTHER fp32 route (fp32_matrix = %s)" % other, other)):
             st, wu = 16, 4
             try:
-                r2 = run_workload(model, dev, 1, 0, size, ch, kc, b, dty, st, wu, False, True, 8, barrier)
+                r2 = run_workload(model, dev, 1, 0, size, ch, kc, b, dty, st, wu, False, True, 8, barrier, fm)
                 ips2, s2 = summarize(r2, r2["dt"], size, ch, kc, b, dty, st, wu, 1)
                 s2.pop("kernels")
                 extras.append(dict({"workload": "%s: synthetic %dx%dx%d, %d classes, batch %d, %s" % (label, size, size, ch, kc, b, dty),
-                                    "value": round(ips2, 3), "unit": "images/sec", "steps": st, "warmup": wu, "dtype": dty}, **s2))
+                                    "value": round(ips2, 3), "unit": "images/sec", "steps": st, "warmup": wu, "dtype": dty,
+                                    "arithmetic": ARITHMETIC[fm] if dty == "f32" else "bf16 contractions, fp32 accumulation and master weights"}, **s2))
             except Exception as e:                      # noqa: BLE001 -- never lose the headline line to an extra run
                 extras.append({"workload": label, "error": repr(e)[:300]})
 
@@ -375,6 +399,7 @@ def main():
             "metric": "training images/sec", "value": round(ips, 3), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": s.pop("ms_per_step"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "arithmetic": ARITHMETIC[args.fp32_matrix] if args.dtype == "f32" else "bf16 contractions, fp32 accumulation and master weights",
             "config": {"workload": "U-Net train step (fwd + softmax-CE + bwd + Keras-Adam%s), synthetic %dx%dx%d tiles, "
                                    "%d classes, batch %d per GPU, random-init weights, dropout on"
                                    % (" + RCCL gradient all-reduce" if world > 1 else "", args.size, args.size,

@@ -454,7 +454,8 @@ def test_full_size_config5_step_properties(dtype):
     # BASELINE config 5's per-GPU workload: 1024x1024x3 tiles, 6 classes, batch 2 (the deep-encoder / large-tile regime)
     counts = _full_size_properties(2, 3, 6, 1024, dtype)
     if dtype == "fp32":
-        assert counts.get("conv3x3_fwd_winograd_fused") == 17 and counts.get("conv3x3_dgrad_winograd_fused") == 17 \
+        # (default fp32_matrix = "bf16x6": forward / data gradient on the BF16x6 kernels, weight gradient on the fp32-MFMA Winograd kernel)
+        assert counts.get("conv3x3_fwd_winograd_x6") == 17 and counts.get("conv3x3_dgrad_winograd_x6") == 17 \
             and counts.get("conv3x3_wgrad_winograd_fused") == 17, counts
     else:
         assert counts.get("conv3x3_fwd_bf16") == 17 and counts.get("conv3x3_dgrad_bf16") == 17 \
