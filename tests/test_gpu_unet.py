@@ -466,9 +466,10 @@ def test_bf16_operand_beyond_2gib_falls_back_to_fp32_kernels():
     # the bf16 kernels address their operands with 32-bit buffer offsets (engine._use_bf16): at 1024x1024, batch 4 the concat
     # input of dec_1a is exactly 2 GiB, so that ONE layer must take the fp32 Winograd kernels and the step must stay sound
     counts = _full_size_properties(4, 3, 6, 1024, "bf16", steps=3)
-    assert counts.get("conv3x3_fwd_bf16") == 16 and counts.get("conv3x3_fwd_winograd_fused") == 1, counts
+    # (the fp32 fallback of that layer is the default fp32 route: the BF16x6 Winograd forward / data gradient, the fp32-MFMA weight gradient)
+    assert counts.get("conv3x3_fwd_bf16") == 16 and counts.get("conv3x3_fwd_winograd_x6") == 1, counts
     assert counts.get("conv3x3_wgrad_bf16", 0) + counts.get("conv3x3_wgrad_winograd_fused", 0) == 17, counts
-    assert counts.get("conv3x3_dgrad_bf16", 0) + counts.get("conv3x3_dgrad_winograd_fused", 0) == 17, counts
+    assert counts.get("conv3x3_dgrad_bf16", 0) + counts.get("conv3x3_dgrad_winograd_x6", 0) == 17, counts
 
 
 @pytest.mark.parametrize("cfg", [(2, 1, 2, 32, "fp32"), (2, 3, 4, 64, "fp32"), (1, 1, 2, 128, "fp32"),
