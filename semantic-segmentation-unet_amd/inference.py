@@ -41,13 +41,16 @@ def _predict(unet, tile_hwc):
     return e.argmax(e.forward(x, training=False))[0].cpu().numpy()
 
 
-def _inference(img, unet):
+def _inference(img, unet, predict=_predict):
+    """(`predict(unet, tile_hwc) -> int32 [H, W]`: the forward + argmax of one tile; the default runs the HIP engine.  The hook exists so that
+    tests/test_inference_golden.py can drive this function's pad / crop index work with the same stand-in network as the fixtures made
+    by the reference's own UNet/inference.py:139-173.)"""
     img, pad_y, pad_x = _pad_to_factor(img)
-    mask = _predict(unet, img)
+    mask = predict(unet, img)
     return mask[:mask.shape[0] - pad_y, :mask.shape[1] - pad_x]
 
 
-def _inference_tiling(img, unet, tile_size):
+def _inference_tiling(img, unet, tile_size, predict=_predict):
     img, pad_y, pad_x = _pad_to_factor(img)
     height, width = img.shape[:2]
     mask = np.zeros((height, width), dtype=np.int32)
@@ -64,7 +67,7 @@ def _inference_tiling(img, unet, tile_size):
             tx0 = x0 - radius if x0 - radius >= 0 else 0
             ty1 = y0 + zone + radius if y0 + zone + radius <= height else height
             tx1 = x0 + zone + radius if x0 + zone + radius <= width else width
-            pred = _predict(unet, img[ty0:ty1, tx0:tx1])
+            pred = predict(unet, img[ty0:ty1, tx0:tx1])
             oy, ox = y0 - ty0, x0 - tx0
             mask[y0:y1, x0:x1] = pred[oy:oy + (y1 - y0), ox:ox + (x1 - x0)]
     return mask[:height - pad_y, :width - pad_x]
