@@ -8,6 +8,7 @@
 #   gpurun_out/<tag>_overlap_standin.txt                           stand-in collective under the backward pass (scripts/overlap_probe.py)
 # Only --kernel-trace / --stats / --pmc are used (never combined with other trace domains); python3 itself follows `--`.
 set -e
+set -o pipefail
 tag=$1; root=$(pwd); out=$root/gpurun_out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 BF="--dtype bf16 --channels 3 --classes 4"

@@ -634,7 +634,7 @@ class Engine:
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
                             n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif lp.wgrad == "winograd":
-                cap = int(self.opt.wgrad_workgroups)
+                cap = int(self.opt.wgrad_workgroups or 0)
                 nb2 = L.unet_conv3x3_wgrad_winograd_fused_workspace(n, ho, wo, cin, cout, cap)
                 self._timed("conv3x3_wgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_winograd_fused,
                             _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)

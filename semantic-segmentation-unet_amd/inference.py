@@ -136,7 +136,7 @@ def _write(path, mask, image_format="tif"):
         try:
             import tifffile                           # what scikit-image's imsave delegates to
             tifffile.imwrite(path, mask, bigtiff=True, tile=(TILE_SIZE, TILE_SIZE), compression="zlib", compressionargs={"level": 6})
-        except ImportError:
+        except (ImportError, TypeError, ValueError):  # no tifffile, or one without the compression / compressionargs keywords: the writer below
             _write_bigtiff_tiled(path, mask, TILE_SIZE, 6)
         return
     from PIL import Image                             # UNet/inference.py:224-227 (compress where the format has it)

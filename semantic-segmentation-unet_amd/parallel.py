@@ -54,14 +54,14 @@ class DataParallel:
         # broadcast from rank 0 anyway
         if hasattr(engine, "dropout_seed"):
             engine.dropout_seed = engine.dropout_seed * self.world_size + self.rank
-        # Overlap-ready by construction: the fused Winograd weight gradient is a persistent grid of 512-register workgroups, one per CU.  A
-        # bucket's all-reduce is released right behind its last weight gradient, into a natural gap of the side stream, so its kernels START
-        # at once (tests/test_gpu_overlap.py measures 0.02-0.35 ms release-to-completion for a stand-in kernel, capped or not); but they then
-        # hold their CUs for the 0.2-1.4 ms a 25 MB bucket takes over xGMI, and a 256-workgroup weight gradient launched meanwhile would run
-        # its last workgroups as a second wave.  With more than one replica the grid is therefore capped at OVERLAP_WORKGROUPS (~4 CUs per XCD
-        # stay free; +12 % on the kernel alone, 0.3 ms gained in the single-GPU step).  (No N > 1 hardware run has confirmed it for RCCL.)
-        if (self.world_size > 1 or force) and hasattr(engine, "opt") and not engine.opt.wgrad_workgroups:
-            engine.opt.wgrad_workgroups = self.OVERLAP_WORKGROUPS
+        # The fused Winograd weight gradient is a persistent grid of 512-register workgroups, one per CU; a collective's kernels that are resident
+        # when it launches push its last workgroups into a second wave.  `EngineOptions.wgrad_workgroups` caps that grid: None (default) =
+        # "auto" -- capped at OVERLAP_WORKGROUPS when there is more than one replica, one workgroup per CU otherwise; 0 = never capped; n = n.
+        # The cap costs the kernel 12 % when timed alone and no N > 1 RCCL run has measured what it buys (tests/test_gpu_overlap.py uses a
+        # stand-in collective), so an explicit 0 is honoured.  The engine's options object may be shared: it is replaced by a copy, never mutated.
+        if hasattr(engine, "opt") and engine.opt.wgrad_workgroups is None and (self.world_size > 1 or force):
+            import dataclasses
+            engine.opt = dataclasses.replace(engine.opt, wgrad_workgroups=self.OVERLAP_WORKGROUPS)
         if broadcast and (self.world_size > 1 or force):
             self.broadcast_state()
 

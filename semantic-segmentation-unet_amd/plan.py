@@ -38,8 +38,9 @@ class EngineOptions:
     bf16_storage: bool = True         # stage 2 (see module docstring)
     bf16_activations: bool = True     # stage 3
     overlap_wgrad: bool = True        # weight gradients on a side stream
-    wgrad_workgroups: int = 0         # cap on the fused Winograd weight gradient's persistent grid (0 = one workgroup per CU); data-parallel
-    #                                   runs leave a few CUs per XCD to the collective's kernels (parallel.DataParallel sets 224)
+    wgrad_workgroups: Optional[int] = None   # cap on the fused Winograd weight gradient's persistent grid: None = auto (one workgroup per CU on one
+    #                                   GPU; parallel.DataParallel caps it at 224 when there is more than one replica, leaving a few CUs per
+    #                                   XCD to the collective's kernels), 0 = never capped, n = at most n workgroups
 
     @staticmethod
     def from_env(env=None):

@@ -165,7 +165,7 @@ class SampleGeneratorReader(_Base):
     def __init__(self, reader):
         import threading
         self.reader = reader
-        self.balance_classes = True             # whatever the wrapped reader was built with is what happens
+        self.balance_classes = bool(getattr(reader, "balance_classes", False))    # what the wrapped reader was built with (UNet/imagereader.py:89-103)
         self._lock = threading.Lock()
         self._gen = None
 
@@ -203,7 +203,15 @@ class SampleGeneratorReader(_Base):
                     if lab.dtype != np.int32 or lab.ndim != 3 or lab.shape[:2] != (h, w):
                         raise IOError("reader sample: expected an int32 one-hot label [H,W,K], got {} {}".format(lab.dtype, lab.shape))
                     imgs.append(img)
-                    labs.append(lab.argmax(-1).astype(np.uint8) if classmap else lab)
+                    if classmap:
+                        # the class map is the argmax of an EXACT one-hot: an all-zero or multi-hot pixel would silently become class 0 / the
+                        # first of the set classes, and more than 256 classes do not fit the uint8 map
+                        if lab.shape[2] > 256:
+                            raise ValueError("the uint8 class-map hand-over holds at most 256 classes ({} given)".format(lab.shape[2]))
+                        if lab.min() < 0 or lab.max() > 1 or not (lab.sum(-1) == 1).all():
+                            raise ValueError("reader sample: the label is not an exact one-hot (every pixel needs exactly one class set)")
+                        lab = lab.argmax(-1).astype(np.uint8)
+                    labs.append(lab)
             except StopIteration:
                 if not imgs:
                     return

@@ -27,7 +27,6 @@ import struct
 
 import numpy as np
 
-from . import _lib
 
 HEADER_KEY = b""
 OBJECT_GRAPH_KEY = b"_CHECKPOINTABLE_OBJECT_GRAPH"
@@ -87,12 +86,26 @@ def _crc32c_numpy(buf, init=0):
     return (~crc) & 0xFFFFFFFF
 
 
+_NATIVE = [False, None]          # [resolved?, function or None]
+
+
 def _native():
-    """the native CRC routine, or None where the HIP library cannot be loaded (no GPU toolchain / stale build)"""
-    try:
-        return _lib.lib().unet_crc32c_extend
-    except Exception:                                     # noqa: BLE001 -- any load failure means "use the fallback"
-        return None
+    """the native CRC routine, or None where the HIP library is not there (no build): resolved ONCE.  A library that is there but stale or of
+    another ABI version is an error (UnetHipError propagates) -- falling back silently would hide it behind a CRC that takes half a minute
+    per shard."""
+    if not _NATIVE[0]:
+        fn = None
+        try:
+            from . import _lib                         # (lazy: importing it pulls in torch; this module otherwise needs numpy only)
+            if os.path.exists(_lib.LIB_PATH):
+                fn = _lib.lib().unet_crc32c_extend      # UnetHipError (stale build / ABI mismatch) is NOT caught
+        except (ImportError, OSError):
+            fn = None
+        if fn is None:
+            import warnings
+            warnings.warn("libunet_hip.so is not available: checkpoint CRC-32C falls back to the numpy routine (slow on 100 MB shards)")
+        _NATIVE[0], _NATIVE[1] = True, fn
+    return _NATIVE[1]
 
 
 def crc32c(data, init=0):

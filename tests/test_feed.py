@@ -164,6 +164,21 @@ def test_reference_style_sample_reader_batches_like_dataset_batch():
     bad = readers.from_sample_generator(Bad(4, 16, 16, 1, 2)); bad.startup()
     with pytest.raises(IOError):
         next(bad.batches(2, pin=False))
+    # the uint8 class-map hand-over is the argmax of an EXACT one-hot: an all-zero or multi-hot pixel is refused (it would otherwise become
+    # class 0 without anybody noticing); the same sample passes on the one-hot path
+    class NotOneHot(FakeReferenceReader):
+        def sample(self, i):
+            img, lab = super().sample(i)
+            lab[3, 5, :] = 0
+            return img, lab
+    noh = readers.from_sample_generator(NotOneHot(4, 16, 16, 1, 3)); noh.startup()
+    with pytest.raises(ValueError):
+        next(noh.batches(2, classmap=True, pin=False))
+    ok = readers.from_sample_generator(NotOneHot(4, 16, 16, 1, 3)); ok.startup()
+    assert tuple(next(ok.batches(2, pin=False))[1].shape) == (2, 16, 16, 3)
+    # the adapter reports the wrapped reader's own class-balancing setting (UNet/imagereader.py:89-103), not a constant
+    plain = FakeReferenceReader(4, 16, 16, 1, 2); assert readers.from_sample_generator(plain).balance_classes is False
+    plain.balance_classes = True; assert readers.from_sample_generator(plain).balance_classes is True
 
 
 @pytest.mark.gpu

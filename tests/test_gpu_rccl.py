@@ -31,7 +31,7 @@ for cd in ("bf16", "fp32"):                                 # the mixed-precisio
     b.parallel = par.DataParallel(b.engine, bucket_bytes=8 << 20, force=True)
     # DataParallel caps the fused Winograd weight gradient's grid so that a collective's kernels find CUs (parallel.py); the cap changes
     # the split count, i.e. the order partial sums are added in -- the single-process twin gets the same cap for the bit-for-bit comparison
-    assert b.engine.opt.wgrad_workgroups == par.DataParallel.OVERLAP_WORKGROUPS
+    assert a.engine.opt.wgrad_workgroups is None and b.engine.opt.wgrad_workgroups == par.DataParallel.OVERLAP_WORKGROUPS      # auto: capped with > 1 replica
     a.engine.opt.wgrad_workgroups = b.engine.opt.wgrad_workgroups
     assert len(b.parallel.buckets) >= 5
     for _ in range(2):
