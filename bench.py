@@ -187,7 +187,7 @@ def cpu_baseline_bounded(args, budget_s=420):
 
 
 def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype, steps, warmup, no_overlap, kernel_events,
-                 sample_every, barrier, fp32_matrix="bf16x6"):
+                 sample_every, barrier, fp32_matrix="bf16x6", max_workgroups=None):
     """W warm-up + K timed optimizer steps of one workload -> dict with dt, per-family kernel figures, final loss."""
     import torch
     G = batch * world
@@ -195,6 +195,7 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
                      compute_dtype={"f32": "fp32", "bf16": "bf16"}[dtype])
     net.engine.overlap_wgrad = not no_overlap
     net.engine.opt.fp32_matrix = fp32_matrix
+    net.engine.opt.max_workgroups = max_workgroups
     if world > 1:
         par = importlib.import_module(PKG + ".parallel")
         net.parallel = par.DataParallel(net.engine)
@@ -216,7 +217,7 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
                    "issued_ms": [round(t0e.elapsed_time(ev), 3) for _, ev in net.parallel.trace],
                    "passed_ms": [round(t0e.elapsed_time(ev), 3) for _, ev in net.parallel.done_trace],
                    "step_ms": round(t0e.elapsed_time(t1e), 3),
-                   "wgrad_workgroups": net.engine.opt.wgrad_workgroups}
+                   "max_workgroups": net.engine.opt.max_workgroups}
         net.parallel.trace = net.parallel.done_trace = None
     prof = {} if kernel_events else None
     sampled = 0
@@ -314,6 +315,9 @@ def main():
     ap.add_argument("--fp32-matrix", choices=["bf16x6", "native"], default="bf16x6",
                     help="fp32 mode: how the fused Winograd forward / data gradient multiply -- fp32-grade on the bf16 matrix pipe (three-piece "
                          "operands, six products; default) or the native fp32 matrix instruction")
+    ap.add_argument("--max-workgroups", type=int, default=None,
+                    help="cap on every persistent kernel's grid (e.g. 224 leaves ~4 CUs per XCD to RCCL's kernels; default: one workgroup per CU -- "
+                         "profiles/r04_overlap_standin.txt is why)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream in every step (A/B switch)")
@@ -353,7 +357,7 @@ def main():
     model = importlib.import_module(PKG + ".model")
     sample_every = max(2, min(args.sample_every, args.steps)) if args.steps > 1 else 1
     res = run_workload(model, dev, world, rank, args.size, args.channels, args.classes, args.batch, args.dtype, args.steps,
-                       args.warmup, args.no_overlap, not args.no_kernel_events, sample_every, barrier, args.fp32_matrix)
+                       args.warmup, args.no_overlap, not args.no_kernel_events, sample_every, barrier, args.fp32_matrix, args.max_workgroups)
     dt = res["dt"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

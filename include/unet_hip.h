@@ -28,8 +28,8 @@ extern "C" {
 #define UNET_ENOSPC (-2)
 
 /* Bumped whenever an exported signature changes; a loader must refuse a library whose unet_hip_abi_version() differs
- * (4: round 4 -- the BF16x6 Winograd route: unet_*_x6; 3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
-#define UNET_HIP_ABI_VERSION 4
+ * (5: round 4 -- the `_wg` (max_workgroups) entry points of every persistent kernel, unet_standin_collective; 4: round 4 -- the BF16x6 Winograd route: unet_*_x6; 3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
+#define UNET_HIP_ABI_VERSION 5
 int unet_hip_abi_version(void);
 
 /* ---- Conv2D(3x3, 'same', relu) of UNet._conv_layer, UNet/model.py:28-35 (18 instances, :88-134) ------------------ */
@@ -307,6 +307,56 @@ int unet_zscore_nhwc_to_nchw(const float* img, float* out, int N, int H, int W, 
  * so the feed ships 1 byte per pixel instead of 4K; *out_of_range (may be NULL, else zeroed by the caller) counts labels >= K,
  * the condition the reference raises IndexError for */
 int unet_labels_onehot(const uint8_t* classmap, int* onehot, long P, int K, unsigned* out_of_range, void* stream);
+
+/* ---- workgroup-capped forms of every kernel whose grid is sized by the CU count ------------------------------------------------------
+ * The reference's data-parallel step (tf.distribute.MirroredStrategy, UNet/train.py:57-61; the gradient all-reduce inside
+ * apply_gradients, UNet/model.py:223) overlaps a collective with the backward pass.  RCCL's kernels need CUs of their own; a persistent
+ * grid of one workgroup per CU leaves none until a workgroup has drained its share of the tiles.  Each function below is the function
+ * of the same name without `_wg` plus max_workgroups (0, or out of [32, CUs): one workgroup per CU -- what the plain name passes); the
+ * `_stats_rows_wg` / `_workspace_wg` query must be given the same value as the launch.  Kernels launched as one workgroup per TILE
+ * (first / last layer, BatchNorm passes, max pool, the bf16 transposed-conv forward / data gradient, Adam) are not listed: their
+ * workgroups retire within microseconds and the hardware scheduler hands the freed CUs to whichever queue is waiting.
+ * (unet_conv3x3_wgrad_winograd_fused has carried the argument since ABI 2.) */
+int unet_conv3x3_fwd_winograd_fused_stats_rows_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
+int unet_conv3x3_fwd_winograd_fused_wg(const float* x, int ldx, const float* pad, const float* Uc, const float* bias, float* out, int ldo,
+                                       int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes,
+                                       int max_workgroups, void* stream);
+int unet_conv3x3_dgrad_winograd_fused_wg(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
+                                         int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+                                         float* stat_part, size_t stat_bytes, int max_workgroups, void* stream);
+int unet_conv3x3_fwd_winograd_x6_wg(const float* x, int ldx, const float* pad, const void* U6, const float* bias, float* out, int ldo,
+                                    int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes,
+                                    int max_workgroups, void* stream);
+int unet_conv3x3_dgrad_winograd_x6_wg(const float* dz, int lddz, const void* U6d, float* dx, int lddx,
+                                      int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+                                      float* stat_part, size_t stat_bytes, int max_workgroups, void* stream);
+size_t unet_conv3x3_wgrad_mfma_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
+int unet_conv3x3_wgrad_mfma_wg(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                               int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream);
+int unet_conv3x3_fwd_bf16_wg(const void* x, int ldx, int x_bf16, const float* in_scale, const float* in_shift, const void* wp,
+                             const float* bias, void* out, int ldo, int out_bf16,
+                             int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes,
+                             int max_workgroups, void* stream);
+int unet_conv3x3_dgrad_bf16_wg(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
+                               int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16, int c0, int c1,
+                               float* stat_part, size_t stat_bytes, int max_workgroups, void* stream);
+size_t unet_conv3x3_wgrad_bf16_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
+int unet_conv3x3_wgrad_bf16_wg(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                               int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream);
+/* (stat_part nullable: the one function covers unet_convT2x2_fwd_stream and unet_convT2x2_fwd_stream_stats) */
+int unet_convT2x2_fwd_stream_stats_rows_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
+int unet_convT2x2_fwd_stream_wg(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, int max_workgroups, void* stream);
+size_t unet_convT2x2_wgrad_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
+int unet_convT2x2_wgrad_wg(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                           int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream);
+size_t unet_convT2x2_wgrad_bf16_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
+int unet_convT2x2_wgrad_bf16_wg(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                                int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream);
+/* Measurement aid for the above (tests/test_gpu_overlap.py, scripts/overlap_probe.py): a kernel that behaves like a collective's --
+ * `workgroups` workgroups of 512 threads, each holding lds_bytes of LDS (<= 65536) and its CU slot for `microseconds` after it STARTS
+ * (every wave leaves when the constant-rate wall clock passes its deadline; nothing else is read or written).  Not called by the engine. */
+int unet_standin_collective(int workgroups, int lds_bytes, int microseconds, void* stream);
 
 /* ---- host-side helper of the checkpoint format (tf.train.Checkpoint = TensorBundle, UNet/train.py:96,184; UNet/model.py:81-83):
  * CRC-32C as TensorFlow's crc32c::Extend(init, data, n) -- the block trailers of `ckpt.index` and the per-tensor checksums of

@@ -70,7 +70,7 @@ class _Lib:
             fn = getattr(self.cdll, name)          # AttributeError = header/library mismatch: fail loudly
             fn.restype = res
             fn.argtypes = args
-            if res is ctypes.c_int and name != "unet_hip_abi_version" and not name.endswith(("_supported", "_rows")):   # predicates / counts
+            if res is ctypes.c_int and name != "unet_hip_abi_version" and not name.endswith(("_supported", "_rows", "_rows_wg")):   # predicates / counts
                 setattr(self, name, self._checked(name, fn))
             else:
                 setattr(self, name, fn)

@@ -706,7 +706,7 @@ struct ConvBf16Stats { int mode; float* part; size_t bytes; const float* r; int 
 
 int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, float* out, int ldo,
                   int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st, const ConvBf16Stats* stats = nullptr, int in16 = 0,
-                  int out16 = 0, const float* in_scale = nullptr, const float* in_shift = nullptr) {
+                  int out16 = 0, const float* in_scale = nullptr, const float* in_shift = nullptr, int max_workgroups = 0) {
     ConvBf16Args a{};
     a.in_scale = in_scale; a.in_shift = in_shift;
     a.in16 = in16; a.out16 = out16; a.r16 = stats ? stats->r16 : 0;
@@ -730,7 +730,7 @@ int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, fl
     const dim3 grid((unsigned)(a.n_px * a.n_co));
     if (in16 && out16 && (mode != 2 || a.r16) && !in_scale && Cin <= 4096) {
         // persistent form: one resident wave of workgroups walks the tiles (the grid is the whole tile count when that is smaller)
-        const long slots = (long)conv_bf16_cus() * (wide ? 1 : 2);
+        const long slots = (long)unet_grid_slots(conv_bf16_cus(), max_workgroups) * (wide ? 1 : 2);
         const dim3 pgrid((unsigned)((long)grid.x < slots ? (long)grid.x : slots));
         if (mode == 0) { if (wide) conv_bf16_stream_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_kernel_64<<<pgrid, 256, 0, st>>>(a); }
         else if (mode == 1) { if (wide) conv_bf16_stream_stats_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_stats_kernel_64<<<pgrid, 256, 0, st>>>(a); }
@@ -1152,12 +1152,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
     }
 }
 
-void wgrad_bf16_plan(WgBf16Args& a) {
+void wgrad_bf16_plan(WgBf16Args& a, int max_workgroups) {
     a.n_ci = a.Cin / 64; a.n_co = a.Cout / 64;
     const int npairs = a.n_ci * a.n_co;
     a.tbx = (a.W + 31) / 32;
     const int strips = a.N * a.tbx;
-    const int slots = conv_bf16_cus();                                   // one workgroup per CU (two: 4-12 % faster alone, nothing in the step -- DESIGN.md 3b)
+    const int slots = unet_grid_slots(conv_bf16_cus(), max_workgroups);  // one workgroup per CU (two: 4-12 % faster alone, nothing in the step -- DESIGN.md 3b)
     const int target = (slots + npairs - 1) / npairs;                    // strip-chunks wanted so that every slot has a workgroup
     int cps = (target + strips - 1) / strips; if (cps < 1) cps = 1;
     int rpc = (a.H + cps - 1) / cps; rpc += rpc & 1; if (rpc < 2) rpc = 2;
@@ -1172,26 +1172,30 @@ extern "C" int unet_conv3x3_wgrad_bf16_supported(int N, int H, int W, int Cin, i
     return (N > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout % 64 == 0 && (size_t)N * H * W * (Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31)) ? 1 : 0;
 }
 
-extern "C" size_t unet_conv3x3_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout) {
+extern "C" size_t unet_conv3x3_wgrad_bf16_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups) {
     if (!unet_conv3x3_wgrad_bf16_supported(N, H, W, Cin, Cout)) return 0;
     WgBf16Args a{}; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    wgrad_bf16_plan(a);
+    wgrad_bf16_plan(a, max_workgroups);
     return a.splits > 1 ? (size_t)a.splits * 9 * Cin * Cout * sizeof(float) : 16;
+}
+extern "C" size_t unet_conv3x3_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout) {
+    return unet_conv3x3_wgrad_bf16_workspace_wg(N, H, W, Cin, Cout, 0);
 }
 
 // dw[a,b,ci,co] (HWIO, UNet/model.py:31) = sum_{n,y,x} bf16(xin[n,y+a-1,x+b-1,ci]) * bf16(dz[n,y,x,co]); x_bf16 / dz_bf16: that
-// operand is already stored as bf16 (leading dimension in elements)
-extern "C" int unet_conv3x3_wgrad_bf16(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
-                                          int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+// operand is already stored as bf16 (leading dimension in elements).  max_workgroups: cap on the one-wave grid (common.h
+// unet_grid_slots); the workspace follows it (.._workspace_wg)
+extern "C" int unet_conv3x3_wgrad_bf16_wg(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                                          int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(xin && dz && dw && ws && unet_conv3x3_wgrad_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG((!x_bf16 || ldx % 8 == 0) && (!dz_bf16 || lddz % 8 == 0));        // 16-byte aligned pixels
     UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
     UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * lddz * 4 < ((size_t)1 << 31));
-    if (ws_bytes < unet_conv3x3_wgrad_bf16_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
+    if (ws_bytes < unet_conv3x3_wgrad_bf16_workspace_wg(N, H, W, Cin, Cout, max_workgroups)) return UNET_ENOSPC;
     WgBf16Args a{};
     a.x = (const float*)xin; a.dz = (const float*)dz; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.x16 = x_bf16 ? 1 : 0; a.z16 = dz_bf16 ? 1 : 0;
-    wgrad_bf16_plan(a);
+    wgrad_bf16_plan(a, max_workgroups);
     a.out = a.splits > 1 ? (float*)ws : dw;
     a.x_bytes = (unsigned)((size_t)N * H * W * ldx * (a.x16 ? 2 : 4)); a.dz_bytes = (unsigned)((size_t)N * H * W * lddz * (a.z16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
@@ -1210,14 +1214,20 @@ extern "C" int unet_conv3x3_wgrad_bf16(const void* xin, int ldx, int x_bf16, con
     return rc;
 }
 
+extern "C" int unet_conv3x3_wgrad_bf16(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                                          int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    return unet_conv3x3_wgrad_bf16_wg(xin, ldx, x_bf16, dz, lddz, dz_bf16, dw, N, H, W, Cin, Cout, 0, ws, ws_bytes, stream);
+}
+
 // out[n,i,j,co] = relu?(bias[co] + sum_{a,b,ci} bf16(x[n,i+a-1,j+b-1,ci]) * bf16(W[a,b,ci,co])), fp32 accumulation.
 // x_bf16: the input is stored as bf16 (ldx in elements); in_scale / in_shift (nullable, Cin floats each, 16-byte aligned): BatchNorm
 // apply on load -- x is the producer's conv output r and the operand is bf16(scale * r + shift) inside the image, 0 outside;
 // out_bf16: the output is stored as bf16; stat_part nullable: BatchNorm sums of the output, [Cout/64][rows][64][2] = (sum y, sum y^2)
 // per 16 x 32 pixel tile, for unet_bn_train_finalize_partials
-extern "C" int unet_conv3x3_fwd_bf16(const void* x, int ldx, int x_bf16, const float* in_scale, const float* in_shift, const void* wp,
-                                     const float* bias, void* out, int ldo, int out_bf16,
-                                     int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+// max_workgroups: cap on the persistent grid (common.h unet_grid_slots; the statistics rows are per tile and do not change)
+extern "C" int unet_conv3x3_fwd_bf16_wg(const void* x, int ldx, int x_bf16, const float* in_scale, const float* in_shift, const void* wp,
+                                        const float* bias, void* out, int ldo, int out_bf16,
+                                        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, int max_workgroups, void* stream) {
     UNET_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr) && (!in_scale || (unet_aligned16(in_scale) && unet_aligned16(in_shift))));
     UNET_CHECK_ARG(x && wp && out && unet_conv3x3_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(wp));
@@ -1225,13 +1235,18 @@ extern "C" int unet_conv3x3_fwd_bf16(const void* x, int ldx, int x_bf16, const f
     UNET_CHECK_ARG(!x_bf16 || ldx % 8 == 0);
     const ConvBf16Stats s{1, stat_part, stat_bytes, nullptr, 0, 0, 0, 0};
     return run_conv_bf16((const float*)x, ldx, wp, bias, (float*)out, ldo, N, H, W, Cin, Cout, relu, (hipStream_t)stream, stat_part ? &s : nullptr,
-                         x_bf16 ? 1 : 0, out_bf16 ? 1 : 0, in_scale, in_shift);
+                         x_bf16 ? 1 : 0, out_bf16 ? 1 : 0, in_scale, in_shift, max_workgroups);
+}
+extern "C" int unet_conv3x3_fwd_bf16(const void* x, int ldx, int x_bf16, const float* in_scale, const float* in_shift, const void* wp,
+                                     const float* bias, void* out, int ldo, int out_bf16,
+                                     int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+    return unet_conv3x3_fwd_bf16_wg(x, ldx, x_bf16, in_scale, in_shift, wp, bias, out, ldo, out_bf16, N, H, W, Cin, Cout, relu, stat_part, stat_bytes, 0, stream);
 }
 
 // data gradient with every option: dz_bf16 (dz stored as bf16), r_prev / stat_part nullable (producer's BatchNorm-backward sums)
-extern "C" int unet_conv3x3_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
+extern "C" int unet_conv3x3_dgrad_bf16_wg(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
                                           int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16, int c0, int c1,
-                                          float* stat_part, size_t stat_bytes, void* stream) {
+                                          float* stat_part, size_t stat_bytes, int max_workgroups, void* stream) {
     UNET_CHECK_ARG(dz && wpd && dx && unet_conv3x3_bf16_supported(N, H, W, Cout, Cin));
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(wpd));
     UNET_CHECK_ARG((r_prev == nullptr) == (stat_part == nullptr));
@@ -1240,7 +1255,12 @@ extern "C" int unet_conv3x3_dgrad_bf16(const void* dz, int lddz, int dz_bf16, co
     UNET_CHECK_ARG(!dz_bf16 || lddz % 8 == 0);
     const ConvBf16Stats s{2, stat_part, stat_bytes, (const float*)r_prev, ldr, c0, c1, r_bf16 ? 1 : 0};
     return run_conv_bf16((const float*)dz, lddz, wpd, nullptr, (float*)dx, lddx, N, H, W, Cout, Cin, 0, (hipStream_t)stream, r_prev ? &s : nullptr,
-                         dz_bf16 ? 1 : 0, dx_bf16 ? 1 : 0);
+                         dz_bf16 ? 1 : 0, dx_bf16 ? 1 : 0, nullptr, nullptr, max_workgroups);
+}
+extern "C" int unet_conv3x3_dgrad_bf16(const void* dz, int lddz, int dz_bf16, const void* wpd, void* dx, int lddx, int dx_bf16,
+                                          int N, int H, int W, int Cin, int Cout, const void* r_prev, int ldr, int r_bf16, int c0, int c1,
+                                          float* stat_part, size_t stat_bytes, void* stream) {
+    return unet_conv3x3_dgrad_bf16_wg(dz, lddz, dz_bf16, wpd, dx, lddx, dx_bf16, N, H, W, Cin, Cout, r_prev, ldr, r_bf16, c0, c1, stat_part, stat_bytes, 0, stream);
 }
 
 // ---- 2x2 / stride-2 transposed convolution on the bf16 matrix cores (forward and data gradient) -----------------------------------
@@ -1820,7 +1840,7 @@ namespace {
 __global__ __launch_bounds__(256, 1) void convt_wgrad_bf16_kernel_128(CtWgBf16Args p) { convt_wgrad_bf16_body<2>(p); }
 __global__ __launch_bounds__(256, 1) void convt_wgrad_bf16_kernel_64(CtWgBf16Args p) { convt_wgrad_bf16_body<1>(p); }
 
-void convt_wgrad_bf16_plan(CtWgBf16Args& a) {
+void convt_wgrad_bf16_plan(CtWgBf16Args& a, int max_workgroups) {
     // 64-output-channel tiles by default: 128 AGPRs + 103 VGPRs, so the kernel shares a CU with the other stream's kernels (the
     // 128-channel tile takes all 256 AGPRs; alone it is as fast, in the step 0.13 ms slower -- compile with -DUNET_CONVT_WGRAD_WIDE to get it)
 #ifdef UNET_CONVT_WGRAD_WIDE
@@ -1831,7 +1851,7 @@ void convt_wgrad_bf16_plan(CtWgBf16Args& a) {
     a.n_co = a.Cout / cot; a.n_ci = a.Cin / 128;
     a.tbx = (a.W + 31) / 32; a.n_units = a.N * a.H * a.tbx;
     const int npairs = a.n_co * a.n_ci;
-    int splits = conv_bf16_cus() / npairs; if (splits < 1) splits = 1; if (splits > a.n_units) splits = a.n_units;
+    int splits = unet_grid_slots(conv_bf16_cus(), max_workgroups) / npairs; if (splits < 1) splits = 1; if (splits > a.n_units) splits = a.n_units;
     a.splits = splits;
 }
 
@@ -1840,24 +1860,27 @@ void convt_wgrad_bf16_plan(CtWgBf16Args& a) {
 extern "C" int unet_convT2x2_wgrad_bf16_supported(int N, int H, int W, int Cin, int Cout) {
     return (unet_convT2x2_bf16_supported(N, H, W, Cin, Cout) && Cin % 128 == 0) ? 1 : 0;
 }
-extern "C" size_t unet_convT2x2_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout) {
+extern "C" size_t unet_convT2x2_wgrad_bf16_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups) {
     if (!unet_convT2x2_wgrad_bf16_supported(N, H, W, Cin, Cout)) return 0;
     CtWgBf16Args a{}; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    convt_wgrad_bf16_plan(a);
+    convt_wgrad_bf16_plan(a, max_workgroups);
     return a.splits > 1 ? (size_t)a.splits * 4 * Cout * Cin * sizeof(float) : 16;
 }
+extern "C" size_t unet_convT2x2_wgrad_bf16_workspace(int N, int H, int W, int Cin, int Cout) {
+    return unet_convT2x2_wgrad_bf16_workspace_wg(N, H, W, Cin, Cout, 0);
+}
 // dw[a,b,co,ci] = sum_{n,i,j} dz[n,2i+a,2j+b,co] * xin[n,i,j,ci], operands rounded to bf16 (or stored as bf16), fp32 accumulation
-extern "C" int unet_convT2x2_wgrad_bf16(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
-                                           int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int unet_convT2x2_wgrad_bf16_wg(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                                           int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(xin && dz && dw && ws && unet_convT2x2_wgrad_bf16_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && (!x_bf16 || ldx % 8 == 0) && (!dz_bf16 || lddz % 8 == 0));
     UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
     UNET_CHECK_ARG((size_t)N * H * W * ldx * 4 < ((size_t)1 << 31) && (size_t)N * H * W * 4 * lddz * 4 < ((size_t)1 << 31));
-    if (ws_bytes < unet_convT2x2_wgrad_bf16_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
+    if (ws_bytes < unet_convT2x2_wgrad_bf16_workspace_wg(N, H, W, Cin, Cout, max_workgroups)) return UNET_ENOSPC;
     CtWgBf16Args a{};
     a.x = (const float*)xin; a.dz = (const float*)dz; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.x16 = x_bf16 ? 1 : 0; a.z16 = dz_bf16 ? 1 : 0;
-    convt_wgrad_bf16_plan(a);
+    convt_wgrad_bf16_plan(a, max_workgroups);
     a.out = a.splits > 1 ? (float*)ws : dw;
     a.x_bytes = (unsigned)((size_t)N * H * W * ldx * (a.x16 ? 2 : 4)); a.dz_bytes = (unsigned)((size_t)N * H * W * 4 * lddz * (a.z16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
@@ -1873,6 +1896,11 @@ extern "C" int unet_convT2x2_wgrad_bf16(const void* xin, int ldx, int x_bf16, co
         rc = UNET_LAUNCH_STATUS();
     }
     return rc;
+}
+
+extern "C" int unet_convT2x2_wgrad_bf16(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
+                                           int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    return unet_convT2x2_wgrad_bf16_wg(xin, ldx, x_bf16, dz, lddz, dz_bf16, dw, N, H, W, Cin, Cout, 0, ws, ws_bytes, stream);
 }
 
 // ---- all weight packs of a step in one launch ---------------------------------------------------------------------------------------

@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-int choose_splits(int mt_nt, int n_tiles) {
-    int s = 256 / mt_nt;           // one persistent workgroup per CU (256 CUs)
+int choose_splits(int mt_nt, int n_tiles, int max_workgroups) {
+    int s = unet_grid_slots(256, max_workgroups) / mt_nt;           // one persistent workgroup per CU (256 CUs), or the caller's cap
     if (s < 1) s = 1;
     if (s > n_tiles) s = n_tiles;
     return s;
@@ -215,7 +215,7 @@ int choose_splits(int mt_nt, int n_tiles) {
 
 template <int MODE>
 int run_wgrad(const float* a, int lda, int Ha, int Wa, const float* b, int ldb, int N, int H, int W, int Cm, int Cn,
-              float* dw, float* ws, size_t ws_bytes, hipStream_t st) {
+              float* dw, float* ws, size_t ws_bytes, hipStream_t st, int max_workgroups) {
     constexpr int NT = MODE == 0 ? 9 : 4;
     constexpr int TH = MODE == 0 ? 2 : 1;
     WgradArgs p{};
@@ -224,7 +224,7 @@ int run_wgrad(const float* a, int lda, int Ha, int Wa, const float* b, int ldb, 
     p.tiles_y = unet_cdiv(H, TH); p.tiles_x = unet_cdiv(W, TW);
     p.n_tiles = N * p.tiles_y * p.tiles_x;
     p.mt = Cm / CT; p.nt = Cn / CT;
-    p.splits = choose_splits(p.mt * p.nt, p.n_tiles);
+    p.splits = choose_splits(p.mt * p.nt, p.n_tiles, max_workgroups);
     const size_t E = (size_t)NT * Cm * Cn;
     if (ws_bytes < (size_t)p.splits * E * sizeof(float)) return UNET_ENOSPC;
     wgrad_kernel<MODE><<<dim3((unsigned)(p.mt * p.nt * p.splits)), 256, 0, st>>>(p);
@@ -237,37 +237,48 @@ int run_wgrad(const float* a, int lda, int Ha, int Wa, const float* b, int ldb, 
     return UNET_LAUNCH_STATUS();
 }
 
-size_t wgrad_ws_bytes(int mode, int N, int H, int W, int Cm, int Cn) {
+size_t wgrad_ws_bytes(int mode, int N, int H, int W, int Cm, int Cn, int max_workgroups) {
     const int NT = mode == 0 ? 9 : 4, TH = mode == 0 ? 2 : 1;
     const int n_tiles = N * unet_cdiv(H, TH) * unet_cdiv(W, TW);
-    const int s = choose_splits((Cm / CT) * (Cn / CT), n_tiles);
+    const int s = choose_splits((Cm / CT) * (Cn / CT), n_tiles, max_workgroups);
     return (size_t)s * NT * Cm * Cn * sizeof(float);
 }
 
 }  // namespace
 
-extern "C" size_t unet_conv3x3_wgrad_mfma_workspace(int N, int H, int W, int Cin, int Cout) {
-    return wgrad_ws_bytes(0, N, H, W, Cin, Cout);
+extern "C" size_t unet_conv3x3_wgrad_mfma_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups) {
+    return wgrad_ws_bytes(0, N, H, W, Cin, Cout, max_workgroups);
 }
+extern "C" size_t unet_conv3x3_wgrad_mfma_workspace(int N, int H, int W, int Cin, int Cout) { return wgrad_ws_bytes(0, N, H, W, Cin, Cout, 0); }
 
 // dw[a][b][ci][co] = sum_{n,y,x} xin[n, y+a-1, x+b-1, ci] * dz[n,y,x,co]
+// max_workgroups: cap on the split-K grid (common.h unet_grid_slots); the workspace follows it (.._workspace_wg)
+extern "C" int unet_conv3x3_wgrad_mfma_wg(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                          int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(xin && dz && dw && ws && N > 0 && H > 0 && W > 0);
+    UNET_CHECK_ARG(Cin % CT == 0 && Cout % CT == 0 && ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0);
+    UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
+    return run_wgrad<0>(xin, ldx, H, W, dz, lddz, N, H, W, Cin, Cout, dw, (float*)ws, ws_bytes, (hipStream_t)stream, max_workgroups);
+}
 extern "C" int unet_conv3x3_wgrad_mfma(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                                        int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
-    UNET_CHECK_ARG(xin && dz && dw && ws && N > 0 && H > 0 && W > 0);
-    UNET_CHECK_ARG(Cin % CT == 0 && Cout % CT == 0 && ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0);
-    UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
-    return run_wgrad<0>(xin, ldx, H, W, dz, lddz, N, H, W, Cin, Cout, dw, (float*)ws, ws_bytes, (hipStream_t)stream);
+    return unet_conv3x3_wgrad_mfma_wg(xin, ldx, dz, lddz, dw, N, H, W, Cin, Cout, 0, ws, ws_bytes, stream);
 }
 
-extern "C" size_t unet_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
-    return wgrad_ws_bytes(1, N, H, W, Cout, Cin);
+extern "C" size_t unet_convT2x2_wgrad_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups) {
+    return wgrad_ws_bytes(1, N, H, W, Cout, Cin, max_workgroups);
 }
+extern "C" size_t unet_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout) { return wgrad_ws_bytes(1, N, H, W, Cout, Cin, 0); }
 
 // dw[a][b][co][ci] = sum_{n,i,j} dz[n,2i+a,2j+b,co] * xin[n,i,j,ci]      (H, W are the INPUT dims of the layer)
-extern "C" int unet_convT2x2_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
-                                   int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int unet_convT2x2_wgrad_wg(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                      int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(xin && dz && dw && ws && N > 0 && H > 0 && W > 0);
     UNET_CHECK_ARG(Cin % CT == 0 && Cout % CT == 0 && ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0);
     UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
-    return run_wgrad<1>(dz, lddz, 2 * H, 2 * W, xin, ldx, N, H, W, Cout, Cin, dw, (float*)ws, ws_bytes, (hipStream_t)stream);
+    return run_wgrad<1>(dz, lddz, 2 * H, 2 * W, xin, ldx, N, H, W, Cout, Cin, dw, (float*)ws, ws_bytes, (hipStream_t)stream, max_workgroups);
+}
+extern "C" int unet_convT2x2_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                   int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    return unet_convT2x2_wgrad_wg(xin, ldx, dz, lddz, dw, N, H, W, Cin, Cout, 0, ws, ws_bytes, stream);
 }

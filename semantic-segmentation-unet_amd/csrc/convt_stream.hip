@@ -258,10 +258,10 @@ extern "C" int unet_convT2x2_fwd_stream_supported(int N, int H, int W, int Cin, 
     return (P % tpx == 0 && (long)4 * Cout * Cin * 4 < (1L << 31) && (long)tpx * 4096 * 4 < (1L << 31)) ? 1 : 0;
 }
 
-extern "C" int unet_convT2x2_fwd_stream_stats_rows(int N, int H, int W, int Cin, int Cout);
+extern "C" int unet_convT2x2_fwd_stream_stats_rows_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
 
 static int convt_fwd_stream_launch(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
-                                   int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream) {
+                                   int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, int max_workgroups, void* stream) {
     UNET_CHECK_ARG(x && w && out && unet_convT2x2_fwd_stream_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0 && ldx <= 4096);
     UNET_CHECK_ARG(unet_aligned16(x) && unet_aligned16(w) && unet_aligned16(out) && (!bias || unet_aligned16(bias)));
@@ -273,10 +273,11 @@ static int convt_fwd_stream_launch(const float* x, int ldx, const float* w, cons
     const long tiles = (long)a.npt * a.nct;
     if (tiles > 0x7fffffffL) return UNET_EINVAL;
     a.ntiles = (int)tiles;
-    const unsigned grid = (unsigned)(tiles < convt_cus() ? tiles : convt_cus());
+    const long slots = unet_grid_slots(convt_cus(), max_workgroups);
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
     hipStream_t st = (hipStream_t)stream;
     if (stat_part) {
-        const int rows = unet_convT2x2_fwd_stream_stats_rows(N, H, W, Cin, Cout);
+        const int rows = unet_convT2x2_fwd_stream_stats_rows_wg(N, H, W, Cin, Cout, max_workgroups);
         UNET_CHECK_ARG(rows > 0);
         if (stat_bytes < (size_t)(Cout / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
         if (wide) convt_fwd_stream_stats_kernel_2x2<<<dim3(grid), 256, 0, st>>>(a);
@@ -289,25 +290,34 @@ static int convt_fwd_stream_launch(const float* x, int ldx, const float* w, cons
 }
 
 // rows of statistics partials per 64-channel block (0: shape not supported / grid not a multiple of the channel-tile count)
-extern "C" int unet_convT2x2_fwd_stream_stats_rows(int N, int H, int W, int Cin, int Cout) {
+extern "C" int unet_convT2x2_fwd_stream_stats_rows_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups) {
     if (!unet_convT2x2_fwd_stream_supported(N, H, W, Cin, Cout)) return 0;
     const bool wide = Cout % 128 == 0;
     const long tiles = ((long)N * H * W / (wide ? 128 : 256)) * (Cout / (wide ? 128 : 64));
-    const long grid = tiles < convt_cus() ? tiles : convt_cus();
+    const long slots = unet_grid_slots(convt_cus(), max_workgroups);
+    const long grid = tiles < slots ? tiles : slots;
     const int nct = Cout / (wide ? 128 : 64);
     return grid % nct == 0 ? (int)((grid / nct) * (wide ? 2 : 4)) : 0;
+}
+extern "C" int unet_convT2x2_fwd_stream_stats_rows(int N, int H, int W, int Cin, int Cout) {
+    return unet_convT2x2_fwd_stream_stats_rows_wg(N, H, W, Cin, Cout, 0);
 }
 
 extern "C" int unet_convT2x2_fwd_stream(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                                         int N, int H, int W, int Cin, int Cout, void* stream) {
-    return convt_fwd_stream_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, nullptr, 0, stream);
+    return convt_fwd_stream_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, nullptr, 0, 0, stream);
+}
+// max_workgroups: cap on the persistent grid (common.h unet_grid_slots); stat_part nullable here
+extern "C" int unet_convT2x2_fwd_stream_wg(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                           int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, int max_workgroups, void* stream) {
+    return convt_fwd_stream_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, stat_part, stat_bytes, max_workgroups, stream);
 }
 
 // + BatchNorm sums of the output (layout and finalize as for unet_conv3x3_fwd_winograd_fused_stats)
 extern "C" int unet_convT2x2_fwd_stream_stats(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                                               int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(stat_part);
-    return convt_fwd_stream_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, stat_part, stat_bytes, stream);
+    return convt_fwd_stream_launch(x, ldx, w, bias, out, ldo, N, H, W, Cin, Cout, stat_part, stat_bytes, 0, stream);
 }
 
 // ---- transposed-conv weight gradient, wide tiles ---------------------------------------------------------------------------

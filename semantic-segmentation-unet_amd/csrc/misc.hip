@@ -408,4 +408,26 @@ extern "C" int unet_conv3x3_dgrad_direct(const float* dz, int lddz, const float*
     return UNET_LAUNCH_STATUS();
 }
 
-extern "C" int unet_hip_abi_version(void) { return 4; }       // == UNET_HIP_ABI_VERSION of include/unet_hip.h
+extern "C" int unet_hip_abi_version(void) { return 5; }       // == UNET_HIP_ABI_VERSION of include/unet_hip.h
+
+// ---- stand-in for a collective's kernel (measurement aid; include/unet_hip.h) -----------------------------------------------------------
+// RCCL's all-reduce kernels are a few dozen large workgroups that stay resident while the data crosses xGMI.  This one reproduces the
+// occupancy, not the traffic: every wave sleeps until the constant-rate wall clock (hipDeviceAttributeWallClockRate) has advanced by
+// `ticks` since the wave started, then leaves -- an exit condition every wave reaches.
+namespace {
+__global__ __launch_bounds__(512) void standin_collective_kernel(long long ticks) {
+    extern __shared__ int standin_lds[];
+    if (threadIdx.x == 0) reinterpret_cast<volatile int*>(standin_lds)[0] = 0;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace
+
+extern "C" int unet_standin_collective(int workgroups, int lds_bytes, int microseconds, void* stream) {
+    UNET_CHECK_ARG(workgroups > 0 && workgroups <= 1024 && lds_bytes >= 0 && lds_bytes <= 65536 && microseconds >= 0 && microseconds <= 100000);
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    const long long ticks = (long long)microseconds * khz / 1000;
+    standin_collective_kernel<<<dim3((unsigned)workgroups), 512, (size_t)(lds_bytes < 4 ? 4 : lds_bytes), (hipStream_t)stream>>>(ticks);
+    return UNET_LAUNCH_STATUS();
+}

@@ -150,11 +150,12 @@ int wino_stream_cus() {
 }
 // rows of statistics partials per 64-channel tile the persistent kernel would write (0: shape not taken by it / grid not a
 // multiple of the n-tile count)
-int wino_stats_rows(int N, int H, int W, int K, int Nout) {
+int wino_stats_rows(int N, int H, int W, int K, int Nout, int max_workgroups = 0) {
     if (!(K % 16 == 0 && K >= 32 && H % 2 == 0 && W % 2 == 0 && Nout % 64 == 0)) return 0;
     const int nt = Nout / 64;
     const long blocks = (long)N * ((H / 2 + 7) / 8) * ((W / 2 + 7) / 8) * nt;
-    const long grid = blocks < wino_stream_cus() ? blocks : wino_stream_cus();
+    const long slots = unet_grid_slots(wino_stream_cus(), max_workgroups);
+    const long grid = blocks < slots ? blocks : slots;
     return grid % nt == 0 ? (int)(2 * (grid / nt)) : 0;
 }
 

@@ -1242,7 +1242,8 @@ __global__ __launch_bounds__(256) void wgrad_fold_fix_kernel(float* __restrict__
 
 
 int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, float* out, int ldo, int N, int H, int W,
-                   int K, int Nout, int relu, float* stat_part, hipStream_t st, const WinoBnBwd* bb = nullptr, const float* pad = nullptr) {
+                   int K, int Nout, int relu, float* stat_part, hipStream_t st, const WinoBnBwd* bb = nullptr, const float* pad = nullptr,
+                   int max_workgroups = 0) {
     WinoFusedArgs a{};
     a.pad = pad;
     a.x = x; a.Uc = Uc; a.bias = bias; a.out = out; a.ldx = ldx; a.ldo = ldo; a.N = N; a.H = H; a.W = W; a.K = K; a.Nout = Nout; a.relu = relu;
@@ -1250,7 +1251,7 @@ int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, 
     const long blocks = (long)N * a.tby * a.tbx * a.nt;
     if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
     if (K % 16 == 0 && K >= 32) {
-        const int cus = wino_stream_cus();
+        const int cus = unet_grid_slots(wino_stream_cus(), max_workgroups);
         const dim3 grid((unsigned)(blocks < cus ? blocks : cus));
         if (bb) {
             a.bn_r = bb->r; a.bn_ldr = bb->ldr; a.bn_c0 = bb->c0; a.bn_c1 = bb->c1;
@@ -1275,23 +1276,31 @@ int run_wino_fused(const float* x, int ldx, const float* Uc, const float* bias, 
 // stat_part (nullable): BatchNorm statistics of the output, stat_part[Cout/64][rows][64][2] floats (sum, sum of squares per channel
 // over the pixels each row's workgroup-half produced), rows = unet_conv3x3_fwd_winograd_fused_stats_rows(...) > 0; consumed by
 // unet_bn_train_finalize_partials.
-extern "C" int unet_conv3x3_fwd_winograd_fused_stats_rows(int N, int H, int W, int Cin, int Cout) {
+extern "C" int unet_conv3x3_fwd_winograd_fused_stats_rows_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || Cout % 64 != 0 || Cin > kWinoFusedMaxK) return 0;
-    return wino_stats_rows(N, H, W, Cin, Cout);
+    return wino_stats_rows(N, H, W, Cin, Cout, max_workgroups);
+}
+extern "C" int unet_conv3x3_fwd_winograd_fused_stats_rows(int N, int H, int W, int Cin, int Cout) {
+    return unet_conv3x3_fwd_winograd_fused_stats_rows_wg(N, H, W, Cin, Cout, 0);
 }
 
-extern "C" int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* pad, const float* Uc, const float* bias, float* out, int ldo,
-        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+// max_workgroups: cap on the persistent grid (common.h unet_grid_slots); the statistics rows follow it (.._stats_rows_wg)
+extern "C" int unet_conv3x3_fwd_winograd_fused_wg(const float* x, int ldx, const float* pad, const float* Uc, const float* bias, float* out, int ldo,
+        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, int max_workgroups, void* stream) {
     UNET_CHECK_ARG(x && Uc && out && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cin % 8 == 0 && Cout % 64 == 0);
     UNET_CHECK_ARG(Cin <= kWinoFusedMaxK);
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(Uc) && unet_aligned16(out));
     UNET_CHECK_ARG((!bias || unet_aligned16(bias)) && (!pad || unet_aligned16(pad)));
     if (stat_part) {
-        const int rows = wino_stats_rows(N, H, W, Cin, Cout);
+        const int rows = wino_stats_rows(N, H, W, Cin, Cout, max_workgroups);
         UNET_CHECK_ARG(rows > 0);
         if (stat_bytes < (size_t)(Cout / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
     }
-    return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, (hipStream_t)stream, nullptr, pad);
+    return run_wino_fused(x, ldx, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, (hipStream_t)stream, nullptr, pad, max_workgroups);
+}
+extern "C" int unet_conv3x3_fwd_winograd_fused(const float* x, int ldx, const float* pad, const float* Uc, const float* bias, float* out, int ldo,
+        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+    return unet_conv3x3_fwd_winograd_fused_wg(x, ldx, pad, Uc, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, stat_bytes, 0, stream);
 }
 
 #if UNET_ABLATE == 8
@@ -1304,19 +1313,24 @@ extern "C" int unet_debug_wf_timeline(long long* out4) {
 // layer that PRODUCED this layer's input: dx channels [c0, c1) (multiples of 64) are that layer's dy, r_prev its saved activation
 // (c1 - c0 channels, pixel stride ldr).  stat_part = (Cin/64) * rows * 128 floats, rows = unet_conv3x3_fwd_winograd_fused_stats_rows(
 // N, H, W, Cout, Cin); blocks c0/64 .. c1/64 - 1 hold sum(dy) and sum(dy * r) per channel, consumed by unet_bn_bwd_from_partials.
-extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
+extern "C" int unet_conv3x3_dgrad_winograd_fused_wg(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
         int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
-        float* stat_part, size_t stat_bytes, void* stream) {
+        float* stat_part, size_t stat_bytes, int max_workgroups, void* stream) {
     UNET_CHECK_ARG(dz && Ucd && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0 && Cin % 64 == 0);
     UNET_CHECK_ARG(Cout <= kWinoFusedMaxK && (r_prev == nullptr) == (stat_part == nullptr));
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && lddx % 4 == 0 && unet_aligned16(dz) && unet_aligned16(Ucd) && unet_aligned16(dx));
-    if (!r_prev) return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, nullptr, (hipStream_t)stream);
+    if (!r_prev) return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, nullptr, (hipStream_t)stream, nullptr, nullptr, max_workgroups);
     UNET_CHECK_ARG(c0 >= 0 && c1 > c0 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0 && ldr % 4 == 0 && unet_aligned16(r_prev));
-    const int rows = wino_stats_rows(N, H, W, Cout, Cin);
+    const int rows = wino_stats_rows(N, H, W, Cout, Cin, max_workgroups);
     UNET_CHECK_ARG(rows > 0);
     if (stat_bytes < (size_t)(Cin / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
     const WinoBnBwd bb{r_prev, ldr, c0, c1};
-    return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, stat_part, (hipStream_t)stream, &bb);
+    return run_wino_fused(dz, lddz, Ucd, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, stat_part, (hipStream_t)stream, &bb, nullptr, max_workgroups);
+}
+extern "C" int unet_conv3x3_dgrad_winograd_fused(const float* dz, int lddz, const float* Ucd, float* dx, int lddx,
+        int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+        float* stat_part, size_t stat_bytes, void* stream) {
+    return unet_conv3x3_dgrad_winograd_fused_wg(dz, lddz, Ucd, dx, lddx, N, H, W, Cin, Cout, r_prev, ldr, c0, c1, stat_part, stat_bytes, 0, stream);
 }
 
 extern "C" int unet_winograd_wgrad_fused_supported(int N, int H, int W, int Cin, int Cout) {

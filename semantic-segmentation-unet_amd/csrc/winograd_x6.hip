@@ -506,7 +506,7 @@ bool x6_shape_ok(int N, int H, int W, int K, int Nout) {
 }
 
 int run_wino_x6(const float* x, int ldx, const uint16_t* U6, const float* bias, float* out, int ldo, int N, int H, int W,
-                int K, int Nout, int relu, float* stat_part, hipStream_t st, const WinoBnBwd* bb, const float* pad) {
+                int K, int Nout, int relu, float* stat_part, hipStream_t st, const WinoBnBwd* bb, const float* pad, int max_workgroups) {
     X6Args q{};
     WinoFusedArgs& a = q.f;
     q.U6 = U6;
@@ -515,7 +515,7 @@ int run_wino_x6(const float* x, int ldx, const uint16_t* U6, const float* bias, 
     a.tby = (H / 2 + 7) / 8; a.tbx = (W / 2 + 7) / 8; a.nt = Nout / 64; a.stat_part = stat_part;
     const long blocks = (long)N * a.tby * a.tbx * a.nt;
     if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
-    const int cus = wino_stream_cus();
+    const int cus = unet_grid_slots(wino_stream_cus(), max_workgroups);
     const dim3 grid((unsigned)(blocks < cus ? blocks : cus));
     if (bb) {
         a.bn_r = bb->r; a.bn_ldr = bb->ldr; a.bn_c0 = bb->c0; a.bn_c1 = bb->c1;
@@ -562,31 +562,40 @@ extern "C" int unet_winograd_weight_fold_x6(const float* w, const float* bias, c
 }
 
 // Forward: the arguments of unet_conv3x3_fwd_winograd_fused with U6 (unet_winograd_weight_transform_x6 mode 0 / _fold_x6) in place of Uc.
-// stat_part rows = unet_conv3x3_fwd_winograd_fused_stats_rows (the persistent grid is the same).
-extern "C" int unet_conv3x3_fwd_winograd_x6(const float* x, int ldx, const float* pad, const void* U6, const float* bias, float* out, int ldo,
-        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+// stat_part rows = unet_conv3x3_fwd_winograd_fused_stats_rows[_wg] (the persistent grid is the same).  max_workgroups as there.
+extern "C" int unet_conv3x3_fwd_winograd_x6_wg(const float* x, int ldx, const float* pad, const void* U6, const float* bias, float* out, int ldo,
+        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, int max_workgroups, void* stream) {
     UNET_CHECK_ARG(x && U6 && out && x6_shape_ok(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(U6) && unet_aligned16(out));
     UNET_CHECK_ARG((!bias || unet_aligned16(bias)) && (!pad || unet_aligned16(pad)));
     if (stat_part) {
-        const int rows = wino_stats_rows(N, H, W, Cin, Cout);
+        const int rows = wino_stats_rows(N, H, W, Cin, Cout, max_workgroups);
         UNET_CHECK_ARG(rows > 0);
         if (stat_bytes < (size_t)(Cout / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
     }
-    return run_wino_x6(x, ldx, (const uint16_t*)U6, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, (hipStream_t)stream, nullptr, pad);
+    return run_wino_x6(x, ldx, (const uint16_t*)U6, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, (hipStream_t)stream, nullptr, pad, max_workgroups);
+}
+extern "C" int unet_conv3x3_fwd_winograd_x6(const float* x, int ldx, const float* pad, const void* U6, const float* bias, float* out, int ldo,
+        int N, int H, int W, int Cin, int Cout, int relu, float* stat_part, size_t stat_bytes, void* stream) {
+    return unet_conv3x3_fwd_winograd_x6_wg(x, ldx, pad, U6, bias, out, ldo, N, H, W, Cin, Cout, relu, stat_part, stat_bytes, 0, stream);
 }
 
 // Data gradient: the arguments of unet_conv3x3_dgrad_winograd_fused with U6d (mode 1) in place of Ucd.
-extern "C" int unet_conv3x3_dgrad_winograd_x6(const float* dz, int lddz, const void* U6d, float* dx, int lddx,
+extern "C" int unet_conv3x3_dgrad_winograd_x6_wg(const float* dz, int lddz, const void* U6d, float* dx, int lddx,
         int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
-        float* stat_part, size_t stat_bytes, void* stream) {
+        float* stat_part, size_t stat_bytes, int max_workgroups, void* stream) {
     UNET_CHECK_ARG(dz && U6d && dx && x6_shape_ok(N, H, W, Cout, Cin) && (r_prev == nullptr) == (stat_part == nullptr));
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && lddx % 4 == 0 && unet_aligned16(dz) && unet_aligned16(U6d) && unet_aligned16(dx));
-    if (!r_prev) return run_wino_x6(dz, lddz, (const uint16_t*)U6d, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, nullptr, (hipStream_t)stream, nullptr, nullptr);
+    if (!r_prev) return run_wino_x6(dz, lddz, (const uint16_t*)U6d, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, nullptr, (hipStream_t)stream, nullptr, nullptr, max_workgroups);
     UNET_CHECK_ARG(c0 >= 0 && c1 > c0 && c1 <= Cin && c0 % 64 == 0 && c1 % 64 == 0 && ldr >= c1 - c0 && ldr % 4 == 0 && unet_aligned16(r_prev));
-    const int rows = wino_stats_rows(N, H, W, Cout, Cin);
+    const int rows = wino_stats_rows(N, H, W, Cout, Cin, max_workgroups);
     UNET_CHECK_ARG(rows > 0);
     if (stat_bytes < (size_t)(Cin / 64) * rows * 128 * sizeof(float)) return UNET_ENOSPC;
     const WinoBnBwd bb{r_prev, ldr, c0, c1};
-    return run_wino_x6(dz, lddz, (const uint16_t*)U6d, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, stat_part, (hipStream_t)stream, &bb, nullptr);
+    return run_wino_x6(dz, lddz, (const uint16_t*)U6d, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, stat_part, (hipStream_t)stream, &bb, nullptr, max_workgroups);
+}
+extern "C" int unet_conv3x3_dgrad_winograd_x6(const float* dz, int lddz, const void* U6d, float* dx, int lddx,
+        int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr, int c0, int c1,
+        float* stat_part, size_t stat_bytes, void* stream) {
+    return unet_conv3x3_dgrad_winograd_x6_wg(dz, lddz, U6d, dx, lddx, N, H, W, Cin, Cout, r_prev, ldr, c0, c1, stat_part, stat_bytes, 0, stream);
 }

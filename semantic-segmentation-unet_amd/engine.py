@@ -323,6 +323,7 @@ class Engine:
         r_out: where the conv output goes (default: the layer's own buffer); stat_out = (scale, shift) destinations of the BatchNorm
         coefficients (default: self.stat[name][2:4]).  Kernel family and storage precisions: self.pl.layer[name]."""
         L, st = self.L, self._stream()
+        cap = self.opt.cap                    # max_workgroups of every persistent kernel (0: one workgroup per CU)
         lp = self.pl.layer[name]
         kind, cin, cout = lp.kind, lp.cin, lp.cout
         n, h, w, _ = x.shape
@@ -343,14 +344,11 @@ class Engine:
                                      int(r16), n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
             fused_stats = (stat_part, rows) if rows > 0 else None
         elif lp.fwd == "convt_stream" and _ld(x) <= 4096:                       # persistent stream kernel
-            rows = L.unet_convT2x2_fwd_stream_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
-            if rows > 0:
-                stat_part = part(rows)
-                L.unet_convT2x2_fwd_stream_stats(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
-                                                 _p(stat_part), stat_part.numel() * 4, st)
-                fused_stats = (stat_part, rows)
-            else:
-                L.unet_convT2x2_fwd_stream(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
+            rows = L.unet_convT2x2_fwd_stream_stats_rows_wg(n, h, w, cin, cout, cap) if lp.fwd_stats else 0
+            stat_part = part(rows)
+            L.unet_convT2x2_fwd_stream_wg(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
+                                          _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, cap, st)
+            fused_stats = (stat_part, rows) if rows > 0 else None
         elif kind == "deconv":
             L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
         elif kind == "conv1":
@@ -359,12 +357,12 @@ class Engine:
         elif lp.fwd == "bf16":
             rows = L.unet_conv3x3_bf16_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
             stat_part = part(rows)
-            self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16,
+            self._timed("conv3x3_fwd_bf16", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_bf16_wg,
                         _p(x), _ld(x), int(x.dtype == torch.bfloat16), None, None, _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
-                        int(r16), n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+                        int(r16), n, h, w, cin, cout, 1, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, cap, st)
             fused_stats = (stat_part, rows) if rows > 0 else None
         elif lp.fwd == "winograd":
-            rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
+            rows = L.unet_conv3x3_fwd_winograd_fused_stats_rows_wg(n, h, w, cin, cout, cap) if lp.fwd_stats else 0
             stat_part = part(rows)
             x6 = lp.fwd_x6
             if in_view is not None:
@@ -387,9 +385,9 @@ class Engine:
                 uc, bias_eff, pad = (self._x6_kernels(name)[0] if x6 else self._fused_kernels(name)[0]), b_, None
             # (with stat_part the conv kernel also leaves the BatchNorm sums of its output: one activation read less per layer)
             self._timed("conv3x3_fwd_winograd_x6" if x6 else "conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout,
-                        L.unet_conv3x3_fwd_winograd_x6 if x6 else L.unet_conv3x3_fwd_winograd_fused,
+                        L.unet_conv3x3_fwd_winograd_x6_wg if x6 else L.unet_conv3x3_fwd_winograd_fused_wg,
                         _p(x), _ld(x), _p(pad), _p(uc), _p(bias_eff), _p(r), _ld(r), n, h, w, cin, cout, 1,
-                        _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+                        _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, cap, st)
             fused_stats = (stat_part, rows) if rows > 0 else None
         elif lp.fwd == "mfma":
             self._timed("conv3x3_fwd", 2.0 * 9 * n * h * w * cin * cout, L.unet_conv3x3_fwd_mfma,
@@ -611,6 +609,7 @@ class Engine:
         hi, wi = x.shape[1], x.shape[2]
         dx = None
         overlap = self.opt.overlap_wgrad
+        cap = self.opt.cap
         z16 = int(dz.dtype == torch.bfloat16)
 
         def wgrad():
@@ -618,23 +617,22 @@ class Engine:
             st2 = self._stream()
             L.unet_bn_bwd_bias(_p(bnws), bias_rows.value, cout, _p(self.g[name + "/bias"]), st2)
             if lp.wgrad == "convt_bf16":
-                nb2 = L.unet_convT2x2_wgrad_bf16_workspace(n, hi, wi, cin, cout)
-                L.unet_convT2x2_wgrad_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
-                                              n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                nb2 = L.unet_convT2x2_wgrad_bf16_workspace_wg(n, hi, wi, cin, cout, cap)
+                L.unet_convT2x2_wgrad_bf16_wg(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
+                                              n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "deconv":
-                nb2 = L.unet_convT2x2_wgrad_workspace(n, hi, wi, cin, cout)
-                L.unet_convT2x2_wgrad(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                nb2 = L.unet_convT2x2_wgrad_workspace_wg(n, hi, wi, cin, cout, cap)
+                L.unet_convT2x2_wgrad_wg(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
                 self._timed("classmap_wgrad", self._nb(x, dz), L.unet_conv1x1_wgrad,
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, _p(dw), P, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif lp.wgrad == "bf16":
-                nb2 = L.unet_conv3x3_wgrad_bf16_workspace(n, ho, wo, cin, cout)
-                self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16,
+                nb2 = L.unet_conv3x3_wgrad_bf16_workspace_wg(n, ho, wo, cin, cout, cap)
+                self._timed("conv3x3_wgrad_bf16", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_bf16_wg,
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
-                            n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                            n, ho, wo, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
             elif lp.wgrad == "winograd":
-                cap = int(self.opt.wgrad_workgroups or 0)
                 nb2 = L.unet_conv3x3_wgrad_winograd_fused_workspace(n, ho, wo, cin, cout, cap)
                 self._timed("conv3x3_wgrad_winograd_fused", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_winograd_fused,
                             _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
@@ -645,9 +643,9 @@ class Engine:
                     L.unet_conv3x3_wgrad_fold_fix(_p(dw), _p(vw[0]), _p(vw[1]), _p(dz), cout, _p(self.g[name + "/bias"]), n, ho, wo, cin, cout,
                                                   _p(self._workspace(nb3, sd)), nb3, st2)
             elif lp.wgrad == "mfma":
-                nb2 = L.unet_conv3x3_wgrad_mfma_workspace(n, ho, wo, cin, cout)
-                self._timed("conv3x3_wgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_mfma,
-                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                nb2 = L.unet_conv3x3_wgrad_mfma_workspace_wg(n, ho, wo, cin, cout, cap)
+                self._timed("conv3x3_wgrad", 2.0 * 9 * n * ho * wo * cin * cout, L.unet_conv3x3_wgrad_mfma_wg,
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, ho, wo, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
             else:
                 nb2 = L.unet_conv3x3_wgrad_direct_workspace(n, ho, wo, cin, cout)
                 self._timed("first_layer_wgrad", self._nb(x, dz), L.unet_conv3x3_wgrad_direct,
@@ -672,7 +670,7 @@ class Engine:
                 r_prev = self.saved[pname][1]
                 rows = (L.unet_convT2x2_bf16_stats_rows(n, hi, wi, cin, cout, 1) if lp.dgrad == "convt_bf16"
                         else L.unet_conv3x3_bf16_stats_rows(n, ho, wo, cout, cin) if lp.dgrad == "bf16"
-                        else L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, ho, wo, cout, cin))
+                        else L.unet_conv3x3_fwd_winograd_fused_stats_rows_wg(n, ho, wo, cout, cin, cap))
                 assert rows > 0
                 part = self._buf("bnbwd_" + name, ((cin // 64) * rows * 128,))
                 self.bnbwd_part[pname] = (part, rows, c0)
@@ -688,17 +686,17 @@ class Engine:
             elif kind == "conv1":
                 self._timed("classmap_dgrad", self._nb(dz, dx), L.unet_conv1x1_dgrad, _p(dz), cout, _p(w_), _p(dx), cin, int(dx16), P, cin, cout, st)
             elif lp.dgrad == "bf16":
-                self._timed("conv3x3_dgrad_bf16", fl, L.unet_conv3x3_dgrad_bf16,
+                self._timed("conv3x3_dgrad_bf16", fl, L.unet_conv3x3_dgrad_bf16_wg,
                             _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx16), n, ho, wo, cin, cout,
-                            _p(r_prev), ldr_prev, r16_prev, c0, c1, _p(part), nbp, st)
+                            _p(r_prev), ldr_prev, r16_prev, c0, c1, _p(part), nbp, cap, st)
             elif lp.dgrad == "winograd" and lp.dgrad_x6:
-                self._timed("conv3x3_dgrad_winograd_x6", fl, L.unet_conv3x3_dgrad_winograd_x6,
+                self._timed("conv3x3_dgrad_winograd_x6", fl, L.unet_conv3x3_dgrad_winograd_x6_wg,
                             _p(dz), cout, _p(self._x6_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
-                            _p(r_prev), ldr_prev, c0, c1, _p(part), nbp, st)
+                            _p(r_prev), ldr_prev, c0, c1, _p(part), nbp, cap, st)
             elif lp.dgrad == "winograd":
-                self._timed("conv3x3_dgrad_winograd_fused", fl, L.unet_conv3x3_dgrad_winograd_fused,
+                self._timed("conv3x3_dgrad_winograd_fused", fl, L.unet_conv3x3_dgrad_winograd_fused_wg,
                             _p(dz), cout, _p(self._fused_kernels(name)[1]), _p(dx), cin, n, ho, wo, cin, cout,
-                            _p(r_prev), ldr_prev, c0, c1, _p(part), nbp, st)
+                            _p(r_prev), ldr_prev, c0, c1, _p(part), nbp, cap, st)
             elif lp.dgrad == "mfma":
                 self._timed("conv3x3_dgrad", fl, L.unet_conv3x3_dgrad_mfma, _p(dz), cout, _p(w_), _p(dx), cin, n, ho, wo, cin, cout, st)
             else:                                   # first layer (Cin = number_channels): only the ERF probe needs it

@@ -54,14 +54,11 @@ class DataParallel:
         # broadcast from rank 0 anyway
         if hasattr(engine, "dropout_seed"):
             engine.dropout_seed = engine.dropout_seed * self.world_size + self.rank
-        # The fused Winograd weight gradient is a persistent grid of 512-register workgroups, one per CU; a collective's kernels that are resident
-        # when it launches push its last workgroups into a second wave.  `EngineOptions.wgrad_workgroups` caps that grid: None (default) =
-        # "auto" -- capped at OVERLAP_WORKGROUPS when there is more than one replica, one workgroup per CU otherwise; 0 = never capped; n = n.
-        # The cap costs the kernel 12 % when timed alone and no N > 1 RCCL run has measured what it buys (tests/test_gpu_overlap.py uses a
-        # stand-in collective), so an explicit 0 is honoured.  The engine's options object may be shared: it is replaced by a copy, never mutated.
-        if hasattr(engine, "opt") and engine.opt.wgrad_workgroups is None and (self.world_size > 1 or force):
-            import dataclasses
-            engine.opt = dataclasses.replace(engine.opt, wgrad_workgroups=self.OVERLAP_WORKGROUPS)
+        # Every persistent kernel of the step takes `EngineOptions.max_workgroups` (the `_wg` entry points of include/unet_hip.h); 224
+        # (OVERLAP_WORKGROUPS) leaves ~4 CUs per XCD to a collective's kernels.  It is NOT applied here: on one GPU with a stand-in
+        # collective resident (tests/test_gpu_overlap.py, profiles/r04_overlap_standin.txt) the capped step is slower than the uncapped one
+        # in every case measured -- the cap costs every CU-bound kernel 1/8 of the chip, the collective costs an uncapped grid a short
+        # second wave.  A caller with an N > 1 RCCL measurement that says otherwise passes EngineOptions(max_workgroups=224).
         if broadcast and (self.world_size > 1 or force):
             self.broadcast_state()
 

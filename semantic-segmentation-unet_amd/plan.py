@@ -38,9 +38,10 @@ class EngineOptions:
     bf16_storage: bool = True         # stage 2 (see module docstring)
     bf16_activations: bool = True     # stage 3
     overlap_wgrad: bool = True        # weight gradients on a side stream
-    wgrad_workgroups: Optional[int] = None   # cap on the fused Winograd weight gradient's persistent grid: None = auto (one workgroup per CU on one
-    #                                   GPU; parallel.DataParallel caps it at 224 when there is more than one replica, leaving a few CUs per
-    #                                   XCD to the collective's kernels), 0 = never capped, n = at most n workgroups
+    max_workgroups: Optional[int] = None     # cap on every persistent grid (the `_wg` entry points of include/unet_hip.h: Winograd forward / data /
+    #                                   weight gradient, bf16 3x3 kernels, transposed-conv forward and weight gradients): None / 0 = one
+    #                                   workgroup per CU, n = at most n workgroups (224 leaves ~4 CUs per XCD to a collective's kernels;
+    #                                   measured on one GPU with a stand-in collective it loses, so nothing sets it -- parallel.py)
 
     @staticmethod
     def from_env(env=None):
@@ -55,8 +56,8 @@ class EngineOptions:
                           ("overlap_wgrad", "UNET_OVERLAP_WGRAD")):
             if var in env:
                 setattr(o, name, env[var] != "0")
-        if "UNET_WGRAD_CUS" in env:
-            o.wgrad_workgroups = int(env["UNET_WGRAD_CUS"])
+        if "UNET_MAX_WORKGROUPS" in env:
+            o.max_workgroups = int(env["UNET_MAX_WORKGROUPS"])
         if o.compute_dtype not in ("fp32", "bf16"):
             raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
         if o.fp32_matrix not in ("bf16x6", "native"):
@@ -65,6 +66,11 @@ class EngineOptions:
 
     def key(self):
         return dataclasses.astuple(self)
+
+    @property
+    def cap(self):
+        """the `max_workgroups` argument the C entry points get (0 = one workgroup per CU)"""
+        return int(self.max_workgroups or 0)
 
 
 # layer -> (producer, first, last, parts): the layer's input channels [first/parts, last/parts) of its Cin are EXACTLY the BatchNorm
@@ -244,13 +250,13 @@ def build_plan(opt, number_channels, number_classes, n, h, w, training, want_gra
         if p.fwd == "bf16":
             p.fwd_stats = L.unet_conv3x3_bf16_stats_rows(n, p.ho, p.wo, p.cin, p.cout) > 0
         elif p.fwd == "winograd":
-            p.fwd_stats = L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, p.ho, p.wo, p.cin, p.cout) > 0
+            p.fwd_stats = L.unet_conv3x3_fwd_winograd_fused_stats_rows_wg(n, p.ho, p.wo, p.cin, p.cout, opt.cap) > 0
         elif p.fwd == "direct":
             p.fwd_stats = L.unet_conv3x3_fwd_direct_stats_rows(n, p.ho, p.wo, p.cin, p.cout) > 0
         elif p.fwd == "convt_bf16":
             p.fwd_stats = L.unet_convT2x2_bf16_stats_rows(n, p.hi, p.wi, p.cin, p.cout, 0) > 0
         elif p.fwd == "convt_stream":
-            p.fwd_stats = L.unet_convT2x2_fwd_stream_stats_rows(n, p.hi, p.wi, p.cin, p.cout) > 0
+            p.fwd_stats = L.unet_convT2x2_fwd_stream_stats_rows_wg(n, p.hi, p.wi, p.cin, p.cout, opt.cap) > 0
 
     # ---- storage -------------------------------------------------------------------------------------------------------------------------
     st2 = bf and opt.bf16_storage
@@ -303,7 +309,7 @@ def build_plan(opt, number_channels, number_classes, n, h, w, training, want_gra
             if p.dgrad == "bf16":
                 ok = L.unet_conv3x3_bf16_stats_rows(n, p.ho, p.wo, p.cout, p.cin) > 0
             elif p.dgrad == "winograd":
-                ok = pp.r == F32 and L.unet_conv3x3_fwd_winograd_fused_stats_rows(n, p.ho, p.wo, p.cout, p.cin) > 0
+                ok = pp.r == F32 and L.unet_conv3x3_fwd_winograd_fused_stats_rows_wg(n, p.ho, p.wo, p.cout, p.cin, opt.cap) > 0
             elif p.dgrad == "convt_bf16":
                 ok = L.unet_convT2x2_bf16_stats_rows(n, p.hi, p.wi, p.cin, p.cout, 1) > 0
             if ok:

@@ -29,10 +29,9 @@ for cd in ("bf16", "fp32"):                                 # the mixed-precisio
     a = model.UNet(2, 2, 1, seed=5, compute_dtype=cd)
     b = model.UNet(2, 2, 1, seed=5, compute_dtype=cd)
     b.parallel = par.DataParallel(b.engine, bucket_bytes=8 << 20, force=True)
-    # DataParallel caps the fused Winograd weight gradient's grid so that a collective's kernels find CUs (parallel.py); the cap changes
-    # the split count, i.e. the order partial sums are added in -- the single-process twin gets the same cap for the bit-for-bit comparison
-    assert a.engine.opt.wgrad_workgroups is None and b.engine.opt.wgrad_workgroups == par.DataParallel.OVERLAP_WORKGROUPS      # auto: capped with > 1 replica
-    a.engine.opt.wgrad_workgroups = b.engine.opt.wgrad_workgroups
+    # DataParallel leaves the persistent grids alone (the workgroup cap is an explicit option, parallel.py): the replica's kernels are the
+    # single-process twin's, which is what makes the comparison below bit for bit
+    assert a.engine.opt.max_workgroups is None and b.engine.opt.max_workgroups is None
     assert len(b.parallel.buckets) >= 5
     for _ in range(2):
         la = a.train_step((img, lab, None, None), dropout_masks=masks).numpy()
