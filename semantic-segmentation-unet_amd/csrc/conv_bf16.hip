@@ -1201,7 +1201,11 @@ extern "C" int unet_conv3x3_wgrad_bf16_wg(const void* xin, int ldx, int x_bf16, 
     hipStream_t st = (hipStream_t)stream;
     // both operands stored as bf16: the staged rows are plain copies of memory -> LDS-DMA staging; otherwise the register-staged
     // kernel converts fp32 operands on the way into LDS
+#ifdef UNET_WGRAD_BF16_NO_DMA    /* diagnostic build (scripts/bf16_onload_ab.py): what a weight gradient with BatchNorm-apply on load would at least cost */
+    if (false) {}
+#else
     if (a.x16 && a.z16) wgrad_bf16_dma_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
+#endif
     else                       wgrad_bf16_kernel<<<(unsigned)(a.n_ci * a.n_co * a.splits), 256, 0, st>>>(a);
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     if (a.splits > 1) {

@@ -410,10 +410,11 @@ __device__ __forceinline__ void x6_transform_g(const float (&g)[3][3], float (&t
     }
 }
 constexpr float kX6FoldScaleFloor = 1e-30f;
-__device__ __forceinline__ void x6_weight_item(const float* __restrict__ w, uint16_t* __restrict__ U6, int Ci, int Co, int mode, long it,
+// One item = 8 consecutive k (k8) x one n: a 16-byte half of the [n][16 k] rows of all 16 points x 3 pieces.  Callers map lanes so that
+// the two halves of a row and consecutive n are neighbours: a wave's store instruction then covers contiguous memory.
+__device__ __forceinline__ void x6_weight_item(const float* __restrict__ w, uint16_t* __restrict__ U6, int Ci, int Co, int mode, int k8, int n,
                                                const float* __restrict__ scale, const float* __restrict__ shift) {
     const int N = mode ? Ci : Co;
-    const int k8 = (int)(it / N), n = (int)(it % N);            // 8 consecutive k, one n
     float t[16][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -447,7 +448,8 @@ __device__ __forceinline__ void x6_weight_item(const float* __restrict__ w, uint
 __global__ __launch_bounds__(256) void wino_x6_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ U6, int Ci, int Co, int mode) {
     const long items = (long)Ci * Co / 8;
     const long it = (long)blockIdx.x * 256 + threadIdx.x;
-    if (it < items) x6_weight_item(w, U6, Ci, Co, mode, it, nullptr, nullptr);
+    const int N = mode ? Ci : Co;
+    if (it < items) x6_weight_item(w, U6, Ci, Co, mode, 2 * (int)((it >> 1) / N) + (int)(it & 1), (int)((it >> 1) % N), nullptr, nullptr);
 }
 // jobs[j] = { w, U6, Ci | Co << 32, first block, mode, 0 }: every direction of every layer in ONE launch
 __global__ __launch_bounds__(256) void wino_x6_weight_batch_kernel(const long long* __restrict__ jobs, int njobs) {
@@ -457,21 +459,24 @@ __global__ __launch_bounds__(256) void wino_x6_weight_batch_kernel(const long lo
     uint16_t* U6 = reinterpret_cast<uint16_t*>(jobs[j * 6 + 1]);
     const int Ci = (int)(jobs[j * 6 + 2] & 0xffffffffll), Co = (int)(jobs[j * 6 + 2] >> 32);
     const long it = ((long)blockIdx.x - (int)jobs[j * 6 + 3]) * 256 + threadIdx.x;
-    if (it < (long)Ci * Co / 8) x6_weight_item(w, U6, Ci, Co, (int)jobs[j * 6 + 4], it, nullptr, nullptr);
+    const int mode = (int)jobs[j * 6 + 4], N = mode ? Ci : Co;
+    if (it < (long)Ci * Co / 8) x6_weight_item(w, U6, Ci, Co, mode, 2 * (int)((it >> 1) / N) + (int)(it & 1), (int)((it >> 1) % N), nullptr, nullptr);
 }
 
 // BatchNorm-apply on load (see winograd.hip, wino_weight_fold_kernel): U6 = pieces of scale . transform(w), bias_out = bias + sum_taps shift . w,
 // pad = -shift / scale.  A workgroup owns kX6FoldCo output channels and all input-channel groups, so the folded bias is finished inside it.
-constexpr int kX6FoldCo = 4, kX6FoldLanes = 256 / kX6FoldCo;
+constexpr int kX6FoldCo = 8, kX6FoldLanes = 256 / kX6FoldCo;
 __global__ __launch_bounds__(256) void wino_x6_weight_fold_kernel(const float* __restrict__ w, const float* __restrict__ scale,
         const float* __restrict__ shift, const float* __restrict__ bias, uint16_t* __restrict__ U6, float* __restrict__ bias_out,
         float* __restrict__ pad, int Ci, int Co) {
     __shared__ double sPart[kX6FoldLanes][kX6FoldCo];
-    const int col = threadIdx.x % kX6FoldCo, gl = threadIdx.x / kX6FoldCo;
+    // lane order: row half (2) fastest, then output channel (8), then 16-channel group: one store instruction covers 256-byte runs
+    const int half = threadIdx.x & 1, col = (threadIdx.x >> 1) % kX6FoldCo, gl = threadIdx.x / (2 * kX6FoldCo);
     const int co = blockIdx.x * kX6FoldCo + col;
     const bool live = co < Co;
     double bsum = 0.0;
-    for (int c8 = gl; c8 < (Ci >> 3) && live; c8 += kX6FoldLanes) {
+    for (int c16 = gl; c16 < (Ci >> 4) && live; c16 += kX6FoldLanes / 2) {
+        const int c8 = 2 * c16 + half;
         float tsum = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -487,12 +492,12 @@ __global__ __launch_bounds__(256) void wino_x6_weight_fold_kernel(const float* _
                 pad[ci] = -sh / sc;
             }
         }
-        x6_weight_item(w, U6, Ci, Co, 0, (long)c8 * Co + co, scale, shift);
+        x6_weight_item(w, U6, Ci, Co, 0, c8, co, scale, shift);
         bsum += (double)tsum;
     }
-    sPart[gl][col] = bsum;
+    sPart[2 * gl + half][col] = bsum;
     __syncthreads();
-    if (gl == 0 && live) {
+    if (gl == 0 && half == 0 && live) {
         double sacc = 0.0;
 #pragma unroll
         for (int l = 0; l < kX6FoldLanes; ++l) sacc += sPart[l][col];

@@ -237,26 +237,39 @@ class Engine:
             self._fused_dirty = False
         return self._fused_U[name]
 
-    def _x6_kernels(self, name):
-        """(U6 forward, U6 data gradient): the layer's Winograd-transformed kernel as three bf16 pieces per value (csrc/winograd_x6.hip), every
-        layer and direction of the BF16x6 route in one batched launch after a parameter change."""
+    def _x6_kernels(self, name, forward=False):
+        """(U6 forward, U6 data gradient): the layer's Winograd-transformed kernel as three bf16 pieces per value (csrc/winograd_x6.hip).
+        After a parameter change ONE batched launch re-transforms every data-gradient operand and the forward operands of the layers the
+        current plan reads without BatchNorm-apply on load (the other layers' forward operands come out of unet_winograd_weight_fold_x6
+        every step: transforming them here as well was 39 % of the launch's bytes).  forward=True: the caller needs [0]; a forward operand
+        the batch skipped (another plan of the same engine, e.g. bn_on_load off) is transformed on demand."""
         if self._x6_U is None:
-            self._x6_U, rows, blk = {}, [], 0
+            self._x6_U, self._x6_jobs = {}, {}
             for n, kind, cin, cout in self.layers:
                 if kind != "conv3" or cin % 16 or cout % 16:
                     continue
                 nb = self.L.unet_winograd_x6_weight_bytes(cin, cout)
-                u = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
-                self._x6_U[n] = u
-                for mode in (0, 1):
-                    rows.append([self.p[n + "/kernel"].data_ptr(), u[mode].data_ptr(), cin | (cout << 32), blk, mode, 0])
-                    blk += (cin * cout + 2047) // 2048
-            self._x6_jobs = torch.tensor(rows, dtype=torch.int64, device=self.dev)
-            self._x6_blocks = blk
+                self._x6_U[n] = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
             self._x6_dirty = True
         if self._x6_dirty:
-            self.L.unet_winograd_weight_transform_x6_batch(_p(self._x6_jobs), self._x6_jobs.shape[0], self._x6_blocks, self._stream())
+            skip = frozenset(n for n in self._x6_U if self.pl is not None and self.pl.layer[n].x_on_load)
+            job = self._x6_jobs.get(skip)
+            if job is None:
+                rows, blk = [], 0
+                for n, u in self._x6_U.items():
+                    cin, cout = self.cin[n], self.cout[n]
+                    for mode in (0, 1):
+                        if mode == 0 and n in skip:
+                            continue
+                        rows.append([self.p[n + "/kernel"].data_ptr(), u[mode].data_ptr(), cin | (cout << 32), blk, mode, 0])
+                        blk += (cin * cout + 2047) // 2048
+                job = self._x6_jobs[skip] = (torch.tensor(rows, dtype=torch.int64, device=self.dev), blk)
+            self.L.unet_winograd_weight_transform_x6_batch(_p(job[0]), job[0].shape[0], job[1], self._stream())
+            self._x6_fwd_valid = set(self._x6_U) - skip
             self._x6_dirty = False
+        if forward and name not in self._x6_fwd_valid:
+            self.L.unet_winograd_weight_transform_x6(_p(self.p[name + "/kernel"]), _p(self._x6_U[name][0]), self.cin[name], self.cout[name], 0, self._stream())
+            self._x6_fwd_valid.add(name)
         return self._x6_U[name]
 
     def parameters_changed(self):
@@ -382,7 +395,7 @@ class Engine:
                     else:
                         self._eval_folded.add(name)
             else:
-                uc, bias_eff, pad = (self._x6_kernels(name)[0] if x6 else self._fused_kernels(name)[0]), b_, None
+                uc, bias_eff, pad = (self._x6_kernels(name, forward=True)[0] if x6 else self._fused_kernels(name)[0]), b_, None
             # (with stat_part the conv kernel also leaves the BatchNorm sums of its output: one activation read less per layer)
             self._timed("conv3x3_fwd_winograd_x6" if x6 else "conv3x3_fwd_winograd_fused", 2.0 * 9 * n * h * w * cin * cout,
                         L.unet_conv3x3_fwd_winograd_x6_wg if x6 else L.unet_conv3x3_fwd_winograd_fused_wg,

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 PKG = "semantic-segmentation-unet_amd"
 
+# The torch restatements the full-size GPU tests compare against run torch's own convolutions (MIOpen).  On a fresh box MIOpen's default
+# find mode benchmarks and compiles candidates for every new shape -- minutes for the ~70 shapes of a U-Net step, none of it ours.  FAST
+# picks a solver from its heuristics instead; the results are the same fp32 convolutions.  (Only the checker is affected: the product
+# path never calls MIOpen.)
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
