@@ -15,14 +15,9 @@ for shape in [(8, 64, 64, 512, 512), (8, 512, 512, 64, 64), (8, 32, 32, 1024, 10
     for _ in range(3):
         L.unet_conv3x3_fwd_winograd_x6(P(x), ci, None, P(u), None, P(y), co, n, h, w, ci, co, 1, None, 0, ST())
     torch.cuda.synchronize()
-    out = (ctypes.c_longlong * 16)()
+    out = (ctypes.c_longlong * 8)()
     L.cdll.unet_debug_x6_timeline(out)
     t = list(out)
-    if "prev" in dir():
-        d = [a - b for a, b in zip(t, prev)]
-    else:
-        d = t
-    prev = t
-    units = max(d[8], 1) / 2.0          # units per group in the MFMA role (each group has the role in half of the units)
-    print("%-26s per unit (cycles): group0 mfma stream %5.0f + wait %5.0f | transform %5.0f + wait %5.0f || group1 mfma %5.0f + %5.0f | transform %5.0f + %5.0f" % (
-        str(shape), d[0] / units, d[1] / units, d[2] / units, d[3] / units, d[4] / units, d[5] / units, d[6] / units, d[7] / units), flush=True)
+    units = max(t[4], 1)
+    print("%-26s units %5d: operand wait %6.0f | stream %6.0f | vm/lgkm wait %6.0f | barrier %6.0f  (cycles per unit); tile total/unit %6.0f" % (
+        str(shape), units, t[0] / units, t[1] / units, t[2] / units, t[3] / units, t[5] / units), flush=True)
