@@ -28,8 +28,8 @@ extern "C" {
 #define UNET_ENOSPC (-2)
 
 /* Bumped whenever an exported signature changes; a loader must refuse a library whose unet_hip_abi_version() differs
- * (5: round 4 -- the `_wg` (max_workgroups) entry points of every persistent kernel, unet_standin_collective; 4: round 4 -- the BF16x6 Winograd route: unet_*_x6; 3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
-#define UNET_HIP_ABI_VERSION 5
+ * (6: round 4 -- unet_convT2x2_*_x6; 5: round 4 -- the `_wg` (max_workgroups) entry points of every persistent kernel, unet_standin_collective; 4: round 4 -- the BF16x6 Winograd route: unet_*_x6; 3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
+#define UNET_HIP_ABI_VERSION 6
 int unet_hip_abi_version(void);
 
 /* ---- Conv2D(3x3, 'same', relu) of UNet._conv_layer, UNet/model.py:28-35 (18 instances, :88-134) ------------------ */
@@ -177,6 +177,22 @@ int unet_convT2x2_fwd_stream_stats(const float* x, int ldx, const float* w, cons
                                    int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream);
 int unet_convT2x2_dgrad(const float* dz, int lddz, const float* w, float* dx, int lddx,
                         int N, int H, int W, int Cin, int Cout, void* stream);
+/* forward / data gradient as GEMMs on the bf16 matrix pipe at fp32 grade (BF16x6, csrc/convt_x6.hip; the arithmetic of the unet_*_x6
+ * 3x3 kernels above): needs N*H*W % 128 == 0, Cin % 128 == 0, Cout % 64 == 0 (unet_convT2x2_x6_supported).  W6 = the layer's kernel as
+ * three bf16 pieces per weight in the GEMM's operand layout, unet_convT2x2_weight_transform_x6 mode 0 (forward) / 1 (data gradient),
+ * unet_convT2x2_x6_weight_bytes each, once per optimizer step.  Forward: stat_part nullable -- BatchNorm sums of the output,
+ * (Cout/64) * rows * 128 floats with rows = unet_convT2x2_x6_stats_rows (one per 128-pixel tile and tap), for
+ * unet_bn_train_finalize_partials.  One workgroup per tile: no max_workgroups form. */
+int unet_convT2x2_x6_supported(int N, int H, int W, int Cin, int Cout);
+size_t unet_convT2x2_x6_weight_bytes(int Cin, int Cout);
+int unet_convT2x2_weight_transform_x6(const float* w, void* W6, int Cin, int Cout, int mode, void* stream);
+/* jobs: device array of njobs x 6 int64 = { w, W6, Cin | Cout << 32, first_block, mode, 0 }, first_block = running sum of ceil(4*Cin*Cout/8 / 256) */
+int unet_convT2x2_weight_transform_x6_batch(const void* jobs, int njobs, int total_blocks, void* stream);
+int unet_convT2x2_x6_stats_rows(int N, int H, int W, int Cin, int Cout);
+int unet_convT2x2_fwd_x6(const float* x, int ldx, const void* W6, const float* bias, float* out, int ldo,
+                         int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream);
+int unet_convT2x2_dgrad_x6(const float* dz, int lddz, const void* W6d, float* dx, int lddx,
+                           int N, int H, int W, int Cin, int Cout, void* stream);
 size_t unet_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_convT2x2_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);

@@ -1,0 +1,328 @@
+// 2x2 / stride-2 transposed convolution (UNet._deconv_layer, UNet/model.py:39-46) forward and data gradient as GEMMs on the BF16 matrix
+// pipe at fp32 grade ("BF16x6", see winograd_x6.hip for the arithmetic: every fp32 operand value is exactly h + m + l with three bf16
+// pieces; the six products hh, hm, mh, hl, lh, mm are exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, the dropped ones are
+// below 2^-24 of the product).  The fp32 reference layer:
+//   forward   z[n,2i+a,2j+b,co] = bias[co] + sum_ci x[n,i,j,ci] * W[a,b,co,ci]          GEMM  M = input pixels, K = Cin,      N = 4 taps x Cout
+//   gradient  dx[n,i,j,ci]      = sum_{a,b,co} dz[n,2i+a,2j+b,co] * W[a,b,co,ci]        GEMM  M = input pixels, K = 4 x Cout, N = Cin
+// Unlike the Winograd kernels there is no transform in front of the products, and one staged A value feeds 128 (256) output columns, so
+// the three-piece split is a few vector instructions per 48 (24) MFMAs and the LDS serves 18 (12) fragment reads per 48 (24) MFMAs.
+// Workgroup = 128 pixels x NT columns (NT = 256 or 128), 4 waves as 2 (pixel halves) x 2 (column halves), a wave owns 2 x NB blocks of
+// 32 x 32 (NB = NT / 64) = 32 NB accumulator registers.  K runs in chunks of 16 through two LDS stages (36 / 24 KB each), so two
+// workgroups share a CU and fill each other's stalls: no hand-written instruction stream here.
+//   A stage: [piece 3][pixel 128][16 k bf16] -- fp32 rows loaded one chunk ahead, split in registers, ds_write_b128
+//   B stage: [piece 3][column NT][16 k bf16] -- LDS-DMA, verbatim from the pre-split weights (unet_convT2x2_weight_transform_x6)
+// Rows are 32 bytes; the 16-byte k half sits in slot (half ^ bit 3 of the row): conflict-free ds_read_b128 for the MFMA operand fetch.
+#include "common.h"
+
+namespace {
+
+typedef int cx_i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void cx_lds_void;
+
+struct ConvtX6Args {
+    const float* a;          // forward: x [P][lda]; gradient: dz [N][2H][2W][lda]
+    const uint16_t* b6;      // pre-split weights [K/16][piece 3][Ncols][16 bf16], swizzled
+    const float* bias;       // forward (nullable)
+    float* out;              // forward: [N][2H][2W][ldo]; gradient: dx [P][ldo]
+    float* stat_part;        // forward, nullable: BatchNorm sums of the output, [Cout/64][rows][64][2], rows = 4 * P / 128
+    int lda, ldo, N, H, W, Cin, Cout;
+    int K, Ncols, nct;       // reduction length, GEMM columns, column tiles per pixel tile
+    long P;
+};
+
+__device__ __forceinline__ unsigned cx_hi2(float lo, float hi) {       // { bf16 bits of lo (truncated), of hi }, lo in the low half
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+}
+__device__ __forceinline__ float cx_trunc(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
+
+// 8 fp32 values -> three 16-byte rows of bf16 pieces (exact: v = h + m + l)
+__device__ __forceinline__ void cx_split8(const f32x4& v0, const f32x4& v1, cx_i32x4& h, cx_i32x4& m, cx_i32x4& l) {
+    float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}, a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = t[e] - cx_trunc(t[e]); b[e] = a[e] - cx_trunc(a[e]); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (int)cx_hi2(t[2 * e], t[2 * e + 1]); m[e] = (int)cx_hi2(a[2 * e], a[2 * e + 1]); l[e] = (int)cx_hi2(b[2 * e], b[2 * e + 1]);
+    }
+}
+
+// MODE 0: forward, MODE 1: data gradient.  NB: 32-column blocks per wave (4: 256-column tile, 2: 128-column tile).
+template <int MODE, int NB, bool STATS>
+__device__ __forceinline__ void convt_x6_body(const ConvtX6Args& p) {
+    constexpr int NT = 64 * NB;                                  // columns per workgroup
+    constexpr int ASZ = 3 * 128 * 32, BSZ = 3 * NT * 32, STG = ASZ + BSZ;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv & 1, wn = wv >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ct = blockIdx.x % p.nct;
+    const long pt = blockIdx.x / p.nct;
+    const long p0 = pt * 128;
+    const int n0 = ct * NT;
+
+    // ---- A staging: thread = (pixel row, k half); 8 consecutive k per chunk
+    const int arow = tid >> 1, akh = tid & 1;
+    const float* abase[MODE == 0 ? 1 : 4];
+    {
+        const long pp = p0 + arow;
+        if constexpr (MODE == 0) abase[0] = p.a + pp * p.lda + akh * 8;
+        else {
+            // input pixel pp = q * W + j (q = image row over the whole batch) -> output pixel (2i+a, 2j+b) has index 4 W q + 2 j + a 2W + b
+            const unsigned q = (unsigned)pp / (unsigned)p.W, j = (unsigned)pp - q * (unsigned)p.W;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                abase[t] = p.a + ((long)4 * p.W * q + 2 * j + (t >> 1) * 2 * p.W + (t & 1)) * p.lda + akh * 8;
+        }
+    }
+    auto a_ptr = [&](int c) -> const float* {
+        if constexpr (MODE == 0) return abase[0] + c * 16;
+        else { const int k0 = c * 16; const int t = k0 / p.Cout; return abase[t] + (k0 - t * p.Cout); }
+    };
+    const unsigned a_wr = (unsigned)(arow * 32 + 16 * (akh ^ ((arow >> 3) & 1)));
+    // ---- B staging: LDS-DMA, NT * 96 bytes per chunk = 3 NT / 32 pieces of 1 KB, spread over the four waves
+    constexpr int BPIECES = 3 * NT / 32, BPW = BPIECES / 4;      // 24 / 6 (NT 256), 12 / 3 (NT 128)
+    const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(p.b6);
+    const size_t bchunk = (size_t)3 * p.Ncols * 32;              // bytes of one 16-k chunk of B
+    auto b_dma = [&](int c, int stage) {
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int q = wv * BPW + j;                          // piece index in the stage: [bf16 piece][NT / 32 KB-pieces]
+            const int pc = q / (NT / 32), sub = q % (NT / 32);
+            const unsigned char* src = bsrc + (size_t)c * bchunk + ((size_t)pc * p.Ncols + n0) * 32 + sub * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (cx_lds_void*)(smem + stage * STG + ASZ + q * 1024), 16, 0, 0);
+        }
+    };
+    // ---- MFMA operand reads
+    unsigned a_rd[2], b_rd[NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) { const int r = wm * 64 + mb * 32 + li; a_rd[mb] = (unsigned)(r * 32 + 16 * (lh ^ ((r >> 3) & 1))); }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { const int r = wn * (NT / 2) + nb * 32 + li; b_rd[nb] = (unsigned)(ASZ + r * 32 + 16 * (lh ^ ((r >> 3) & 1))); }
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+    const int nchunks = p.K / 16;
+    f32x4 v0, v1;
+    {
+        const float* ap = a_ptr(0);
+        v0 = *reinterpret_cast<const f32x4*>(ap); v1 = *reinterpret_cast<const f32x4*>(ap + 4);
+        b_dma(0, 0);
+        cx_i32x4 h, m, l;
+        cx_split8(v0, v1, h, m, l);
+        *reinterpret_cast<cx_i32x4*>(smem + a_wr) = h;
+        *reinterpret_cast<cx_i32x4*>(smem + 128 * 32 + a_wr) = m;
+        *reinterpret_cast<cx_i32x4*>(smem + 2 * 128 * 32 + a_wr) = l;
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int s = c & 1;
+        const bool more = c + 1 < nchunks;
+        if (more) {
+            const float* ap = a_ptr(c + 1);
+            v0 = *reinterpret_cast<const f32x4*>(ap); v1 = *reinterpret_cast<const f32x4*>(ap + 4);
+            b_dma(c + 1, s ^ 1);
+        }
+        const unsigned char* st = smem + s * STG;
+        cx_bf16x8 af[2][3];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) af[mb][k] = *reinterpret_cast<const cx_bf16x8*>(st + k * 128 * 32 + a_rd[mb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            cx_bf16x8 bf[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bf[k] = *reinterpret_cast<const cx_bf16x8*>(st + k * NT * 32 + b_rd[nb]);
+            // piece pairs (data, weight), smallest products first: l h, h l, m m, m h, h m, h h; the two pixel blocks alternate
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][PA[q]], bf[PB[q]], acc[mb][nb], 0, 0, 0);
+        }
+        if (more) {
+            cx_i32x4 h, m, l;
+            cx_split8(v0, v1, h, m, l);
+            unsigned char* nx = smem + (s ^ 1) * STG;
+            *reinterpret_cast<cx_i32x4*>(nx + a_wr) = h;
+            *reinterpret_cast<cx_i32x4*>(nx + 128 * 32 + a_wr) = m;
+            *reinterpret_cast<cx_i32x4*>(nx + 2 * 128 * 32 + a_wr) = l;
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[mb][nb][i]: pixel row = wm*64 + mb*32 + 8*(i/4) + 4*lh + i%4, column = n0 + wn*NT/2 + nb*32 + li
+    float ssum[NB], ssq[NB];
+    int tap[NB], cho[NB]; float bia[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        ssum[nb] = 0.f; ssq[nb] = 0.f;
+        const int n = n0 + wn * (NT / 2) + nb * 32 + li;
+        if constexpr (MODE == 0) { tap[nb] = n / p.Cout; cho[nb] = n - tap[nb] * p.Cout; bia[nb] = p.bias ? p.bias[cho[nb]] : 0.f; }
+        else { tap[nb] = 0; cho[nb] = n; bia[nb] = 0.f; }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        // the block's 16 rows of this lane are pixels base + {0..3, 8..11, 16..19, 24..27}; forward: output pixel index of input pixel
+        // pp = q W + j is 4 W q + 2 j (+ a 2W + b per tap): one division for the base, the rest by stepping
+        const unsigned base = (unsigned)(p0 + wm * 64 + mb * 32 + 4 * lh);
+        const unsigned q0 = base / (unsigned)p.W, j0 = base - q0 * (unsigned)p.W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned d = 8 * (i >> 2) + (i & 3);
+            if constexpr (MODE == 0) {
+                unsigned q = q0, j = j0 + d;
+                while (j >= (unsigned)p.W) { j -= (unsigned)p.W; ++q; }
+                const long obase = (long)4 * p.W * q + 2 * j;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float y = acc[mb][nb][i] + bia[nb];
+                    p.out[(obase + (tap[nb] >> 1) * 2 * p.W + (tap[nb] & 1)) * p.ldo + cho[nb]] = y;
+                    if constexpr (STATS) { ssum[nb] += y; ssq[nb] = fmaf(y, y, ssq[nb]); }
+                }
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) p.out[(long)(base + d) * p.ldo + cho[nb]] = acc[mb][nb][i];
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // per column: the two lane halves, then the two pixel halves of the workgroup; one row of partials per (pixel tile, tap, 64-channel block)
+        float* red = reinterpret_cast<float*>(smem);             // [wm 2][NT][2] floats (the stages are dead: the loop ended with a barrier)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float s2 = ssum[nb] + __shfl_xor(ssum[nb], 32), q2 = ssq[nb] + __shfl_xor(ssq[nb], 32);
+            if (lh == 0) { const int col = wn * (NT / 2) + nb * 32 + li; red[(wm * NT + col) * 2] = s2; red[(wm * NT + col) * 2 + 1] = q2; }
+        }
+        __syncthreads();
+        if (tid < NT) {
+            const int n = n0 + tid, t = n / p.Cout, co = n - t * p.Cout;
+            const long rows = 4 * (p.P / 128);
+            float2 o; o.x = red[tid * 2] + red[(NT + tid) * 2]; o.y = red[tid * 2 + 1] + red[(NT + tid) * 2 + 1];
+            *reinterpret_cast<float2*>(p.stat_part + (((size_t)(co >> 6) * rows + (pt * 4 + t)) * 64 + (co & 63)) * 2) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void convt_x6_fwd_kernel(ConvtX6Args p) { convt_x6_body<0, 4, false>(p); }
+__global__ __launch_bounds__(256, 2) void convt_x6_fwd_stats_kernel(ConvtX6Args p) { convt_x6_body<0, 4, true>(p); }
+__global__ __launch_bounds__(256, 2) void convt_x6_dgrad_kernel_256(ConvtX6Args p) { convt_x6_body<1, 4, false>(p); }
+__global__ __launch_bounds__(256, 2) void convt_x6_dgrad_kernel_128(ConvtX6Args p) { convt_x6_body<1, 2, false>(p); }
+
+// Weights W [tap 4][Cout][Cin] (Keras Conv2DTranspose layout, UNet/model.py:41) = Wflat [R = 4 Cout][Cin]  ->  B [K/16][piece 3][Ncols][16 bf16]
+//   mode 0 (forward):       B[k = ci][n = tap * Cout + co] = Wflat[n][k]
+//   mode 1 (data gradient): B[k = tap * Cout + co][n = ci] = Wflat[k][n]
+// item = (16-k chunk, column n, k half): lane order half, then n -> a wave's stores cover contiguous memory
+__device__ __forceinline__ void convt_x6_weight_item(const float* __restrict__ w, uint16_t* __restrict__ b6, int Cin, int Cout, int mode, long it) {
+    const int R = 4 * Cout;
+    const int K = mode ? R : Cin, Nc = mode ? Cin : R;
+    if (it >= (long)K * Nc / 8) return;
+    const int half = (int)(it & 1), n = (int)((it >> 1) % Nc), c16 = (int)((it >> 1) / Nc);
+    const int k0 = c16 * 16 + half * 8;
+    f32x4 v0, v1;
+    if (mode == 0) { const float* s = w + (size_t)n * Cin + k0; v0 = *reinterpret_cast<const f32x4*>(s); v1 = *reinterpret_cast<const f32x4*>(s + 4); }
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] = w[(size_t)(k0 + e) * Cin + n]; v1[e] = w[(size_t)(k0 + 4 + e) * Cin + n]; }
+    }
+    cx_i32x4 h, m, l;
+    cx_split8(v0, v1, h, m, l);
+    uint16_t* o = b6 + (((size_t)c16 * 3) * Nc + n) * 16 + 8 * (half ^ ((n >> 3) & 1));
+    *reinterpret_cast<cx_i32x4*>(o) = h;
+    *reinterpret_cast<cx_i32x4*>(o + (size_t)Nc * 16) = m;
+    *reinterpret_cast<cx_i32x4*>(o + (size_t)2 * Nc * 16) = l;
+}
+
+// jobs[j] = { w, W6, Cin | Cout << 32, first block, mode, 0 }: both directions of every transposed conv in ONE launch
+__global__ __launch_bounds__(256) void convt_x6_weight_batch_kernel(const long long* __restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)jobs[(j + 1) * 6 + 3] <= (int)blockIdx.x) ++j;
+    convt_x6_weight_item(reinterpret_cast<const float*>(jobs[j * 6 + 0]), reinterpret_cast<uint16_t*>(jobs[j * 6 + 1]),
+                         (int)(jobs[j * 6 + 2] & 0xffffffffll), (int)(jobs[j * 6 + 2] >> 32), (int)jobs[j * 6 + 4],
+                         ((long)blockIdx.x - (int)jobs[j * 6 + 3]) * 256 + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void convt_x6_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ b6, int Cin, int Cout, int mode) {
+    convt_x6_weight_item(w, b6, Cin, Cout, mode, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+bool convt_x6_shape_ok(int N, int H, int W, int Cin, int Cout) {
+    const long P = (long)N * H * W;
+    return N > 0 && H > 0 && W > 0 && Cin % 128 == 0 && Cout % 64 == 0 && P % 128 == 0 && Cin <= 4096 && Cout <= 4096 &&
+           4 * P < ((long)1 << 31);
+}
+
+}  // namespace
+
+// 1 when the BF16x6 transposed-conv kernels take the layer (N, H, W: INPUT dims): N*H*W a multiple of the 128-pixel tile, Cin % 128 == 0
+// (the data gradient's column tile), Cout % 64 == 0
+extern "C" int unet_convT2x2_x6_supported(int N, int H, int W, int Cin, int Cout) { return convt_x6_shape_ok(N, H, W, Cin, Cout) ? 1 : 0; }
+
+// bytes of one direction's weight operand (three bf16 pieces per weight)
+extern "C" size_t unet_convT2x2_x6_weight_bytes(int Cin, int Cout) { return (size_t)4 * Cin * Cout * 3 * sizeof(uint16_t); }
+
+// mode 0: forward operand, mode 1: data-gradient operand; w = the layer's fp32 kernel [2][2][Cout][Cin]
+extern "C" int unet_convT2x2_weight_transform_x6(const float* w, void* W6, int Cin, int Cout, int mode, void* stream) {
+    UNET_CHECK_ARG(w && W6 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0 && (mode == 0 || mode == 1) && unet_aligned16(w) && unet_aligned16(W6));
+    const long items = (long)4 * Cin * Cout / 8;
+    convt_x6_weight_kernel<<<(unsigned)((items + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, (uint16_t*)W6, Cin, Cout, mode);
+    return UNET_LAUNCH_STATUS();
+}
+
+// jobs: device array of njobs x 6 int64 = { w, W6, Cin | Cout << 32, first_block, mode, 0 }, first_block = running sum of ceil(4*Cin*Cout/8 / 256)
+extern "C" int unet_convT2x2_weight_transform_x6_batch(const void* jobs, int njobs, int total_blocks, void* stream) {
+    UNET_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0);
+    convt_x6_weight_batch_kernel<<<dim3((unsigned)total_blocks), 256, 0, (hipStream_t)stream>>>((const long long*)jobs, njobs);
+    return UNET_LAUNCH_STATUS();
+}
+
+// rows of statistics partials per 64-channel block the forward kernel writes: one per (128-pixel tile, tap)
+extern "C" int unet_convT2x2_x6_stats_rows(int N, int H, int W, int Cin, int Cout) {
+    return convt_x6_shape_ok(N, H, W, Cin, Cout) ? (int)(4 * ((long)N * H * W / 128)) : 0;
+}
+
+// Forward: the arguments of unet_convT2x2_fwd_stream_stats with W6 (mode 0) in place of w; stat_part nullable ((Cout/64) * rows * 128 floats,
+// rows = unet_convT2x2_x6_stats_rows; finish with unet_bn_train_finalize_partials)
+extern "C" int unet_convT2x2_fwd_x6(const float* x, int ldx, const void* W6, const float* bias, float* out, int ldo,
+                                    int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream) {
+    UNET_CHECK_ARG(x && W6 && out && convt_x6_shape_ok(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && unet_aligned16(x) && unet_aligned16(W6) && (!stat_part || unet_aligned16(stat_part)));
+    ConvtX6Args a{};
+    a.a = x; a.b6 = (const uint16_t*)W6; a.bias = bias; a.out = out; a.stat_part = stat_part; a.lda = ldx; a.ldo = ldo;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.P = (long)N * H * W;
+    a.K = Cin; a.Ncols = 4 * Cout; a.nct = a.Ncols / 256;
+    const long blocks = (a.P / 128) * a.nct;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
+    if (stat_part) {
+        if (stat_bytes < (size_t)(Cout / 64) * unet_convT2x2_x6_stats_rows(N, H, W, Cin, Cout) * 128 * sizeof(float)) return UNET_ENOSPC;
+        convt_x6_fwd_stats_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+    } else convt_x6_fwd_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+    return UNET_LAUNCH_STATUS();
+}
+
+// Data gradient: the arguments of unet_convT2x2_dgrad with W6d (mode 1) in place of w
+extern "C" int unet_convT2x2_dgrad_x6(const float* dz, int lddz, const void* W6d, float* dx, int lddx,
+                                      int N, int H, int W, int Cin, int Cout, void* stream) {
+    UNET_CHECK_ARG(dz && W6d && dx && convt_x6_shape_ok(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(W6d));
+    ConvtX6Args a{};
+    a.a = dz; a.b6 = (const uint16_t*)W6d; a.out = dx; a.lda = lddz; a.ldo = lddx;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.P = (long)N * H * W;
+    a.K = 4 * Cout; a.Ncols = Cin;
+    const bool wide = Cin % 256 == 0;
+    a.nct = Cin / (wide ? 256 : 128);
+    const long blocks = (a.P / 128) * a.nct;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
+    if (wide) convt_x6_dgrad_kernel_256<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+    else      convt_x6_dgrad_kernel_128<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+    return UNET_LAUNCH_STATUS();
+}

@@ -118,6 +118,7 @@ class Engine:
         self.view = {}
         self._fused_U, self._fused_dirty = None, True
         self._x6_U, self._x6_dirty = None, True
+        self._ctx6_W, self._ctx6_dirty = None, True
         self._bf16_W, self._bf16_dirty = {}, True
         self.bnbwd_part = {}
         self.init_parameters(seed)
@@ -251,6 +252,7 @@ class Engine:
                 nb = self.L.unet_winograd_x6_weight_bytes(cin, cout)
                 self._x6_U[n] = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
             self._x6_dirty = True
+            self._ctx6_dirty = True
         if self._x6_dirty:
             skip = frozenset(n for n in self._x6_U if self.pl is not None and self.pl.layer[n].x_on_load)
             job = self._x6_jobs.get(skip)
@@ -272,10 +274,33 @@ class Engine:
             self._x6_fwd_valid.add(name)
         return self._x6_U[name]
 
+    def _convt_x6_kernels(self, name):
+        """(forward operand, data-gradient operand) of a transposed conv on the BF16x6 route: the layer's kernel as three bf16 pieces per
+        weight in the GEMM operand layouts (csrc/convt_x6.hip); all layers and both directions in one launch after a parameter change."""
+        if self._ctx6_W is None:
+            self._ctx6_W, rows, blk = {}, [], 0
+            for n, kind, cin, cout in self.layers:
+                if kind != "deconv" or cin % 16 or cout % 16:
+                    continue
+                nb = self.L.unet_convT2x2_x6_weight_bytes(cin, cout)
+                u = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
+                self._ctx6_W[n] = u
+                for mode in (0, 1):
+                    rows.append([self.p[n + "/kernel"].data_ptr(), u[mode].data_ptr(), cin | (cout << 32), blk, mode, 0])
+                    blk += (4 * cin * cout // 8 + 255) // 256
+            self._ctx6_jobs = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+            self._ctx6_blocks = blk
+            self._ctx6_dirty = True
+        if self._ctx6_dirty:
+            self.L.unet_convT2x2_weight_transform_x6_batch(_p(self._ctx6_jobs), self._ctx6_jobs.shape[0], self._ctx6_blocks, self._stream())
+            self._ctx6_dirty = False
+        return self._ctx6_W[name]
+
     def parameters_changed(self):
         """theta was written from outside (broadcast, checkpoint): every cached transform of the kernels is stale."""
         self._fused_dirty = True
         self._x6_dirty = True
+        self._ctx6_dirty = True
         self._bf16_dirty = True
         self._eval_folded.clear(); self._eval_coefs.clear()
 
@@ -355,6 +380,12 @@ class Engine:
             stat_part = part(rows)
             L.unet_convT2x2_fwd_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
                                      int(r16), n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+            fused_stats = (stat_part, rows) if rows > 0 else None
+        elif lp.fwd == "convt_x6":                                              # GEMM on the bf16 matrix pipe at fp32 grade (csrc/convt_x6.hip)
+            rows = L.unet_convT2x2_x6_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
+            stat_part = part(rows)
+            L.unet_convT2x2_fwd_x6(_p(x), _ld(x), _p(self._convt_x6_kernels(name)[0]), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
+                                   _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
             fused_stats = (stat_part, rows) if rows > 0 else None
         elif lp.fwd == "convt_stream" and _ld(x) <= 4096:                       # persistent stream kernel
             rows = L.unet_convT2x2_fwd_stream_stats_rows_wg(n, h, w, cin, cout, cap) if lp.fwd_stats else 0
@@ -694,6 +725,8 @@ class Engine:
             if lp.dgrad == "convt_bf16":
                 L.unet_convT2x2_dgrad_bf16(_p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx16), n, hi, wi, cin, cout,
                                            _p(r_prev), ldr_prev, r16_prev, _p(part), nbp, st)
+            elif lp.dgrad == "convt_x6":
+                L.unet_convT2x2_dgrad_x6(_p(dz), cout, _p(self._convt_x6_kernels(name)[1]), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "deconv":
                 L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
@@ -770,6 +803,7 @@ class Engine:
         self.iterations += 1
         self._fused_dirty = True
         self._x6_dirty = True
+        self._ctx6_dirty = True
         self._bf16_dirty = True
         self._eval_folded.clear(); self._eval_coefs.clear()
         t = self.iterations

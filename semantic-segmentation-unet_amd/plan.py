@@ -28,7 +28,7 @@ class EngineOptions:
     variables ONCE at construction -- the C library itself reads no environment)."""
     compute_dtype: str = "fp32"       # "fp32": the reference's arithmetic | "bf16": BASELINE config 4 (bf16 contractions, fp32 master weights)
     conv_route: str = "fused"         # 3x3 forward / data gradient: "fused" = fused Winograd F(2x2,3x3) where it applies | "direct" = implicit GEMM
-    fp32_matrix: str = "bf16x6"       # how the fused Winograd forward / data gradient multiply in fp32 mode: "bf16x6" = fp32 operands as three bf16
+    fp32_matrix: str = "bf16x6"       # how the fused Winograd and transposed-conv forward / data gradient multiply in fp32 mode: "bf16x6" = fp32 operands as three bf16
     #                                   pieces, six products on the bf16 matrix pipe, fp32 accumulation (fp32-grade; csrc/winograd_x6.hip) where
     #                                   the shape allows | "native" = v_mfma_f32_32x32x2_f32 everywhere (csrc/winograd.hip)
     wgrad_route: str = "fused"        # 3x3 weight gradient: "fused" Winograd | "direct"
@@ -103,7 +103,7 @@ class LayerPlan:
     wi: int
     ho: int
     wo: int
-    fwd: str = ""                  # conv3: bf16 | winograd | mfma | direct;  deconv: convt_bf16 | convt_stream | convt_igemm;  conv1: conv1x1
+    fwd: str = ""                  # conv3: bf16 | winograd | mfma | direct;  deconv: convt_bf16 | convt_x6 | convt_stream | convt_igemm;  conv1: conv1x1
     dgrad: str = ""                # same families; "none" = not computed in a training step (first layer)
     wgrad: str = ""
     fwd_x6: bool = False           # fwd == "winograd": the BF16x6 kernel (fp32-grade products on the bf16 matrix pipe) instead of the fp32-MFMA one
@@ -228,8 +228,10 @@ def build_plan(opt, number_channels, number_classes, n, h, w, training, want_gra
         elif p.kind == "deconv":
             b16 = (bf and n * p.hi * p.wi * 4 * p.cout * 4 < two_gib and n * p.hi * p.wi * p.cin * 4 < two_gib
                    and L.unet_convT2x2_bf16_supported(n, p.hi, p.wi, p.cin, p.cout) == 1)
-            p.fwd = "convt_bf16" if b16 else "convt_stream" if L.unet_convT2x2_fwd_stream_supported(n, p.hi, p.wi, p.cin, p.cout) == 1 else "convt_igemm"
-            p.dgrad = "convt_bf16" if b16 else "convt_igemm"
+            x6 = (not b16) and opt.fp32_matrix == "bf16x6" and L.unet_convT2x2_x6_supported(n, p.hi, p.wi, p.cin, p.cout) == 1
+            p.fwd = ("convt_bf16" if b16 else "convt_x6" if x6 else
+                     "convt_stream" if L.unet_convT2x2_fwd_stream_supported(n, p.hi, p.wi, p.cin, p.cout) == 1 else "convt_igemm")
+            p.dgrad = "convt_bf16" if b16 else "convt_x6" if x6 else "convt_igemm"
             p.wgrad = "convt_bf16" if (b16 and L.unet_convT2x2_wgrad_bf16_supported(n, p.hi, p.wi, p.cin, p.cout) == 1) else "convt"
         else:
             p.fwd = p.dgrad = p.wgrad = "conv1x1"
@@ -255,6 +257,8 @@ def build_plan(opt, number_channels, number_classes, n, h, w, training, want_gra
             p.fwd_stats = L.unet_conv3x3_fwd_direct_stats_rows(n, p.ho, p.wo, p.cin, p.cout) > 0
         elif p.fwd == "convt_bf16":
             p.fwd_stats = L.unet_convT2x2_bf16_stats_rows(n, p.hi, p.wi, p.cin, p.cout, 0) > 0
+        elif p.fwd == "convt_x6":
+            p.fwd_stats = L.unet_convT2x2_x6_stats_rows(n, p.hi, p.wi, p.cin, p.cout) > 0
         elif p.fwd == "convt_stream":
             p.fwd_stats = L.unet_convT2x2_fwd_stream_stats_rows_wg(n, p.hi, p.wi, p.cin, p.cout, opt.cap) > 0
 

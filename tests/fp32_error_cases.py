@@ -116,7 +116,7 @@ def run_case(L, family, shape, seed, kind="normal"):
             nb = L.unet_conv3x3_wgrad_mfma_workspace(n, h, w_, ci, co); ws = _ws(nb)
             L.unet_conv3x3_wgrad_mfma(P(x), ci, P(dz), co, P(dw), n, h, w_, ci, co, P(ws), nb, ST())
         return errs(dw, ref_wgrad(x, dz))
-    if family in ("convt_fwd", "convt_fwd_stream", "convt_dgrad", "convt_wgrad"):
+    if family in ("convt_fwd", "convt_fwd_stream", "convt_dgrad", "convt_wgrad", "convt_x6_fwd", "convt_x6_dgrad"):
         g = torch.Generator(device=DEV).manual_seed(seed + 1)
         wT = torch.randn(2, 2, co, ci, device=DEV, generator=g) / float(np.sqrt(ci))
         if family in ("convt_fwd", "convt_fwd_stream"):
@@ -125,6 +125,18 @@ def run_case(L, family, shape, seed, kind="normal"):
             fn(P(x), ci, P(wT), P(b), P(out), co, n, h, w_, ci, co, ST())
             return errs(out, ref_convt(x, wT, b))
         dzT = torch.randn(n, 2 * h, 2 * w_, co, device=DEV, generator=g)
+        if family in ("convt_x6_fwd", "convt_x6_dgrad"):
+            mode = 0 if family == "convt_x6_fwd" else 1
+            u = torch.empty(L.unet_convT2x2_x6_weight_bytes(ci, co), dtype=torch.uint8, device=DEV)
+            L.unet_convT2x2_weight_transform_x6(P(wT), P(u), ci, co, mode, ST())
+            if mode == 0:
+                out = torch.empty(n, 2 * h, 2 * w_, co, device=DEV)
+                L.unet_convT2x2_fwd_x6(P(x), ci, P(u), P(b), P(out), co, n, h, w_, ci, co, None, 0, ST())
+                return errs(out, ref_convt(x, wT, b))
+            dx = torch.empty(n, h, w_, ci, device=DEV)
+            L.unet_convT2x2_dgrad_x6(P(dzT), co, P(u), P(dx), ci, n, h, w_, ci, co, ST())
+            ref = torch.nn.functional.conv2d(dzT.double().permute(0, 3, 1, 2), wT.double().permute(3, 2, 0, 1), None, stride=2).permute(0, 2, 3, 1)
+            return errs(dx, ref)
         if family == "convt_dgrad":
             dx = torch.empty(n, h, w_, ci, device=DEV)
             L.unet_convT2x2_dgrad(P(dzT), co, P(wT), P(dx), ci, n, h, w_, ci, co, ST())
@@ -150,6 +162,7 @@ CASES = [
     ("mfma_dgrad", (2, 8, 32, 64, 64), 1), ("mfma_wgrad", (2, 8, 32, 64, 64), 1),
     ("convt_fwd", (2, 4, 32, 128, 64), 1), ("convt_fwd_stream", (2, 8, 16, 128, 128), 1), ("convt_fwd_stream", (4, 8, 16, 64, 192), 2),
     ("convt_dgrad", (2, 4, 32, 128, 64), 1), ("convt_wgrad", (2, 4, 32, 128, 64), 1),
+    ("convt_x6_fwd", (2, 4, 32, 128, 64), 1), ("convt_x6_fwd", (2, 8, 16, 256, 128), 2), ("convt_x6_dgrad", (2, 4, 32, 128, 64), 1), ("convt_x6_dgrad", (2, 8, 16, 256, 128), 2),
 ]
 
 
