@@ -11,9 +11,9 @@ Two things are read off a run (scripts/overlap_probe.py prints the whole table -
     its first workgroup has drained its tiles;
   * the step time with the stand-ins resident against the same step without them: what the resident workgroups cost the backward pass
     (a persistent grid launched while 32 CUs are held runs its last workgroups as a second wave unless it is capped).
-Measured (MI355X, profiles/r04_overlap_standin.txt): capped at 224, every stand-in gets its CUs within 0.02-0.04 ms; uncapped, it waits
-up to one persistent kernel (0.46-0.49 ms in the fp32 step) -- but the capped STEP is slower than the uncapped step with the same
-stand-ins resident in every cell of the table (fp32 +0.9 .. +2.6 ms, bf16 +0.7 .. +1.0 ms): the cap costs every CU-bound kernel 1/8 of
+Measured (MI355X, profiles/r04_overlap_standin.txt): capped at 224, every stand-in gets its CUs within 0.01-0.08 ms; uncapped, it waits
+up to one persistent kernel (0.24-0.47 ms in the fp32 step) -- but the capped STEP is slower than the uncapped step with the same
+stand-ins resident in 11 of the table's 12 cells (by 0.7 .. 1.0 ms; the twelfth 0.2 ms the other way): the cap costs every CU-bound kernel 1/8 of
 the chip all the time, the resident stand-in costs an uncapped grid a short second wave some of the time.  So `DataParallel` does NOT cap
 by default (EngineOptions.max_workgroups stays an explicit option for an N > 1 RCCL measurement to decide); the test pins both halves."""
 import ctypes
