@@ -178,7 +178,7 @@ int unet_convT2x2_fwd_stream_stats(const float* x, int ldx, const float* w, cons
 int unet_convT2x2_dgrad(const float* dz, int lddz, const float* w, float* dx, int lddx,
                         int N, int H, int W, int Cin, int Cout, void* stream);
 /* forward / data gradient as GEMMs on the bf16 matrix pipe at fp32 grade (BF16x6, csrc/convt_x6.hip; the arithmetic of the unet_*_x6
- * 3x3 kernels above): needs N*H*W % 128 == 0, Cin % 128 == 0, Cout % 64 == 0 (unet_convT2x2_x6_supported).  W6 = the layer's kernel as
+ * 3x3 kernels above): need N*H*W % 128 == 0, Cin % 128 == 0, Cout % 64 == 0 (unet_convT2x2_x6_supported).  W6 = the layer's kernel as
  * three bf16 pieces per weight in the GEMM's operand layout, unet_convT2x2_weight_transform_x6 mode 0 (forward) / 1 (data gradient),
  * unet_convT2x2_x6_weight_bytes each, once per optimizer step.  Forward: stat_part nullable -- BatchNorm sums of the output,
  * (Cout/64) * rows * 128 floats with rows = unet_convT2x2_x6_stats_rows (one per 128-pixel tile and tap), for
@@ -193,6 +193,11 @@ int unet_convT2x2_fwd_x6(const float* x, int ldx, const void* W6, const float* b
                          int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream);
 int unet_convT2x2_dgrad_x6(const float* dz, int lddz, const void* W6d, float* dx, int lddx,
                            int N, int H, int W, int Cin, int Cout, void* stream);
+/* weight gradient on the same arithmetic: both operands are activations, split into three bf16 pieces inside the kernel; split-K partials
+ * in ws (unet_convT2x2_wgrad_x6_workspace bytes), reduced in split order */
+size_t unet_convT2x2_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout);
+int unet_convT2x2_wgrad_x6(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                           int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 size_t unet_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
 int unet_convT2x2_wgrad(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);

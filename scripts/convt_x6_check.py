@@ -47,15 +47,21 @@ for (n, h, ci, co, timed) in [(2, 8, 128, 64, False), (1, 16, 256, 128, False), 
     fn = lambda: L.unet_convT2x2_fwd_stream(P(x), ci, P(wT), P(b), P(yn), co, n, h, w_, ci, co, ST()) if L.unet_convT2x2_fwd_stream_supported(n, h, w_, ci, co) else L.unet_convT2x2_fwd(P(x), ci, P(wT), P(b), P(yn), co, n, h, w_, ci, co, ST())
     g6 = lambda: L.unet_convT2x2_dgrad_x6(P(dz), co, P(W6d), P(d6), ci, n, h, w_, ci, co, ST())
     gn = lambda: L.unet_convT2x2_dgrad(P(dz), co, P(wT), P(dn), ci, n, h, w_, ci, co, ST())
-    f6(); fn(); g6(); gn(); torch.cuda.synchronize()
+    nbw = L.unet_convT2x2_wgrad_x6_workspace(n, h, w_, ci, co); ws6 = torch.empty(nbw + 256, dtype=torch.uint8, device=DEV)
+    nbn = L.unet_convT2x2_wgrad_workspace(n, h, w_, ci, co); wsn = torch.empty(nbn + 256, dtype=torch.uint8, device=DEV)
+    w6 = torch.full((2, 2, co, ci), 7.0, device=DEV); wn = torch.full_like(w6, 7.0)
+    h6 = lambda: L.unet_convT2x2_wgrad_x6(P(x), ci, P(dz), co, P(w6), n, h, w_, ci, co, P(ws6), nbw, ST())
+    hn = lambda: L.unet_convT2x2_wgrad(P(x), ci, P(dz), co, P(wn), n, h, w_, ci, co, P(wsn), nbn, ST())
+    f6(); fn(); g6(); gn(); h6(); hn(); torch.cuda.synchronize()
+    refw = torch.einsum("nyaxbk,nyxc->abkc", dz.double().reshape(n, h, 2, w_, 2, co), x.double())
     sums = part.view(co // 64, rows, 64, 2).double().sum(1).reshape(co, 2)
     rs = ref.reshape(-1, co).sum(0); rq = ref.reshape(-1, co).pow(2).sum(0)
     se = float((sums[:, 0] - rs).abs().max() / rs.abs().max()), float((sums[:, 1] - rq).abs().max() / rq.abs().max())
-    row = "%-24s fwd x6 max %.2e rms %.2e | native max %.2e rms %.2e || dgrad x6 max %.2e rms %.2e | native max %.2e rms %.2e || sums %.1e %.1e" % (
-        (str((n, h, w_, ci, co)),) + errs(y6, ref) + errs(yn, ref) + errs(d6, refd) + errs(dn, refd) + se)
+    row = "%-24s fwd x6 max %.2e rms %.2e | native max %.2e rms %.2e || dgrad x6 max %.2e rms %.2e | native max %.2e rms %.2e || wgrad x6 max %.2e rms %.2e | native max %.2e rms %.2e || sums %.1e %.1e" % (
+        (str((n, h, w_, ci, co)),) + errs(y6, ref) + errs(yn, ref) + errs(d6, refd) + errs(dn, refd) + errs(w6, refw) + errs(wn, refw) + se)
     if timed:
         fs = lambda: L.unet_convT2x2_fwd_stream_stats(P(x), ci, P(wT), P(b), P(yn), co, n, h, w_, ci, co, P(torch.empty((co // 64) * max(1, L.unet_convT2x2_fwd_stream_stats_rows(n, h, w_, ci, co)) * 128, device=DEV)), (co // 64) * L.unet_convT2x2_fwd_stream_stats_rows(n, h, w_, ci, co) * 512, ST())
         pn = torch.empty((co // 64) * L.unet_convT2x2_fwd_stream_stats_rows(n, h, w_, ci, co) * 128, device=DEV)
         fs = lambda: L.unet_convT2x2_fwd_stream_stats(P(x), ci, P(wT), P(b), P(yn), co, n, h, w_, ci, co, P(pn), pn.numel() * 4, ST())
-        row += " || ms fwd+sums x6 %.3f native %.3f | dgrad x6 %.3f native %.3f" % (timeit(f6), timeit(fs), timeit(g6), timeit(gn))
+        row += " || ms fwd+sums x6 %.3f native %.3f | dgrad x6 %.3f native %.3f | wgrad x6 %.3f native %.3f" % (timeit(f6), timeit(fs), timeit(g6), timeit(gn), timeit(h6), timeit(hn))
     print(row, flush=True)

@@ -18,6 +18,7 @@ namespace {
 
 typedef int cx_i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned cx_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void cx_lds_void;
 
 struct ConvtX6Args {
@@ -255,6 +256,152 @@ __global__ __launch_bounds__(256) void convt_x6_weight_kernel(const float* __res
     convt_x6_weight_item(w, b6, Cin, Cout, mode, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------------------
+//   dW[a,b,co,ci] = sum_{n,i,j} dz[n,2i+a,2j+b,co] * x[n,i,j,ci]:   per tap a GEMM  M = co, N = ci, K = input pixels, in BF16x6.
+// Both operands are activations: both are split into three bf16 pieces in registers and staged in their NATURAL [pixel][channel] order;
+// the MFMA operands (8 consecutive pixels of one channel per lane) come out of ds_read_b64_tr_b16, gfx950's transposing LDS read
+// (a 16-lane group reads a 4-pixel x 16-channel block and each lane receives one channel's four pixels).  Row pitches carry 64 bytes
+// of padding (x: 128 channels -> 320 B, dz: 64 channels -> 192 B) so that the four pixel rows of a block start 16 banks apart.
+// Workgroup = 64 co x 128 ci x 4 taps, wave = one tap (2 x 4 blocks of 32 x 32 = 128 accumulator registers), persistent over a contiguous
+// range of 16-pixel chunks (split-K: partials [split][tap][co][ci] -> fixed-order reduction).  One 51 KB LDS stage; the next chunk's
+// rows are loaded into registers before the MFMAs of this one and written behind them; two workgroups per CU overlap each other's barriers.
+typedef short cx_s16x4 __attribute__((ext_vector_type(4)));
+typedef short cx_s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) cx_s16x4 cx_lds_s16x4;
+
+struct ConvtWgX6Args {
+    const float* x; const float* dz; float* out;   // out: dw (splits == 1) or the split-K workspace
+    int ldx, lddz, N, H, W, Cin, Cout;
+    int nco, nci, splits;
+    long P, chunks;                                  // input pixels, 16-pixel chunks (P / 16)
+};
+
+constexpr int kWgXP = 320, kWgZP = 192;                          // row pitches of the x (128 channels) and dz (64 channels) images, bytes
+constexpr int kWgXImg = 16 * kWgXP, kWgZImg = 16 * kWgZP;        // one piece of one chunk
+constexpr int kWgStage = 3 * kWgXImg + 12 * kWgZImg;             // 15360 + 36864 = 52224 B
+
+__device__ __forceinline__ void cx_split4(const f32x4& v, cx_u32x2& h, cx_u32x2& m, cx_u32x2& l) {
+    float a[4], b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = v[e] - cx_trunc(v[e]); b[e] = a[e] - cx_trunc(a[e]); }
+    h = cx_u32x2{cx_hi2(v[0], v[1]), cx_hi2(v[2], v[3])};
+    m = cx_u32x2{cx_hi2(a[0], a[1]), cx_hi2(a[2], a[3])};
+    l = cx_u32x2{cx_hi2(b[0], b[1]), cx_hi2(b[2], b[3])};
+}
+
+__global__ __launch_bounds__(256, 2) void convt_x6_wgrad_kernel(ConvtWgX6Args p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kWgStage];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // = tap (a, b) = (wv >> 1, wv & 1)
+    const int tile = blockIdx.x % (p.nco * p.nci), split = blockIdx.x / (p.nco * p.nci);
+    const int co0 = (tile % p.nco) * 64, ci0 = (tile / p.nco) * 128;
+    const long c_lo = p.chunks * split / p.splits, c_hi = p.chunks * (split + 1) / p.splits;
+
+    // ---- staging roles: x rows r and r + 8, channel quad xc (two float4 per chunk); dz row zr, channel quad zc, all four taps
+    const int xr = tid >> 5, xc = tid & 31, zr = tid >> 4, zc = tid & 15;
+    f32x4 vx[2], vz[4];
+    auto load = [&](long c) {
+        const unsigned pp = (unsigned)(c * 16);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) vx[u] = *reinterpret_cast<const f32x4*>(p.x + (long)(pp + xr + 8 * u) * p.ldx + ci0 + 4 * xc);
+        const unsigned pz = pp + zr;
+        const unsigned q = pz / (unsigned)p.W, j = pz - q * (unsigned)p.W;          // input pixel = q W + j  ->  output pixel 4 W q + 2 j + a 2W + b
+        const float* zb = p.dz + ((long)4 * p.W * q + 2 * j) * p.lddz + co0 + 4 * zc;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vz[t] = *reinterpret_cast<const f32x4*>(zb + (long)((t >> 1) * 2 * p.W + (t & 1)) * p.lddz);
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            cx_u32x2 h, m, l; cx_split4(vx[u], h, m, l);
+            unsigned char* d = smem + (xr + 8 * u) * kWgXP + xc * 8;
+            *reinterpret_cast<cx_u32x2*>(d) = h; *reinterpret_cast<cx_u32x2*>(d + kWgXImg) = m; *reinterpret_cast<cx_u32x2*>(d + 2 * kWgXImg) = l;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            cx_u32x2 h, m, l; cx_split4(vz[t], h, m, l);
+            unsigned char* d = smem + 3 * kWgXImg + (t * 3) * kWgZImg + zr * kWgZP + zc * 8;
+            *reinterpret_cast<cx_u32x2*>(d) = h; *reinterpret_cast<cx_u32x2*>(d + kWgZImg) = m; *reinterpret_cast<cx_u32x2*>(d + 2 * kWgZImg) = l;
+        }
+    };
+    // ---- transposing operand reads: lane = 16 g + 4 q + pq supplies the address of pixel row 8 (g >> 1) + q, channels 16 (g & 1) + 4 pq .. + 3
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, pq = lane & 3;
+    const unsigned x_rd = (unsigned)((8 * (g >> 1) + q4) * kWgXP + (16 * (g & 1) + 4 * pq) * 2);
+    const unsigned z_rd = (unsigned)(3 * kWgXImg + (wv * 3) * kWgZImg + (8 * (g >> 1) + q4) * kWgZP + (16 * (g & 1) + 4 * pq) * 2);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+    if (c_lo < c_hi) load(c_lo);
+    for (long c = c_lo; c < c_hi; ++c) {
+        store();
+        __syncthreads();
+        if (c + 1 < c_hi) load(c + 1);
+        cx_bf16x8 af[2][3];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const cx_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cx_lds_s16x4*)(smem + z_rd + k * kWgZImg + mb * 64));
+                const cx_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cx_lds_s16x4*)(smem + z_rd + k * kWgZImg + mb * 64 + 4 * kWgZP));
+                af[mb][k] = __builtin_bit_cast(cx_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            cx_bf16x8 bf[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const cx_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cx_lds_s16x4*)(smem + x_rd + k * kWgXImg + nb * 64));
+                const cx_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cx_lds_s16x4*)(smem + x_rd + k * kWgXImg + nb * 64 + 4 * kWgXP));
+                bf[k] = __builtin_bit_cast(cx_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int qq = 0; qq < 6; ++qq)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][PA[qq]], bf[PB[qq]], acc[mb][nb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- partial result: out[split][tap][co][ci]; acc[mb][nb][i]: co = co0 + mb*32 + 8*(i/4) + 4*(lane/32) + i%4, ci = ci0 + nb*32 + lane%32
+    float* o = p.out + ((size_t)split * 4 + wv) * p.Cout * p.Cin;
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = co0 + mb * 32 + 8 * (i >> 2) + 4 * lh + (i & 3);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) o[(size_t)co * p.Cin + ci0 + nb * 32 + li] = acc[mb][nb][i];
+        }
+}
+
+// dw[i] = sum over the splits, in split order (float4 per thread)
+__global__ __launch_bounds__(256) void convt_x6_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
+    for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
+    reinterpret_cast<f32x4*>(dw)[i] = s;
+}
+
+int convt_x6_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
+    const long chunks = (long)N * H * W / 16;
+    const int tiles = (Cout / 64) * (Cin / 128);
+    long s = (2 * 256 + tiles - 1) / tiles;                      // two workgroups per CU
+    if (s > chunks / 8) s = chunks / 8;                          // at least 8 chunks (128 pixels) per workgroup
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return (int)s;
+}
+
 bool convt_x6_shape_ok(int N, int H, int W, int Cin, int Cout) {
     const long P = (long)N * H * W;
     return N > 0 && H > 0 && W > 0 && Cin % 128 == 0 && Cout % 64 == 0 && P % 128 == 0 && Cin <= 4096 && Cout <= 4096 &&
@@ -325,4 +472,33 @@ extern "C" int unet_convT2x2_dgrad_x6(const float* dz, int lddz, const void* W6d
     if (wide) convt_x6_dgrad_kernel_256<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
     else      convt_x6_dgrad_kernel_128<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
     return UNET_LAUNCH_STATUS();
+}
+
+// Weight gradient dw [2][2][Cout][Cin] (H, W: INPUT dims); supported as the forward (N*H*W % 128 == 0, Cin % 128 == 0, Cout % 64 == 0).
+// ws: unet_convT2x2_wgrad_x6_workspace bytes (split-K partials; untouched when the layer needs no split)
+extern "C" size_t unet_convT2x2_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout) {
+    if (!convt_x6_shape_ok(N, H, W, Cin, Cout)) return 0;
+    const int s = convt_x6_wgrad_splits(N, H, W, Cin, Cout);
+    return s > 1 ? (size_t)s * 4 * Cin * Cout * sizeof(float) : 16;
+}
+
+extern "C" int unet_convT2x2_wgrad_x6(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                      int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    UNET_CHECK_ARG(xin && dz && dw && ws && convt_x6_shape_ok(N, H, W, Cin, Cout));
+    UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
+    if (ws_bytes < unet_convT2x2_wgrad_x6_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
+    ConvtWgX6Args a{};
+    a.x = xin; a.dz = dz; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.nco = Cout / 64; a.nci = Cin / 128; a.P = (long)N * H * W; a.chunks = a.P / 16;
+    a.splits = convt_x6_wgrad_splits(N, H, W, Cin, Cout);
+    a.out = a.splits > 1 ? (float*)ws : dw;
+    hipStream_t st = (hipStream_t)stream;
+    convt_x6_wgrad_kernel<<<dim3((unsigned)(a.nco * a.nci * a.splits)), 256, 0, st>>>(a);
+    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+    if (a.splits > 1) {
+        const long n4 = (long)4 * Cin * Cout / 4;
+        convt_x6_wgrad_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>((const float*)ws, dw, n4, a.splits);
+        rc = UNET_LAUNCH_STATUS();
+    }
+    return rc;
 }

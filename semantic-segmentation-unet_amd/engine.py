@@ -664,6 +664,9 @@ class Engine:
                 nb2 = L.unet_convT2x2_wgrad_bf16_workspace_wg(n, hi, wi, cin, cout, cap)
                 L.unet_convT2x2_wgrad_bf16_wg(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
                                               n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
+            elif lp.wgrad == "convt_x6":
+                nb2 = L.unet_convT2x2_wgrad_x6_workspace(n, hi, wi, cin, cout)
+                L.unet_convT2x2_wgrad_x6(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "deconv":
                 nb2 = L.unet_convT2x2_wgrad_workspace_wg(n, hi, wi, cin, cout, cap)
                 L.unet_convT2x2_wgrad_wg(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)

@@ -232,7 +232,8 @@ def build_plan(opt, number_channels, number_classes, n, h, w, training, want_gra
             p.fwd = ("convt_bf16" if b16 else "convt_x6" if x6 else
                      "convt_stream" if L.unet_convT2x2_fwd_stream_supported(n, p.hi, p.wi, p.cin, p.cout) == 1 else "convt_igemm")
             p.dgrad = "convt_bf16" if b16 else "convt_x6" if x6 else "convt_igemm"
-            p.wgrad = "convt_bf16" if (b16 and L.unet_convT2x2_wgrad_bf16_supported(n, p.hi, p.wi, p.cin, p.cout) == 1) else "convt"
+            p.wgrad = ("convt_bf16" if (b16 and L.unet_convT2x2_wgrad_bf16_supported(n, p.hi, p.wi, p.cin, p.cout) == 1) else
+                       "convt_x6" if x6 else "convt")
         else:
             p.fwd = p.dgrad = p.wgrad = "conv1x1"
     first = pl.layer["conv_1a"]

@@ -116,7 +116,7 @@ def run_case(L, family, shape, seed, kind="normal"):
             nb = L.unet_conv3x3_wgrad_mfma_workspace(n, h, w_, ci, co); ws = _ws(nb)
             L.unet_conv3x3_wgrad_mfma(P(x), ci, P(dz), co, P(dw), n, h, w_, ci, co, P(ws), nb, ST())
         return errs(dw, ref_wgrad(x, dz))
-    if family in ("convt_fwd", "convt_fwd_stream", "convt_dgrad", "convt_wgrad", "convt_x6_fwd", "convt_x6_dgrad"):
+    if family in ("convt_fwd", "convt_fwd_stream", "convt_dgrad", "convt_wgrad", "convt_x6_fwd", "convt_x6_dgrad", "convt_x6_wgrad"):
         g = torch.Generator(device=DEV).manual_seed(seed + 1)
         wT = torch.randn(2, 2, co, ci, device=DEV, generator=g) / float(np.sqrt(ci))
         if family in ("convt_fwd", "convt_fwd_stream"):
@@ -142,9 +142,13 @@ def run_case(L, family, shape, seed, kind="normal"):
             L.unet_convT2x2_dgrad(P(dzT), co, P(wT), P(dx), ci, n, h, w_, ci, co, ST())
             ref = torch.nn.functional.conv2d(dzT.double().permute(0, 3, 1, 2), wT.double().permute(3, 2, 0, 1), None, stride=2).permute(0, 2, 3, 1)
             return errs(dx, ref)
-        nb = L.unet_convT2x2_wgrad_workspace(n, h, w_, ci, co); ws = _ws(nb)
         dw = torch.empty(2, 2, co, ci, device=DEV)
-        L.unet_convT2x2_wgrad(P(x), ci, P(dzT), co, P(dw), n, h, w_, ci, co, P(ws), nb, ST())
+        if family == "convt_x6_wgrad":
+            nb = L.unet_convT2x2_wgrad_x6_workspace(n, h, w_, ci, co); ws = _ws(nb)
+            L.unet_convT2x2_wgrad_x6(P(x), ci, P(dzT), co, P(dw), n, h, w_, ci, co, P(ws), nb, ST())
+        else:
+            nb = L.unet_convT2x2_wgrad_workspace(n, h, w_, ci, co); ws = _ws(nb)
+            L.unet_convT2x2_wgrad(P(x), ci, P(dzT), co, P(dw), n, h, w_, ci, co, P(ws), nb, ST())
         d6 = dzT.double().reshape(n, h, 2, w_, 2, co)
         ref = torch.einsum("nyaxbk,nyxc->abkc", d6, x.double())
         return errs(dw, ref)
@@ -163,6 +167,7 @@ CASES = [
     ("convt_fwd", (2, 4, 32, 128, 64), 1), ("convt_fwd_stream", (2, 8, 16, 128, 128), 1), ("convt_fwd_stream", (4, 8, 16, 64, 192), 2),
     ("convt_dgrad", (2, 4, 32, 128, 64), 1), ("convt_wgrad", (2, 4, 32, 128, 64), 1),
     ("convt_x6_fwd", (2, 4, 32, 128, 64), 1), ("convt_x6_fwd", (2, 8, 16, 256, 128), 2), ("convt_x6_dgrad", (2, 4, 32, 128, 64), 1), ("convt_x6_dgrad", (2, 8, 16, 256, 128), 2),
+    ("convt_x6_wgrad", (2, 4, 32, 128, 64), 1), ("convt_x6_wgrad", (2, 8, 16, 256, 128), 2),
 ]
 
 

@@ -65,6 +65,19 @@ def test_forward_and_data_gradient_are_fp32_grade(shape):
     L.unet_convT2x2_dgrad_x6(P(dz), co, P(W6d), P(dx), ci, n, h, w, ci, co, ST())
     L.unet_convT2x2_fwd(P(x), ci, P(wT), P(b), P(yn), co, n, h, w, ci, co, ST())
     L.unet_convT2x2_dgrad(P(dz), co, P(wT), P(dn), ci, n, h, w, ci, co, ST())
+    # weight gradient: dw[a,b,co,ci] = sum_{n,i,j} dz[n,2i+a,2j+b,co] x[n,i,j,ci]
+    nbw = L.unet_convT2x2_wgrad_x6_workspace(*shape); ws = torch.empty(nbw + 256, dtype=torch.uint8, device=DEV)
+    nbn = L.unet_convT2x2_wgrad_workspace(*shape); wsn = torch.empty(nbn + 256, dtype=torch.uint8, device=DEV)
+    dw = torch.full((2, 2, co, ci), float("nan"), device=DEV); dwn = torch.empty_like(dw)
+    L.unet_convT2x2_wgrad_x6(P(x), ci, P(dz), co, P(dw), n, h, w, ci, co, P(ws), nbw, ST())
+    L.unet_convT2x2_wgrad(P(x), ci, P(dz), co, P(dwn), n, h, w, ci, co, P(wsn), nbn, ST())
+    rw = torch.einsum("nyaxbk,nyxc->abkc", dz.double().reshape(n, h, 2, w, 2, co), x.double())
+    (wm_, wr_), (vm_, vr_) = rel(dw, rw), rel(dwn, rw)
+    # (sums over up to 5e5 pixels: the error is the accumulation order's -- split-K partials of 16-pixel MFMA steps here, 2-pixel steps natively)
+    assert wr_ <= 2.5 * vr_ and wm_ <= 3.0 * vm_ and wr_ < 2e-6, (wm_, wr_, vm_, vr_)
+    if nbw > 16:
+        with pytest.raises(pkg("_lib").UnetHipError, match="workspace too small"):
+            L.unet_convT2x2_wgrad_x6(P(x), ci, P(dz), co, P(dw), n, h, w, ci, co, P(ws), nbw - 16, ST())
     rf, rd = ref_fwd(x, wT, b), ref_dgrad(dz, wT)
     assert torch.equal(y, y2)
     (fm, fr), (nm, nr) = rel(y, rf), rel(yn, rf)
@@ -116,6 +129,13 @@ def test_channel_slices_and_strides():
     ref = torch.empty(n, 2 * h, 2 * w, co, device=DEV)
     L.unet_convT2x2_fwd_x6(P(x), ci, P(W6), P(b), P(ref), co, n, h, w, ci, co, None, 0, ST())
     assert torch.equal(cat[..., co:], ref) and bool((cat[..., :co] == -3.0).all())
+    # weight gradient with strided operands (x inside a wider buffer, dz with padding channels)
+    nbw = L.unet_convT2x2_wgrad_x6_workspace(n, h, w, ci, co); ws = torch.empty(nbw + 256, dtype=torch.uint8, device=DEV)
+    dw1 = torch.empty(2, 2, co, ci, device=DEV); dw2 = torch.empty_like(dw1)
+    dzp = torch.randn(n, 2 * h, 2 * w, co + 12, device=DEV); dzp[..., :co] = dz
+    L.unet_convT2x2_wgrad_x6(P(x), ci, P(dz), co, P(dw1), n, h, w, ci, co, P(ws), nbw, ST())
+    L.unet_convT2x2_wgrad_x6(P(xs), ci + 8, P(dzp), co + 12, P(dw2), n, h, w, ci, co, P(ws), nbw, ST())
+    assert torch.equal(dw1, dw2)
     dzs = torch.randn(n, 2 * h, 2 * w, co + 12, device=DEV); dzs[..., :co] = dz
     dxs = torch.full((n, h, w, ci + 4), -5.0, device=DEV); dref = torch.empty(n, h, w, ci, device=DEV)
     L.unet_convT2x2_dgrad_x6(P(dzs), co + 12, P(W6d), P(dxs), ci + 4, n, h, w, ci, co, ST())
@@ -127,8 +147,8 @@ def test_plan_routes_the_fp32_transposed_convs_to_bf16x6():
     plan, L = pkg("plan"), pkg("_lib").lib()
     pl = plan.build_plan(plan.EngineOptions(), 1, 2, 8, 512, 512, True, True, L)
     for name in ("up_4", "up_3", "up_2", "up_1"):
-        assert pl.layer[name].fwd == "convt_x6" and pl.layer[name].dgrad == "convt_x6" and pl.layer[name].fwd_stats, name
+        assert pl.layer[name].fwd == "convt_x6" and pl.layer[name].dgrad == "convt_x6" and pl.layer[name].wgrad == "convt_x6" and pl.layer[name].fwd_stats, name
     nat = plan.build_plan(plan.EngineOptions(fp32_matrix="native"), 1, 2, 8, 512, 512, True, True, L)
-    assert all(nat.layer[n].fwd == "convt_stream" and nat.layer[n].dgrad == "convt_igemm" for n in ("up_4", "up_3", "up_2", "up_1"))
+    assert all(nat.layer[n].fwd == "convt_stream" and nat.layer[n].dgrad == "convt_igemm" and nat.layer[n].wgrad == "convt" for n in ("up_4", "up_3", "up_2", "up_1"))
     odd = plan.build_plan(plan.EngineOptions(), 1, 2, 1, 48, 80, True, True, L)          # 3 x 5 pixels at level 5: not a multiple of the 128-pixel tile
     assert odd.layer["up_4"].fwd != "convt_x6"
