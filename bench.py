@@ -50,8 +50,8 @@ TRAFFIC_TAG = "r04"                  # profiles/<tag>_*_pmc_traffic.json of the 
 WINOGRAD_MULT_RATIO = 2.25           # F(2x2,3x3): 36 direct multiplies per tile and channel pair -> 16
 
 X6_PRODUCTS = 6                      # BF16x6: six bf16 piece products per fp32-grade product (hh hm mh hl lh mm)
-ARITHMETIC = {"bf16x6": "fp32 operands as 3 bf16 pieces, 6 products, fp32 accumulate (3x3 and transposed-conv forward / data gradient: "
-                        "csrc/winograd_x6.hip, csrc/convt_x6.hip; weight gradients and everything else: native fp32)",
+ARITHMETIC = {"bf16x6": "fp32 operands as 3 bf16 pieces, 6 products, fp32 accumulate (3x3 forward / data gradient: csrc/winograd_x6.hip; transposed "
+                        "convs, all three directions: csrc/convt_x6.hip; 3x3 weight gradient and everything else: native fp32)",
               "native": "fp32 (v_mfma_f32_32x32x2_f32 for every contraction)"}
 
 FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16 matrix pipe?, offline PMC traffic file)
