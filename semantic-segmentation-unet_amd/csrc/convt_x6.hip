@@ -384,13 +384,24 @@ __global__ __launch_bounds__(256, 2) void convt_x6_wgrad_kernel(ConvtWgX6Args p)
         }
 }
 
-// dw[i] = sum over the splits, in split order (float4 per thread)
-__global__ __launch_bounds__(256) void convt_x6_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
-    for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
-    reinterpret_cast<f32x4*>(dw)[i] = s;
+// dw[i] = sum over the splits in a fixed order: SL slices of the split range per output (float4), summed slice by slice -- few outputs x
+// many splits (up_1: 8192 float4 x 512 splits) still fill the chip (the scheme of conv_wgrad.hip's wgrad_reduce_kernel)
+__global__ __launch_bounds__(256) void convt_x6_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int splits, int sl) {
+    __shared__ f32x4 part[256];
+    const int per = 256 / sl;
+    const int o = threadIdx.x % per, sj = threadIdx.x / per;
+    const long i = (long)blockIdx.x * per + o;
+    const int k0 = (int)((long)splits * sj / sl), k1 = (int)((long)splits * (sj + 1) / sl);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int k = k0; k < k1; ++k) s += reinterpret_cast<const f32x4*>(ws)[(size_t)k * n4 + i];
+    if (sl == 1) { if (i < n4) reinterpret_cast<f32x4*>(dw)[i] = s; return; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (sj == 0 && i < n4) {
+        for (int j = 1; j < sl; ++j) s += part[j * per + o];
+        reinterpret_cast<f32x4*>(dw)[i] = s;
+    }
 }
 
 int convt_x6_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
@@ -498,7 +509,9 @@ extern "C" int unet_convT2x2_wgrad_x6(const float* xin, int ldx, const float* dz
     int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
     if (a.splits > 1) {
         const long n4 = (long)4 * Cin * Cout / 4;
-        convt_x6_wgrad_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>((const float*)ws, dw, n4, a.splits);
+        int sl = 1;
+        while (sl < 16 && 2 * sl <= a.splits && n4 * sl < 256 * 1024) sl *= 2;
+        convt_x6_wgrad_reduce_kernel<<<(unsigned)((n4 * sl + 255) / 256), 256, 0, st>>>((const float*)ws, dw, n4, a.splits, sl);
         rc = UNET_LAUNCH_STATUS();
     }
     return rc;
