@@ -66,6 +66,18 @@ FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16 matrix
 }
 
 
+GEMM_FAMILY = {   # the transposed convs (plain GEMMs, not candidates for the `roofline` block): engine profile key -> (kernel description, bf16 matrix pipe?)
+    "convt_fwd_x6": ("convt_x6_fwd_stats_kernel (2x2/stride-2 transposed conv forward + BatchNorm sums, one GEMM over the input pixels, fp32-grade products as 6 x v_mfma_f32_32x32x16_bf16)", True),
+    "convt_dgrad_x6": ("convt_x6_dgrad_kernel_{256,128} (transposed conv data gradient, GEMM over the input pixels, BF16x6)", True),
+    "convt_wgrad_x6": ("convt_x6_wgrad_kernel + reduce (transposed conv weight gradient, GEMM over pixels with transposing LDS reads, BF16x6, split-K)", True),
+    "convt_fwd": ("convt_fwd_stream_stats_kernel (transposed conv forward + BatchNorm sums on v_mfma_f32_32x32x2_f32)", False),
+    "convt_dgrad": ("igemm_kernel (transposed conv data gradient on v_mfma_f32_32x32x2_f32)", False),
+    "convt_wgrad": ("wgrad_kernel<1> + reduce (transposed conv weight gradient on v_mfma_f32_32x32x2_f32)", False),
+    "convt_fwd_bf16": ("convt_bf16_fwd_stats_dma_kernel (transposed conv forward + BatchNorm sums on v_mfma_f32_32x32x16_bf16)", True),
+    "convt_dgrad_bf16": ("convt_bf16_dgrad[_bnbwd]_dma_kernel (transposed conv data gradient + producer BatchNorm-backward sums on v_mfma_f32_32x32x16_bf16)", True),
+    "convt_wgrad_bf16": ("convt_wgrad_bf16_kernel_64 + reduce (transposed conv weight gradient on v_mfma_f32_32x32x16_bf16)", True),
+}
+
 PEAK_HBM_SPEC_GBS = 8000.0           # same guide: HBM3E ~8 TB/s spec
 PEAK_HBM_COPY_GBS = 6290.0           # ... and its measured copy bandwidth (the figure HBM-bound kernels are priced against)
 
@@ -245,13 +257,16 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
                                 "achieved_gbs": round(gbs, 1), "frac_of_copy_bw": round(gbs / PEAK_HBM_COPY_GBS, 4),
                                 "frac_of_spec_bw": round(gbs / PEAK_HBM_SPEC_GBS, 4), "exclusive": True}
                 continue
-            desc, wino, bf16, _ = FAMILY.get(key, (key, False, False, None))
+            if key in GEMM_FAMILY:
+                desc, wino, bf16 = GEMM_FAMILY[key][0], False, GEMM_FAMILY[key][1]
+            else:
+                desc, wino, bf16, _ = FAMILY.get(key, (key, False, False, None))
             eff = fl / (ms * 1e-3) / 1e12
             x6 = key.endswith("_x6")
             grade = eff / WINOGRAD_MULT_RATIO if wino else eff           # fp32-grade multiply-adds actually performed (as FLOP/s)
             ex = grade * X6_PRODUCTS if x6 else grade                    # matrix-pipe FLOP/s executed (BF16x6: six bf16 products each)
             peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-            kernels[key] = {"launches_per_step": len(evs) // sampled, "ms_per_step": round(ms / sampled, 3),
+            kernels[key] = {"kernel": desc, "launches_per_step": len(evs) // sampled, "ms_per_step": round(ms / sampled, 3),
                             "avg_launch_ms": round(ms / len(evs), 4), "effective_tflops": round(eff, 2),
                             "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4), "exclusive": True}
             if x6:

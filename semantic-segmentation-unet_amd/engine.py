@@ -378,20 +378,23 @@ class Engine:
         if lp.fwd == "convt_bf16":
             rows = L.unet_convT2x2_bf16_stats_rows(n, h, w, cin, cout, 0) if lp.fwd_stats else 0
             stat_part = part(rows)
-            L.unet_convT2x2_fwd_bf16(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
-                                     int(r16), n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+            self._timed("convt_fwd_bf16", 8.0 * n * h * w * cin * cout, L.unet_convT2x2_fwd_bf16,
+                        _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(self._bf16_kernels(name)[0]), _p(b_), _p(r), _ld(r),
+                        int(r16), n, h, w, cin, cout, _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
             fused_stats = (stat_part, rows) if rows > 0 else None
         elif lp.fwd == "convt_x6":                                              # GEMM on the bf16 matrix pipe at fp32 grade (csrc/convt_x6.hip)
             rows = L.unet_convT2x2_x6_stats_rows(n, h, w, cin, cout) if lp.fwd_stats else 0
             stat_part = part(rows)
-            L.unet_convT2x2_fwd_x6(_p(x), _ld(x), _p(self._convt_x6_kernels(name)[0]), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
-                                   _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
+            self._timed("convt_fwd_x6", 8.0 * n * h * w * cin * cout, L.unet_convT2x2_fwd_x6,
+                        _p(x), _ld(x), _p(self._convt_x6_kernels(name)[0]), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
+                        _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, st)
             fused_stats = (stat_part, rows) if rows > 0 else None
         elif lp.fwd == "convt_stream" and _ld(x) <= 4096:                       # persistent stream kernel
             rows = L.unet_convT2x2_fwd_stream_stats_rows_wg(n, h, w, cin, cout, cap) if lp.fwd_stats else 0
             stat_part = part(rows)
-            L.unet_convT2x2_fwd_stream_wg(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
-                                          _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, cap, st)
+            self._timed("convt_fwd", 8.0 * n * h * w * cin * cout, L.unet_convT2x2_fwd_stream_wg,
+                        _p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout,
+                        _p(stat_part), stat_part.numel() * 4 if rows > 0 else 0, cap, st)
             fused_stats = (stat_part, rows) if rows > 0 else None
         elif kind == "deconv":
             L.unet_convT2x2_fwd(_p(x), _ld(x), _p(w_), _p(b_), _p(r), _ld(r), n, h, w, cin, cout, st)
@@ -662,14 +665,17 @@ class Engine:
             L.unet_bn_bwd_bias(_p(bnws), bias_rows.value, cout, _p(self.g[name + "/bias"]), st2)
             if lp.wgrad == "convt_bf16":
                 nb2 = L.unet_convT2x2_wgrad_bf16_workspace_wg(n, hi, wi, cin, cout, cap)
-                L.unet_convT2x2_wgrad_bf16_wg(_p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
-                                              n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
+                self._timed("convt_wgrad_bf16", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_wgrad_bf16_wg,
+                            _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
+                            n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
             elif lp.wgrad == "convt_x6":
                 nb2 = L.unet_convT2x2_wgrad_x6_workspace(n, hi, wi, cin, cout)
-                L.unet_convT2x2_wgrad_x6(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                self._timed("convt_wgrad_x6", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_wgrad_x6,
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "deconv":
                 nb2 = L.unet_convT2x2_wgrad_workspace_wg(n, hi, wi, cin, cout, cap)
-                L.unet_convT2x2_wgrad_wg(_p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
+                self._timed("convt_wgrad", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_wgrad_wg,
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "conv1":
                 nb2 = L.unet_conv1x1_wgrad_workspace(P, cin, cout)
                 self._timed("classmap_wgrad", self._nb(x, dz), L.unet_conv1x1_wgrad,
@@ -726,12 +732,14 @@ class Engine:
             r16_prev = int(r_prev is not None and r_prev.dtype == torch.bfloat16)
             fl = 2.0 * 9 * n * ho * wo * cin * cout
             if lp.dgrad == "convt_bf16":
-                L.unet_convT2x2_dgrad_bf16(_p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx16), n, hi, wi, cin, cout,
-                                           _p(r_prev), ldr_prev, r16_prev, _p(part), nbp, st)
+                self._timed("convt_dgrad_bf16", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_dgrad_bf16,
+                            _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx16), n, hi, wi, cin, cout,
+                            _p(r_prev), ldr_prev, r16_prev, _p(part), nbp, st)
             elif lp.dgrad == "convt_x6":
-                L.unet_convT2x2_dgrad_x6(_p(dz), cout, _p(self._convt_x6_kernels(name)[1]), _p(dx), cin, n, hi, wi, cin, cout, st)
+                self._timed("convt_dgrad_x6", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_dgrad_x6,
+                            _p(dz), cout, _p(self._convt_x6_kernels(name)[1]), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "deconv":
-                L.unet_convT2x2_dgrad(_p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
+                self._timed("convt_dgrad", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_dgrad, _p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":
                 self._timed("classmap_dgrad", self._nb(dz, dx), L.unet_conv1x1_dgrad, _p(dz), cout, _p(w_), _p(dx), cin, int(dx16), P, cin, cout, st)
             elif lp.dgrad == "bf16":

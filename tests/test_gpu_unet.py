@@ -457,6 +457,8 @@ def test_full_size_config5_step_properties(dtype):
         # (default fp32_matrix = "bf16x6": forward / data gradient on the BF16x6 kernels, weight gradient on the fp32-MFMA Winograd kernel)
         assert counts.get("conv3x3_fwd_winograd_x6") == 17 and counts.get("conv3x3_dgrad_winograd_x6") == 17 \
             and counts.get("conv3x3_wgrad_winograd_fused") == 17, counts
+        # ... and the four transposed convs the BF16x6 GEMMs in all three directions (the last up layer's input gradient included)
+        assert counts.get("convt_fwd_x6") == 4 and counts.get("convt_dgrad_x6") == 4 and counts.get("convt_wgrad_x6") == 4, counts
     else:
         assert counts.get("conv3x3_fwd_bf16") == 17 and counts.get("conv3x3_dgrad_bf16") == 17 \
             and counts.get("conv3x3_wgrad_bf16") == 17, counts
