@@ -477,7 +477,8 @@ def test_bf16_operand_beyond_2gib_falls_back_to_fp32_kernels():
 @pytest.mark.parametrize("cfg", [(2, 1, 2, 32, "fp32"), (2, 3, 4, 64, "fp32"), (1, 1, 2, 128, "fp32"),
                                  (3, 1, 2, (48, 80), "fp32"), (1, 3, 6, (16, 176), "fp32"),             # non-square tiles, odd batch
                                  (1, 2, 11, 32, "fp32"), (5, 4, 3, 32, "fp32"),                        # other channel / class counts
-                                 (2, 5, 3, 32, "fp32")])                                               # five image channels: the generic first-layer kernels, separate statistics pass
+                                 (2, 5, 3, 32, "fp32"),                                                # five image channels: the generic first-layer kernels, separate statistics pass
+                                 (2, 1, 2, 128, "fp32")])                                              # every level a multiple of the 128-pixel GEMM tile: all four transposed convs on the BF16x6 kernels
 def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
     # End-to-end gradients at 1e-4 instead of 5e-2.  The network is piecewise linear: its gradient is discontinuous only in the
     # branch decisions (ReLU masks, max-pool winners), and fp32 rounding flips a few of those for pre-activations within ~1e-7
@@ -493,6 +494,8 @@ def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
     e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
     e.backward()
     torch.cuda.synchronize()
+    if cfg == (2, 1, 2, 128, "fp32"):
+        assert all(e.pl.layer["up_%d" % l].fwd == e.pl.layer["up_%d" % l].dgrad == e.pl.layer["up_%d" % l].wgrad == "convt_x6" for l in (1, 2, 3, 4))
     relu = {name: (e.saved[name][1].float().permute(0, 3, 1, 2) > 0).cpu().numpy() for name, kind, _, _ in e.layers if kind != "deconv"}
     pidx = {"pool_%d" % l: e.idx[l].permute(0, 3, 1, 2).cpu().numpy().astype(np.int64) for l in (1, 2, 3, 4)}
     ref = on.OracleUNet(k, n, c, params=prm, dtype=np.float64)
@@ -567,6 +570,8 @@ def test_dead_channels_keep_parity_on_both_batchnorm_routes(cfg, on_load):
     e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
     e.backward()
     torch.cuda.synchronize()
+    if cfg == (2, 1, 2, 128, "fp32"):
+        assert all(e.pl.layer["up_%d" % l].fwd == e.pl.layer["up_%d" % l].dgrad == e.pl.layer["up_%d" % l].wgrad == "convt_x6" for l in (1, 2, 3, 4))
     relu = {name: (e.saved[name][1].float().permute(0, 3, 1, 2) > 0).cpu().numpy() for name, kind, _, _ in e.layers if kind != "deconv"}
     pidx = {"pool_%d" % l: e.idx[l].permute(0, 3, 1, 2).cpu().numpy().astype(np.int64) for l in (1, 2, 3, 4)}
     loss_ref, _, g_ref, _, _ = ref.loss_and_grads(img, lab, masks, relu_masks=relu, pool_idx=pidx)
