@@ -182,7 +182,8 @@ int unet_convT2x2_dgrad(const float* dz, int lddz, const float* w, float* dx, in
  * three bf16 pieces per weight in the GEMM's operand layout, unet_convT2x2_weight_transform_x6 mode 0 (forward) / 1 (data gradient),
  * unet_convT2x2_x6_weight_bytes each, once per optimizer step.  Forward: stat_part nullable -- BatchNorm sums of the output,
  * (Cout/64) * rows * 128 floats with rows = unet_convT2x2_x6_stats_rows (one per 128-pixel tile and tap), for
- * unet_bn_train_finalize_partials.  One workgroup per tile: no max_workgroups form. */
+ * unet_bn_train_finalize_partials.  Forward and data gradient launch one workgroup per tile (no max_workgroups form); the weight
+ * gradient's grid is sized by the CU count and has one (unet_convT2x2_wgrad_x6_wg below). */
 int unet_convT2x2_x6_supported(int N, int H, int W, int Cin, int Cout);
 size_t unet_convT2x2_x6_weight_bytes(int Cin, int Cout);
 int unet_convT2x2_weight_transform_x6(const float* w, void* W6, int Cin, int Cout, int mode, void* stream);
@@ -371,6 +372,9 @@ int unet_convT2x2_fwd_stream_wg(const float* x, int ldx, const float* w, const f
 size_t unet_convT2x2_wgrad_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
 int unet_convT2x2_wgrad_wg(const float* xin, int ldx, const float* dz, int lddz, float* dw,
                            int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream);
+size_t unet_convT2x2_wgrad_x6_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
+int unet_convT2x2_wgrad_x6_wg(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                              int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream);
 size_t unet_convT2x2_wgrad_bf16_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups);
 int unet_convT2x2_wgrad_bf16_wg(const void* xin, int ldx, int x_bf16, const void* dz, int lddz, int dz_bf16, float* dw,
                                 int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream);

@@ -404,10 +404,10 @@ __global__ __launch_bounds__(256) void convt_x6_wgrad_reduce_kernel(const float*
     }
 }
 
-int convt_x6_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
+int convt_x6_wgrad_splits(int N, int H, int W, int Cin, int Cout, int max_workgroups) {
     const long chunks = (long)N * H * W / 16;
     const int tiles = (Cout / 64) * (Cin / 128);
-    long s = (2 * 256 + tiles - 1) / tiles;                      // two workgroups per CU
+    long s = (2 * unet_grid_slots(256, max_workgroups) + tiles - 1) / tiles;     // two workgroups per CU (or per slot of the caller's cap)
     if (s > chunks / 8) s = chunks / 8;                          // at least 8 chunks (128 pixels) per workgroup
     if (s < 1) s = 1;
     if (s > 1024) s = 1024;
@@ -488,21 +488,25 @@ extern "C" int unet_convT2x2_dgrad_x6(const float* dz, int lddz, const void* W6d
 
 // Weight gradient dw [2][2][Cout][Cin] (H, W: INPUT dims); supported as the forward (N*H*W % 128 == 0, Cin % 128 == 0, Cout % 64 == 0).
 // ws: unet_convT2x2_wgrad_x6_workspace bytes (split-K partials; untouched when the layer needs no split)
-extern "C" size_t unet_convT2x2_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout) {
+// max_workgroups: cap on the one-wave grid (common.h unet_grid_slots; the kernel runs two workgroups per slot), same value for both calls
+extern "C" size_t unet_convT2x2_wgrad_x6_workspace_wg(int N, int H, int W, int Cin, int Cout, int max_workgroups) {
     if (!convt_x6_shape_ok(N, H, W, Cin, Cout)) return 0;
-    const int s = convt_x6_wgrad_splits(N, H, W, Cin, Cout);
+    const int s = convt_x6_wgrad_splits(N, H, W, Cin, Cout, max_workgroups);
     return s > 1 ? (size_t)s * 4 * Cin * Cout * sizeof(float) : 16;
 }
+extern "C" size_t unet_convT2x2_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout) {
+    return unet_convT2x2_wgrad_x6_workspace_wg(N, H, W, Cin, Cout, 0);
+}
 
-extern "C" int unet_convT2x2_wgrad_x6(const float* xin, int ldx, const float* dz, int lddz, float* dw,
-                                      int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int unet_convT2x2_wgrad_x6_wg(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                         int N, int H, int W, int Cin, int Cout, int max_workgroups, void* ws, size_t ws_bytes, void* stream) {
     UNET_CHECK_ARG(xin && dz && dw && ws && convt_x6_shape_ok(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
-    if (ws_bytes < unet_convT2x2_wgrad_x6_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
+    if (ws_bytes < unet_convT2x2_wgrad_x6_workspace_wg(N, H, W, Cin, Cout, max_workgroups)) return UNET_ENOSPC;
     ConvtWgX6Args a{};
     a.x = xin; a.dz = dz; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.nco = Cout / 64; a.nci = Cin / 128; a.P = (long)N * H * W; a.chunks = a.P / 16;
-    a.splits = convt_x6_wgrad_splits(N, H, W, Cin, Cout);
+    a.splits = convt_x6_wgrad_splits(N, H, W, Cin, Cout, max_workgroups);
     a.out = a.splits > 1 ? (float*)ws : dw;
     hipStream_t st = (hipStream_t)stream;
     convt_x6_wgrad_kernel<<<dim3((unsigned)(a.nco * a.nci * a.splits)), 256, 0, st>>>(a);
@@ -515,4 +519,8 @@ extern "C" int unet_convT2x2_wgrad_x6(const float* xin, int ldx, const float* dz
         rc = UNET_LAUNCH_STATUS();
     }
     return rc;
+}
+extern "C" int unet_convT2x2_wgrad_x6(const float* xin, int ldx, const float* dz, int lddz, float* dw,
+                                      int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    return unet_convT2x2_wgrad_x6_wg(xin, ldx, dz, lddz, dw, N, H, W, Cin, Cout, 0, ws, ws_bytes, stream);
 }

@@ -669,9 +669,9 @@ class Engine:
                             _p(x), _ld(x), int(x.dtype == torch.bfloat16), _p(dz), cout, z16, _p(dw),
                             n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
             elif lp.wgrad == "convt_x6":
-                nb2 = L.unet_convT2x2_wgrad_x6_workspace(n, hi, wi, cin, cout)
-                self._timed("convt_wgrad_x6", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_wgrad_x6,
-                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, _p(self._workspace(nb2, sd)), nb2, st2)
+                nb2 = L.unet_convT2x2_wgrad_x6_workspace_wg(n, hi, wi, cin, cout, cap)
+                self._timed("convt_wgrad_x6", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_wgrad_x6_wg,
+                            _p(x), _ld(x), _p(dz), cout, _p(dw), n, hi, wi, cin, cout, cap, _p(self._workspace(nb2, sd)), nb2, st2)
             elif kind == "deconv":
                 nb2 = L.unet_convT2x2_wgrad_workspace_wg(n, hi, wi, cin, cout, cap)
                 self._timed("convt_wgrad", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_wgrad_wg,

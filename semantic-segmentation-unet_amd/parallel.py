@@ -57,8 +57,9 @@ class DataParallel:
         # Every persistent kernel of the step takes `EngineOptions.max_workgroups` (the `_wg` entry points of include/unet_hip.h); 224
         # (OVERLAP_WORKGROUPS) leaves ~4 CUs per XCD to a collective's kernels.  It is NOT applied here: on one GPU with a stand-in
         # collective resident (tests/test_gpu_overlap.py, profiles/r04_overlap_standin.txt) the capped step is slower than the uncapped one
-        # in every case measured -- the cap costs every CU-bound kernel 1/8 of the chip, the collective costs an uncapped grid a short
-        # second wave.  A caller with an N > 1 RCCL measurement that says otherwise passes EngineOptions(max_workgroups=224).
+        # in 11 of 12 cases of the committed table and faster in the test's case on another box -- the cap costs every CU-bound kernel
+        # 1/8 of the chip, the collective costs an uncapped grid a second wave some of the time; no stable sign.  A caller with an
+        # N > 1 RCCL measurement passes EngineOptions(max_workgroups=224) (bench.py --max-workgroups 224).
         if broadcast and (self.world_size > 1 or force):
             self.broadcast_state()
 

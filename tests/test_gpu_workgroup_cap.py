@@ -103,7 +103,10 @@ def test_transposed_conv_kernels_follow_the_cap():
         nb16 = L.unet_convT2x2_wgrad_bf16_workspace_wg(n, h, w, ci, co, cap); ws16 = torch.empty(nb16 + 256, dtype=torch.uint8, device=DEV)
         dw16 = torch.full((2, 2, co, ci), float("nan"), device=DEV)
         L.unet_convT2x2_wgrad_bf16_wg(P(x.bfloat16()), ci, 1, P(dz.bfloat16()), co, 1, P(dw16), n, h, w, ci, co, cap, P(ws16), nb16, ST())
-        got = (out, _sums(part, co // 64, rows), dw, dw16)
+        nbx = L.unet_convT2x2_wgrad_x6_workspace_wg(n, h, w, ci, co, cap); wsx = torch.empty(nbx + 256, dtype=torch.uint8, device=DEV)
+        dwx = torch.full((2, 2, co, ci), float("nan"), device=DEV)
+        L.unet_convT2x2_wgrad_x6_wg(P(x), ci, P(dz), co, P(dwx), n, h, w, ci, co, cap, P(wsx), nbx, ST())
+        got = (out, _sums(part, co // 64, rows), dw, dw16, dwx)
         assert torch.equal(out, out2)
         if cap == 0:
             ref = got
