@@ -199,7 +199,7 @@ def cpu_baseline_bounded(args, budget_s=420):
 
 
 def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype, steps, warmup, no_overlap, kernel_events,
-                 sample_every, barrier, fp32_matrix="bf16x6", max_workgroups=None):
+                 sample_every, barrier, fp32_matrix="bf16x6", max_workgroups=None, bucket_mb=25.0):
     """W warm-up + K timed optimizer steps of one workload -> dict with dt, per-family kernel figures, final loss."""
     import torch
     G = batch * world
@@ -210,7 +210,7 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
     net.engine.opt.max_workgroups = max_workgroups
     if world > 1:
         par = importlib.import_module(PKG + ".parallel")
-        net.parallel = par.DataParallel(net.engine)
+        net.parallel = par.DataParallel(net.engine, bucket_bytes=int(bucket_mb * 1024 * 1024))
     img, lab = synthetic(batch, channels, classes, size, 1234 + rank, dev)
     inputs = (img, lab, None, None)          # no metric objects -> no per-step host sync inside the timed loop
     step = net.train_step if world == 1 else (lambda inp: net.dist_train_step(net.parallel, inp))   # N>1: + the loss SUM (X2)
@@ -333,6 +333,8 @@ def main():
     ap.add_argument("--max-workgroups", type=int, default=None,
                     help="cap on every persistent kernel's grid (e.g. 224 leaves ~4 CUs per XCD to RCCL's kernels; default: one workgroup per CU -- "
                          "profiles/r04_overlap_standin.txt is why)")
+    ap.add_argument("--bucket-mb", type=float, default=25.0,
+                    help="N > 1: size of the gradient all-reduce buckets (default 25; 1000 = one all-reduce behind the whole backward pass, no overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run weight gradients on the main stream in every step (A/B switch)")
@@ -372,7 +374,7 @@ def main():
     model = importlib.import_module(PKG + ".model")
     sample_every = max(2, min(args.sample_every, args.steps)) if args.steps > 1 else 1
     res = run_workload(model, dev, world, rank, args.size, args.channels, args.classes, args.batch, args.dtype, args.steps,
-                       args.warmup, args.no_overlap, not args.no_kernel_events, sample_every, barrier, args.fp32_matrix, args.max_workgroups)
+                       args.warmup, args.no_overlap, not args.no_kernel_events, sample_every, barrier, args.fp32_matrix, args.max_workgroups, args.bucket_mb)
     dt = res["dt"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
