@@ -85,7 +85,7 @@ def test_standin_kernel_holds_its_workgroups_for_the_requested_time():
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); L.unet_standin_collective(32, 32768, us, ctypes.c_void_p(st.cuda_stream)); b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b)
-        assert us / 1000.0 <= ms < us / 1000.0 + 0.15, (us, ms)
+        assert us / 1000.0 <= ms < us / 1000.0 + 0.5, (us, ms)
     for bad in ((0, 0, 10), (32, 1 << 20, 10), (32, 0, -1)):
         with pytest.raises(pkg("_lib").UnetHipError, match="bad argument"):
             L.unet_standin_collective(*bad, None)
