@@ -6,7 +6,7 @@ L = importlib.import_module("semantic-segmentation-unet_amd._lib").lib()
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 out = []
-for shape in [(8, 64, 64, 512, 512), (8, 512, 512, 64, 64), (8, 32, 32, 1024, 1024)]:
+for shape in [(8, 64, 64, 512, 512), (8, 512, 512, 64, 64), (8, 512, 512, 128, 64), (8, 256, 256, 128, 128), (8, 32, 32, 1024, 1024)]:
     n, h, w, ci, co = shape
     x = torch.randn(n, h, w, ci, device="cuda"); wt = torch.randn(3, 3, ci, co, device="cuda") / float(np.sqrt(9 * ci))
     u = torch.empty(L.unet_winograd_x6_weight_bytes(ci, co), dtype=torch.uint8, device="cuda")
