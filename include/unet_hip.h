@@ -88,7 +88,7 @@ int unet_conv3x3_wgrad_fold_fix(float* dw, const float* scale, const float* shif
 /* ---- the same Winograd F(2x2,3x3) layers with the 16 point products on the BF16 matrix pipe at fp32 grade ("BF16x6") ---------------
  * A second route to the fp32 result of UNet._conv_layer (UNet/model.py:28-35), beside unet_conv3x3_*_winograd_fused: every fp32 operand of a
  * Winograd-domain product is split EXACTLY into three bf16 pieces (h + m + l), the six piece products hh, hm, mh, hl, lh, mm are exact
- * and accumulate in fp32 (v_mfma_f32_32x32x16_bf16); the three dropped products are below 2^-24 of the product, i.e. one fp32 multiply's
+ * and accumulate in fp32 (v_mfma_f32_32x32x16_bf16); the three dropped products sum to at most 2^-21, on average 2^-24.5 of the product, i.e. one fp32 multiply's
  * rounding, so the error against an fp64 evaluation equals that of the fp32 matrix instruction (tests/test_gpu_x6.py asserts <= 1.25 x).
  * The transforms stay fp32.  Shapes: H, W even, reduce channels % 32 == 0 and >= 64, output channels % 64 == 0 (unet_winograd_x6_supported).
  * Weight operands (16 * 3 * Cin * Cout bf16 = unet_winograd_x6_weight_bytes): _x6(w, mode 0 forward / 1 data gradient), every layer and

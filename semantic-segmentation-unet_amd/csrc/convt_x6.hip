@@ -1,7 +1,7 @@
 // 2x2 / stride-2 transposed convolution (UNet._deconv_layer, UNet/model.py:39-46) forward, data gradient and weight gradient as GEMMs on
 // the BF16 matrix pipe at fp32 grade ("BF16x6", see winograd_x6.hip for the arithmetic: every fp32 operand value is exactly h + m + l with three bf16
-// pieces; the six products hh, hm, mh, hl, lh, mm are exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, the dropped ones are
-// below 2^-24 of the product).  The fp32 reference layer:
+// pieces; the six products hh, hm, mh, hl, lh, mm are exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, the dropped ones sum
+// to at most 2^-21, on average 2^-24.5 of the product).  The fp32 reference layer:
 //   forward   z[n,2i+a,2j+b,co] = bias[co] + sum_ci x[n,i,j,ci] * W[a,b,co,ci]          GEMM  M = input pixels, K = Cin,      N = 4 taps x Cout
 //   gradient  dx[n,i,j,ci]      = sum_{a,b,co} dz[n,2i+a,2j+b,co] * W[a,b,co,ci]        GEMM  M = input pixels, K = 4 x Cout, N = Cin
 //   weights   dW[a,b,co,ci]     = sum_{n,i,j} dz[n,2i+a,2j+b,co] * x[n,i,j,ci]          GEMM  per tap: M = Cout, N = Cin, K = input pixels   (further down)

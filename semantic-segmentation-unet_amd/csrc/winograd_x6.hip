@@ -5,8 +5,9 @@
 // Arithmetic.  An fp32 value is EXACTLY the sum of three bf16 pieces h + m + l (8 + 8 + 8 significant bits, taken by truncation: every
 // piece has the sign of the value and the low piece ends where the fp32 mantissa ends).  With both operands of a product split this way,
 //     a b  =  ah bh + ah bm + am bh + ah bl + al bh + am bm   +  (am bl + al bm + al bl),
-// the six kept piece products are exact in an fp32 accumulator and the three dropped ones are below 2^-24 |a b| each -- the size of
-// ONE fp32 multiply's rounding.  Accumulation is fp32 (v_mfma_f32_32x32x16_bf16).  So the result carries the rounding of an fp32
+// the six kept piece products are exact in an fp32 accumulator and the three dropped ones (all of the product's sign: truncation pieces
+// carry their value's sign) sum to at most 2^-21 |a b|, on average 2^-24.5 |a b| -- the size of ONE fp32 multiply's rounding
+// (tests/test_bf16x6_arithmetic.py restates and checks this on the CPU).  Accumulation is fp32 (v_mfma_f32_32x32x16_bf16).  So the result carries the rounding of an fp32
 // dot product (measured against fp64: profiles/r03_bf16x6_micro.txt, tests/test_gpu_x6.py), at 6 x 32 matrix-pipe cycles per
 // 32 x 32 x 16 block instead of 8 x 64.  The Winograd transforms themselves (B^T d B on the data, G g G^T on the weights, A^T m A on the
 // result) stay fp32 vector arithmetic, identical to winograd.hip.
