@@ -199,7 +199,7 @@ def train_model(output_folder, batch_size, reader_count, train_lmdb_filepath, te
                                                            test_loss_metric, test_acc_metric))
                 epoch_test_loss.append(loss_value.numpy())
                 step += 1
-            test_loss.append(float(np.mean(epoch_test_loss)))
+            test_loss.append(np.mean(epoch_test_loss))             # (kept as numpy's fp32 scalar: test_loss.csv then carries the reference's text, UNet/train.py:162,173-176)
             check_labels()                                         # before the csv / checkpoint of this epoch are written
             say("Test Epoch: {}: Loss = {} Accuracy = {}".format(epoch, test_loss_metric.result(), test_acc_metric.result()))
             if writers:

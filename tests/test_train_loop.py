@@ -1,9 +1,11 @@
 """Loop semantics of `train_model` (reference UNet/train.py:123-200), checked on CPU with a scripted stand-in for the model:
 lr/10 warm-up over min(1000, N) steps in epoch 0, N+1 optimizer steps per epoch (`if step > N: break`), test-epoch length from
 the PER-REPLICA batch size (floor(count / batch_size) + 1 steps), test_loss.csv rewritten every epoch, checkpoint only on a new
-best test loss, early stopping counted from the FIRST epoch within 1e-4 of the best.  The expected trace comes from a direct
-restatement of those reference lines below; also covers the reader-side flags (--balance_classes, --reader_count) and the
-rank-strided test readers."""
+best test loss, early stopping counted from the FIRST epoch within 1e-4 of the best.  The expected trace was RECORDED FROM THE
+REFERENCE'S OWN `train_model` (tests/golden/make_train_loop_golden.py imports UNet/train.py in the build container with recording
+stand-ins for TensorFlow, model.UNet and imagereader.ImageReader; tests/golden/train_loop_trace.json), one case with two replicas.
+Also covers the reader-side flags (--balance_classes, --reader_count) and the rank-strided test readers."""
+import json
 import os
 
 import numpy as np
@@ -11,45 +13,6 @@ import pytest
 import torch
 
 from conftest import pkg
-
-
-def reference_loop(test_losses, learning_rate, test_every_n_steps, test_count, batch_size, early_stopping_count):
-    """UNet/train.py:123-200 with the model calls replaced by a trace.  test_losses[e] = mean test loss of epoch e."""
-    trace = {"lr": [], "train_steps": [], "test_steps": [], "ckpt_epochs": [], "csv": None}
-    train_epoch_size = test_every_n_steps                       # :99
-    test_epoch_size = test_count / batch_size                   # :100
-    test_loss = []
-    epoch = 0
-    while True:
-        if epoch == 0:                                          # :126-132
-            cur = min(1000, train_epoch_size); lr = learning_rate / 10
-        else:
-            cur = train_epoch_size; lr = learning_rate
-        n = 0
-        step = 0
-        while True:                                             # :136-141  for step, batch in enumerate(ds): if step > cur: break
-            if step > cur:
-                break
-            trace["lr"].append(lr); n += 1; step += 1
-        trace["train_steps"].append(n)
-        n = 0
-        step = 0
-        while True:                                             # :153-156
-            if step > test_epoch_size:
-                break
-            n += 1; step += 1
-        trace["test_steps"].append(n)
-        test_loss.append(test_losses[epoch])                    # :162
-        trace["csv"] = list(test_loss)                          # :173-176
-        if (len(test_loss) - 1) == np.argmin(test_loss):        # :181-184
-            trace["ckpt_epochs"].append(epoch)
-        error_from_best = np.abs(np.asarray(test_loss) - np.min(test_loss))      # :187-196
-        error_from_best[error_from_best < 1e-4] = 0
-        best_epoch = np.where(error_from_best == 0)[0][0]
-        if len(test_loss) - best_epoch > early_stopping_count:  # :198-199
-            break
-        epoch += 1
-    return trace
 
 
 class ScriptedUNet:
@@ -95,33 +58,130 @@ class ScriptedUNet:
         return self.trace
 
 
-@pytest.mark.parametrize("case", [
-    dict(script=[0.9, 0.7, 0.70005, 0.8, 0.75, 0.9, 0.9], n=3, count=10, batch=4, stop=2),      # 0.70005 is within 1e-4 of the best: not a new best epoch
-    dict(script=[0.5, 0.6, 0.7, 0.8], n=5, count=8, batch=2, stop=1),                            # never improves after epoch 0
-    dict(script=[0.9, 0.8, 0.7, 0.6, 0.65, 0.66, 0.67], n=1200, count=3, batch=4, stop=2),       # warm-up capped at 1000 steps
-])
-def test_train_model_loop_matches_reference_semantics(tmp_path, case):
-    train, readers = pkg("train"), pkg("readers")
+GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_loop_trace.json")))["traces"]
+
+
+class RecordingReader:
+    """SyntheticReader that records how the loop drives it (worker streams, start-up / shut-down)."""
+
+    def __init__(self, who, events, count, seed):
+        self.who, self.events, self.calls = who, events, []
+        self.r = pkg("readers").SyntheticReader(count, 16, 16, 3, 2, seed=seed)
+
+    def startup(self):
+        self.events.append("startup " + self.who)
+
+    def shutdown(self):
+        self.events.append("shutdown " + self.who)
+
+    def get_image_count(self):
+        return self.r.get_image_count()
+
+    def get_image_size(self):
+        return self.r.get_image_size()
+
+    def batches(self, batch_size, classmap=False, pin=True, raw=False, worker=0, num_workers=1):
+        self.calls.append((batch_size, worker, num_workers))
+        return self.r.batches(batch_size, classmap=classmap, pin=pin, raw=raw, worker=worker, num_workers=num_workers)
+
+
+def _expand_lr(rle):
+    return [v for v, n in rle for _ in range(n)]
+
+
+def _run_product_loop(case, out_dir):
+    """this repository's train_model on the golden case, with the scripted model -> a trace in the golden file's terms"""
+    train = pkg("train")
     ScriptedUNet.script = case["script"]
-    tr = readers.SyntheticReader(64, 16, 16, 1, 2, seed=1)
-    te = readers.SyntheticReader(case["count"], 16, 16, 1, 2, seed=2)
-    lr = 3e-4
-    out = train.train_model(str(tmp_path), case["batch"], 1, None, None, 0, 2, 0, lr, case["n"], case["stop"],
+    events = []
+    tr = RecordingReader("train_db", events, 64, 1)
+    te = RecordingReader("test_db", events, case["count"], 2)
+    out = train.train_model(out_dir, case["batch"], case["readers"], "train_db", "test_db", 0, 2, 0, 3e-4, case["n"], case["stop"],
                             train_reader=tr, test_reader=te, quiet=True, unet_factory=ScriptedUNet)
     got = ScriptedUNet.last.finish()
-    exp = reference_loop(case["script"], lr, case["n"], case["count"], case["batch"], case["stop"])
+    got.update(unet_args=list(ScriptedUNet.last.args), events=events, reader_calls={"train_db": tr.calls, "test_db": te.calls}, returned=[str(v) for v in out])
+    return got
+
+
+def _check_against_reference_trace(got, exp, out_dir, rank=0):
+    case = exp["case"]
+    R = case["replicas"]
     assert got["train_steps"] == exp["train_steps"]
     assert got["test_steps"] == exp["test_steps"]
-    assert got["lr"] == pytest.approx(exp["lr"], rel=1e-12)
-    assert got["ckpt_epochs"] == exp["ckpt_epochs"]
-    assert out == pytest.approx(exp["csv"], rel=1e-6)
-    csv = [float(v) for v in open(os.path.join(str(tmp_path), "test_loss.csv")).read().split()]
-    assert csv == pytest.approx(exp["csv"], rel=1e-6)
-    # properties spelled out (so a wrong restatement above cannot hide a wrong loop): N+1 steps, warm-up epoch, test length
+    assert got["lr"] == pytest.approx(_expand_lr(exp["lr"]), rel=1e-12)
+    assert got["ckpt_epochs"] == (exp["ckpt_epochs"] if rank == 0 else [])          # rank 0 writes the files
+    # model constructor: (number_classes, GLOBAL batch, channels of the training reader, learning rate)  (UNet/train.py:61,93-94)
+    assert got["unet_args"] == exp["unet_args"] and exp["unet_args"][1] == case["batch"] * R
+    # readers: the reference hands reader_count x replicas workers to each reader (UNet/train.py:63-76); here every rank opens
+    # `reader_count` worker streams with GLOBAL ids out of reader_count x replicas, at the per-replica batch size
+    for who in ("train_db", "test_db"):
+        total = exp["reader_kwargs"][who]["num_workers"]
+        assert total == case["readers"] * R
+        assert got["reader_calls"][who] == [(case["batch"], rank * case["readers"] + w, total) for w in range(case["readers"])]
+        assert exp["dataset"][who]["batch"] == case["batch"] * R            # the reference's global batch = replicas x this rank's batch
+    # readers are started before the first step and shut down at the end, train first (UNet/train.py:78-83,201-206)
+    assert got["events"] == exp["events"]
+    if rank != 0:
+        return
+    # files: test_loss.csv holds the reference's TEXT (fp32 means printed by numpy), the checkpoint lands where the reference writes it,
+    # and the scalar log carries the reference's tags and step numbers
+    assert open(os.path.join(out_dir, "test_loss.csv")).read() == exp["csv_text"]
+    assert "\n".join(got["returned"]) + "\n" == exp["csv_text"]
+    assert os.path.exists(os.path.join(out_dir, exp["ckpt_relpath"] + ".marker"))
+    entries = sorted("tensorboard-*" if e.startswith("tensorboard-") else e for e in os.listdir(out_dir))
+    assert entries == exp["output_entries"]
+    tb = [e for e in os.listdir(out_dir) if e.startswith("tensorboard-")][0]
+    for kind in ("train", "test"):
+        rows = [json.loads(l) for l in open(os.path.join(out_dir, tb, kind, "scalars.jsonl"))]
+        steps = exp["scalars"][kind]["steps"]
+        if kind == "train":
+            steps = [a + i for a, n in steps for i in range(n)]
+        assert [(r["tag"], r["step"]) for r in rows] == [(t, s) for s in steps for t in exp["scalars"][kind]["tags"]]
+
+
+@pytest.mark.parametrize("index", [i for i, t in enumerate(GOLDEN) if t["case"]["replicas"] == 1])
+def test_train_model_loop_reproduces_the_reference_trace(tmp_path, index):
+    """tests/golden/train_loop_trace.json was recorded from the reference's own train_model (tests/golden/make_train_loop_golden.py)."""
+    exp = GOLDEN[index]
+    got = _run_product_loop(exp["case"], str(tmp_path))
+    _check_against_reference_trace(got, exp, str(tmp_path))
+    # properties spelled out as well: N+1 steps, warm-up epoch of min(1000, N) + 1 steps at lr / 10, test length from the per-replica batch
+    case = exp["case"]
     assert got["train_steps"][0] == min(1000, case["n"]) + 1 and all(v == case["n"] + 1 for v in got["train_steps"][1:])
     assert all(v == case["count"] // case["batch"] + 1 for v in got["test_steps"])
-    assert got["lr"][0] == pytest.approx(lr / 10) and got["lr"][-1] == pytest.approx(lr)
-    assert ScriptedUNet.last.args[1] == case["batch"]             # global batch = batch_size x replicas (1 here)
+    assert got["lr"][0] == pytest.approx(3e-4 / 10) and got["lr"][-1] == pytest.approx(3e-4)
+
+
+def _rank_worker(rank, world, port, index, out_dir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    try:
+        import torch.distributed as dist
+        mine = os.path.join(out_dir, "rank%d" % rank)
+        got = _run_product_loop(GOLDEN[index]["case"], mine)
+        _check_against_reference_trace(got, GOLDEN[index], mine, rank)
+        q.put((rank, "ok"))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:                           # surface the failure in the parent
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("index", [i for i, t in enumerate(GOLDEN) if t["case"]["replicas"] > 1])
+def test_train_model_loop_two_replicas_reproduces_the_reference_trace(tmp_path, index):
+    """The reference's MirroredStrategy run with R replicas in one process == R processes here (gloo on the CPU): every rank takes the
+    reference's decisions (steps, learning rates, test length from the PER-REPLICA batch, stopping epoch); rank 0 writes its files."""
+    import socket
+    import torch.multiprocessing as mp
+    world = GOLDEN[index]["case"]["replicas"]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, index, str(tmp_path), q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=180) for _ in procs)
+    [p.join(30) for p in procs]
+    assert res == {r: "ok" for r in range(world)}, res
 
 
 def _write_tiles(folder, masks):
