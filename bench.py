@@ -198,6 +198,48 @@ def cpu_baseline_bounded(args, budget_s=420):
     return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port", "sample": "cpu baseline: " + (note or "no output")}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N child processes of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, rendezvous on 127.0.0.1), started from a parent that never initialises HIP and never exec()s.  Rank 0's
+    stdout (the ONE JSON line) is relayed verbatim; the other ranks' stdout goes to stderr.  Returns the exit code: 0 only if every rank
+    exited 0.  If a rank dies, exactly the children started here are terminated."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+    chunks = []
+    drain = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)     # rank 0's line may exceed a pipe buffer
+    drain.start()
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:                       # a rank is gone: the others would wait in a collective forever
+                        procs[q].terminate()
+            time.sleep(0.05)
+        drain.join(10)
+        sys.stdout.write("".join(chunks))
+        sys.stdout.flush()
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    return rc
+
+
 def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype, steps, warmup, no_overlap, kernel_events,
                  sample_every, barrier, fp32_matrix="bf16x6", max_workgroups=None, bucket_mb=25.0):
     """W warm-up + K timed optimizer steps of one workload -> dict with dt, per-family kernel figures, final loss."""
@@ -277,6 +319,14 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
     return {"dt": dt, "kernels": kernels, "final_loss": final_loss, "sampled_steps": sampled, "G": G, "buckets": buckets}
 
 
+def baseline_config_id(args, world):
+    """which BASELINE.json config the command-line workload is ("2", "3" = config 2's per-GPU work on N > 1 GPUs, "4", "5", else "custom")"""
+    key = (args.size, args.channels, args.classes, args.batch, args.dtype)
+    if key == (512, 1, 2, 8, "f32"):
+        return "2" if world == 1 else "3"
+    return {(512, 3, 4, 8, "bf16"): "4", (1024, 3, 6, 2, "f32"): "5"}.get(key, "custom")
+
+
 def roofline_of(kernels, workload_key):
     """The 3x3 family with the most exclusive ms per step."""
     cands = {k: v for k, v in kernels.items() if k in FAMILY}
@@ -345,14 +395,18 @@ def main():
         cpu_baseline(args.size, args.channels, args.classes, batch=args.batch)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU), BEFORE anything in this process has touched
+        # the GPU (torch is not even imported yet), and relay rank 0's line.  Under torch.distributed.run WORLD_SIZE is set and this is skipped.
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     # UNET_BENCH_REHEARSAL=1: every rank on GPU 0, collectives over gloo -- runs the N>1 code path (rank-sharded synthetic data,
     # DataParallel buckets, barriers, MAX over ranks) on a ONE-GPU box.  The line is marked "rehearsal": it is not a scaling figure.
     rehearsal = world > 1 and os.environ.get("UNET_BENCH_REHEARSAL") == "1"
@@ -400,19 +454,20 @@ def main():
     extras = []
     if world == 1 and not args.no_extra and (args.size, args.channels, args.classes, args.batch, args.dtype) == (512, 1, 2, 8, "f32"):
         other = "native" if args.fp32_matrix == "bf16x6" else "bf16x6"
-        for (size, ch, kc, b, dty, label, fm) in ((512, 3, 4, 8, "bf16", "BASELINE config 4 per-GPU workload", args.fp32_matrix),
-                                                  (1024, 3, 6, 2, "f32", "BASELINE config 5 per-GPU workload", args.fp32_matrix),
-                                                  (512, 1, 2, 8, "f32", "BASELINE config 2 on the OTHER fp32 route (fp32_matrix = %s)" % other, other)):
+        for (size, ch, kc, b, dty, label, fm, cid) in (
+                (512, 3, 4, 8, "bf16", "BASELINE config 4 per-GPU workload", args.fp32_matrix, "4"),
+                (1024, 3, 6, 2, "f32", "BASELINE config 5 per-GPU workload", args.fp32_matrix, "5/" + args.fp32_matrix),
+                (512, 1, 2, 8, "f32", "BASELINE config 2 on the OTHER fp32 route (fp32_matrix = %s)" % other, other, "2/" + other)):
             st, wu = 16, 4
             try:
                 r2 = run_workload(model, dev, 1, 0, size, ch, kc, b, dty, st, wu, False, True, 8, barrier, fm)
                 ips2, s2 = summarize(r2, r2["dt"], size, ch, kc, b, dty, st, wu, 1)
                 s2.pop("kernels")
-                extras.append(dict({"workload": "%s: synthetic %dx%dx%d, %d classes, batch %d, %s" % (label, size, size, ch, kc, b, dty),
+                extras.append(dict({"id": cid, "workload": "%s: synthetic %dx%dx%d, %d classes, batch %d, %s" % (label, size, size, ch, kc, b, dty),
                                     "value": round(ips2, 3), "unit": "images/sec", "steps": st, "warmup": wu, "dtype": dty,
                                     "arithmetic": ARITHMETIC[fm] if dty == "f32" else "bf16 contractions, fp32 accumulation and master weights"}, **s2))
             except Exception as e:                      # noqa: BLE001 -- never lose the headline line to an extra run
-                extras.append({"workload": label, "error": repr(e)[:300]})
+                extras.append({"id": cid, "workload": label, "error": repr(e)[:300]})
 
     if rank == 0:
         ips, s = summarize(res, dt, args.size, args.channels, args.classes, args.batch, args.dtype, args.steps, args.warmup, world)
@@ -421,12 +476,23 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": s.pop("ms_per_step"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "arithmetic": ARITHMETIC[args.fp32_matrix] if args.dtype == "f32" else "bf16 contractions, fp32 accumulation and master weights",
-            "config": {"workload": "U-Net train step (fwd + softmax-CE + bwd + Keras-Adam%s), synthetic %dx%dx%d tiles, "
-                                   "%d classes, batch %d per GPU, random-init weights, dropout on"
-                                   % (" + RCCL gradient all-reduce" if world > 1 else "", args.size, args.size,
-                                      args.channels, args.classes, args.batch),
+            "config": {"workload": "U-Net train step%s, synthetic %dx%dx%d, %d classes, batch %d/GPU, %s (BASELINE config %s)"
+                                   % (" + RCCL all-reduce" if world > 1 else "", args.size, args.size, args.channels, args.classes, args.batch,
+                                      args.dtype, baseline_config_id(args, world)),
                        "global_batch": res["G"], "parallelism": "dp%d" % world},
         }
+        # every workload this run measured, compact and FIRST (a record that keeps only the head or only known keys still shows all of them);
+        # the same list closes the line as `summary` (a record that keeps only the tail shows it too).  Full blocks: `extra_configs`.
+        rf = s.get("roofline") or {}
+        compact = [{"id": baseline_config_id(args, world) + ("" if args.dtype == "bf16" else "/" + args.fp32_matrix), "img_s": round(ips, 1),
+                    "ms": out["ms_per_step"], "roofline_frac": rf.get("frac"), "roofline_family": rf.get("family")}]
+        for e in extras:
+            if "value" in e:
+                r2 = e.get("roofline") or {}
+                compact.append({"id": e["id"], "img_s": round(e["value"], 1), "ms": e["ms_per_step"], "roofline_frac": r2.get("frac"),
+                                "roofline_family": r2.get("family")})
+        out["config"]["measured"] = "; ".join("%s: %.1f img/s" % (c["id"], c["img_s"]) for c in compact)
+        out["configs"] = compact
         out.update(s)
         if world > 1:
             out["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
@@ -436,6 +502,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline_bounded(args) if (world == 1 and not args.no_cpu_baseline) else None
         if extras:
             out["extra_configs"] = extras
+        out["summary"] = compact
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

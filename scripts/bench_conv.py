@@ -25,7 +25,7 @@ for name, h, ci, co in shapes:
     out = torch.empty(B, h, h, co, device="cuda"); dx = torch.empty(B, h, h, ci, device="cuda"); dw = torch.empty_like(w)
     nb = L.unet_conv3x3_wgrad_mfma_workspace(B, h, h, ci, co); ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
     fl = 2.0 * 9 * B * h * h * ci * co
-    wok = wwok = False          # (the unfused Winograd pipeline left the default library: UNET_EXPERIMENTAL builds only)
+    wok = wwok = False          # (the unfused Winograd pipeline was removed in round 5: git history has it)
     Uc = torch.empty(16 * ci * co, device="cuda"); Ucd = torch.empty(16 * ci * co, device="cuda")
     L.unet_winograd_weight_transform(P(w), P(Uc), ci, co, 2, ST()); L.unet_winograd_weight_transform(P(w), P(Ucd), ci, co, 3, ST())
     nbq = L.unet_conv3x3_wgrad_winograd_fused_workspace(B, h, h, ci, co, 0); wsq = torch.empty(nbq + 256, dtype=torch.uint8, device="cuda")

@@ -27,10 +27,6 @@ for name, h, ci, co in [("up4", 32, 1024, 512), ("up3", 64, 512, 256), ("up2", 1
     if L.unet_convT2x2_fwd_stream_supported(B, h, h, ci, co) == 1:
         t3 = timeit(lambda: L.unet_convT2x2_fwd_stream(P(x), ci, P(w), P(b), P(out), co, B, h, h, ci, co, ST()))
         print("        fwd (stream kernel) %6.3f ms %6.1f TF" % (t3, fl / t3 / 1e9))
-    if hasattr(L, 'unet_convT2x2_wgrad_wide') and L.unet_convT2x2_wgrad_wide_supported(B, h, h, ci, co) == 1:      # UNET_EXPERIMENTAL builds only
-        nbw = L.unet_convT2x2_wgrad_wide_workspace(B, h, h, ci, co); wsw = torch.empty(nbw + 256, dtype=torch.uint8, device="cuda")
-        t4 = timeit(lambda: L.unet_convT2x2_wgrad_wide(P(x), ci, P(dz), co, P(dw), B, h, h, ci, co, P(wsw), nbw, ST()))
-        print("        wgrad (wide kernel) %6.3f ms %6.1f TF" % (t4, fl / t4 / 1e9))
     if L.unet_convT2x2_bf16_supported(B, h, h, ci, co) == 1:
         nbp = L.unet_convT2x2_bf16_packed_bytes(ci, co)
         wp = torch.empty(nbp, dtype=torch.uint8, device="cuda"); wpd = torch.empty(nbp, dtype=torch.uint8, device="cuda")

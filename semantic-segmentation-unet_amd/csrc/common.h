@@ -51,7 +51,7 @@ static inline bool unet_aligned16(const void* p) { return (reinterpret_cast<uint
 static inline int unet_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // Workgroup slots a persistent kernel sizes its grid by: one per CU, or the caller's max_workgroups when that lies in [32, cus).  A
 // data-parallel caller passes ~224 so that the collective's kernels (RCCL runs 16-32 workgroups of its own) find ~4 free CUs per XCD
-// instead of waiting for a resident workgroup to drain its share of the tiles (parallel.py; scripts/overlap_standin.py measures it).
+// instead of waiting for a resident workgroup to drain its share of the tiles (parallel.py; scripts/overlap_probe.py measures it).
 static inline int unet_grid_slots(int cus, int max_workgroups) { return (max_workgroups >= 32 && max_workgroups < cus) ? max_workgroups : cus; }
 
 // counter-based RNG for dropout: one 32-bit hash per element, keep = top bit.  The same (seed, index)

@@ -499,41 +499,3 @@ int convt_wg_splits(int N, int H, int W, int Cin, int Cout) {
 
 }  // namespace
 
-#ifdef UNET_EXPERIMENTAL      /* wide-tile transposed-conv weight gradient: 22 % faster alone, no faster inside the step (it cannot share a CU with the
-                                 data-gradient stream); kept for A/B builds, not part of include/unet_hip.h */
-extern "C" int unet_convT2x2_wgrad_wide_supported(int N, int H, int W, int Cin, int Cout) {
-    return (N > 0 && H > 0 && W > 0 && W % 16 == 0 && Cin % 128 == 0 && Cout % 64 == 0 &&
-            (long)2 * W * 4096 * 4 < (1L << 31)) ? 1 : 0;
-}
-
-extern "C" size_t unet_convT2x2_wgrad_wide_workspace(int N, int H, int W, int Cin, int Cout) {
-    if (!unet_convT2x2_wgrad_wide_supported(N, H, W, Cin, Cout)) return 0;
-    return (size_t)convt_wg_splits(N, H, W, Cin, Cout) * 4 * Cout * Cin * sizeof(float);
-}
-
-// dw[a][b][co][ci] = sum_{n,i,j} dz[n,2i+a,2j+b,co] * xin[n,i,j,ci]      (H, W are the INPUT dims of the layer)
-extern "C" int unet_convT2x2_wgrad_wide(const float* xin, int ldx, const float* dz, int lddz, float* dw,
-                                        int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
-    UNET_CHECK_ARG(xin && dz && dw && ws && unet_convT2x2_wgrad_wide_supported(N, H, W, Cin, Cout));
-    UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0 && ldx <= 4096 && lddz <= 4096);
-    UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
-    if (ws_bytes < unet_convT2x2_wgrad_wide_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
-    ConvtWgArgs a{};
-    a.x = xin; a.dz = dz; a.ws = (float*)ws; a.ldx = ldx; a.lddz = lddz; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    const bool wide = Cout % 128 == 0;
-    a.mt = Cout / (wide ? 128 : 64); a.nt = Cin / 128;
-    a.splits = convt_wg_splits(N, H, W, Cin, Cout);
-    a.n_tiles = N * H * (W / 16);
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)(a.mt * a.nt * a.splits));
-    if (wide) convt_wgrad_wide_kernel_128<<<grid, 256, 0, st>>>(a);
-    else      convt_wgrad_wide_kernel_64<<<grid, 256, 0, st>>>(a);
-    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    const long n4 = (long)4 * Cout * Cin / 4;
-    int sl = 1;
-    while (sl < 16 && 2 * sl <= a.splits && n4 * sl < 256 * 1024) sl *= 2;
-    const long blocks = (n4 * sl + 255) / 256;
-    convt_wgrad_reduce_kernel<<<(unsigned)blocks, 256, 0, st>>>((const float*)ws, dw, n4, a.splits, sl);
-    return UNET_LAUNCH_STATUS();
-}
-#endif  // UNET_EXPERIMENTAL

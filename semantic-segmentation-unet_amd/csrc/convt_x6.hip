@@ -123,6 +123,9 @@ __device__ __forceinline__ void convt_x6_body(const ConvtX6Args& p) {
         *reinterpret_cast<cx_i32x4*>(smem + 128 * 32 + a_wr) = m;
         *reinterpret_cast<cx_i32x4*>(smem + 2 * 128 * 32 + a_wr) = l;
     }
+    // the B stage is written by LDS-DMA (global_load ... lds): its completion is tracked by vmcnt, which a workgroup barrier does not wait for
+    // by itself -- every wave drains its own DMA pieces before the barrier publishes the stage to the other waves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int s = c & 1;
@@ -159,6 +162,7 @@ __device__ __forceinline__ void convt_x6_body(const ConvtX6Args& p) {
             *reinterpret_cast<cx_i32x4*>(nx + 128 * 32 + a_wr) = m;
             *reinterpret_cast<cx_i32x4*>(nx + 2 * 128 * 32 + a_wr) = l;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces of the next B stage have landed
         __syncthreads();
     }
 

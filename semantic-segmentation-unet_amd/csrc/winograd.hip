@@ -111,241 +111,6 @@ __global__ __launch_bounds__(256) void wino_weight_batch_kernel(const long long*
     }
 }
 
-#ifdef UNET_EXPERIMENTAL      /* the unfused pipeline (planes + batched GEMMs): superseded on every layer shape measured, kept for A/B builds */
-// V[xi][tile][c] = (B^T d B)[xi]; thread = (tile, channel quad); patch rows 2ty-1..2ty+2, zero outside the image
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V,
-                                                         int N, int H, int W, int C) {
-    const int Th = H >> 1, Tw = W >> 1, nq = C >> 2;
-    const long T = (long)N * Th * Tw, total = T * nq, stride = (long)gridDim.x * 256;
-    const size_t plane = (size_t)T * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const long tile = i / nq; const int c0 = (int)(i - tile * nq) * 4;
-        long t = tile; const int tx = (int)(t % Tw); t /= Tw; const int ty = (int)(t % Th); const int n = (int)(t / Th);
-        f32x4 d[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gy = 2 * ty - 1 + r;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int gx = 2 * tx - 1 + c;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                    v = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + gy) * W + gx) * ldx + c0);
-                d[r][c] = v;
-            }
-        }
-        f32x4 tt[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            tt[0][c] = d[0][c] - d[2][c]; tt[1][c] = d[1][c] + d[2][c];
-            tt[2][c] = d[2][c] - d[1][c]; tt[3][c] = d[1][c] - d[3][c];
-        }
-        float* dst = V + (size_t)tile * C + c0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            *reinterpret_cast<f32x4*>(dst + (size_t)(4 * r + 0) * plane) = tt[r][0] - tt[r][2];
-            *reinterpret_cast<f32x4*>(dst + (size_t)(4 * r + 1) * plane) = tt[r][1] + tt[r][2];
-            *reinterpret_cast<f32x4*>(dst + (size_t)(4 * r + 2) * plane) = tt[r][2] - tt[r][1];
-            *reinterpret_cast<f32x4*>(dst + (size_t)(4 * r + 3) * plane) = tt[r][1] - tt[r][3];
-        }
-    }
-}
-
-// out[2ty+i][2tx+j] = (A^T m A)[i][j] + bias, ReLU; thread = (tile, channel quad)
-__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
-        float* __restrict__ out, int ldo, int N, int H, int W, int C, int relu) {
-    const int Th = H >> 1, Tw = W >> 1, nq = C >> 2;
-    const long T = (long)N * Th * Tw, total = T * nq, stride = (long)gridDim.x * 256;
-    const size_t plane = (size_t)T * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const long tile = i / nq; const int c0 = (int)(i - tile * nq) * 4;
-        long t = tile; const int tx = (int)(t % Tw); t /= Tw; const int ty = (int)(t % Th); const int n = (int)(t / Th);
-        const float* src = M + (size_t)tile * C + c0;
-        f32x4 m[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) m[r][c] = *reinterpret_cast<const f32x4*>(src + (size_t)(4 * r + c) * plane);
-        f32x4 rr[2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { rr[0][c] = m[0][c] + m[1][c] + m[2][c]; rr[1][c] = m[1][c] - m[2][c] - m[3][c]; }
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + c0);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            f32x4 y0 = rr[r][0] + rr[r][1] + rr[r][2] + bv, y1 = rr[r][1] - rr[r][2] - rr[r][3] + bv;
-            if (relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], 0.f); y1[e] = fmaxf(y1[e], 0.f); }
-            }
-            float* o = out + ((size_t)(n * H + 2 * ty + r) * W + 2 * tx) * ldo + c0;
-            *reinterpret_cast<f32x4*>(o) = y0;
-            *reinterpret_cast<f32x4*>(o + ldo) = y1;
-        }
-    }
-}
-
-// dM[xi][tile][c] = (A dY A^T)[xi] for the 2x2 output-gradient tile dY; A = [1 0; 1 1; 1 -1; 0 -1]
-__global__ __launch_bounds__(256) void wino_dz_kernel(const float* __restrict__ dz, int lddz, float* __restrict__ dM,
-                                                      int N, int H, int W, int C) {
-    const int Th = H >> 1, Tw = W >> 1, nq = C >> 2;
-    const long T = (long)N * Th * Tw, total = T * nq, stride = (long)gridDim.x * 256;
-    const size_t plane = (size_t)T * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const long tile = i / nq; const int c0 = (int)(i - tile * nq) * 4;
-        long t = tile; const int tx = (int)(t % Tw); t /= Tw; const int ty = (int)(t % Th); const int n = (int)(t / Th);
-        const float* src = dz + ((size_t)(n * H + 2 * ty) * W + 2 * tx) * lddz + c0;
-        const f32x4 y00 = *reinterpret_cast<const f32x4*>(src), y01 = *reinterpret_cast<const f32x4*>(src + lddz);
-        const f32x4 y10 = *reinterpret_cast<const f32x4*>(src + (size_t)W * lddz), y11 = *reinterpret_cast<const f32x4*>(src + (size_t)W * lddz + lddz);
-        // rows of A dY: r0 = y0*, r1 = y0* + y1*, r2 = y0* - y1*, r3 = -y1*
-        const f32x4 r[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
-        float* dst = dM + (size_t)tile * C + c0;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            *reinterpret_cast<f32x4*>(dst + (size_t)(4 * a + 0) * plane) = r[a][0];
-            *reinterpret_cast<f32x4*>(dst + (size_t)(4 * a + 1) * plane) = r[a][0] + r[a][1];
-            *reinterpret_cast<f32x4*>(dst + (size_t)(4 * a + 2) * plane) = r[a][0] - r[a][1];
-            *reinterpret_cast<f32x4*>(dst + (size_t)(4 * a + 3) * plane) = -r[a][1];
-        }
-    }
-}
-
-// out[split][z][m][n] = sum over this split's rows t of A[z][t][m] * B[z][t][n]   (fp32 MFMA 32x32x2)
-// 128x128 output tile per workgroup (wave = 64x64 quadrant, 64 accumulator regs), K tiles of 64 rows, channel-contiguous
-// [row][128] LDS images filled by LDS-DMA and double-buffered -- the machinery of conv_wgrad.hip with one "tap".
-struct GemmTnArgs {
-    const float* a; const float* b; float* out;
-    long T; int M, N;            // rows per plane, A channels, B channels
-    int mt, nt, planes, splits;
-    long ktiles;                 // K tiles (of 64 rows) per plane
-};
-typedef __attribute__((address_space(3))) void lds_void_w;
-__device__ __attribute__((aligned(256))) float g_zero_page_w[128];
-
-__global__ __launch_bounds__(256, 1) void gemm_tn_planes_kernel(GemmTnArgs p) {
-    constexpr int KT = 64, CTW = 128;
-    constexpr int TILE_FLOATS = 2 * KT * CTW;          // A image + B image
-    constexpr int KP = (2 * KT * CTW * 4 / 1024) / 4;  // DMA pieces (1 KB = 2 rows) per wave: 16 (8 A + 8 B)
-    constexpr int STEPS = KT / 2;
-    __shared__ __attribute__((aligned(1024))) float smem[2 * TILE_FLOATS];
-    int bid = blockIdx.x;
-    const int tn = bid % p.nt; bid /= p.nt;
-    const int tm = bid % p.mt; bid /= p.mt;
-    const int z = bid % p.planes; const int split = bid / p.planes;
-    const int m0 = tm * CTW, n0 = tn * CTW;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mi = wv & 1, ni = wv >> 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const float* ap = p.a + (size_t)z * p.T * p.M + m0 + 4 * (lane & 31);
-    const float* bp = p.b + (size_t)z * p.T * p.N + n0 + 4 * (lane & 31);
-    const float* zsrc = g_zero_page_w + 4 * (lane & 31);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-
-    // piece k of wave w: k < 8 -> A rows 2*(4k+w) + lane/32 ; else B rows
-    auto issue_piece = [&](int k, long row0, float* dst) {
-        const bool isA = k < KP / 2;
-        const int piece = 4 * (isA ? k : k - KP / 2) + wv;
-        const long row = row0 + 2 * piece + (lane >> 5);
-        const float* g = isA ? ap + (size_t)row * p.M : bp + (size_t)row * p.N;
-        const float* src = row < p.T ? g : zsrc;
-        __builtin_amdgcn_global_load_lds(src, (lds_void_w*)(dst + (isA ? 0 : KT * CTW) + piece * 2 * CTW), 16, 0, 0);
-    };
-
-    long kt = split;
-    if (kt < p.ktiles) {
-#pragma unroll
-        for (int k = 0; k < KP; ++k) issue_piece(k, kt * KT, smem);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (; kt < p.ktiles; kt += p.splits) {
-        const float* sA = smem + cur * TILE_FLOATS;
-        const float* sB = sA + KT * CTW;
-        float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
-        const bool more = kt + p.splits < p.ktiles;
-        const long nrow0 = (kt + p.splits) * KT;
-        float ac[2], bc[2], an[2], bn[2];
-        auto load_frag = [&](int st, float (&av)[2], float (&bv)[2]) {
-            const int row = 2 * st + lh;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) av[t] = sA[row * CTW + mi * 64 + t * 32 + li];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) bv[u] = sB[row * CTW + ni * 64 + u * 32 + li];
-        };
-        load_frag(0, ac, bc);
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            if (st + 1 < STEPS) load_frag(st + 1, an, bn);
-            if ((st & 1) == 0 && (st >> 1) < KP && more) issue_piece(st >> 1, nrow0, nxt);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t], bc[u], acc[t][u], 0, 0, 0);
-            ac[0] = an[0]; ac[1] = an[1]; bc[0] = bn[0]; bc[1] = bn[1];
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-    }
-    float* o = p.out + ((size_t)split * p.planes + z) * p.M * p.N;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                o[(size_t)(m0 + mi * 64 + t * 32 + row) * p.N + n0 + ni * 64 + u * 32 + li] = acc[t][u][r];
-            }
-}
-
-// dw[a][b][ci][co] = (G^T dU G)[a][b] with dU = sum over splits of part[split][xi][ci][co]
-__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ part, int splits, float* __restrict__ dw, int Ci, int Co) {
-    const long nq = (long)Ci * Co / 4, stride = (long)gridDim.x * 256;
-    const size_t plane = (size_t)Ci * Co;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nq; i += stride) {
-        f32x4 u[16];
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            f32x4 s = *reinterpret_cast<const f32x4*>(part + (size_t)xi * plane + 4 * i);
-            for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + ((size_t)k * 16 + xi) * plane + 4 * i);
-            u[xi] = s;
-        }
-        f32x4 sv[3][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sv[0][j] = u[0 + j] + 0.5f * (u[4 + j] + u[8 + j]);
-            sv[1][j] = 0.5f * (u[4 + j] - u[8 + j]);
-            sv[2][j] = 0.5f * (u[4 + j] + u[8 + j]) + u[12 + j];
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            *reinterpret_cast<f32x4*>(dw + (size_t)(3 * a + 0) * plane + 4 * i) = sv[a][0] + 0.5f * (sv[a][1] + sv[a][2]);
-            *reinterpret_cast<f32x4*>(dw + (size_t)(3 * a + 1) * plane + 4 * i) = 0.5f * (sv[a][1] - sv[a][2]);
-            *reinterpret_cast<f32x4*>(dw + (size_t)(3 * a + 2) * plane + 4 * i) = 0.5f * (sv[a][1] + sv[a][2]) + sv[a][3];
-        }
-    }
-}
-
-int wgrad_splits(long T, int Ci, int Co) {
-    const long wgs = (long)(Ci / 128) * (Co / 128) * 16;
-    long s = (256 + wgs - 1) / wgs;
-    const long ktiles = T / 64;
-    if (s > ktiles) s = ktiles;
-    if (s < 1) s = 1;
-    return (int)s;
-}
-
-#endif  // UNET_EXPERIMENTAL
 
 // ---- fully fused Winograd F(2x2,3x3) forward / data-gradient convolution ------------------------------------------------
 // One workgroup = 8x8 Winograd tiles (16x16 output pixels) x 64 output channels; wave (mi, ni) owns [32 tiles x 32 channels]
@@ -1055,23 +820,6 @@ int wgrad_fused_splits(int N, int H, int W, int Ci, int Co, int max_workgroups) 
 
 int grid_for(long total, int cap) { long b = (total + 255) / 256; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b; }
 
-#ifdef UNET_EXPERIMENTAL
-bool wino_ok(int N, int H, int W, int Ci, int Co) {
-    const long T = (long)N * (H / 2) * (W / 2);
-    return H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && T % 32 == 0 && Ci % 32 == 0 && Co % 64 == 0 && Ci % 4 == 0;
-}
-
-int run_wino(const float* x, int ldx, const float* U, const float* bias, float* out, int ldo, int N, int H, int W,
-             int Kc, int Nc, int relu, float* V, float* M, hipStream_t st) {
-    const long T = (long)N * (H / 2) * (W / 2);
-    wino_input_kernel<<<grid_for(T * (Kc / 4), 16384), 256, 0, st>>>(x, ldx, V, N, H, W, Kc);
-    int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    rc = unet_igemm_batched_planes(V, U, M, T, Kc, Nc, 16, st); if (rc) return rc;
-    wino_output_kernel<<<grid_for(T * (Nc / 4), 16384), 256, 0, st>>>(M, bias, out, ldo, N, H, W, Nc, relu);
-    return UNET_LAUNCH_STATUS();
-}
-
-#endif  // UNET_EXPERIMENTAL
 
 // ---- BatchNorm-apply on load for the fused forward kernel (SURVEY.md 7 "hard parts": the consumer applies the producer's
 // BatchNorm on load and padded positions must contribute exactly 0) ---------------------------------------------------------------
@@ -1363,12 +1111,6 @@ extern "C" int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, cons
     return UNET_LAUNCH_STATUS();
 }
 
-#ifdef UNET_EXPERIMENTAL
-extern "C" int unet_winograd_supported(int N, int H, int W, int Cin, int Cout) {
-    return (wino_ok(N, H, W, Cin, Cout) && Cin % 64 == 0) ? 1 : 0;
-}
-
-#endif
 
 // U must hold 16*Cin*Cout floats.  mode 0: forward kernel transform; mode 1: data-gradient kernel transform.
 extern "C" int unet_winograd_weight_transform(const float* w, float* U, int Cin, int Cout, int mode, void* stream) {
@@ -1415,72 +1157,3 @@ extern "C" int unet_winograd_weight_transform_batch(const void* jobs, int njobs,
     return UNET_LAUNCH_STATUS();
 }
 
-#ifdef UNET_EXPERIMENTAL      /* entry points of the unfused pipeline: not part of include/unet_hip.h */
-extern "C" size_t unet_conv3x3_winograd_workspace(int N, int H, int W, int Cin, int Cout) {
-    const size_t T = (size_t)N * (H / 2) * (W / 2);
-    return 16 * T * ((size_t)Cin + Cout) * sizeof(float);
-}
-
-// forward: out = relu?(conv3x3_same(x, w) + bias) with U = unet_winograd_weight_transform(w, mode 0)
-extern "C" int unet_conv3x3_fwd_winograd(const float* x, int ldx, const float* U, const float* bias, float* out, int ldo,
-        int N, int H, int W, int Cin, int Cout, int relu, float* V_keep, void* ws, size_t ws_bytes, void* stream) {
-    UNET_CHECK_ARG(x && U && out && ws && N > 0 && wino_ok(N, H, W, Cin, Cout) && ldx >= Cin && ldo >= Cout);
-    UNET_CHECK_ARG(ldx % 4 == 0 && ldo % 4 == 0 && unet_aligned16(x) && unet_aligned16(out) && unet_aligned16(ws) && unet_aligned16(U));
-    UNET_CHECK_ARG(!bias || unet_aligned16(bias));
-    if (ws_bytes < unet_conv3x3_winograd_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
-    const size_t T = (size_t)N * (H / 2) * (W / 2);
-    UNET_CHECK_ARG(!V_keep || unet_aligned16(V_keep));
-    float* V = V_keep ? V_keep : (float*)ws;          // V_keep (16*T*Cin floats): keep B^T d B for the weight gradient
-    float* M = (float*)ws + 16 * T * Cin;
-    return run_wino(x, ldx, U, bias, out, ldo, N, H, W, Cin, Cout, relu, V, M, (hipStream_t)stream);
-}
-
-extern "C" int unet_winograd_wgrad_supported(int N, int H, int W, int Cin, int Cout) {
-    const long T = (long)N * (H / 2) * (W / 2);
-    return (H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && T % 64 == 0 && Cin % 128 == 0 && Cout % 128 == 0) ? 1 : 0;
-}
-
-extern "C" size_t unet_conv3x3_wgrad_winograd_workspace(int N, int H, int W, int Cin, int Cout) {
-    const size_t T = (size_t)N * (H / 2) * (W / 2);
-    return (16 * T * ((size_t)Cin + Cout) + (size_t)wgrad_splits((long)T, Cin, Cout) * 16 * Cin * Cout) * sizeof(float);
-}
-
-// dw[a][b][ci][co] = sum_{n,y,x} xin[n, y+a-1, x+b-1, ci] * dz[n,y,x,co], through the Winograd domain:
-// dU[xi] = V[xi]^T dM[xi] (V = B^T d B of xin, dM = A dY A^T of dz), dw = G^T dU G
-extern "C" int unet_conv3x3_wgrad_winograd(const float* xin, int ldx, const float* V_saved, const float* dz, int lddz, float* dw,
-        int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
-    UNET_CHECK_ARG((xin || V_saved) && dz && dw && ws && N > 0 && unet_winograd_wgrad_supported(N, H, W, Cin, Cout));
-    UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0);
-    UNET_CHECK_ARG((V_saved ? unet_aligned16(V_saved) : unet_aligned16(xin)) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
-    if (ws_bytes < unet_conv3x3_wgrad_winograd_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
-    hipStream_t st = (hipStream_t)stream;
-    const long T = (long)N * (H / 2) * (W / 2);
-    float* Vw = (float*)ws; float* dM = Vw + 16 * (size_t)T * Cin; float* part = dM + 16 * (size_t)T * Cout;
-    const float* V = V_saved ? V_saved : Vw;           // V_saved: B^T d B kept by the forward pass (same xin)
-    int rc = UNET_OK;
-    if (!V_saved) {
-        wino_input_kernel<<<grid_for(T * (Cin / 4), 16384), 256, 0, st>>>(xin, ldx, Vw, N, H, W, Cin);
-        rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    }
-    wino_dz_kernel<<<grid_for(T * (Cout / 4), 16384), 256, 0, st>>>(dz, lddz, dM, N, H, W, Cout);
-    rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    GemmTnArgs g{};
-    g.a = V; g.b = dM; g.out = part; g.T = T; g.M = Cin; g.N = Cout; g.mt = Cin / 128; g.nt = Cout / 128; g.planes = 16;
-    g.splits = wgrad_splits(T, Cin, Cout); g.ktiles = T / 64;
-    gemm_tn_planes_kernel<<<dim3((unsigned)(g.mt * g.nt * 16 * g.splits)), 256, 0, st>>>(g);
-    rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
-    wino_dw_kernel<<<grid_for((long)Cin * Cout / 4, 4096), 256, 0, st>>>(part, g.splits, dw, Cin, Cout);
-    return UNET_LAUNCH_STATUS();
-}
-
-// dgrad: dx = conv3x3_same(dz, rot180(w)^T) with Ud = unet_winograd_weight_transform(w, mode 1)
-extern "C" int unet_conv3x3_dgrad_winograd(const float* dz, int lddz, const float* Ud, float* dx, int lddx,
-        int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
-    UNET_CHECK_ARG(dz && Ud && dx && ws && N > 0 && wino_ok(N, H, W, Cout, Cin) && lddz >= Cout && lddx >= Cin);
-    UNET_CHECK_ARG(lddz % 4 == 0 && lddx % 4 == 0 && unet_aligned16(dz) && unet_aligned16(dx) && unet_aligned16(ws) && unet_aligned16(Ud));
-    if (ws_bytes < unet_conv3x3_winograd_workspace(N, H, W, Cin, Cout)) return UNET_ENOSPC;
-    const size_t T = (size_t)N * (H / 2) * (W / 2);
-    float* V = (float*)ws; float* M = V + 16 * T * Cout;
-    return run_wino(dz, lddz, Ud, nullptr, dx, lddx, N, H, W, Cout, Cin, 0, V, M, (hipStream_t)stream);
-}
-#endif  // UNET_EXPERIMENTAL

@@ -240,38 +240,45 @@ class Engine:
 
     def _x6_kernels(self, name, forward=False):
         """(U6 forward, U6 data gradient): the layer's Winograd-transformed kernel as three bf16 pieces per value (csrc/winograd_x6.hip).
-        After a parameter change ONE batched launch re-transforms every data-gradient operand and the forward operands of the layers the
-        current plan reads without BatchNorm-apply on load (the other layers' forward operands come out of unet_winograd_weight_fold_x6
-        every step: transforming them here as well was 39 % of the launch's bytes).  forward=True: the caller needs [0]; a forward operand
-        the batch skipped (another plan of the same engine, e.g. bn_on_load off) is transformed on demand."""
+        Buffers exist only for the layers and directions the CURRENT plan routes through BF16x6 (96 B per weight and direction: ~600 MB for
+        the whole network, so a bf16-mode plan with one fp32 fallback layer allocates and re-splits that one layer).  After a parameter
+        change ONE batched launch re-transforms every data-gradient operand in use and the forward operands of the layers the plan reads
+        without BatchNorm-apply on load (the other layers' forward operands come out of unet_winograd_weight_fold_x6 every step:
+        transforming them here as well was 39 % of the launch's bytes).  forward=True: the caller needs [0]; a forward operand the batch
+        skipped (another plan of the same engine, e.g. bn_on_load off) is transformed on demand."""
         if self._x6_U is None:
-            self._x6_U, self._x6_jobs = {}, {}
-            for n, kind, cin, cout in self.layers:
-                if kind != "conv3" or cin % 16 or cout % 16:
-                    continue
-                nb = self.L.unet_winograd_x6_weight_bytes(cin, cout)
-                self._x6_U[n] = (torch.empty(nb, dtype=torch.uint8, device=self.dev), torch.empty(nb, dtype=torch.uint8, device=self.dev))
-            self._x6_dirty = True
-            self._ctx6_dirty = True
+            self._x6_U, self._x6_jobs, self._x6_fwd_valid, self._x6_valid_d = {}, {}, set(), set()
+        pl = self.pl
+        want_f = frozenset(n for n, p in pl.layer.items() if p.fwd_x6 and not p.x_on_load) | ({name} if forward else frozenset())
+        want_d = frozenset(n for n, p in pl.layer.items() if p.dgrad_x6) | (frozenset() if forward else {name})
+        for n in want_f | want_d:
+            u = self._x6_U.setdefault(n, [None, None])
+            for mode, want in ((0, want_f), (1, want_d)):
+                if n in want and u[mode] is None:
+                    u[mode] = torch.empty(self.L.unet_winograd_x6_weight_bytes(self.cin[n], self.cout[n]), dtype=torch.uint8, device=self.dev)
+                    self._x6_dirty = True
         if self._x6_dirty:
-            skip = frozenset(n for n in self._x6_U if self.pl is not None and self.pl.layer[n].x_on_load)
-            job = self._x6_jobs.get(skip)
+            key = (want_f, want_d)
+            job = self._x6_jobs.get(key)
             if job is None:
                 rows, blk = [], 0
-                for n, u in self._x6_U.items():
+                for n in sorted(want_f | want_d):
                     cin, cout = self.cin[n], self.cout[n]
-                    for mode in (0, 1):
-                        if mode == 0 and n in skip:
-                            continue
-                        rows.append([self.p[n + "/kernel"].data_ptr(), u[mode].data_ptr(), cin | (cout << 32), blk, mode, 0])
-                        blk += (cin * cout + 2047) // 2048
-                job = self._x6_jobs[skip] = (torch.tensor(rows, dtype=torch.int64, device=self.dev), blk)
+                    for mode, want in ((0, want_f), (1, want_d)):
+                        if n in want:
+                            rows.append([self.p[n + "/kernel"].data_ptr(), self._x6_U[n][mode].data_ptr(), cin | (cout << 32), blk, mode, 0])
+                            blk += (cin * cout + 2047) // 2048
+                job = self._x6_jobs[key] = (torch.tensor(rows, dtype=torch.int64, device=self.dev), blk)
             self.L.unet_winograd_weight_transform_x6_batch(_p(job[0]), job[0].shape[0], job[1], self._stream())
-            self._x6_fwd_valid = set(self._x6_U) - skip
+            self._x6_fwd_valid = set(want_f)
+            self._x6_valid_d = set(want_d)
             self._x6_dirty = False
         if forward and name not in self._x6_fwd_valid:
             self.L.unet_winograd_weight_transform_x6(_p(self.p[name + "/kernel"]), _p(self._x6_U[name][0]), self.cin[name], self.cout[name], 0, self._stream())
             self._x6_fwd_valid.add(name)
+        if not forward and name not in self._x6_valid_d:
+            self.L.unet_winograd_weight_transform_x6(_p(self.p[name + "/kernel"]), _p(self._x6_U[name][1]), self.cin[name], self.cout[name], 1, self._stream())
+            self._x6_valid_d.add(name)
         return self._x6_U[name]
 
     def _convt_x6_kernels(self, name):
@@ -415,7 +422,7 @@ class Engine:
             if in_view is not None:
                 # BatchNorm-apply on load: scaled weight transform, folded bias, per-channel padding value (this step's coefficients)
                 uc, bias_eff, pad = self._fold_buffers(name, x6)
-                if training or name not in self._eval_folded:
+                if training or (name, x6) not in self._eval_folded:
                     # (inference: the coefficients come from the moving statistics -- constants until the parameters change -- so
                     # the fold of one forward serves every later tile)
                     if x6:
@@ -425,9 +432,9 @@ class Engine:
                         L.unet_winograd_weight_fold(_p(w_), _p(b_), _p(in_view[0]), _p(in_view[1]), _p(uc), _p(bias_eff), _p(pad), cin, cout,
                                                     _p(self._workspace(nbf)), nbf, st)
                     if training:
-                        self._eval_folded.discard(name)
+                        self._eval_folded.discard((name, x6))
                     else:
-                        self._eval_folded.add(name)
+                        self._eval_folded.add((name, x6))      # (keyed by the route too: the two routes fold into different buffers)
             else:
                 uc, bias_eff, pad = (self._x6_kernels(name, forward=True)[0] if x6 else self._fused_kernels(name)[0]), b_, None
             # (with stat_part the conv kernel also leaves the BatchNorm sums of its output: one activation read less per layer)

@@ -47,8 +47,10 @@ def rel(a, r):
     return float(d.abs().max() / r.abs().max()), float(d.pow(2).mean().sqrt() / r.pow(2).mean().sqrt())
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 8, 128, 64), (1, 16, 16, 256, 128), (4, 8, 8, 128, 192), (2, 8, 24, 128, 64), (1, 12, 32, 384, 64),
-                                   (8, 32, 32, 1024, 512), (8, 256, 256, 128, 64)])
+BASELINE_SHAPES = [(8, 32, 32, 1024, 512), (8, 64, 64, 512, 256), (8, 128, 128, 256, 128), (8, 256, 256, 128, 64)]      # up_4 .. up_1 of BASELINE config 2
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 128, 64), (1, 16, 16, 256, 128), (4, 8, 8, 128, 192), (2, 8, 24, 128, 64), (1, 12, 32, 384, 64)] + BASELINE_SHAPES)
 def test_forward_and_data_gradient_are_fp32_grade(shape):
     L = pkg("_lib").lib()
     n, h, w, ci, co = shape
@@ -73,8 +75,17 @@ def test_forward_and_data_gradient_are_fp32_grade(shape):
     L.unet_convT2x2_wgrad(P(x), ci, P(dz), co, P(dwn), n, h, w, ci, co, P(wsn), nbn, ST())
     rw = torch.einsum("nyaxbk,nyxc->abkc", dz.double().reshape(n, h, 2, w, 2, co), x.double())
     (wm_, wr_), (vm_, vr_) = rel(dw, rw), rel(dwn, rw)
-    # (sums over up to 5e5 pixels: the error is the accumulation order's -- split-K partials of 16-pixel MFMA steps here, 2-pixel steps natively)
-    assert wr_ <= 2.5 * vr_ and wm_ <= 3.0 * vm_ and wr_ < 2e-6, (wm_, wr_, vm_, vr_)
+    if shape in BASELINE_SHAPES:
+        # the layers the route exists for (sums over 8e3 .. 5e5 pixels): fp32-grade by the same criterion as every other BF16x6 kernel --
+        # rms error at most 1.25x, max error at most 1.5x the native fp32-MFMA kernel's
+        assert wr_ <= 1.25 * vr_ and wm_ <= 1.5 * vm_ and wr_ < 2e-6, (wm_, wr_, vm_, vr_)
+    else:
+        # sums over 128 .. 384 pixels: the native kernel's error is a handful of fp32 roundings of the accumulator (measured 0.9e-7 .. 1.0e-7
+        # rms, 1.3e-7 .. 1.9e-7 max: there is nothing below it), while the six-product form adds its dropped piece products -- at most 2^-21,
+        # on average 2^-24.5 of each product and of the product's sign (tests/test_bf16x6_arithmetic.py), which no longer hides under an
+        # accumulation error that has not had time to grow.  A ratio to a kernel sitting on the rounding floor says nothing, so the bound
+        # here is ABSOLUTE: 2.5e-7 rms / 5e-7 max of the result's scale = two / four fp32 ulps (measured 1.7e-7 / 3.8e-7)
+        assert wr_ < 2.5e-7 and wm_ < 5e-7, (wm_, wr_, vm_, vr_)
     if nbw > 16:
         with pytest.raises(pkg("_lib").UnetHipError, match="workspace too small"):
             L.unet_convT2x2_wgrad_x6(P(x), ci, P(dz), co, P(dw), n, h, w, ci, co, P(ws), nbw - 16, ST())

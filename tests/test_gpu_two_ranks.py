@@ -108,13 +108,17 @@ def test_two_rank_hip_step_equals_the_global_batch_semantics(tmp_path, bucket):
     assert not np.array_equal(res[0]["theta"], res[0]["theta0"])
 
 
-def test_bench_two_rank_rehearsal():
-    """bench.py's N > 1 path, launched the way the driver launches it (torch.distributed.run, one process per rank), on the
-    one-GPU box: UNET_BENCH_REHEARSAL=1 puts both ranks on GPU 0 over gloo.  The line must carry the whole-job aggregate."""
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_rank_rehearsal(launcher):
+    """bench.py's N > 1 path on the one-GPU box (UNET_BENCH_REHEARSAL=1 puts both ranks on GPU 0 over gloo), started both ways a driver may
+    start it: through torch.distributed.run (one process per rank), and as plain `python bench.py --gpus 2` (bench.py then starts the two
+    ranks itself from a parent that never touches the GPU).  The ONE line must carry the whole-job aggregate."""
     env = dict(os.environ, UNET_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--size", "256", "--no-extra"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    head = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(_free_port())] if launcher == "torchrun" else [sys.executable])
+    cmd = head + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--size", "256", "--no-extra"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
@@ -122,3 +126,4 @@ def test_bench_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
     assert d["cpu_baseline"] is None and "rehearsal" in d and np.isfinite(d["final_loss"])
+    assert d["configs"] == d["summary"] and d["configs"][0]["img_s"] == pytest.approx(d["value"], abs=0.06)

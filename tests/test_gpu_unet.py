@@ -49,6 +49,41 @@ def grad_errors(g_hip, g_ref):
     return out
 
 
+ROUTES = ["bf16x6", "native"]        # plan.EngineOptions.fp32_matrix: both fp32 routes are the product, so every end-to-end oracle test runs on both
+
+
+def make_net(route, *args, **kw):
+    """model.UNet(...) with the fp32 matrix route chosen (before anything is planned or transformed)"""
+    net = pkg("model").UNet(*args, **kw)
+    net.engine.opt.fp32_matrix = route
+    return net
+
+
+def recorded(e, fn):
+    """fn() with the engine's launch recording on -> (fn's result, {family: launches})"""
+    e.profile = {}
+    try:
+        out = fn()
+    finally:
+        counts = {key: len(v) for key, v in e.profile.items()}
+        e.profile = None
+    return out, counts
+
+
+def assert_route_taken(counts, route, hw, training, first_dgrad=False):
+    """The launches of a forward (+ backward) pass prove the route: all MFMA-eligible 3x3 layers (17; 15 when the bottleneck tile is odd and
+    takes the implicit-GEMM kernels) on the route's Winograd family, none on the other's, and no BF16x6 launch of any kind on the native route."""
+    hh, ww = hw if isinstance(hw, tuple) else (hw, hw)
+    want = 15 if ((hh // 16) % 2 or (ww // 16) % 2) else 17
+    mine, other = ("_x6", "_fused") if route == "bf16x6" else ("_fused", "_x6")
+    assert counts.get("conv3x3_fwd_winograd" + mine) == want and "conv3x3_fwd_winograd" + other not in counts, (route, counts)
+    if training:
+        assert counts.get("conv3x3_dgrad_winograd" + mine) == want and "conv3x3_dgrad_winograd" + other not in counts, (route, counts)
+        assert counts.get("conv3x3_wgrad_winograd_fused") == want, (route, counts)       # the weight gradient is native fp32 on both routes
+    if route == "native":
+        assert not [key for key in counts if key.endswith("_x6")], counts
+
+
 def argmax_agreement(p_hip, p_ref, margin=1e-4):
     """argmax must be identical on every pixel whose top-2 margin in the oracle exceeds `margin`."""
     a, b = np.argmax(p_hip, -1), np.argmax(p_ref, -1)
@@ -58,18 +93,20 @@ def argmax_agreement(p_hip, p_ref, margin=1e-4):
     return (a == b)[decided].all(), int((~decided).sum()), int((a != b).sum())
 
 
+@pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("cfg", [(2, 1, 2, 32), (2, 3, 4, 32)])
-def test_unet_matches_numpy_oracle(cfg):
+def test_unet_matches_numpy_oracle(cfg, route):
     n, c, k, hw = cfg
     img, lab, prm, masks = make_case(17, n, c, k, hw)
     model = pkg("model")
     G = 2 * n                                   # pretend this replica holds half of the global batch
-    net = model.UNet(k, G, c, learning_rate=3e-4)
+    net = make_net(route, k, G, c, learning_rate=3e-4)
     net.engine.load_parameters(prm)
     ref = on.OracleUNet(k, G, c, learning_rate=3e-4, params=prm, dtype=np.float64)
 
     # --- inference path: eval-mode forward + argmax mask (reference UNet/inference.py:159-166)
-    sm = net.get_keras_model()(img)
+    sm, counts = recorded(net.engine, lambda: net.get_keras_model()(img))
+    assert_route_taken(counts, route, hw, training=False)
     sm_ref, _ = ref.forward(img, training=False)
     assert isinstance(sm, np.ndarray) and sm.shape == (n, hw, hw, k)         # numpy in -> numpy out
     # the reference's own post-processing lines run unchanged on the return value (UNet/inference.py:104-107)
@@ -85,9 +122,12 @@ def test_unet_matches_numpy_oracle(cfg):
 
     # --- training forward, loss and every gradient (reference UNet/model.py:208-219)
     e = net.engine
-    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab),
-              global_batch_size=G, want_grad=True)
-    e.backward()
+
+    def step():
+        e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=G, want_grad=True)
+        e.backward()
+    _, counts = recorded(e, step)
+    assert_route_taken(counts, route, hw, training=True)
     loss_ref, _, g_ref, _, _ = ref.loss_and_grads(img, lab, masks)
     assert abs(e.loss_buf[0].item() - loss_ref) < 1e-5 * abs(loss_ref)
     g = e.export_gradients()
@@ -412,7 +452,7 @@ def test_bf16_activation_storage_tracks_the_stage2_bf16_mode():
     assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0]
 
 
-def _full_size_properties(n, c, k, hw, dtype, steps=4):
+def _full_size_properties(n, c, k, hw, dtype, steps=4, route="bf16x6"):
     """size-independent properties of the train step at a BASELINE shape (the oracle never sees tiles this large):
     bit-reproducible steps from the same seed, finite and falling loss on a fixed batch, proper softmax in eval mode, device
     argmax == torch argmax of the same probabilities, reported loss == mean pixel cross-entropy recomputed from the softmax."""
@@ -425,6 +465,7 @@ def _full_size_properties(n, c, k, hw, dtype, steps=4):
     runs = []
     for _ in range(2):
         net = model.UNet(k, n, c, learning_rate=1e-3, seed=0, compute_dtype=dtype)
+        net.engine.opt.fp32_matrix = route
         losses = [float(net.train_step((img, lab, None, None)).numpy()) for _ in range(steps)]
         runs.append((losses, net.engine.theta.clone()))
         if len(runs) == 1:
@@ -449,9 +490,15 @@ def _full_size_properties(n, c, k, hw, dtype, steps=4):
     return counts
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp32-native", "bf16"])
 def test_full_size_config5_step_properties(dtype):
     # BASELINE config 5's per-GPU workload: 1024x1024x3 tiles, 6 classes, batch 2 (the deep-encoder / large-tile regime)
+    if dtype == "fp32-native":
+        counts = _full_size_properties(2, 3, 6, 1024, "fp32", route="native")
+        assert counts.get("conv3x3_fwd_winograd_fused") == 17 and counts.get("conv3x3_dgrad_winograd_fused") == 17 \
+            and counts.get("conv3x3_wgrad_winograd_fused") == 17 and not [key for key in counts if key.endswith("_x6")], counts
+        assert counts.get("convt_fwd") == 4 and counts.get("convt_dgrad") == 4 and counts.get("convt_wgrad") == 4, counts
+        return
     counts = _full_size_properties(2, 3, 6, 1024, dtype)
     if dtype == "fp32":
         # (default fp32_matrix = "bf16x6": forward / data gradient on the BF16x6 kernels, weight gradient on the fp32-MFMA Winograd kernel)
@@ -479,7 +526,8 @@ def test_bf16_operand_beyond_2gib_falls_back_to_fp32_kernels():
                                  (1, 2, 11, 32, "fp32"), (5, 4, 3, 32, "fp32"),                        # other channel / class counts
                                  (2, 5, 3, 32, "fp32"),                                                # five image channels: the generic first-layer kernels, separate statistics pass
                                  (2, 1, 2, 128, "fp32")])                                              # every level a multiple of the 128-pixel GEMM tile: all four transposed convs on the BF16x6 kernels
-def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
+@pytest.mark.parametrize("route", ROUTES)
+def test_gradients_match_oracle_given_the_same_branch_decisions(cfg, route):
     # End-to-end gradients at 1e-4 instead of 5e-2.  The network is piecewise linear: its gradient is discontinuous only in the
     # branch decisions (ReLU masks, max-pool winners), and fp32 rounding flips a few of those for pre-activations within ~1e-7
     # of zero -- which is all the 5e-2 bound of test_unet_matches_numpy_oracle has to absorb.  Here the fp64 oracle's BACKWARD
@@ -487,15 +535,23 @@ def test_gradients_match_oracle_given_the_same_branch_decisions(cfg):
     # function evaluated in fp32 vs fp64, so a 2-3 % systematic error in any weight-gradient kernel cannot hide.
     n, c, k, hw, _ = cfg
     img, lab, prm, masks = make_case(41, n, c, k, hw)
-    model = pkg("model")
-    net = model.UNet(k, n, c)
+    net = make_net(route, k, n, c)
     net.engine.load_parameters(prm)
     e = net.engine
-    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
-    e.backward()
+
+    def step():
+        e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+        e.backward()
+    _, counts = recorded(e, step)
     torch.cuda.synchronize()
+    assert_route_taken(counts, route, hw, training=True)
     if cfg == (2, 1, 2, 128, "fp32"):
-        assert all(e.pl.layer["up_%d" % l].fwd == e.pl.layer["up_%d" % l].dgrad == e.pl.layer["up_%d" % l].wgrad == "convt_x6" for l in (1, 2, 3, 4))
+        fam = ("convt_x6", "convt_x6", "convt_x6") if route == "bf16x6" else ("convt_stream", "convt_igemm", "convt")
+        assert all((e.pl.layer["up_%d" % l].fwd, e.pl.layer["up_%d" % l].dgrad, e.pl.layer["up_%d" % l].wgrad) == fam for l in (1, 2, 3, 4))
+        if route == "bf16x6":
+            assert counts.get("convt_fwd_x6") == 4 and counts.get("convt_dgrad_x6") == 4 and counts.get("convt_wgrad_x6") == 4, counts
+        else:
+            assert counts.get("convt_fwd") == 4 and counts.get("convt_dgrad") == 4 and counts.get("convt_wgrad") == 4, counts
     relu = {name: (e.saved[name][1].float().permute(0, 3, 1, 2) > 0).cpu().numpy() for name, kind, _, _ in e.layers if kind != "deconv"}
     pidx = {"pool_%d" % l: e.idx[l].permute(0, 3, 1, 2).cpu().numpy().astype(np.int64) for l in (1, 2, 3, 4)}
     ref = on.OracleUNet(k, n, c, params=prm, dtype=np.float64)
@@ -543,9 +599,10 @@ def _dead_channel_case(seed, n, c, k, hw):
     return img, lab, prm, masks
 
 
-@pytest.mark.parametrize("cfg", [(2, 1, 2, 32), (1, 3, 4, 64), (2, 1, 2, (48, 80))])
+@pytest.mark.parametrize("route", ROUTES)
+@pytest.mark.parametrize("cfg", [(2, 1, 2, 32), (1, 3, 4, 64), (2, 1, 2, (48, 80)), (2, 1, 2, 128)])
 @pytest.mark.parametrize("on_load", [True, False])
-def test_dead_channels_keep_parity_on_both_batchnorm_routes(cfg, on_load):
+def test_dead_channels_keep_parity_on_both_batchnorm_routes(cfg, on_load, route):
     # BatchNorm-apply on load (13 layers of the fp32 route) folds scale and shift into the consumer's weights and a per-channel padding
     # value -shift / scale: checked here in the regime where that value is huge or undefined -- gamma exactly 0 and |gamma| down to 1e-6
     # with beta = O(1) in every layer -- against the fp64 oracle at the usual bounds: eval-mode softmax 2e-5 with identical arg-max mask
@@ -553,13 +610,13 @@ def test_dead_channels_keep_parity_on_both_batchnorm_routes(cfg, on_load):
     # two-pass route (on_load=False) runs the same case: both routes are the product, neither is a fallback for the other any more.
     n, c, k, hw = cfg
     img, lab, prm, masks = _dead_channel_case(97, n, c, k, hw)
-    model = pkg("model")
-    net = model.UNet(k, n, c)
+    net = make_net(route, k, n, c)
     e = net.engine
     e.opt.bn_on_load = on_load
     e.load_parameters(prm)
     ref = on.OracleUNet(k, n, c, params=prm, dtype=np.float64)
-    sm = net.get_keras_model()(img)
+    sm, counts = recorded(e, lambda: net.get_keras_model()(img))
+    assert_route_taken(counts, route, hw, training=False)
     hh, ww = hw if isinstance(hw, tuple) else (hw, hw)
     odd = (hh // 16) % 2 or (ww // 16) % 2              # an odd bottleneck tile takes the implicit-GEMM kernels: bott_a is then materialised
     assert sum(p.defer_y for p in e.pl.layer.values()) == ((12 if odd else 13) if on_load else 0)
@@ -567,11 +624,15 @@ def test_dead_channels_keep_parity_on_both_batchnorm_routes(cfg, on_load):
     assert np.abs(sm - sm_ref).max() < 2e-5
     ok, undecided, differ = argmax_agreement(sm, sm_ref)
     assert ok and differ == 0, (undecided, differ)
-    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
-    e.backward()
+    def step():
+        e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+        e.backward()
+    _, counts = recorded(e, step)
     torch.cuda.synchronize()
-    if cfg == (2, 1, 2, 128, "fp32"):
-        assert all(e.pl.layer["up_%d" % l].fwd == e.pl.layer["up_%d" % l].dgrad == e.pl.layer["up_%d" % l].wgrad == "convt_x6" for l in (1, 2, 3, 4))
+    assert_route_taken(counts, route, hw, training=True)
+    if cfg == (2, 1, 2, 128):          # every level a multiple of the 128-pixel GEMM tile: the four transposed convs follow the route as well
+        fam = ("convt_x6", "convt_x6", "convt_x6") if route == "bf16x6" else ("convt_stream", "convt_igemm", "convt")
+        assert all((e.pl.layer["up_%d" % l].fwd, e.pl.layer["up_%d" % l].dgrad, e.pl.layer["up_%d" % l].wgrad) == fam for l in (1, 2, 3, 4))
     relu = {name: (e.saved[name][1].float().permute(0, 3, 1, 2) > 0).cpu().numpy() for name, kind, _, _ in e.layers if kind != "deconv"}
     pidx = {"pool_%d" % l: e.idx[l].permute(0, 3, 1, 2).cpu().numpy().astype(np.int64) for l in (1, 2, 3, 4)}
     loss_ref, _, g_ref, _, _ = ref.loss_and_grads(img, lab, masks, relu_masks=relu, pool_idx=pidx)
@@ -581,7 +642,6 @@ def test_dead_channels_keep_parity_on_both_batchnorm_routes(cfg, on_load):
     for l in (1, 2, 3, 4):
         errs.pop("up_%d/bias" % l)
     worst = max((v, key) for key, v in errs.items())
-    hh, ww = hw if isinstance(hw, tuple) else (hw, hw)
     tol = 5e-4 if n * (hh // 16) * (ww // 16) <= 4 else 1e-4
     assert worst[0] < tol, sorted(errs.items(), key=lambda t: -t[1])[:6]
 
@@ -606,34 +666,59 @@ def test_clipped_probability_cross_entropy_mode_matches_oracle():
     assert max(errs.values()) < 5e-2 and errs["logits/kernel"] < 5e-5, errs
 
 
-def test_full_size_tile_matches_torch_restatement():
+_FULL_TILE_REF = {}
+
+
+def _fp64_reference_of_the_full_size_tile(prm):
+    """the torch fp64 restatement on the one full-size tile (seed 53), evaluated once for both routes (~10 s of host time)"""
+    if "ref" not in _FULL_TILE_REF:
+        import types
+        img = make_case(53, 1, 1, 2, 512)[0]
+        net = ot.TorchUNet(2, 1, 1, params=prm, dtype=torch.float64)
+        with torch.no_grad():
+            sm = net.forward(img, False)[0].numpy()
+        _FULL_TILE_REF["ref"] = types.SimpleNamespace(net=net, sm_eval=sm)
+    return _FULL_TILE_REF["ref"]
+
+
+@pytest.mark.parametrize("route", ROUTES)
+def test_full_size_tile_matches_torch_restatement(route):
     # The oracle on a FULL-SIZE tile of BASELINE config 2 (512x512x1, 2 classes; one image -- the torch fp64 restatement needs ~10 s
     # of host time): eval-mode softmax + argmax mask, training loss, and the gradients nearest the loss tightly, all others to the
     # branch-decision bound of test_unet_matches_numpy_oracle.  (The per-kernel tiling / persistence logic sees its real launch
     # shapes here: 4096-tile grids, 17 persistent Winograd launches, the BatchNorm-apply-on-load route.)
     n, c, k, hw = 1, 1, 2, 512
     img, lab, prm, masks = make_case(53, n, c, k, hw)
-    model = pkg("model")
-    net = model.UNet(k, n, c)
+    net = make_net(route, k, n, c)
     net.engine.load_parameters(prm)
-    ref = ot.TorchUNet(k, n, c, params=prm, dtype=torch.float64)
-    sm = net.get_keras_model()(img)
-    with torch.no_grad():
-        sm_ref = ref.forward(img, False)[0].numpy()
+    ref = _fp64_reference_of_the_full_size_tile(prm)
+    sm, counts = recorded(net.engine, lambda: net.get_keras_model()(img))
+    assert_route_taken(counts, route, hw, training=False)
+    sm_ref = ref.sm_eval
     assert np.abs(sm - sm_ref).max() < 5e-5
+    # arg-max mask (UNet/inference.py:107,166) against the fp64 evaluation, in absolute pixel counts out of 262 144: every pixel whose fp64
+    # top-2 margin exceeds 1e-4 must agree (`differ_decided == 0`); a pixel can differ only inside that margin (where an fp32 evaluation of the
+    # same network legitimately lands on either side), and both counts are bounded by numbers, not by "ok"
     ok, undecided, differ = argmax_agreement(sm, sm_ref)
-    assert ok, (undecided, differ)
+    print("full-size tile, route %s: %d of %d pixels differ from the fp64 arg-max, all inside the 1e-4 margin: %s; %d pixels are inside the margin"
+          % (route, differ, n * hw * hw, ok, undecided))
+    assert ok and differ <= undecided, (undecided, differ)
+    assert undecided <= 64 and differ <= 8, (undecided, differ)
     e = net.engine
-    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
-    e.backward()
+
+    def step():
+        e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+        e.backward()
+    _, counts = recorded(e, step)
+    assert_route_taken(counts, route, hw, training=True)
     # The tight tensors see two ReLU layers between themselves and the loss (dec_1b, logits): the reference takes the device run's decisions
     # there.  fp32 evaluation error reaches 5e-5 (max) at the last layers of a 512^2 tile, so one to five of the 524 288 class-map
     # pre-activations sit close enough to zero to flip, and ONE flip at a pixel with a large loss gradient moves these sums by 1e-4 (seen when
     # the first layer's kernel, and with it the rounding pattern downstream, changed: 3e-7 -> 1.6e-4).  The imposed decisions may differ from
     # the reference's own only at pre-activations of that size (the rule of test_gradients_match_oracle_given_the_same_branch_decisions).
     relu = {name: (e.saved[name][1].float().permute(0, 3, 1, 2) > 0).cpu().numpy() for name in ("dec_1b", "logits")}
-    loss_ref, _, g_ref, _ = ref.loss_and_grads(img, lab, masks, relu_masks=relu)
-    assert max(ref.imposed_flips.values()) < 1e-4, ref.imposed_flips
+    loss_ref, _, g_ref, _ = ref.net.loss_and_grads(img, lab, masks, relu_masks=relu)
+    assert max(ref.net.imposed_flips.values()) < 1e-4, ref.net.imposed_flips
     assert abs(e.loss_buf[0].item() - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
     errs = grad_errors(e.export_gradients(), {k2: v.numpy() for k2, v in g_ref.items()})
     worst = max((v, key) for key, v in errs.items())
@@ -641,7 +726,8 @@ def test_full_size_tile_matches_torch_restatement():
     assert errs["logits/kernel"] < 5e-5 and errs["dec_1b/gamma"] < 5e-5, errs
 
 
-def test_config2_full_size_batch8_matches_the_torch_restatement_run_on_the_gpu():
+@pytest.mark.parametrize("route", ROUTES)
+def test_config2_full_size_batch8_matches_the_torch_restatement_run_on_the_gpu(route):
     # BASELINE config 2 exactly -- 512x512x1, 2 classes, batch 8 -- against the oracle's torch restatement evaluated with torch's OWN
     # GPU kernels (fp32): an independent implementation at the one size the CPU oracle cannot reach in a test (it sees one full-size image in
     # test_full_size_tile_matches_torch_restatement).  Eval-mode softmax + arg-max mask, training loss, every gradient tensor.  Both sides
@@ -649,19 +735,30 @@ def test_config2_full_size_batch8_matches_the_torch_restatement_run_on_the_gpu()
     # loss 2e-5, gradients 5e-2 with the tensors nearest the loss at 1e-3.
     n, c, k, hw = 8, 1, 2, 512
     img, lab, prm, masks = make_case(71, n, c, k, hw)
-    model = pkg("model")
-    net = model.UNet(k, n, c)
+    net = make_net(route, k, n, c)
     net.engine.load_parameters(prm)
     ref = ot.TorchUNet(k, n, c, params=prm, dtype=torch.float32, device="cuda")
-    sm = net.get_keras_model()(img)
+    sm, counts = recorded(net.engine, lambda: net.get_keras_model()(img))
+    assert_route_taken(counts, route, hw, training=False)
     with torch.no_grad():
         sm_ref = ref.forward(img, False)[0].cpu().numpy()
     assert np.abs(sm - sm_ref).max() < 1e-4
+    # two fp32 evaluations of the same network: their arg-max masks (2 097 152 pixels) may differ only where the top-2 margin is inside the
+    # sum of the two evaluations' errors (2e-4).  Counts are absolute and bounded by numbers
     ok, undecided, differ = argmax_agreement(sm, sm_ref, margin=2e-4)
-    assert ok and undecided < 1e-3 * sm.shape[0] * hw * hw, (undecided, differ)
+    print("config 2 at full size, route %s: %d of %d pixels differ from torch's fp32 arg-max, all inside the 2e-4 margin: %s; %d pixels are "
+          "inside the margin" % (route, differ, n * hw * hw, ok, undecided))
+    assert ok and differ <= undecided, (undecided, differ)
+    assert undecided <= 1200 and differ <= 100, (undecided, differ)
     e = net.engine
-    e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
-    e.backward()
+
+    def step():
+        e.forward(torch.as_tensor(img), training=True, dropout_masks=masks, labels=torch.as_tensor(lab), global_batch_size=n, want_grad=True)
+        e.backward()
+    _, counts = recorded(e, step)
+    assert_route_taken(counts, route, hw, training=True)
+    fam = ("convt_fwd_x6", "convt_dgrad_x6", "convt_wgrad_x6") if route == "bf16x6" else ("convt_fwd", "convt_dgrad", "convt_wgrad")
+    assert all(counts.get(f) == 4 for f in fam), counts
     loss_ref, _, g_ref, _ = ref.loss_and_grads(img, lab, masks)
     assert abs(e.loss_buf[0].item() - float(loss_ref)) < 2e-5 * abs(float(loss_ref))
     errs = grad_errors(e.export_gradients(), {k2: v.cpu().numpy() for k2, v in g_ref.items()})
