@@ -50,3 +50,37 @@ def test_learns_real_tiles_with_device_augmentation(tmp_path, compute_dtype):
     print("%s: held-out pixel accuracy %.4f, IoU %.4f, background fraction %.4f" % (compute_dtype, acc, inter / max(union, 1), (truth == 0).mean()))
     assert acc > max(0.9, (truth == 0).mean() + 0.05), acc
     assert inter / max(union, 1) > 0.6, inter / max(union, 1)
+
+
+def test_config1_exact_form_bundled_tiles_batch2_through_the_cli(tmp_path):
+    """BASELINE config 1 in its exact form: the reference's bundled tiles (256x256, 1 channel, uint16, 2 classes) through the train CLI at
+    --batch_size 2 with the reference's default flags (augmentation on, one reader), then the inference CLI on the held-out tiles as uint16
+    TIFFs from the checkpoint the run wrote.  (The LMDB container itself is out of scope -- `lmdb` is not installable here; the folder store
+    of readers.TileFolderReader holds the same tiles.)  Plumbing, not throughput: files, shapes, dtypes, finite losses, a mask per image."""
+    from PIL import Image
+    d = np.load(FIX)
+    imgs, masks = d["images"], d["masks"]
+    _write_tiles(tmp_path / "train", imgs[:12], masks[:12])
+    _write_tiles(tmp_path / "test", imgs[12:], masks[12:])
+    train, inf = pkg("train"), pkg("inference")
+    out = str(tmp_path / "out")
+    train.main(["--train_database", str(tmp_path / "train"), "--test_database", str(tmp_path / "test"), "--output_dir", out,
+                "--batch_size", "2", "--number_classes", "2", "--test_every_n_steps", "6", "--early_stopping", "1", "--max_epochs", "2"])
+    losses = [float(v) for v in open(os.path.join(out, "test_loss.csv")).read().split()]
+    assert len(losses) == 2 and all(np.isfinite(losses))
+    assert sorted(os.listdir(os.path.join(out, "checkpoint"))) == ["ckpt.data-00000-of-00001", "ckpt.index"]
+    tb = [e for e in os.listdir(out) if e.startswith("tensorboard-")]
+    assert len(tb) == 1 and sorted(os.listdir(os.path.join(out, tb[0]))) == ["test", "train"]
+    # 7 + 7 optimizer steps (N + 1 per epoch, UNet/train.py:137-138), each logged once per tag; 4 held-out tiles / batch 2 -> 3 test steps per epoch
+    rows = [l for l in open(os.path.join(out, tb[0], "train", "scalars.jsonl"))]
+    assert len(rows) == 2 * 14
+    folder = tmp_path / "images"; folder.mkdir()
+    for i, im in enumerate(imgs[12:]):
+        Image.fromarray(im).save(str(folder / ("tile%02d.tif" % i)))
+    inf.main(["--checkpoint_filepath", os.path.join(out, "checkpoint", "ckpt"), "--image_folder", str(folder),
+              "--output_folder", str(tmp_path / "masks"), "--number_classes", "2", "--number_channels", "1"])
+    names = sorted(os.listdir(tmp_path / "masks"))
+    assert names == ["tile%02d.tif" % i for i in range(4)]
+    for nm in names:
+        m = np.array(Image.open(str(tmp_path / "masks" / nm)))
+        assert m.shape == (256, 256) and m.dtype == np.uint8 and m.max() <= 1
