@@ -703,7 +703,7 @@ def test_full_size_tile_matches_torch_restatement(route):
     print("full-size tile, route %s: %d of %d pixels differ from the fp64 arg-max, all inside the 1e-4 margin: %s; %d pixels are inside the margin"
           % (route, differ, n * hw * hw, ok, undecided))
     assert ok and differ <= undecided, (undecided, differ)
-    assert undecided <= 64 and differ <= 8, (undecided, differ)
+    assert undecided <= 16 and differ <= 2, (undecided, differ)         # measured (both routes): 0 pixels inside the margin, 0 differ
     e = net.engine
 
     def step():
@@ -749,7 +749,7 @@ def test_config2_full_size_batch8_matches_the_torch_restatement_run_on_the_gpu(r
     print("config 2 at full size, route %s: %d of %d pixels differ from torch's fp32 arg-max, all inside the 2e-4 margin: %s; %d pixels are "
           "inside the margin" % (route, differ, n * hw * hw, ok, undecided))
     assert ok and differ <= undecided, (undecided, differ)
-    assert undecided <= 1200 and differ <= 100, (undecided, differ)
+    assert undecided <= 1200 and differ <= 20, (undecided, differ)      # measured (both routes): 579 pixels inside the margin, 1 differs
     e = net.engine
 
     def step():
