@@ -1,5 +1,5 @@
 """Diagnostic: s_memtime phases of the BF16x6 forward kernel's units (build: scripts/build_variant.sh x6tl winograd_x6.hip "-DUNET_X6_ABLATE=8";
-run with UNET_HIP_LIB=.../libunet_hip_x6tl.so).  Prints, per unit of workgroup 0 / wave 0: operand wait, MFMA stream, DMA/LDS wait, barrier."""
+run with UNET_HIP_LIB=.../libunet_hip_x6tl.so).  Prints, per chunk of workgroup 0 / wave 0: stream + wait cycles of the four periods, the barrier; per tile: chunk loop and epilogue."""
 import ctypes, importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -15,9 +15,10 @@ for shape in [(8, 64, 64, 512, 512), (8, 512, 512, 64, 64), (8, 32, 32, 1024, 10
     for _ in range(3):
         L.unet_conv3x3_fwd_winograd_x6(P(x), ci, None, P(u), None, P(y), co, n, h, w, ci, co, 1, None, 0, ST())
     torch.cuda.synchronize()
-    out = (ctypes.c_longlong * 8)()
+    out = (ctypes.c_longlong * 16)()
     L.cdll.unet_debug_x6_timeline(out)
     t = list(out)
-    units = max(t[4], 1)
-    print("%-26s units %5d: operand wait %6.0f | stream %6.0f | vm/lgkm wait %6.0f | barrier %6.0f  (cycles per unit); tile total/unit %6.0f" % (
-        str(shape), units, t[0] / units, t[1] / units, t[2] / units, t[3] / units, t[5] / units), flush=True)
+    ch, tiles = max(t[9], 1), max(t[12], 1)
+    print("%-26s chunks %4d tiles %3d | per chunk: " % (str(shape), ch, tiles) + " ".join("P%d %5.0f+%-5.0f" % (j, t[2 * j] / ch, t[2 * j + 1] / ch) for j in range(4))
+          + " barrier %5.0f | per tile: loop %7.0f epilogue %6.0f (column stage + sends %5.0f, barrier %5.0f, combine %5.0f, finish %5.0f)" % (
+              t[8] / ch, t[10] / tiles, t[11] / tiles, t[13] / tiles, t[14] / tiles, t[15] / tiles, (t[11] - t[13] - t[14] - t[15]) / tiles), flush=True)

@@ -7,97 +7,100 @@
 //     a b  =  ah bh + ah bm + am bh + ah bl + al bh + am bm   +  (am bl + al bm + al bl),
 // the six kept piece products are exact in an fp32 accumulator and the three dropped ones (all of the product's sign: truncation pieces
 // carry their value's sign) sum to at most 2^-21 |a b|, on average 2^-24.5 |a b| -- the size of ONE fp32 multiply's rounding
-// (tests/test_bf16x6_arithmetic.py restates and checks this on the CPU).  Accumulation is fp32 (v_mfma_f32_32x32x16_bf16).  So the result carries the rounding of an fp32
-// dot product (measured against fp64: profiles/r03_bf16x6_micro.txt, tests/test_gpu_x6.py), at 6 x 32 matrix-pipe cycles per
-// 32 x 32 x 16 block instead of 8 x 64.  The Winograd transforms themselves (B^T d B on the data, G g G^T on the weights, A^T m A on the
-// result) stay fp32 vector arithmetic, identical to winograd.hip.
+// (tests/test_bf16x6_arithmetic.py restates and checks this on the CPU).  Accumulation is fp32 (v_mfma_f32_32x32x16_bf16).  So the result
+// carries the rounding of an fp32 dot product (measured against fp64: tests/test_gpu_fp32_errors.py, tests/test_gpu_x6.py), at 6 x 32
+// matrix-pipe cycles per 32 x 32 x 16 block instead of 8 x 64.  The Winograd transforms themselves (B^T d B on the data, G g G^T on the
+// weights, A^T m A on the result) stay fp32 vector arithmetic.
 // Not covered: Inf / NaN inputs give NaN (Inf - Inf in the split); values below ~1e-33 lose their low pieces to bf16 underflow.
 //
-// Tiling.  As winograd.hip: workgroup = 8x8 Winograd tiles x 64 output channels, wave (mi, ni) = [32 channels x 32 tiles] x 16 points in
-// 256 accumulator registers, same element order, so the epilogue (wino_epilogue.h) is shared.  The reduction runs in chunks of 16 input
-// channels = one MFMA K; a chunk is four UNITS of four Winograd points (one row of the 4x4 point grid), and per unit a wave runs
-// 4 points x 6 piece products = 24 MFMAs between two barriers.  LDS (144 KB):
-//   D  raw patch 18x18 px x 16 ch fp32, two chunk buffers x 24 KB; pixel slots permuted so that the transform's ds_read_b128 is conflict-free
-//   V  [point 4][piece 3][tile 64][16 ch bf16] of one unit, two buffers x 24 KB     <- in-kernel B^T d B + split, every lane one (tile, channel quad)
-//   U  [point 4][piece 3][co 64][16 ci bf16]  of one unit, two buffers x 24 KB     <- LDS-DMA from the pre-split weights (L2-resident)
-// Pipeline, everything one unit ahead of its use: during unit g the wave issues the DMA of U(g+1) and its share of a later D chunk, turns
-// the row-stage registers of unit g+1 into V(g+1) (column stage + split + 12 LDS writes), and reads the raw rows of unit g+2 from D and
-// row-stages them in place.  Unlike the fp32 MFMA, the bf16 MFMA leaves the vector ALU free: ~5 vector instructions are slotted behind
-// every MFMA (sched_barrier-pinned), the stream is vector-issue-bound rather than matrix-bound.
+// Round 5: ONE POINT ROW PER WAVE, both MFMA operands straight from registers.  (Round 4's kernel kept a wave's [32 channels x 32 tiles]
+// x 16 points and passed the split data operand V and the weights U through LDS: 1030 LDS cycles per 768 matrix cycles, profiles/
+// r04_x6_ablation.txt -- every schedule of that shape landed at the same time.)  Workgroup = 8x8 Winograd tiles x 64 output channels as
+// before; wave r (0..3) owns the four Winograd points of point ROW r for ALL 64 channels x 64 tiles: 4 points x 2 channel blocks x 2 tile
+// blocks of 32 x 32 = 256 accumulator registers.  Then
+//   * the data operand of a lane IS what that lane transforms: MFMA B-operand lane (li, lh) holds tile li, reduce channels 8 lh .. 8 lh + 7,
+//     so the lane reads its tile's raw rows ra, rb of the patch (row stage r: d[ra] -/+ d[rb]), forms the column stage of point j and splits
+//     the 8 values into pieces in its own registers -- V never touches LDS, no barrier sits between transform and product;
+//   * the weight operand is loaded from global memory (L2-resident, pre-split, stored in MFMA A-operand order: one contiguous 1-KB
+//     global_load_dwordx4 per fragment) straight into registers, one point ahead -- no LDS, no LDS-DMA issue cost for U;
+//   * LDS carries only the raw patch D (18 x 18 px x 16 ch fp32 per 16-channel chunk, by LDS-DMA, two buffers) in four channel-quad PLANES
+//     [quad][row][20 slots] with even columns first: the 16 lanes of a ds_read_b128 group then hit 16 different 16-byte bank groups
+//     (row pitch 20 slots: tile rows two apart land 8 slots apart mod 16), and the end-of-tile exchange below.
+// Per 16-channel chunk a wave issues 96 MFMAs, 480 vector instructions (128 transform adds + 352 for the split: 5 per MFMA gap, the
+// figure one wave per SIMD can hide), 32 ds_read_b128, 24 global_load_dwordx4, 6 LDS-DMA pieces and ONE barrier -- against 96 MFMAs, the
+// same 480 vector instructions, 128 ds_read_b128, 48 ds_write_b64, 30 LDS-DMA pieces and four barriers in round 4.
+// The price: the output transform needs all four point rows of a (tile, channel): the waves reduce their rows' column stage
+// (m0 + m1 + m2, m1 - m2 - m3) locally and exchange the halves through LDS once per tile (96 KB), each wave finishing one
+// [32 channels x 32 tiles] quarter with the epilogue element order of the other Winograd kernels (bias, ReLU, BatchNorm sums).
 #include "common.h"
 #include "wino_epilogue.h"
 #include <cstdlib>
 
 #ifndef UNET_X6_ABLATE
-#define UNET_X6_ABLATE 0        /* diagnostic builds (scripts/build_variant.sh), bits: 8 = s_memtime stamps around the phases of a unit, 16 = no split, 32 = no MFMAs, 64 = no DMA, 128 = no operand reads, 256 = no V writes, 512 = no row reads (results wrong) */
+#define UNET_X6_ABLATE 0        /* diagnostic builds (scripts/build_variant.sh), bits: 8 = s_memtime stamps, 16 = no split, 32 = no MFMAs, 64 = no patch DMA, 128 = no weight loads, 512 = no row reads (results wrong) */
 #endif
 
 namespace {
 
-#if (UNET_X6_ABLATE & 8)
-__device__ long long g_x6_timeline[8];
+typedef int x6_i32x4 __attribute__((ext_vector_type(4)));
+
+#if (UNET_X6_ABLATE & 8)        /* diagnostics: s_memtime stamps around the phases of a period (workgroup 0, wave 0) */
+__device__ long long g_x6_timeline[16];
 #define X6_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
 #else
 #define X6_STAMP(t)
 #endif
 
-typedef int x6_i32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned x6_u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kX6DB = 24 * 1024;                  // one D chunk buffer: 324 pixel slots x 64 B in 24 1-KB DMA pieces (21 used + 3 dummies)
-constexpr int kX6IB = 24 * 1024;                  // one V or U unit image
-constexpr int kX6Blk = 2048;                      // one (point, piece) block: 64 rows x 32 B
-constexpr int kX6V = 2 * kX6DB, kX6U = kX6V + 2 * kX6IB, kX6Smem = kX6U + 2 * kX6IB;      // 147456 B
-constexpr int kX6RowB = 18 * 64;                  // bytes between patch rows in D
+constexpr int kX6RowB = 20 * 16;                  // bytes between patch rows inside a plane: 18 pixel slots + 2 pad slots of 16 B
+constexpr int kX6PlaneB = 18 * kX6RowB;           // one channel-quad plane of a chunk: 5760 B
+constexpr int kX6DB = 24 * 1024;                  // one D chunk buffer: 4 planes = 23040 B in 24 1-KB DMA pieces (the last 1.5 are dummies)
+constexpr int kX6X = 2 * kX6DB;                   // end-of-tile exchange: per owner wave 3 sources x 8 KB
+constexpr int kX6XW = 24 * 1024;
+constexpr int kX6Smem = kX6X + 4 * kX6XW;         // 147456 B
+constexpr int kX6UPoint = 6 * 1024;               // bytes of one point's weight fragments: [piece 3][channel block 2][lane 64][16 B]
+constexpr int kX6UChunkWave = 4 * kX6UPoint;      // one point row of a chunk
+constexpr int kX6UChunk = 4 * kX6UChunkWave;      // all four point rows
+constexpr int kX6RowWaveMinK = 256;               // layers with fewer reduce channels take the round-4 tiling (winograd_x6s.hip): a tile of theirs has too few chunks for this kernel's end-of-tile exchange
 
 #define X6_RD128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
-#define X6_WR64(base, off, val) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(val), "n"(off) : "memory")
+#define X6_WR128(base, off, val) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "v"(val), "n"(off) : "memory")
 #define X6_MFMA(accv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(accv) : "v"(av), "v"(bv) : "memory")
-// LDS-DMA of one 1-KB piece (16 B per lane) to LDS byte address `ldsaddr` (wave-uniform): M0 carries the LDS address.  Written as asm so
-// that the U pieces take the SGPR-base + 32-bit lane offset form (no per-piece 64-bit vector add); every DMA of this file goes through
-// these two macros, so the compiler never manages M0 itself here.
-// (ldsw = the wave's LDS base in ONE scalar register, ldsoff an immediate: the sum is formed in M0 itself)
-#define X6_DMA_S(voff, sbase, ldsw, ldsoff) asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(ldsw), "n"(ldsoff) : "memory", "scc")
-#define X6_DMA_V(vptr, ldsw, ldsoff) asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vptr), "s"(ldsw), "n"(ldsoff) : "memory", "scc")
 #define X6_MFMA0(accv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(accv) : "v"(av), "v"(bv) : "memory")
+// LDS-DMA of one 1-KB piece (16 B per lane) to LDS byte address ldsw + ldsoff (wave-uniform): M0 carries the LDS address.
+#define X6_DMA_V(vptr, ldsw, ldsoff) asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vptr), "s"(ldsw), "n"(ldsoff) : "memory", "scc")
+// one weight fragment: 16 B per lane at sbase + voff + imm (sbase wave-uniform)
+#define X6_LDU(dst, voff, sbase, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
 
-// slot of patch column x (0..17) inside a patch row: pixels two apart (the stride between neighbouring tiles) must land on different
-// 64-byte bank quarters for the hardware's ds_read_b128 lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: slot mod 4 = (x/2 + x) mod 4
-__host__ __device__ constexpr int x6_slot_of(int x) { return x >= 16 ? x : (x & ~7) + ((x & 7) == 0 ? 0 : (x & 7) == 1 ? 1 : (x & 7) == 2 ? 5 : (x & 7) == 3 ? 2 : (x & 7) == 4 ? 6 : (x & 7) == 5 ? 3 : (x & 7) == 6 ? 7 : 4); }
-__host__ __device__ constexpr int x6_col_of(int s) { return s >= 16 ? s : (s & ~7) + ((s & 7) == 0 ? 0 : (s & 7) == 1 ? 1 : (s & 7) == 2 ? 3 : (s & 7) == 3 ? 5 : (s & 7) == 4 ? 7 : (s & 7) == 5 ? 2 : (s & 7) == 6 ? 4 : 6); }
+// slot of patch column x (0..17) inside a plane row: even columns first (0, 2, .., 16 -> slots 0..8), then the odd ones (slots 9..17)
+__host__ __device__ constexpr int x6_pos_of(int x) { return (x & 1) * 9 + (x >> 1); }
+__host__ __device__ constexpr int x6_col_of(int pos) { return pos < 9 ? 2 * pos : 2 * (pos - 9) + 1; }
 
-struct X6Frag { x6_i32x4 u[3], v[3]; };           // MFMA operands of one point: weight pieces (h, m, l), data pieces (h, m, l)
 struct X6Split { float v[4], a[4], b[4]; unsigned h[2], m[2], l[2]; };
-
-// operand reads of point PT of the unit in buffers PAR: 6 ds_read_b128
-template <int PAR, int PT> __device__ __forceinline__ void x6_read_ops(X6Frag& f, unsigned a_base, unsigned b_base) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        X6_RD128(f.u[k], b_base, PAR * kX6IB + (PT * 3 + k) * kX6Blk);
-        X6_RD128(f.v[k], a_base, PAR * kX6IB + (PT * 3 + k) * kX6Blk);
-    }
-}
-#define X6_TIE_FRAG(f) "+v"(f.u[0]), "+v"(f.u[1]), "+v"(f.u[2]), "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2])
 
 __device__ __forceinline__ unsigned x6_hi2(float lo, float hi) {       // { bf16 bits of lo (truncated) , of hi } packed, lo in the low half
     return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
 }
 __device__ __forceinline__ float x6_trunc(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
 
-// Column stage + split of point J (column J of the unit's row of points) in five steps of 5-6 vector instructions; tt[c] = the row-stage
-// result of patch column c (4 channels).  V[.][0] = t0 - t2, [1] = t1 + t2, [2] = t2 - t1, [3] = t1 - t3.
+// Column stage + split of four channels of point J (column J of the wave's row of points) in five steps of 5-6 vector instructions;
+// T[c] = the row-stage result of patch column c.  V[.][0] = t0 - t2, [1] = t1 + t2, [2] = t2 - t1, [3] = t1 - t3.
 // X6_PIN: an empty volatile asm over a step's inputs / results.  Instruction selection orders pure arithmetic freely between the volatile
 // MFMAs (sched_barrier only binds the machine scheduler); tied to a volatile statement on both sides a step stays in its gap.
 #define X6_PIN(...) asm volatile("" : __VA_ARGS__)
-template <int K, int J> __device__ __forceinline__ void x6_split_step(X6Split& s, f32x4 (&tt)[8]) {
+template <int K, int J, int G> __device__ __forceinline__ void x6_split_step(X6Split& s, f32x4 (&T)[4][4]) {
 #if (UNET_X6_ABLATE & 16)        /* diagnostics: no column stage / split (results wrong) */
     return;
 #endif
     if constexpr (K == 0) {
         constexpr int TA = J == 0 ? 0 : J == 2 ? 2 : 1, TB = J == 0 ? 2 : J == 1 ? 2 : J == 2 ? 1 : 3;
-        X6_PIN("+v"(tt[TA]), "+v"(tt[TB]));
-        const f32x4 vv = J == 1 ? tt[TA] + tt[TB] : tt[TA] - tt[TB];
-        s.v[0] = vv[0]; s.v[1] = vv[1]; s.v[2] = vv[2]; s.v[3] = vv[3];
+        X6_PIN("+v"(T[TA][G]), "+v"(T[TB][G]));
+        if constexpr (J == 1) {          // (as above: no v_pk_add_f32)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm("v_add_f32 %0, %1, %2" : "=v"(s.v[e]) : "v"(T[TA][G][e]), "v"(T[TB][G][e]));
+        } else {
+            const f32x4 vv = T[TA][G] - T[TB][G];
+            s.v[0] = vv[0]; s.v[1] = vv[1]; s.v[2] = vv[2]; s.v[3] = vv[3];
+        }
         s.h[0] = x6_hi2(s.v[0], s.v[1]);
         X6_PIN("+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.h[0]));
     } else if constexpr (K == 1) {
@@ -117,152 +120,240 @@ template <int K, int J> __device__ __forceinline__ void x6_split_step(X6Split& s
         s.l[0] = x6_hi2(s.b[0], s.b[1]); s.l[1] = x6_hi2(s.b[2], s.b[3]);
     }
 }
-// the three pieces of point J -> V image PAR (3 ds_write_b64)
-template <int PAR, int J> __device__ __forceinline__ void x6_write_v(const X6Split& s, unsigned v_base) {
-    X6_WR64(v_base, PAR * kX6IB + (J * 3 + 0) * kX6Blk, (x6_u32x2{s.h[0], s.h[1]}));
-    X6_WR64(v_base, PAR * kX6IB + (J * 3 + 1) * kX6Blk, (x6_u32x2{s.m[0], s.m[1]}));
-    X6_WR64(v_base, PAR * kX6IB + (J * 3 + 2) * kX6Blk, (x6_u32x2{s.l[0], s.l[1]}));
+// the pieces of channel quad QQ of tile block TB -> the MFMA data operands of buffer vb (dwords 2 QQ, 2 QQ + 1 of pieces h, m, l)
+template <int TB, int QQ> __device__ __forceinline__ void x6_take_pieces(const X6Split& s, x6_i32x4 (&vb)[6]) {
+    vb[3 * TB + 0][2 * QQ] = (int)s.h[0]; vb[3 * TB + 0][2 * QQ + 1] = (int)s.h[1];
+    vb[3 * TB + 1][2 * QQ] = (int)s.m[0]; vb[3 * TB + 1][2 * QQ + 1] = (int)s.m[1];
+    vb[3 * TB + 2][2 * QQ] = (int)s.l[0]; vb[3 * TB + 2][2 * QQ + 1] = (int)s.l[1];
+}
+// one (tile block, channel quad) group G = 2 TB + QQ of point J, step K
+template <int K, int J, int G> __device__ __forceinline__ void x6_build_step(X6Split& s, f32x4 (&T)[4][4], x6_i32x4 (&vb)[6]) {
+    x6_split_step<K, J, G>(s, T);
+    if constexpr (K == 4) x6_take_pieces<(G >> 1), (G & 1)>(s, vb);
 }
 
-// raw rows of the unit with point row R2 from D buffer DPR -> dd[0..3] (row ra), dd[4..7] (row rb); tt = ra -/+ rb:
-//   R2 = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
-template <int R2> struct X6Rows {
-    static constexpr int RA = R2 == 0 ? 0 : R2 == 2 ? 2 : 1, RB = R2 == 0 ? 2 : R2 == 1 ? 2 : R2 == 2 ? 1 : 3;
-    static constexpr bool ADD = R2 == 1;
-};
-template <int R2, int DPR, int C> __device__ __forceinline__ void x6_read_rows(f32x4 (&dd)[8], const unsigned (&d_base)[4]) {
-    X6_RD128(dd[C], d_base[C], DPR * kX6DB + X6Rows<R2>::RA * kX6RowB);
-    X6_RD128(dd[4 + C], d_base[C], DPR * kX6DB + X6Rows<R2>::RB * kX6RowB);
+// raw rows ra, rb of patch column C, group G (tile block G >> 1: tiles 32 (G >> 1) + li, channel quad 2 lh + (G & 1)) from D buffer DPR
+template <int DPR, int C, int G> __device__ __forceinline__ void x6_read_rows(f32x4 (&dd)[2], unsigned d_a, unsigned d_b) {
+    constexpr int OFF = DPR * kX6DB + (G & 1) * kX6PlaneB + (G >> 1) * 8 * kX6RowB + x6_pos_of(C) * 16;
+    X6_RD128(dd[0], d_a, OFF);
+    X6_RD128(dd[1], d_b, OFF);
 }
-template <int R2, int C> __device__ __forceinline__ void x6_row_stage(f32x4 (&dd)[8]) {
-    X6_PIN("+v"(dd[C]), "+v"(dd[4 + C]));
-    dd[C] = X6Rows<R2>::ADD ? dd[C] + dd[4 + C] : dd[C] - dd[4 + C];
-    X6_PIN("+v"(dd[C]));
+// row stage of the wave's point row: d[ra] + sgn d[rb]  (r = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3; an fma by +-1 is exact)
+template <int PENDING> __device__ __forceinline__ void x6_row_stage(f32x4& t, f32x4 (&dd)[2], float sgn) {
+    if constexpr (PENDING == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dd[0]), "+v"(dd[1]));
+    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(dd[0]), "+v"(dd[1]));
+    // (scalar fmas written out: left to the compiler they become v_pk_fma_f32, which costs an MFMA-paced stream more than two plain ones)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(dd[1][e]), "v"(sgn), "v"(dd[0][e])); t[e] = r; }
+    X6_PIN("+v"(t));
 }
-#define X6_TIE_DD(d) "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+#define X6_TIE6(f) "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5])
 
-// One unit: the 24 MFMAs of point row R of a chunk with D parity DP (V / U buffers R & 1), and everything that runs in their shadow.
-//   S0 / S1: the two sets of 8 row registers; set (R & 1) holds the row stage of unit g+1 (consumed here), the other one takes the raw
-//            rows of unit g+2 and ends as its row stage;
-//   us: source of U(g+1) for this wave's first block (uniform), uoff[j]: the lane's byte offset of its piece j from there;
-//   dptr: this lane's running sources of its six D pieces -- the two issued in this unit (R != 1) advance by one chunk, or jump to the next
-//         tile's patch (dnxt) when `dswitch` says this was the tile's last chunk (uniform).
-// LDS instructions retire in order; the lgkmcnt immediates count the LDS instructions issued behind the one waited for.
-template <int R, int DP, bool FIRST>
-__device__ __forceinline__ void x6_unit(f32x16 (&acc)[16], f32x4 (&S0)[8], f32x4 (&S1)[8], X6Frag (&fr)[2], X6Split& sp,
-                                        unsigned a_base, unsigned b_base, const unsigned (&d_base)[4], unsigned v_base,
-                                        const char* us, const unsigned (&uoff)[6], const float* (&dptr)[6], const float* (&dnxt)[6], bool dswitch,
-                                        unsigned lds_w, long long (&tl)[6]) {
-    constexpr int P = R & 1, PN = P ^ 1;
+// End of period J: the weight fragments the NEXT period multiplies with have landed.  Vector-memory operations return in order, so
+// vmcnt(n) = "all but the n youngest": period 0 (loaded u(1), no DMA; the barrier behind it needs every DMA piece of the wave): 0;
+// period 1 (u(2), then u(3), then 2 DMA pieces): u(2) -> 6 + 2 younger; period 2 (2 DMA pieces): u(3) -> period 1's and period 2's pieces
+// younger = 4, so the first-touch pieces of period 1 may still be in flight; period 3 (u(0'), 2 pieces): 2.
+template <int J> __device__ __forceinline__ void x6_period_wait(x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6]) {
+    if constexpr (J == 0) asm volatile("s_waitcnt vmcnt(0)" : X6_TIE6(uf[1]) :: "memory");
+    else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(8)" : X6_TIE6(uf[0]) :: "memory");
+    else if constexpr (J == 2) asm volatile("s_waitcnt vmcnt(4)" : X6_TIE6(ue) :: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" : X6_TIE6(uf[0]) :: "memory");
+}
+
+// One PERIOD: the 24 MFMAs of point J of a chunk with D parity DP (operand buffers J & 1), and everything that runs in their shadow:
+//   * the data operand of the NEXT point JN = J + 1 (of the next chunk for J = 3): column stage + split of 4 groups x 5 steps (gaps n % 6 != 5);
+//   * the row stage of ONE patch column (PC: 3, 0, 2, 1 for J = 0..3; column 3 belongs to this chunk, the others to the next one) in the
+//     gaps n % 6 == 5, its two ds_read_b128 issued four gaps earlier -- so that every column register set is written right after its last
+//     reader: no double buffering of the 64 row-stage registers;
+//   * the six weight fragments of point JN (global loads, gaps 0..5) and, for J >= 1, two LDS-DMA pieces of the patch of chunk
+//     c + 2 into the buffer chunk c left behind at the barrier after period 0 (gaps 6, 8: right behind the weight loads -- a piece that is the
+//     first touch of its cache lines holds up every later vector-memory instruction of the wave until it returns).
+// At the end the wave waits for the fragments it loaded (vector-memory operations return in order: everything older has landed too,
+// in particular the wave's DMA pieces of earlier periods), and after period 0 all waves meet: D(c) is dead, D(c + 1) complete.
+template <int J, int DP, bool FIRST>
+__device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f32x4 (&dd)[2][2], x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6], x6_i32x4 (&vf)[2][6], X6Split& sp,
+                                          unsigned d_a, unsigned d_b, float sgn, const char* us, unsigned voff0, unsigned voff1,
+                                          const float* (&dptr)[6], unsigned lds_w, long long (&tl)[16]) {
+    constexpr int CB = J & 1, NB = CB ^ 1;
+    // weight fragments: u(0), u(2) live in uf[0], u(1) in uf[1], u(3) in ue.  Period 0 loads u(1); period 1 loads u(2) AND u(3); period 2
+    // loads nothing; period 3 loads the next chunk's u(0).  So no weight load is issued in the period behind the chunk's first-touch DMA
+    // pieces (period 1's: they return after ~1900 cycles from HBM and hold up every vector-memory instruction issued meanwhile --
+    // profiles/r05_x6_timeline.txt), and nothing has to wait for those pieces before the end of period 3.
+    x6_i32x4 (&ucur)[6] = J == 3 ? ue : uf[CB];
+    x6_i32x4 (&unew)[6] = J == 0 ? uf[1] : uf[0];
+    constexpr int NLOAD = J == 1 ? 12 : J == 2 ? 0 : 6;
 #if (UNET_X6_ABLATE & 8)
-    long long q0, q1, q2, q3;
+    long long q0, q1, q2;
     X6_STAMP(q0);
 #endif
-    constexpr int R2 = (R + 2) & 3, DPR = DP ^ (R >= 2 ? 1 : 0);
-    // D pieces issued here: R = 2: chunk c+2 pieces 0,1 (wave's j = 0,1); R = 3: pieces j = 2,3; R = 0: chunk c+1, j = 4,5; R = 1: none
-    constexpr int ND = R == 1 ? 0 : 2;
-    constexpr int DJ = R == 2 ? 0 : R == 3 ? 2 : 4;
-    constexpr int DPW = R == 0 ? (DP ^ 1) : DP;                       // buffer of that chunk
-    f32x4 (&tt)[8] = P ? S1 : S0;
-    f32x4 (&dd)[8] = P ? S0 : S1;
-    asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_FRAG(fr[0]));        // point 0's operands (issued by the caller side of the barrier)
-    X6_STAMP(q1);
+    constexpr int JN = (J + 1) & 3;
+    constexpr int PC = J == 0 ? 3 : J == 1 ? 0 : J == 2 ? 2 : 1;
+    constexpr int DPR = J == 0 ? DP : (DP ^ 1);
+    constexpr int ND = J == 0 ? 0 : 2;
+    constexpr int DJ = J == 0 ? 0 : 2 * (J - 1);
 #pragma unroll
     for (int n = 0; n < 24; ++n) {
-        const int p = n / 6, k = n % 6;
-        X6Frag& f = fr[p & 1];
-        if (k == 0 && p > 0) asm volatile("s_waitcnt lgkmcnt(3)" : X6_TIE_FRAG(f));       // behind its reads: the previous point's 3 V writes
+        const int q = n >> 2, cb = (n >> 1) & 1, tb = n & 1;
         // piece products, small to large: (m,m) (l,h) (h,l) (m,h) (h,m) (h,h);  u = weights (rows = channels), v = data (columns = tiles)
-        const int ui = k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 0 : k == 3 ? 1 : 0;
-        const int vi = k == 0 ? 1 : k == 1 ? 0 : k == 2 ? 2 : k == 3 ? 0 : k == 4 ? 1 : 0;
-#if !(UNET_X6_ABLATE & 32)       /* diagnostics: 32 = no MFMAs (results wrong) */
-        if (FIRST && k == 0) X6_MFMA0(acc[4 * R + p], f.u[ui], f.v[vi]);
-        else X6_MFMA(acc[4 * R + p], f.u[ui], f.v[vi]);
+        const int ui = q == 0 ? 1 : q == 1 ? 2 : q == 2 ? 0 : q == 3 ? 1 : 0;
+        const int vi = q == 0 ? 1 : q == 1 ? 0 : q == 2 ? 2 : q == 3 ? 0 : q == 4 ? 1 : 0;
+#if !(UNET_X6_ABLATE & 32)
+        if (FIRST && q == 0) X6_MFMA0(acc[4 * J + 2 * cb + tb], ucur[2 * ui + cb], vf[CB][3 * tb + vi]);
+        else X6_MFMA(acc[4 * J + 2 * cb + tb], ucur[2 * ui + cb], vf[CB][3 * tb + vi]);
 #endif
         // ---- in the shadow of MFMA n
-        if (k == 0 && p < 3 && !(UNET_X6_ABLATE & 128)) {        // operands of the next point
-            if (p == 0) x6_read_ops<P, 1>(fr[1], a_base, b_base);
-            if (p == 1) x6_read_ops<P, 2>(fr[0], a_base, b_base);
-            if (p == 2) x6_read_ops<P, 3>(fr[1], a_base, b_base);
+        constexpr int L0 = 0;                                            // first gap with a weight load (period 3, measured: starting at gap 8 instead -- further behind period 1's first-touch pieces -- turns a 250-cycle issue stall into a 300-cycle wait)
+        if (n >= L0 && n < L0 + NLOAD && !(UNET_X6_ABLATE & 128)) {      // weight fragments [piece][channel block], 1 KB each
+            if (n - L0 < 4) X6_LDU(unew[n - L0], voff0, us, (n - L0) * 1024);
+            else if (n - L0 < 6) X6_LDU(unew[n - L0], voff1, us, (n - L0 - 4) * 1024);
+            else if (n < 8) X6_LDU(ue[n - 6], voff1, us, (n - 4) * 1024);         // (period 1: point 3 follows point 2 in memory)
+            else X6_LDU(ue[n - 6], voff1 + 4096u, us, (n - 8) * 1024);
         }
-        if (n >= 1 && n <= 4 && !(UNET_X6_ABLATE & 512)) {       // raw rows of unit g+2, two reads per gap
-            if (n == 1) x6_read_rows<R2, DPR, 0>(dd, d_base);
-            if (n == 2) x6_read_rows<R2, DPR, 1>(dd, d_base);
-            if (n == 3) x6_read_rows<R2, DPR, 2>(dd, d_base);
-            if (n == 4) x6_read_rows<R2, DPR, 3>(dd, d_base);
+        if (!(UNET_X6_ABLATE & 512)) {                                   // raw rows of the four groups of column PC: 5 / 10 gaps ahead of their row stage
+            if (n == 0) x6_read_rows<DPR, PC, 0>(dd[0], d_a, d_b);
+            if (n == 1) x6_read_rows<DPR, PC, 1>(dd[1], d_a, d_b);
+            if (n == 7) x6_read_rows<DPR, PC, 2>(dd[0], d_a, d_b);
+            if (n == 13) x6_read_rows<DPR, PC, 3>(dd[1], d_a, d_b);
         }
-        if ((n & 1) == 0 && n < 12 && !(UNET_X6_ABLATE & 64))    // U(g+1): one DMA every second MFMA (the vector-memory issue path is busy ~64 cycles per DMA)
-            X6_DMA_S(uoff[n >> 1], us, lds_w, kX6U + PN * kX6IB + (n >> 1) * 4096);
-        if (ND && n == 12 && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ], lds_w, DPW * kX6DB + DJ * 4096);
-        if (ND && n == 14 && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ + 1], lds_w, DPW * kX6DB + (DJ + 1) * 4096);
-        if (ND && n == 17) {                                     // (a light gap) the two pointers move on
-            if (dswitch) { dptr[DJ] = dnxt[DJ]; dptr[DJ + 1] = dnxt[DJ + 1]; }
-            else { dptr[DJ] += 16; dptr[DJ + 1] += 16; }
-            X6_PIN("+v"(dptr[DJ]), "+v"(dptr[DJ + 1]));
-        }
-        if (k < 5) {                                             // column stage + split of point p of unit g+1
-            if (p == 0) { if (k == 0) x6_split_step<0, 0>(sp, tt); if (k == 1) x6_split_step<1, 0>(sp, tt); if (k == 2) x6_split_step<2, 0>(sp, tt); if (k == 3) x6_split_step<3, 0>(sp, tt); if (k == 4) x6_split_step<4, 0>(sp, tt); }
-            if (p == 1) { if (k == 0) x6_split_step<0, 1>(sp, tt); if (k == 1) x6_split_step<1, 1>(sp, tt); if (k == 2) x6_split_step<2, 1>(sp, tt); if (k == 3) x6_split_step<3, 1>(sp, tt); if (k == 4) x6_split_step<4, 1>(sp, tt); }
-            if (p == 2) { if (k == 0) x6_split_step<0, 2>(sp, tt); if (k == 1) x6_split_step<1, 2>(sp, tt); if (k == 2) x6_split_step<2, 2>(sp, tt); if (k == 3) x6_split_step<3, 2>(sp, tt); if (k == 4) x6_split_step<4, 2>(sp, tt); }
-            if (p == 3) { if (k == 0) x6_split_step<0, 3>(sp, tt); if (k == 1) x6_split_step<1, 3>(sp, tt); if (k == 2) x6_split_step<2, 3>(sp, tt); if (k == 3) x6_split_step<3, 3>(sp, tt); if (k == 4) x6_split_step<4, 3>(sp, tt); }
-            if (k == 4 && !(UNET_X6_ABLATE & 256)) {
-                if (p == 0) x6_write_v<PN, 0>(sp, v_base);
-                if (p == 1) x6_write_v<PN, 1>(sp, v_base);
-                if (p == 2) x6_write_v<PN, 2>(sp, v_base);
-                if (p == 3) x6_write_v<PN, 3>(sp, v_base);
-            }
-        } else {                                                 // row stage of unit g+2, one patch column per point
-            if (p == 0) { asm volatile("s_waitcnt lgkmcnt(3)" : X6_TIE_DD(dd)); x6_row_stage<R2, 0>(dd); }      // behind the row reads: point 0's V writes
-            if (p == 1) x6_row_stage<R2, 1>(dd);
-            if (p == 2) x6_row_stage<R2, 2>(dd);
-            if (p == 3) x6_row_stage<R2, 3>(dd);
+        if (ND && n == (J == 1 ? 12 : 6) && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ], lds_w, DP * kX6DB + DJ * 4096);
+        if (ND && n == (J == 1 ? 14 : 8) && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ + 1], lds_w, DP * kX6DB + (DJ + 1) * 4096);
+        if (n % 6 == 5) {
+            if (n == 5) x6_row_stage<2>(T[PC][0], dd[0], sgn);            // (LDS reads retire in order: 2 = the other pair may still be in flight)
+            if (n == 11) x6_row_stage<2>(T[PC][1], dd[1], sgn);
+            if (n == 17) x6_row_stage<2>(T[PC][2], dd[0], sgn);
+            if (n == 23) x6_row_stage<0>(T[PC][3], dd[1], sgn);
+            if (ND && n == 17) { dptr[DJ] += 16; dptr[DJ + 1] += 16; X6_PIN("+v"(dptr[DJ]), "+v"(dptr[DJ + 1])); }     // the two pointers move on by one chunk
+        } else {
+            const int sidx = n - n / 6;                                  // 0..19: group sidx / 5, step sidx % 5
+#define X6_BS(S) if (sidx == S) x6_build_step<S % 5, JN, S / 5>(sp, T, vf[NB]);
+            X6_BS(0) X6_BS(1) X6_BS(2) X6_BS(3) X6_BS(4) X6_BS(5) X6_BS(6) X6_BS(7) X6_BS(8) X6_BS(9)
+            X6_BS(10) X6_BS(11) X6_BS(12) X6_BS(13) X6_BS(14) X6_BS(15) X6_BS(16) X6_BS(17) X6_BS(18) X6_BS(19)
+#undef X6_BS
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    X6_STAMP(q2);
 #if (UNET_X6_ABLATE & 8)
-    if (ND) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    X6_STAMP(q3);
-    asm volatile("s_barrier" ::: "memory");
-    { long long q4; X6_STAMP(q4); tl[0] += q1 - q0; tl[1] += q2 - q1; tl[2] += q3 - q2; tl[3] += q4 - q3; tl[4] += 1; }
+    X6_STAMP(q1);
+    x6_period_wait<J>(uf, ue);
+    X6_STAMP(q2);
+    tl[2 * J] += q1 - q0; tl[2 * J + 1] += q2 - q1;
+    if (J == 0) { asm volatile("s_barrier" ::: "memory"); long long q3; X6_STAMP(q3); tl[8] += q3 - q2; tl[9] += 1; }
 #else
-    if (ND) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    x6_period_wait<J>(uf, ue);
+    if (J == 0) asm volatile("s_barrier" ::: "memory");
 #endif
-    x6_read_ops<PN, 0>(fr[0], a_base, b_base);                   // point 0 of the next unit
+    asm volatile("" : X6_TIE6(vf[NB]));
 }
 
 struct X6Args {
     WinoFusedArgs f;             // x, bias, out, geometry, stats, pad; f.Uc unused
-    const uint16_t* U6;          // [K/16][unit 4][point 4][piece 3][Nout][16] bf16
+    const uint16_t* U6;          // [Nout / 64][K / 16][point row 4][point 4][piece 3][channel block 2][lane 64][8] bf16
 };
+
+// The finished quarter of owner wave (tile block tb, channel block cb): lane (li, lh) holds tile li, channels 16 lh + e of the block in
+// element e of y[out row][out col] (the weight operand's rows are ordered for this: row 8 g + 4 lh + i of a fragment = channel 16 lh + 4 g + i).
+// Stored that way every lane would write 16-byte pieces of 64 different pixels per instruction.  The quarter goes through the wave's own
+// (now free) exchange area instead -- [tile 32][pixel 4][32 channels] fp32, tile stride 528 B: conflict-free both ways -- and comes back with
+// lane = (pixel L / 8, channel quad L % 8): a store instruction then covers 8 pixels x 128 contiguous bytes, the lane's channel quad is
+// the same in all 16 passes (bias: 4 values; BatchNorm sums: 2 x 4 registers instead of 2 x 16), and the STATS 2 reads of the producer's
+// activation are coalesced the same way.  STATS 1: sum, sum of squares of the stored values; STATS 2: sum dy, sum dy r.
+constexpr int kX6TileB = 528;
+template <int STATS>
+__device__ __forceinline__ void x6_finish(float (&y)[2][2][16], const WinoFusedArgs& p, int img, int by, int bx, int n0, int tb, int cb, int lane_in,
+                                          unsigned t_area, f32x4 b4, f32x4& s1, f32x4& s2) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));                                // (everything per-lane below is re-derived here: kept live across the chunk loop it is spilled)
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned tw = t_area + (unsigned)(li * kX6TileB + lh * 64);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                X6_WR128(tw, (2 * a + b) * 128 + g * 16, (f32x4{y[a][b][4 * g], y[a][b][4 * g + 1], y[a][b][4 * g + 2], y[a][b][4 * g + 3]}));
+    const int cq = lane & 7, pl = lane >> 3;                     // reader: channel quad, pixel of a pass (tile pl >> 2 of the pass, pixel pl & 3)
+    const unsigned tr = t_area + (unsigned)((pl >> 2) * kX6TileB + (pl & 3) * 128 + cq * 16);
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    const bool rok = STATS == 2 && n0 >= p.bn_c0 && n0 < p.bn_c1;
+    const int oa = (pl >> 1) & 1, ob = pl & 1;
+    // addresses: a wave-uniform 64-bit base (the tile block's first pixel, the quarter's first channel) + a 32-bit lane offset in elements
+    // (16 rows x W x ld of the tensor: far below 2^31 for every shape the entry points admit)
+    const int ch = 32 * cb + 4 * cq;
+    const int gy = 16 * by + 8 * tb + oa, gx = 16 * bx + 2 * (pl >> 2) + ob;       // the lane's pixel in pass (hp = 0, k = 0)
+    float* const ob_ = p.out + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.ldo + n0;
+    const float* const rb_ = STATS == 2 ? p.bn_r + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.bn_ldr + (n0 - p.bn_c0) : nullptr;
+    const int pix0 = (8 * tb + oa) * p.W + 2 * (pl >> 2) + ob;                     // pixel offset of that pixel from the block's first pixel
+    // STATS 2: the producer's saved activation at the lane's 16 pixels, ALL loaded here (y is dead behind the LDS writes: the registers are
+    // there) -- loaded pass by pass, every pass paid a global-memory round trip
+    f32x4 rall[16];
+    if (STATS == 2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const bool okq = gy + 2 * (q >> 2) < p.H && gx + 4 * (q & 3) < p.W;
+            rall[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rok && okq) rall[q] = *reinterpret_cast<const f32x4*>(rb_ + (unsigned)((pix0 + 2 * (q >> 2) * p.W + 4 * (q & 3)) * p.bn_ldr + ch));
+        }
+    }
+#pragma unroll
+    for (int h2 = 0; h2 < 8; ++h2) {                             // two passes at a time: half of tile row h2 / 2 of the block
+        const int hp = h2 >> 1, k0 = 2 * (h2 & 1);
+        f32x4 v[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) X6_RD128(v[k], tr, (4 * hp + k0 + k) * 2 * kX6TileB);
+        bool ok[2];
+        int pix[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            ok[k] = gy + 2 * hp < p.H && gx + 4 * (k0 + k) < p.W;
+            pix[k] = pix0 + 2 * hp * p.W + 4 * (k0 + k);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!ok[k]) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] = fmaxf(v[k][e] + b4[e], lo);
+            *reinterpret_cast<f32x4*>(ob_ + (unsigned)(pix[k] * p.ldo + ch)) = v[k];
+            if (STATS == 1) { s1 += v[k]; s2 += v[k] * v[k]; }
+            if (STATS == 2) { s1 += v[k]; s2 += v[k] * rall[4 * hp + k0 + k]; }
+        }
+    }
+}
+// Per-lane running sums -> one row of partials per wave (the layout of wf_write_stats: stat_part[tn][row][64 channels][2],
+// row = 2 * (first tile / nt) + tile block): the lanes with one channel quad (lane % 8) are reduced, lanes 0..7 write.
+__device__ __forceinline__ void x6_write_stats(const WinoFusedArgs& p, int t0, int rows_per_tn, int tb, int cb, int lane, f32x4 s1, f32x4 s2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) { s1[e] += __shfl_xor(s1[e], m, 64); s2[e] += __shfl_xor(s2[e], m, 64); }
+    if (lane >= 8) return;
+    const int tn = t0 % p.nt, row = 2 * (t0 / p.nt) + tb;
+    float* o = p.stat_part + ((size_t)tn * rows_per_tn + row) * 128 + 2 * (32 * cb + 4 * lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
+}
 
 template <int STATS>
 __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
     const WinoFusedArgs& p = q.f;
     __shared__ __attribute__((aligned(1024))) char smem[kX6Smem];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mi = wv & 1, ni = wv >> 1;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);              // = the wave's point row r
     const int li = lane & 31, lh = lane >> 5;
     const int nchunks = p.K / 16;
 
-    // ---- DMA duty.  U: piece wv + 4 j of a unit image = block (wv >> 1) + 2 j, rows 32 (wv & 1) + lane / 2, 16-byte slot lane & 1
-    //      (source-side swizzle: slot ^ bit 3 of the row).  D: piece wv + 4 j = pixel slots 16 (wv + 4 j) + lane / 4, channel quad lane & 3.
-    const int urow = 32 * (wv & 1) + (lane >> 1);
-    const unsigned u_lane = (unsigned)(urow * 32 + 16 * ((lane & 1) ^ ((urow >> 3) & 1)));
-    unsigned uoff[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) uoff[j] = u_lane + (unsigned)j * 2u * (unsigned)p.Nout * 32u;      // blocks b and b + 2 are 2 N rows apart
-    const size_t ustep = (size_t)12 * p.Nout * 32;                                    // bytes between units
+    // ---- DMA duty: piece wv + 4 j of a chunk = 16-byte slots 64 (wv + 4 j) + lane of [quad 4][row 18][pos 20]
     int ppy[6], ppx[6], poff[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        const int s = 16 * (wv + 4 * j) + (lane >> 2);
-        const int py = s / 18, px = x6_col_of(s % 18);
-        ppy[j] = s < 324 ? py : (1 << 20);                                            // past the patch: never inside the image
+        const int s = 64 * (wv + 4 * j) + lane;
+        const int qd = s / 360, rem = s - 360 * qd, py = rem / 20, pos = rem - 20 * py;
+        const bool real = s < 1440 && pos < 18;
+        const int px = x6_col_of(pos < 18 ? pos : 0);
+        ppy[j] = real ? py : (1 << 20);                                               // past the patch: never inside the image
         ppx[j] = px;
-        poff[j] = (py * p.W + px) * p.ldx + 4 * (lane & 3);
+        poff[j] = (py * p.W + px) * p.ldx + 4 * (qd & 3);
     }
     struct TileCoord { int tn, bx, by, img; };
     auto decode = [&](int t) { TileCoord c; c.tn = t % p.nt; t /= p.nt; c.bx = t % p.tbx; t /= p.tbx; c.by = t % p.tby; c.img = t / p.tby; return c; };
@@ -275,112 +366,186 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         return c;
     };
     const float* const padsrc = p.pad ? p.pad : g_zero_page_f;
-    auto tile_sources = [&](const TileCoord& c, const float* (&dp)[6], const char*& ub0) {
+    auto tile_sources = [&](const TileCoord& c, const float* (&dp)[6]) {
         const int gy0 = 16 * c.by - 1, gx0 = 16 * c.bx - 1;
         const float* xb = p.x + ((long long)(c.img * p.H + gy0) * p.W + gx0) * p.ldx;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
+            const int s = 64 * (wv + 4 * j) + lane;
             const bool ok = (unsigned)(gy0 + ppy[j]) < (unsigned)p.H && (unsigned)(gx0 + ppx[j]) < (unsigned)p.W;
-            dp[j] = ok ? xb + poff[j] : padsrc + 4 * (lane & 3);
+            dp[j] = ok ? xb + poff[j] : padsrc + 4 * ((s / 360) & 3);
         }
-        ub0 = reinterpret_cast<const char*>(q.U6) + ((size_t)(wv >> 1) * p.Nout + (size_t)c.tn * 64) * 32;
+    };
+    auto u_source = [&](const TileCoord& c) {
+        return reinterpret_cast<const char*>(q.U6) + ((size_t)c.tn * nchunks * 4 + wv) * kX6UChunkWave;
     };
 
     // ---- LDS byte addresses
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_f*)smem;
-    const int arow = 32 * mi + li, brow = 32 * ni + li;
-    const unsigned a_base = lds0 + kX6V + (unsigned)(arow * 32 + 16 * (lh ^ ((arow >> 3) & 1)));
-    const unsigned b_base = lds0 + kX6U + (unsigned)(brow * 32 + 16 * (lh ^ ((brow >> 3) & 1)));
-    const int t_lt = 16 * wv + (lane >> 2), t_q = lane & 3;                      // transform duty: (tile, channel quad)
-    unsigned d_base[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        d_base[c] = lds0 + (unsigned)(((2 * (t_lt >> 3)) * 18 + x6_slot_of(2 * (t_lt & 7) + c)) * 64 + 16 * t_q);
-    const unsigned v_base = lds0 + kX6V + (unsigned)(t_lt * 32 + 16 * ((t_q >> 1) ^ ((t_lt >> 3) & 1)) + 8 * (t_q & 1));
-    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wv * 1024));       // this wave's first piece, as an M0 value
+    // the lane's patch corner: tile (li / 8, li % 8) of a tile block, channel quads 2 lh, 2 lh + 1; raw rows ra / rb of the wave's point row
+    const int ra = wv == 0 ? 0 : wv == 2 ? 2 : 1, rb = wv == 0 ? 2 : wv == 1 ? 2 : wv == 2 ? 1 : 3;
+    const float sgn = wv == 1 ? 1.f : -1.f;
+    const unsigned d_lane = lds0 + (unsigned)(2 * lh * kX6PlaneB + (li >> 3) * 2 * kX6RowB + (li & 7) * 16);
+    const unsigned d_a = d_lane + (unsigned)(ra * kX6RowB), d_b = d_lane + (unsigned)(rb * kX6RowB);
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wv * 1024));       // this wave's first DMA piece, as an M0 value
+    const unsigned voff0 = (unsigned)lane * 16u, voff1 = voff0 + 4096u;
+    const unsigned x_lane = lds0 + kX6X + (unsigned)lane * 16u;
 
     f32x16 acc[16];
-    f32x4 S0[8], S1[8];
-    X6Frag fr[2];
+    f32x4 T[4][4];
+    f32x4 dd[2][2];
+    x6_i32x4 uf[2][6], ue[6], vf[2][6];
     X6Split sp;
-    const float* dptr[6]; const float* dnxt[6]; const char* ucur; const char* unxt;
+    const float* dptr[6]; const char* ucur; const char* unxt;
     int t = blockIdx.x;
     if ((gridDim.x & 7) == 0 && (p.nt & 7) != 0) t = (t & 7) * (int)(gridDim.x >> 3) + (t >> 3);       // XCD-aware renumbering, as winograd.hip
     const int t_first = t;
-    f32x2 s1[8], s2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { s1[i] = f32x2{0.f, 0.f}; s2[i] = f32x2{0.f, 0.f}; }
+    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
     TileCoord tc = decode(t);
-    tile_sources(tc, dptr, ucur);
+    tile_sources(tc, dptr);
+    ucur = u_source(tc);
 
-    // ---- prologue of the workgroup's first tile: D(0), D(1) pieces 0..3, U(unit 0) -> LDS; V(unit 0) by a full transform; row stage of unit 1
+    // ---- prologue of the workgroup's first tile: D(0), D(1) -> LDS; u(point 0); row stage of columns 1, 0, 2 of chunk 0; V(point 0)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         X6_DMA_V(dptr[j], lds_w, j * 4096);
-        if (j < 4) X6_DMA_V(dptr[j] + 16, lds_w, kX6DB + j * 4096);
-        X6_DMA_S(uoff[j], ucur, lds_w, kX6U + j * 4096);
-        dptr[j] += j < 4 ? 32 : 16;                              // next issue: chunk 2 (pieces 0..3), chunk 1 (pieces 4, 5)
+        X6_DMA_V(dptr[j] + 16, lds_w, kX6DB + j * 4096);
+        dptr[j] += 32;                                           // next issue: chunk 2
     }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    x6_read_rows<0, 0, 0>(S1, d_base); x6_read_rows<0, 0, 1>(S1, d_base); x6_read_rows<0, 0, 2>(S1, d_base); x6_read_rows<0, 0, 3>(S1, d_base);
-    x6_read_rows<1, 0, 0>(S0, d_base); x6_read_rows<1, 0, 1>(S0, d_base); x6_read_rows<1, 0, 2>(S0, d_base); x6_read_rows<1, 0, 3>(S0, d_base);
-    asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_DD(S1));
-    asm volatile("" : X6_TIE_DD(S0));
-    x6_row_stage<0, 0>(S1); x6_row_stage<0, 1>(S1); x6_row_stage<0, 2>(S1); x6_row_stage<0, 3>(S1);
-    x6_row_stage<1, 0>(S0); x6_row_stage<1, 1>(S0); x6_row_stage<1, 2>(S0); x6_row_stage<1, 3>(S0);
-    x6_split_step<0, 0>(sp, S1); x6_split_step<1, 0>(sp, S1); x6_split_step<2, 0>(sp, S1); x6_split_step<3, 0>(sp, S1); x6_split_step<4, 0>(sp, S1); x6_write_v<0, 0>(sp, v_base);
-    x6_split_step<0, 1>(sp, S1); x6_split_step<1, 1>(sp, S1); x6_split_step<2, 1>(sp, S1); x6_split_step<3, 1>(sp, S1); x6_split_step<4, 1>(sp, S1); x6_write_v<0, 1>(sp, v_base);
-    x6_split_step<0, 2>(sp, S1); x6_split_step<1, 2>(sp, S1); x6_split_step<2, 2>(sp, S1); x6_split_step<3, 2>(sp, S1); x6_split_step<4, 2>(sp, S1); x6_write_v<0, 2>(sp, v_base);
-    x6_split_step<0, 3>(sp, S1); x6_split_step<1, 3>(sp, S1); x6_split_step<2, 3>(sp, S1); x6_split_step<3, 3>(sp, S1); x6_split_step<4, 3>(sp, S1); x6_write_v<0, 3>(sp, v_base);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    x6_read_ops<0, 0>(fr[0], a_base, b_base);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { if (k < 4) X6_LDU(uf[0][k], voff0, ucur, k * 1024); else X6_LDU(uf[0][k], voff1, ucur, (k - 4) * 1024); }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : X6_TIE6(uf[0]) :: "memory");
+#define X6_COL(C) \
+    x6_read_rows<0, C, 0>(dd[0], d_a, d_b); x6_row_stage<0>(T[C][0], dd[0], sgn); x6_read_rows<0, C, 1>(dd[0], d_a, d_b); x6_row_stage<0>(T[C][1], dd[0], sgn); \
+    x6_read_rows<0, C, 2>(dd[0], d_a, d_b); x6_row_stage<0>(T[C][2], dd[0], sgn); x6_read_rows<0, C, 3>(dd[0], d_a, d_b); x6_row_stage<0>(T[C][3], dd[0], sgn);
+    X6_COL(1) X6_COL(0) X6_COL(2)
+#undef X6_COL
+#define X6_G(G) x6_build_step<0, 0, G>(sp, T, vf[0]); x6_build_step<1, 0, G>(sp, T, vf[0]); x6_build_step<2, 0, G>(sp, T, vf[0]); x6_build_step<3, 0, G>(sp, T, vf[0]); x6_build_step<4, 0, G>(sp, T, vf[0]);
+    X6_G(0) X6_G(1) X6_G(2) X6_G(3)
+#undef X6_G
+    asm volatile("" : X6_TIE6(vf[0]));
 
-    long long tl[6] = {0, 0, 0, 0, 0, 0};
+    long long tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (; t < ntiles; t += gridDim.x) {
 #if (UNET_X6_ABLATE & 8)
         long long e0; X6_STAMP(e0);
 #endif
         const TileCoord tcn = t + (int)gridDim.x < ntiles ? advance(tc) : tc;            // the last tile prefetches itself again
-        tile_sources(tcn, dnxt, unxt);
-        f32x4 bias4[4];
-        wf_load_bias(p, tc.tn * 64, ni, lh, bias4);
-        // U(g + 1) of unit g = 4 c + R, continuing into the next tile.  D pieces: unit R = 0 issues chunk c + 1 (the tile's last one when
-        // c = nchunks - 2), R = 2, 3 issue chunk c + 2 (the last one when c = nchunks - 3); behind the last chunk the pointers jump to the next tile
-#define X6_US(c, R) ((4 * (c) + (R) + 1 < 4 * nchunks) ? ucur + (size_t)(4 * (c) + (R) + 1) * ustep : unxt)
-#define X6_UNIT(R, DP, FIRST, c) \
-        x6_unit<R, DP, FIRST>(acc, S0, S1, fr, sp, a_base, b_base, d_base, v_base, X6_US(c, R), uoff, dptr, dnxt, \
-                              (R) == 0 ? (c) == nchunks - 2 : (c) == nchunks - 3, lds_w, tl)
-        X6_UNIT(0, 0, true, 0); X6_UNIT(1, 0, true, 0); X6_UNIT(2, 0, true, 0); X6_UNIT(3, 0, true, 0);
-        X6_UNIT(0, 1, false, 1); X6_UNIT(1, 1, false, 1); X6_UNIT(2, 1, false, 1); X6_UNIT(3, 1, false, 1);
+        unxt = u_source(tcn);
+        // weight fragments of point J + 1 (period J of chunk c): this chunk's next point, the next chunk's point 0, or the next tile's
+#define X6_US(c, J) ((J) < 3 ? ucur + (size_t)(c) * kX6UChunk + ((J) + 1) * kX6UPoint : ((c) + 1 < nchunks ? ucur + (size_t)((c) + 1) * kX6UChunk : unxt))
+#define X6_PERIOD(J, DP, FIRST, c) x6_period<J, DP, FIRST>(acc, T, dd, uf, ue, vf, sp, d_a, d_b, sgn, X6_US(c, J), voff0, voff1, dptr, lds_w, tl)
+        // (the patch pieces issued from chunk nchunks - 2 on belong to the next tile: its pointers are formed in the one period without DMA)
+#define X6_CHUNK(DP, FIRST, c) \
+        if ((c) == nchunks - 2) tile_sources(tcn, dptr); \
+        X6_PERIOD(0, DP, FIRST, c); X6_PERIOD(1, DP, FIRST, c); X6_PERIOD(2, DP, FIRST, c); X6_PERIOD(3, DP, FIRST, c);
+        X6_CHUNK(0, true, 0)
+        X6_CHUNK(1, false, 1)
         for (int c = 2; c < nchunks; c += 2) {
-            X6_UNIT(0, 0, false, c); X6_UNIT(1, 0, false, c); X6_UNIT(2, 0, false, c); X6_UNIT(3, 0, false, c);
-            X6_UNIT(0, 1, false, c + 1); X6_UNIT(1, 1, false, c + 1); X6_UNIT(2, 1, false, c + 1); X6_UNIT(3, 1, false, c + 1);
+            X6_CHUNK(0, false, c)
+            X6_CHUNK(1, false, c + 1)
         }
-#undef X6_UNIT
+#undef X6_CHUNK
+#undef X6_PERIOD
 #undef X6_US
-        asm volatile("s_waitcnt lgkmcnt(0)" : X6_TIE_FRAG(fr[0]));           // the next unit's first operands have landed before anything below may move them
+        // ---- end of tile.  Column stage of the wave's point row (lane-local), halves to their owners through LDS, row stage at the owner
+#if (UNET_X6_ABLATE & 8)
+        long long e1; X6_STAMP(e1);
+#endif
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMAs are invisible to the compiler's hazard recogniser
-        f32x4 rv[4][4];
-        if (STATS == 2) wf_load_r(p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, rv);
-        wf_epilogue<STATS>(acc, p, tc.img, tc.by, tc.bx, tc.tn * 64, mi, ni, li, lh, bias4, s1, s2, rv);
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};                    // the bias of the lane's channel quad in the finish (latency behind the column stage)
+        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + tc.tn * 64 + 32 * (wv >> 1) + 4 * (lane & 7));
+        float zown[2][16];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {                        // quarter (channel block qd >> 1, tile block qd & 1), owner = wave qd
+            const unsigned xw = x_lane + (unsigned)(qd * kX6XW) + (unsigned)((wv - (wv > qd ? 1 : 0)) * 8192);
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                f32x4 z0, z1;
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {                 // two elements at a time: packed adds on aligned register pairs (no MFMA runs here)
+                    f32x2 m0, m1, m2, m3;
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(m0.x) : "a"(acc[0 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m0.y) : "a"(acc[0 + qd][4 * e4 + i + 1]));
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(m1.x) : "a"(acc[4 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m1.y) : "a"(acc[4 + qd][4 * e4 + i + 1]));
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(m2.x) : "a"(acc[8 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m2.y) : "a"(acc[8 + qd][4 * e4 + i + 1]));
+                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(m3.x) : "a"(acc[12 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m3.y) : "a"(acc[12 + qd][4 * e4 + i + 1]));
+                    const f32x2 r0 = (m0 + m1) + m2, r1 = wf_pk_sub(wf_pk_sub(m1, m2), m3);
+                    z0[i] = r0.x; z0[i + 1] = r0.y; z1[i] = r1.x; z1[i + 1] = r1.y;
+                }
+                if (qd == wv) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { zown[0][4 * e4 + i] = z0[i]; zown[1][4 * e4 + i] = z1[i]; }
+                } else {
+                    X6_WR128(xw, (2 * e4) * 1024, z0);
+                    X6_WR128(xw, (2 * e4 + 1) * 1024, z1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if (UNET_X6_ABLATE & 8)
+        long long e3, e4, e5; X6_STAMP(e3);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        X6_STAMP(e4);
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+        // owner: y[0][b] = z_b(row 0) + z_b(row 1) + z_b(row 2), y[1][b] = z_b(row 1) - z_b(row 2) - z_b(row 3)
+        float y[2][2][16];
+        {
+            const float a0 = wv == 3 ? 0.f : 1.f, a1 = wv == 0 ? 0.f : wv == 1 ? 1.f : -1.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { y[0][b][e] = a0 * zown[b][e]; y[1][b][e] = a1 * zown[b][e]; }
+        }
+        const unsigned xr = x_lane + (unsigned)(wv * kX6XW);
+        {
+            // value index vi = 2 e4 + b (1 KB each) of the three other rows, one value quad ahead of its use
+            f32x4 zr[2][3];
+            X6_RD128(zr[0][0], xr, 0 * 8192); X6_RD128(zr[0][1], xr, 1 * 8192); X6_RD128(zr[0][2], xr, 2 * 8192);
+#pragma unroll
+            for (int vi = 0; vi < 8; ++vi) {
+                const int e4 = vi >> 1, b = vi & 1;
+                if (vi < 7) { X6_RD128(zr[(vi + 1) & 1][0], xr, 0 * 8192 + (vi + 1) * 1024); X6_RD128(zr[(vi + 1) & 1][1], xr, 1 * 8192 + (vi + 1) * 1024); X6_RD128(zr[(vi + 1) & 1][2], xr, 2 * 8192 + (vi + 1) * 1024); }
+                if (vi < 7) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(zr[vi & 1][0]), "+v"(zr[vi & 1][1]), "+v"(zr[vi & 1][2]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zr[vi & 1][0]), "+v"(zr[vi & 1][1]), "+v"(zr[vi & 1][2]));
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int src = s < wv ? s : s + 1;
+                    const float a0 = src == 3 ? 0.f : 1.f, a1 = src == 0 ? 0.f : src == 1 ? 1.f : -1.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        y[0][b][4 * e4 + i] = __builtin_fmaf(a0, zr[vi & 1][s][i], y[0][b][4 * e4 + i]);
+                        y[1][b][4 * e4 + i] = __builtin_fmaf(a1, zr[vi & 1][s][i], y[1][b][4 * e4 + i]);
+                    }
+                }
+            }
+        }
+#if (UNET_X6_ABLATE & 8)
+        X6_STAMP(e5);
+#endif
+        x6_finish<STATS>(y, p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane, lds0 + kX6X + (unsigned)(wv * kX6XW), b4, s1, s2);
         ucur = unxt; tc = tcn;
 #if (UNET_X6_ABLATE & 8)
-        { long long e1; X6_STAMP(e1); tl[5] += e1 - e0; }
+        { long long e2; X6_STAMP(e2); tl[10] += e1 - e0; tl[11] += e2 - e1; tl[12] += 1; tl[13] += e3 - e1; tl[14] += e4 - e3; tl[15] += e5 - e4; }
 #endif
     }
 #if (UNET_X6_ABLATE & 8)
-    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 6; ++i) g_x6_timeline[i] = tl[i];
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 16; ++i) g_x6_timeline[i] = tl[i];
 #endif
-    // retire the prefetches of the tile that never runs (LDS reads into fr[0], DMAs) before the wave ends
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : X6_TIE_FRAG(fr[0]) :: "memory");
-    if (STATS) wf_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), mi, ni, li, lh, s1, s2);
+    // retire the prefetches of the tile that never runs (weight fragments, DMA pieces) before the wave ends
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : X6_TIE6(uf[0]) :: "memory");
+    if (STATS) x6_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), wv & 1, wv >> 1, lane, s1, s2);
 }
 __global__ __launch_bounds__(256, 1) void wino_x6_stream_kernel(X6Args q, int ntiles) { x6_stream_body<0>(q, ntiles); }
 __global__ __launch_bounds__(256, 1) void wino_x6_stream_stats_kernel(X6Args q, int ntiles) { x6_stream_body<1>(q, ntiles); }
 __global__ __launch_bounds__(256, 1) void wino_x6_stream_bnbwd_kernel(X6Args q, int ntiles) { x6_stream_body<2>(q, ntiles); }
 
-// ---- weight operands: G g G^T in fp32 (as winograd.hip), then the exact three-piece split, in the kernel's unit layout -----------------
-//   U6[((((k/16) * 4 + r) * 4 + j) * 3 + piece) * N + n) * 16 + k % 16],   point xi = 4 r + j
+// ---- weight operands: G g G^T in fp32 (as winograd.hip), then the exact three-piece split, in MFMA A-operand order ----------------------
+//   U6[(((((n/64) * (K/16) + k/16) * 4 + r) * 4 + j) * 3 + piece) * 2 + (n%64)/32) * 512 + (row(n%32) + 32 * ((k%16)/8)) * 8 + k%8],   point xi = 4 r + j,
+//   row(16 a + 4 g + i) = 8 g + 4 a + i
+// : per 64-channel output tile, 16-channel reduce chunk and point ROW r one contiguous 24-KB block (a wave's stream), in it per point and
+// piece the two 1-KB fragments a wave loads with one global_load_dwordx4 each (lane (li, lh) = fragment row li, reduce channels 8 lh + 0..7).
 // mode 0 (forward): k = ci, n = co;  thread = 8 consecutive ci x one co (adjacent threads = adjacent co: coalesced reads of w, 16-byte stores).
 // mode 1 (data gradient): k = co, n = ci, filter rotated by 180 degrees = the forward transform with points 0 and 3 swapped in both directions;
 //         thread = 8 consecutive co x one ci (32 contiguous bytes of w per tap).
@@ -411,8 +576,8 @@ __device__ __forceinline__ void x6_transform_g(const float (&g)[3][3], float (&t
     }
 }
 constexpr float kX6FoldScaleFloor = 1e-30f;
-// One item = 8 consecutive k (k8) x one n: a 16-byte half of the [n][16 k] rows of all 16 points x 3 pieces.  Callers map lanes so that
-// the two halves of a row and consecutive n are neighbours: a wave's store instruction then covers contiguous memory.
+// One item = 8 consecutive k (k8) x one n: ONE lane's 16 bytes of the fragments of all 16 points x 3 pieces.  Callers map threads so that
+// consecutive n are neighbours: a wave's store instruction then covers two 512-byte runs.
 __device__ __forceinline__ void x6_weight_item(const float* __restrict__ w, uint16_t* __restrict__ U6, int Ci, int Co, int mode, int k8, int n,
                                                const float* __restrict__ scale, const float* __restrict__ shift) {
     const int N = mode ? Ci : Co;
@@ -434,16 +599,26 @@ __device__ __forceinline__ void x6_weight_item(const float* __restrict__ w, uint
         for (int xi = 0; xi < 16; ++xi) t[xi][e] = tt[xi];
     }
     const int c16 = k8 >> 1, half = k8 & 1;
+    const int nchunks = (mode ? Co : Ci) >> 4;
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) {
         int r = xi >> 2, j = xi & 3;
         if (mode) { r = r == 0 ? 3 : (r == 3 ? 0 : r); j = j == 0 ? 3 : (j == 3 ? 0 : j); }
         x6_i32x4 h, m, l;
         x6_pieces8(t[xi], h, m, l);
-        uint16_t* o = U6 + (((size_t)((c16 * 4 + r) * 4 + j) * 3) * N + n) * 16 + 8 * half;
+        if (nchunks * 16 < kX6RowWaveMinK) {                       // the layer goes to winograd_x6s.hip: its [point][piece][n][16 k] layout
+            uint16_t* o = U6 + (((size_t)((c16 * 4 + r) * 4 + j) * 3) * N + n) * 16 + 8 * half;
+            *reinterpret_cast<x6_i32x4*>(o) = h;
+            *reinterpret_cast<x6_i32x4*>(o + (size_t)N * 16) = m;
+            *reinterpret_cast<x6_i32x4*>(o + (size_t)2 * N * 16) = l;
+            continue;
+        }
+        // fragment row of channel n % 32 = 16 a + 4 g + i:  8 g + 4 a + i  (a lane of the accumulator then holds 16 consecutive channels)
+        const int nl = n & 31, frow = 8 * ((nl >> 2) & 3) + 4 * (nl >> 4) + (nl & 3);
+        uint16_t* o = U6 + ((((size_t)(((n >> 6) * nchunks + c16) * 4 + r) * 4 + j) * 3) * 2 + ((n >> 5) & 1)) * 512 + (frow + 32 * half) * 8;
         *reinterpret_cast<x6_i32x4*>(o) = h;
-        *reinterpret_cast<x6_i32x4*>(o + (size_t)N * 16) = m;
-        *reinterpret_cast<x6_i32x4*>(o + (size_t)2 * N * 16) = l;
+        *reinterpret_cast<x6_i32x4*>(o + 2 * 512) = m;
+        *reinterpret_cast<x6_i32x4*>(o + 4 * 512) = l;
     }
 }
 __global__ __launch_bounds__(256) void wino_x6_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ U6, int Ci, int Co, int mode) {
@@ -513,6 +688,9 @@ bool x6_shape_ok(int N, int H, int W, int K, int Nout) {
 
 int run_wino_x6(const float* x, int ldx, const uint16_t* U6, const float* bias, float* out, int ldo, int N, int H, int W,
                 int K, int Nout, int relu, float* stat_part, hipStream_t st, const WinoBnBwd* bb, const float* pad, int max_workgroups) {
+    if (K < kX6RowWaveMinK)
+        return unet_run_wino_x6_small_k(x, ldx, U6, bias, out, ldo, N, H, W, K, Nout, relu, stat_part, st, bb ? bb->r : nullptr, bb ? bb->ldr : 0,
+                                        bb ? bb->c0 : 0, bb ? bb->c1 : 0, pad, max_workgroups);
     X6Args q{};
     WinoFusedArgs& a = q.f;
     q.U6 = U6;
@@ -535,7 +713,7 @@ int run_wino_x6(const float* x, int ldx, const uint16_t* U6, const float* bias, 
 }  // namespace
 
 #if (UNET_X6_ABLATE & 8)
-extern "C" int unet_debug_x6_timeline(long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x6_timeline), 64); }
+extern "C" int unet_debug_x6_timeline(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_x6_timeline), 128); }
 #endif
 
 // 1 when the BF16x6 kernels take the layer: H, W even, reduce channels K a multiple of 32 (>= 64), output channels a multiple of 64.

@@ -21,12 +21,20 @@ def ws_bytes(n):
 
 
 def unpack_u6(u, K, N):
-    """U6 bytes -> float64 [K/16][unit 4][point 4][piece 3][N][16]"""
+    """U6 bytes (MFMA A-operand order: [N/64][K/16][point row 4][point 4][piece 3][channel block 2][lane: k half 2, row 32][8 k], one 1-KB
+    fragment per (.., channel block), rows in the order the kernel's epilogue wants) -> float64 [K/16][point row 4][point 4][piece 3][N][16]"""
     bits = u.view(torch.int16).to(torch.int32) << 16
-    return bits.view(torch.float32).double().reshape(K // 16, 4, 4, 3, N, 16)
+    if K < 256:                  # layers with fewer than 256 reduce channels take the round-4 kernel (winograd_x6s.hip) and its layout
+        return bits.view(torch.float32).double().reshape(K // 16, 4, 4, 3, N, 16)
+    t = bits.view(torch.float32).double().reshape(N // 64, K // 16, 4, 4, 3, 2, 2, 32, 8)        # [tn][c][r][j][piece][cb][lh][row][e]
+    # fragment row 8 g + 4 a + i holds channel 16 a + 4 g + i of the block (an accumulator lane then owns 16 consecutive channels)
+    ch = torch.arange(32, device=t.device)
+    row_of = 8 * ((ch >> 2) & 3) + 4 * (ch >> 4) + (ch & 3)
+    t = t.index_select(7, row_of)                                                               # [..][channel of the block][e]
+    return t.permute(1, 2, 3, 4, 0, 5, 7, 6, 8).reshape(K // 16, 4, 4, 3, N, 16)
 
 
-@pytest.mark.parametrize("ci,co", [(64, 64), (128, 64), (64, 192), (256, 128)])
+@pytest.mark.parametrize("ci,co", [(64, 64), (128, 64), (64, 192), (256, 128), (256, 256), (512, 320)])
 def test_x6_weight_operand_is_an_exact_split_of_the_fp32_transform(hip, ci, co):
     g = torch.Generator(device=DEV).manual_seed(ci + co)
     w = torch.randn(3, 3, ci, co, device=DEV, generator=g) * torch.pow(10.0, torch.randint(-3, 3, (3, 3, ci, co), device=DEV, generator=g).float())
@@ -56,7 +64,8 @@ def test_x6_weight_operand_is_an_exact_split_of_the_fp32_transform(hip, ci, co):
     assert torch.equal(a0, fc.x6_weights(hip, w, 0)) and torch.equal(a1, fc.x6_weights(hip, w, 1))
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (5, 104, 136, 64, 64), (2, 32, 48, 64, 192)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (5, 104, 136, 64, 64), (2, 32, 48, 64, 192),
+                                   (2, 16, 16, 256, 64), (3, 40, 24, 512, 128), (5, 104, 136, 256, 64)])          # (>= 256 reduce channels: the round-5 kernel)
 def test_x6_fused_bn_stats_match_bn_train_stats(hip, shape):
     # BatchNorm sums from the BF16x6 conv epilogue -> finalize == the separate statistics pass over the stored activation; the stored
     # activation itself is identical with and without the statistics
@@ -86,7 +95,8 @@ def test_x6_fused_bn_stats_match_bn_train_stats(hip, shape):
 
 
 @pytest.mark.parametrize("shape,crange", [((2, 16, 16, 64, 64), (0, 64)), ((1, 16, 32, 128, 64), (64, 128)), ((5, 104, 136, 64, 64), (0, 64)),
-                                          ((2, 32, 32, 256, 128), (128, 256))])
+                                          ((2, 32, 32, 256, 128), (128, 256)),
+                                          ((2, 16, 16, 64, 256), (0, 64)), ((1, 16, 32, 128, 512), (64, 128)), ((3, 40, 56, 64, 256), (0, 64))])        # (reduce channels = Cout >= 256: the round-5 kernel)
 def test_x6_dgrad_bn_backward_sums_match_reduction(hip, shape, crange):
     # BF16x6 data gradient + (sum dy, sum dy * r) of the producer's BatchNorm from the epilogue -> bn_bwd_from_partials == the plain
     # data gradient followed by the full unet_bn_bwd, for a channel sub-range too
@@ -123,7 +133,7 @@ def test_x6_dgrad_bn_backward_sums_match_reduction(hip, shape, crange):
         assert (a_ - b_).abs().max().item() < 2e-5 * scale + 1e-6, (a_ - b_).abs().max().item() / scale
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 18, 34, 64, 128), (1, 8, 8, 256, 256), (3, 40, 56, 128, 64)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 18, 34, 64, 128), (1, 8, 8, 256, 256), (3, 40, 56, 128, 64), (2, 18, 34, 512, 64)])
 @pytest.mark.parametrize("vanishing", [False, True])
 def test_x6_batchnorm_apply_on_load_matches_the_oracle(hip, shape, vanishing):
     # BatchNorm-apply on load through the BF16x6 kernel (unet_winograd_weight_fold_x6: scaled three-piece weights, folded bias, per-channel
@@ -162,7 +172,7 @@ def test_x6_batchnorm_apply_on_load_matches_the_oracle(hip, shape, vanishing):
     assert err.max() < 3e-5 * scale_ and err[:, border].max() < 3e-5 * scale_, (err.max() / scale_, err[:, border].max() / scale_)
 
 
-@pytest.mark.parametrize("shape", [(8, 512, 512, 64, 64), (8, 512, 512, 128, 64), (8, 32, 32, 1024, 1024)])
+@pytest.mark.parametrize("shape", [(8, 512, 512, 64, 64), (8, 512, 512, 128, 64), (8, 32, 32, 1024, 1024), (8, 128, 128, 256, 256)])
 def test_x6_forward_and_data_gradient_at_full_size(hip, shape):
     # BASELINE config-2 layer shapes (the oracle is too slow here): the BF16x6 forward agrees with the native fused Winograd kernel to
     # fp32 rounding, and forward / data gradient are adjoint:  <conv(x, w), dz> == <x, dgrad(dz, w)>  (inner products in fp64);
