@@ -15,7 +15,7 @@ plan = importlib.import_module("semantic-segmentation-unet_amd.plan")
 path, dtype, C, K = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 size = int(sys.argv[5]) if len(sys.argv) > 5 else 512
 batch = int(sys.argv[6]) if len(sys.argv) > 6 else 8
-fams = {"f32": {"fwd": ["wino_x6_stream_stats_kernel", "wino_x6s_stream_stats_kernel"], "dgrad": ["wino_x6_stream_bnbwd_kernel", "wino_x6_stream_kernel", "wino_x6s_stream_bnbwd_kernel", "wino_x6s_stream_kernel"], "wgrad": ["wino_wgrad_fused_kernel"]},
+fams = {"f32": {"fwd": ["wino_x6_stream_stats_kernel"], "dgrad": ["wino_x6_stream_bnbwd_kernel", "wino_x6_stream_kernel"], "wgrad": ["wino_wgrad_fused_kernel"]},
         "f32native": {"fwd": ["wino_fused_stream_stats_kernel", "wino_fused_stats_kernel"], "dgrad": ["wino_fused_stream_bnbwd_kernel", "wino_fused_stream_kernel", "wino_fused_bnbwd_kernel", "wino_fused_kernel"],
                 "wgrad": ["wino_wgrad_fused_kernel"]},
         "bf16": {"fwd": ["conv_bf16_stream_stats_kernel", "conv_bf16_stats_kernel"], "dgrad": ["conv_bf16_stream_bnbwd_kernel", "conv_bf16_stream_kernel_", "conv_bf16_bnbwd_kernel", "conv_bf16_kernel_"],

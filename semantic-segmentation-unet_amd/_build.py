@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libunet_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_direct.hip", "winograd.hip", "winograd_x6.hip", "winograd_x6s.hip", "convt_stream.hip", "convt_x6.hip", "conv_bf16.hip", "augment.hip",
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_direct.hip", "winograd.hip", "winograd_x6.hip", "convt_stream.hip", "convt_x6.hip", "conv_bf16.hip", "augment.hip",
            "norm.hip", "misc.hip", "crc32c.hip"]
 HEADERS = ["common.h", "wino_epilogue.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

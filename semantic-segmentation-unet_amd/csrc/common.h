@@ -67,7 +67,3 @@ __device__ __forceinline__ uint32_t unet_hash32(uint32_t seed, uint64_t idx) {
 // conv_igemm.hip: `planes` independent fp32-MFMA GEMMs out[z][t][n] = sum_k x[z][t][k] * w[z][k][n] (T % 32 == 0)
 int unet_igemm_batched_planes(const float* x, const float* w, float* out, long T, int K, int N, int planes, hipStream_t st);
 
-// winograd_x6s.hip: the BF16x6 Winograd kernel for layers with fewer than 256 reduce channels (called from winograd_x6.hip's entry points)
-int unet_run_wino_x6_small_k(const float* x, int ldx, const void* U6, const float* bias, float* out, int ldo, int N, int H, int W,
-                             int K, int Nout, int relu, float* stat_part, hipStream_t st, const float* bn_r, int bn_ldr, int bn_c0, int bn_c1,
-                             const float* pad, int max_workgroups);

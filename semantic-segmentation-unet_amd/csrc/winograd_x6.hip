@@ -60,7 +60,6 @@ constexpr int kX6Smem = kX6X + 4 * kX6XW;         // 147456 B
 constexpr int kX6UPoint = 6 * 1024;               // bytes of one point's weight fragments: [piece 3][channel block 2][lane 64][16 B]
 constexpr int kX6UChunkWave = 4 * kX6UPoint;      // one point row of a chunk
 constexpr int kX6UChunk = 4 * kX6UChunkWave;      // all four point rows
-constexpr int kX6RowWaveMinK = 256;               // layers with fewer reduce channels take the round-4 tiling (winograd_x6s.hip): a tile of theirs has too few chunks for this kernel's end-of-tile exchange
 
 #define X6_RD128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
 #define X6_WR128(base, off, val) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "v"(val), "n"(off) : "memory")
@@ -343,18 +342,6 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
     const int li = lane & 31, lh = lane >> 5;
     const int nchunks = p.K / 16;
 
-    // ---- DMA duty: piece wv + 4 j of a chunk = 16-byte slots 64 (wv + 4 j) + lane of [quad 4][row 18][pos 20]
-    int ppy[6], ppx[6], poff[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int s = 64 * (wv + 4 * j) + lane;
-        const int qd = s / 360, rem = s - 360 * qd, py = rem / 20, pos = rem - 20 * py;
-        const bool real = s < 1440 && pos < 18;
-        const int px = x6_col_of(pos < 18 ? pos : 0);
-        ppy[j] = real ? py : (1 << 20);                                               // past the patch: never inside the image
-        ppx[j] = px;
-        poff[j] = (py * p.W + px) * p.ldx + 4 * (qd & 3);
-    }
     struct TileCoord { int tn, bx, by, img; };
     auto decode = [&](int t) { TileCoord c; c.tn = t % p.nt; t /= p.nt; c.bx = t % p.tbx; t /= p.tbx; c.by = t % p.tby; c.img = t / p.tby; return c; };
     const TileCoord dstep = decode((int)gridDim.x);
@@ -366,14 +353,22 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         return c;
     };
     const float* const padsrc = p.pad ? p.pad : g_zero_page_f;
+    // DMA duty: piece wv + 4 j of a chunk = 16-byte slots 64 (wv + 4 j) + lane of [quad 4][row 18][pos 20].  The per-lane slot geometry is
+    // re-derived at every tile switch (a few dozen integer instructions): kept live across the chunk loop it was spilled, and the reloads --
+    // serialised vector-memory round trips behind the DMA pieces in flight -- cost microseconds per tile.
     auto tile_sources = [&](const TileCoord& c, const float* (&dp)[6]) {
         const int gy0 = 16 * c.by - 1, gx0 = 16 * c.bx - 1;
         const float* xb = p.x + ((long long)(c.img * p.H + gy0) * p.W + gx0) * p.ldx;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int s = 64 * (wv + 4 * j) + lane;
-            const bool ok = (unsigned)(gy0 + ppy[j]) < (unsigned)p.H && (unsigned)(gx0 + ppx[j]) < (unsigned)p.W;
-            dp[j] = ok ? xb + poff[j] : padsrc + 4 * ((s / 360) & 3);
+            const int s = 64 * (wv + 4 * j) + ln;
+            const int qd = s / 360, rem = s - 360 * qd, py = rem / 20, pos = rem - 20 * py;
+            const bool real = s < 1440 && pos < 18;
+            const int px = x6_col_of(pos < 18 ? pos : 0);
+            const bool ok = real && (unsigned)(gy0 + py) < (unsigned)p.H && (unsigned)(gx0 + px) < (unsigned)p.W;
+            dp[j] = ok ? xb + ((py * p.W + px) * p.ldx + 4 * qd) : padsrc + 4 * (qd & 3);
         }
     };
     auto u_source = [&](const TileCoord& c) {
@@ -600,19 +595,13 @@ __device__ __forceinline__ void x6_weight_item(const float* __restrict__ w, uint
     }
     const int c16 = k8 >> 1, half = k8 & 1;
     const int nchunks = (mode ? Co : Ci) >> 4;
+    (void)N;
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) {
         int r = xi >> 2, j = xi & 3;
         if (mode) { r = r == 0 ? 3 : (r == 3 ? 0 : r); j = j == 0 ? 3 : (j == 3 ? 0 : j); }
         x6_i32x4 h, m, l;
         x6_pieces8(t[xi], h, m, l);
-        if (nchunks * 16 < kX6RowWaveMinK) {                       // the layer goes to winograd_x6s.hip: its [point][piece][n][16 k] layout
-            uint16_t* o = U6 + (((size_t)((c16 * 4 + r) * 4 + j) * 3) * N + n) * 16 + 8 * half;
-            *reinterpret_cast<x6_i32x4*>(o) = h;
-            *reinterpret_cast<x6_i32x4*>(o + (size_t)N * 16) = m;
-            *reinterpret_cast<x6_i32x4*>(o + (size_t)2 * N * 16) = l;
-            continue;
-        }
         // fragment row of channel n % 32 = 16 a + 4 g + i:  8 g + 4 a + i  (a lane of the accumulator then holds 16 consecutive channels)
         const int nl = n & 31, frow = 8 * ((nl >> 2) & 3) + 4 * (nl >> 4) + (nl & 3);
         uint16_t* o = U6 + ((((size_t)(((n >> 6) * nchunks + c16) * 4 + r) * 4 + j) * 3) * 2 + ((n >> 5) & 1)) * 512 + (frow + 32 * half) * 8;
@@ -688,9 +677,6 @@ bool x6_shape_ok(int N, int H, int W, int K, int Nout) {
 
 int run_wino_x6(const float* x, int ldx, const uint16_t* U6, const float* bias, float* out, int ldo, int N, int H, int W,
                 int K, int Nout, int relu, float* stat_part, hipStream_t st, const WinoBnBwd* bb, const float* pad, int max_workgroups) {
-    if (K < kX6RowWaveMinK)
-        return unet_run_wino_x6_small_k(x, ldx, U6, bias, out, ldo, N, H, W, K, Nout, relu, stat_part, st, bb ? bb->r : nullptr, bb ? bb->ldr : 0,
-                                        bb ? bb->c0 : 0, bb ? bb->c1 : 0, pad, max_workgroups);
     X6Args q{};
     WinoFusedArgs& a = q.f;
     q.U6 = U6;

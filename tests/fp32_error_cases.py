@@ -162,7 +162,7 @@ CASES = [
     ("wino_wgrad", (2, 16, 16, 64, 64), 1), ("wino_wgrad", (3, 8, 24, 64, 192), 2), ("wino_wgrad", (2, 32, 48, 128, 128), 3),
     ("x6_fwd", (2, 16, 16, 64, 64), 1), ("x6_fwd", (1, 20, 36, 256, 128), 2), ("x6_fwd", (5, 104, 136, 64, 64), 3),
     ("x6_dgrad", (2, 16, 16, 64, 64), 1), ("x6_dgrad", (1, 20, 36, 256, 128), 2), ("x6_dgrad", (5, 104, 136, 64, 64), 3),
-    # (round 5: reduce channels >= 256 take the point-row-per-wave kernel, fewer the round-4 tiling: both directions on both kernels)
+    # (round 5: more reduce-channel counts in both directions)
     ("x6_fwd", (2, 24, 40, 512, 64), 4), ("x6_dgrad", (2, 16, 24, 64, 256), 4), ("x6_dgrad", (1, 32, 16, 128, 512), 5),
     ("wino_fwd", (2, 24, 40, 512, 64), 4), ("wino_dgrad", (2, 16, 24, 64, 256), 4), ("wino_dgrad", (1, 32, 16, 128, 512), 5),
     ("mfma_fwd", (2, 8, 32, 64, 64), 1), ("mfma_fwd", (1, 5, 33, 64, 192), 2),

@@ -23,7 +23,7 @@ def test_fp32_kernel_error_within_4x_of_the_committed_table(hip, family, shape, 
 
 
 X6_SHAPES = [(2, 16, 16, 64, 64), (1, 20, 36, 256, 128), (5, 104, 136, 64, 64), (2, 32, 48, 128, 192), (1, 16, 16, 1024, 64),
-             (2, 16, 24, 64, 256), (1, 32, 16, 256, 512)]          # (data gradient reduces over Cout: >= 256 takes the round-5 kernel)
+             (2, 16, 24, 64, 256), (1, 32, 16, 256, 512)]
 
 
 @pytest.mark.parametrize("kind", ["normal", "raw16", "mixed", "edges"])

@@ -24,8 +24,6 @@ def unpack_u6(u, K, N):
     """U6 bytes (MFMA A-operand order: [N/64][K/16][point row 4][point 4][piece 3][channel block 2][lane: k half 2, row 32][8 k], one 1-KB
     fragment per (.., channel block), rows in the order the kernel's epilogue wants) -> float64 [K/16][point row 4][point 4][piece 3][N][16]"""
     bits = u.view(torch.int16).to(torch.int32) << 16
-    if K < 256:                  # layers with fewer than 256 reduce channels take the round-4 kernel (winograd_x6s.hip) and its layout
-        return bits.view(torch.float32).double().reshape(K // 16, 4, 4, 3, N, 16)
     t = bits.view(torch.float32).double().reshape(N // 64, K // 16, 4, 4, 3, 2, 2, 32, 8)        # [tn][c][r][j][piece][cb][lh][row][e]
     # fragment row 8 g + 4 a + i holds channel 16 a + 4 g + i of the block (an accumulator lane then owns 16 consecutive channels)
     ch = torch.arange(32, device=t.device)
@@ -65,7 +63,7 @@ def test_x6_weight_operand_is_an_exact_split_of_the_fp32_transform(hip, ci, co):
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (5, 104, 136, 64, 64), (2, 32, 48, 64, 192),
-                                   (2, 16, 16, 256, 64), (3, 40, 24, 512, 128), (5, 104, 136, 256, 64)])          # (>= 256 reduce channels: the round-5 kernel)
+                                   (2, 16, 16, 256, 64), (3, 40, 24, 512, 128), (5, 104, 136, 256, 64)])
 def test_x6_fused_bn_stats_match_bn_train_stats(hip, shape):
     # BatchNorm sums from the BF16x6 conv epilogue -> finalize == the separate statistics pass over the stored activation; the stored
     # activation itself is identical with and without the statistics
@@ -96,7 +94,7 @@ def test_x6_fused_bn_stats_match_bn_train_stats(hip, shape):
 
 @pytest.mark.parametrize("shape,crange", [((2, 16, 16, 64, 64), (0, 64)), ((1, 16, 32, 128, 64), (64, 128)), ((5, 104, 136, 64, 64), (0, 64)),
                                           ((2, 32, 32, 256, 128), (128, 256)),
-                                          ((2, 16, 16, 64, 256), (0, 64)), ((1, 16, 32, 128, 512), (64, 128)), ((3, 40, 56, 64, 256), (0, 64))])        # (reduce channels = Cout >= 256: the round-5 kernel)
+                                          ((2, 16, 16, 64, 256), (0, 64)), ((1, 16, 32, 128, 512), (64, 128)), ((3, 40, 56, 64, 256), (0, 64))])
 def test_x6_dgrad_bn_backward_sums_match_reduction(hip, shape, crange):
     # BF16x6 data gradient + (sum dy, sum dy * r) of the producer's BatchNorm from the epilogue -> bn_bwd_from_partials == the plain
     # data gradient followed by the full unet_bn_bwd, for a channel sub-range too
