@@ -37,7 +37,7 @@
 #include <cstdlib>
 
 #ifndef UNET_X6_ABLATE
-#define UNET_X6_ABLATE 0        /* diagnostic builds (scripts/build_variant.sh), bits: 8 = s_memtime stamps, 16 = no split, 32 = no MFMAs, 64 = no patch DMA, 128 = no weight loads, 512 = no row reads (results wrong) */
+#define UNET_X6_ABLATE 0        /* diagnostic builds (scripts/build_variant.sh), bits: 8 = s_memtime stamps, 16 = no split, 32 = no MFMAs, 64 = no patch DMA, 128 = no weight loads, 512 = no row reads, 1024 = no output stores (results wrong) */
 #endif
 
 namespace {
@@ -313,7 +313,7 @@ __device__ __forceinline__ void x6_finish(float (&y)[2][2][16], const WinoFusedA
             if (!ok[k]) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[k][e] = fmaxf(v[k][e] + b4[e], lo);
-            *reinterpret_cast<f32x4*>(ob_ + (unsigned)(pix[k] * p.ldo + ch)) = v[k];
+            if (!(UNET_X6_ABLATE & 1024)) *reinterpret_cast<f32x4*>(ob_ + (unsigned)(pix[k] * p.ldo + ch)) = v[k];
             if (STATS == 1) { s1 += v[k]; s2 += v[k] * v[k]; }
             if (STATS == 2) { s1 += v[k]; s2 += v[k] * rall[4 * hp + k0 + k]; }
         }
@@ -400,6 +400,10 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
     tile_sources(tc, dptr);
     ucur = u_source(tc);
 
+#ifdef UNET_X6_STAGGER
+    // workgroups start UNET_X6_STAGGER x 64 cycles apart in 8 phases: identical tiles otherwise keep every CU's end-of-tile store burst in step
+    for (int i = 0; i < (int)(blockIdx.x & 7) * UNET_X6_STAGGER; ++i) __builtin_amdgcn_s_sleep(1);
+#endif
     // ---- prologue of the workgroup's first tile: D(0), D(1) -> LDS; u(point 0); row stage of columns 1, 0, 2 of chunk 0; V(point 0)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -629,19 +633,26 @@ __global__ __launch_bounds__(256) void wino_x6_weight_batch_kernel(const long lo
 }
 
 // BatchNorm-apply on load (see winograd.hip, wino_weight_fold_kernel): U6 = pieces of scale . transform(w), bias_out = bias + sum_taps shift . w,
-// pad = -shift / scale.  A workgroup owns kX6FoldCo output channels and all input-channel groups, so the folded bias is finished inside it.
+// pad = -shift / scale.  ONE launch, two kinds of workgroup: the first `tblocks` transform 256 items each (the batch transform's item, with the
+// producer's scale on the weights: as many workgroups as the plain transform has -- round 4 ran the items inside the Cout / 8 bias
+// workgroups, 8 .. 128 of them on 256 CUs, 12-45 us per layer); the others own kX6FoldCo output channels and all input channels each and finish
+// the folded bias in a fixed order (and the padding values).
 constexpr int kX6FoldCo = 8, kX6FoldLanes = 256 / kX6FoldCo;
 __global__ __launch_bounds__(256) void wino_x6_weight_fold_kernel(const float* __restrict__ w, const float* __restrict__ scale,
         const float* __restrict__ shift, const float* __restrict__ bias, uint16_t* __restrict__ U6, float* __restrict__ bias_out,
-        float* __restrict__ pad, int Ci, int Co) {
+        float* __restrict__ pad, int Ci, int Co, int tblocks) {
+    if ((int)blockIdx.x < tblocks) {
+        const long it = (long)blockIdx.x * 256 + threadIdx.x;
+        if (it < (long)Ci * Co / 8) x6_weight_item(w, U6, Ci, Co, 0, 2 * (int)((it >> 1) / Co) + (int)(it & 1), (int)((it >> 1) % Co), scale, shift);
+        return;
+    }
     __shared__ double sPart[kX6FoldLanes][kX6FoldCo];
-    // lane order: row half (2) fastest, then output channel (8), then 16-channel group: one store instruction covers 256-byte runs
-    const int half = threadIdx.x & 1, col = (threadIdx.x >> 1) % kX6FoldCo, gl = threadIdx.x / (2 * kX6FoldCo);
-    const int co = blockIdx.x * kX6FoldCo + col;
+    const int bb = (int)blockIdx.x - tblocks;
+    const int col = threadIdx.x % kX6FoldCo, gl = threadIdx.x / kX6FoldCo;      // output channel of the workgroup, input-channel octet lane
+    const int co = bb * kX6FoldCo + col;
     const bool live = co < Co;
     double bsum = 0.0;
-    for (int c16 = gl; c16 < (Ci >> 4) && live; c16 += kX6FoldLanes / 2) {
-        const int c8 = 2 * c16 + half;
+    for (int c8 = gl; c8 < (Ci >> 3) && live; c8 += kX6FoldLanes) {
         float tsum = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -657,18 +668,17 @@ __global__ __launch_bounds__(256) void wino_x6_weight_fold_kernel(const float* _
                 pad[ci] = -sh / sc;
             }
         }
-        x6_weight_item(w, U6, Ci, Co, 0, c8, co, scale, shift);
         bsum += (double)tsum;
     }
-    sPart[2 * gl + half][col] = bsum;
+    sPart[gl][col] = bsum;
     __syncthreads();
-    if (gl == 0 && half == 0 && live) {
+    if (gl == 0 && live) {
         double sacc = 0.0;
 #pragma unroll
         for (int l = 0; l < kX6FoldLanes; ++l) sacc += sPart[l][col];
         bias_out[co] = (float)((double)(bias ? bias[co] : 0.f) + sacc);
     }
-    if (blockIdx.x == 0 && threadIdx.x < 8) pad[Ci + threadIdx.x] = 0.f;
+    if (bb == 0 && threadIdx.x < 8) pad[Ci + threadIdx.x] = 0.f;
 }
 
 bool x6_shape_ok(int N, int H, int W, int K, int Nout) {
@@ -727,7 +737,8 @@ extern "C" int unet_winograd_weight_transform_x6_batch(const void* jobs, int njo
 extern "C" int unet_winograd_weight_fold_x6(const float* w, const float* bias, const float* scale, const float* shift, void* U6, float* bias_out,
                                             float* pad, int Cin, int Cout, void* stream) {
     UNET_CHECK_ARG(w && scale && shift && U6 && bias_out && pad && Cin > 0 && Cin % 16 == 0 && Cout > 0 && Cout % 16 == 0 && unet_aligned16(U6));
-    wino_x6_weight_fold_kernel<<<(unsigned)((Cout + kX6FoldCo - 1) / kX6FoldCo), 256, 0, (hipStream_t)stream>>>(w, scale, shift, bias, (uint16_t*)U6, bias_out, pad, Cin, Cout);
+    const int tblocks = (int)(((long)Cin * Cout / 8 + 255) / 256);
+    wino_x6_weight_fold_kernel<<<(unsigned)(tblocks + (Cout + kX6FoldCo - 1) / kX6FoldCo), 256, 0, (hipStream_t)stream>>>(w, scale, shift, bias, (uint16_t*)U6, bias_out, pad, Cin, Cout, tblocks);
     return UNET_LAUNCH_STATUS();
 }
 
