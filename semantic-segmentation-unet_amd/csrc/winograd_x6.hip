@@ -60,6 +60,7 @@ constexpr int kX6Smem = kX6X + 4 * kX6XW;         // 147456 B
 constexpr int kX6UPoint = 6 * 1024;               // bytes of one point's weight fragments: [piece 3][channel block 2][lane 64][16 B]
 constexpr int kX6UChunkWave = 4 * kX6UPoint;      // one point row of a chunk
 constexpr int kX6UChunk = 4 * kX6UChunkWave;      // all four point rows
+constexpr int kX6TileB = 528;                     // bytes per tile in a wave's transposed output area [tile 32][pixel 4][32 channels] (512 + 16: conflict-free both ways)
 
 #define X6_RD128(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
 #define X6_WR128(base, off, val) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "v"(val), "n"(off) : "memory")
@@ -140,7 +141,9 @@ template <int DPR, int C, int G> __device__ __forceinline__ void x6_read_rows(f3
 // row stage of the wave's point row: d[ra] + sgn d[rb]  (r = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3; an fma by +-1 is exact)
 template <int PENDING> __device__ __forceinline__ void x6_row_stage(f32x4& t, f32x4 (&dd)[2], float sgn) {
     if constexpr (PENDING == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dd[0]), "+v"(dd[1]));
-    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(dd[0]), "+v"(dd[1]));
+    else if constexpr (PENDING == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(dd[0]), "+v"(dd[1]));
+    else if constexpr (PENDING == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(dd[0]), "+v"(dd[1]));
+    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(dd[0]), "+v"(dd[1]));
     // (scalar fmas written out: left to the compiler they become v_pk_fma_f32, which costs an MFMA-paced stream more than two plain ones)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(dd[1][e]), "v"(sgn), "v"(dd[0][e])); t[e] = r; }
@@ -152,12 +155,38 @@ template <int PENDING> __device__ __forceinline__ void x6_row_stage(f32x4& t, f3
 // vmcnt(n) = "all but the n youngest": period 0 (loaded u(1), no DMA; the barrier behind it needs every DMA piece of the wave): 0;
 // period 1 (u(2), then u(3), then 2 DMA pieces): u(2) -> 6 + 2 younger; period 2 (2 DMA pieces): u(3) -> period 1's and period 2's pieces
 // younger = 4, so the first-touch pieces of period 1 may still be in flight; period 3 (u(0'), 2 pieces): 2.
-template <int J> __device__ __forceinline__ void x6_period_wait(x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6]) {
-    if constexpr (J == 0) asm volatile("s_waitcnt vmcnt(0)" : X6_TIE6(uf[1]) :: "memory");
-    else if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(8)" : X6_TIE6(uf[0]) :: "memory");
-    else if constexpr (J == 2) asm volatile("s_waitcnt vmcnt(4)" : X6_TIE6(ue) :: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" : X6_TIE6(uf[0]) :: "memory");
+// NS = deferred output stores this period issued behind its loads and DMA pieces (x6_period), P1S = period 1 of this chunk issued one: they
+// may stay in flight -- period 0: NS (the barrier needs the wave's DMA pieces, which are older); period 1: 8 + NS; period 2: period 1's
+// store and pieces and its own = 4 + P1S + NS; period 3: 2 + NS.  A store issued in period X is older than the loads of period X + 1 (X + 2
+// for period 1's), so it has until the end of that period to leave the CU: one or two stores per wave and period are well inside the ~75
+// cycles per KB a CU's store path sustains.
+template <int J, int NS, int P1S> __device__ __forceinline__ void x6_period_wait(x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6]) {
+#define X6_VMW(N, F) asm volatile("s_waitcnt vmcnt(" #N ")" : X6_TIE6(F) :: "memory")
+    if constexpr (J == 0) { if constexpr (NS == 0) X6_VMW(0, uf[1]); else X6_VMW(1, uf[1]); }
+    else if constexpr (J == 1) { if constexpr (NS == 0) X6_VMW(8, uf[0]); else X6_VMW(9, uf[0]); }
+    else if constexpr (J == 2) {
+        if constexpr (NS + P1S == 0) X6_VMW(4, ue); else if constexpr (NS + P1S == 1) X6_VMW(5, ue); else if constexpr (NS + P1S == 2) X6_VMW(6, ue); else X6_VMW(7, ue);
+    }
+    else { if constexpr (NS == 0) X6_VMW(2, uf[0]); else X6_VMW(3, uf[0]); }
+#undef X6_VMW
 }
+
+// The output stores of a tile are DEFERRED into the first four chunks of the next one (every tile has at least four): a CU's store path takes
+// ~75 cycles per 1-KB store instruction, so the 64 stores of a tile issued back to back held the four waves for ~4,700 cycles with the
+// matrix pipe idle (profiles/r05_x6_timeline.txt); one store per wave and period (two in period 2, which loads nothing) disappears behind the
+// MFMAs: five per chunk in chunks 0..2, the sixteenth in period 0 of chunk 3 -- in front of that chunk's barrier, so that every read of the
+// transposed area is over before another wave can reach the next end-of-tile exchange, which writes there.  The finished values wait in
+// the wave's transposed area (x6_finish); state of the wave's pending tile:
+struct X6Pending {
+    float* base;             // wave-uniform: the tile block's first pixel, the output tile's first channel -- or the sink when nothing is pending
+    unsigned off;            // per lane, bytes: the lane's pixel of pass 0 and its channel quad
+    unsigned rowstep, colstep;      // wave-uniform, bytes: two image rows / four pixels (0 when nothing is pending: all 16 stores hit the lane's sink slot)
+};
+__device__ float g_x6_sink[256];
+// (s_nop 2: a store of more than 64 bits reads its data registers for a few cycles after issue; the compiler, which keeps that distance for
+// its own stores, does not see into the asm and may hand the data registers to the very next vector instruction -- seen: the first dword
+// of one pass of the BatchNorm-sum kernels overwritten by the next store's address arithmetic)
+#define X6_STORE(voff, data, sbase) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 2" :: "v"(voff), "v"(data), "s"(sbase) : "memory")
 
 // One PERIOD: the 24 MFMAs of point J of a chunk with D parity DP (operand buffers J & 1), and everything that runs in their shadow:
 //   * the data operand of the NEXT point JN = J + 1 (of the next chunk for J = 3): column stage + split of 4 groups x 5 steps (gaps n % 6 != 5);
@@ -169,10 +198,16 @@ template <int J> __device__ __forceinline__ void x6_period_wait(x6_i32x4 (&uf)[2
 //     first touch of its cache lines holds up every later vector-memory instruction of the wave until it returns).
 // At the end the wave waits for the fragments it loaded (vector-memory operations return in order: everything older has landed too,
 // in particular the wave's DMA pieces of earlier periods), and after period 0 all waves meet: D(c) is dead, D(c + 1) complete.
-template <int J, int DP, bool FIRST>
+// SI >= 0: this period also issues NS deferred stores SI, SI + 1 (passes of the previous tile's quarter): ds_read_b128 from the transposed
+// area at gaps 2, 3, global_store_dwordx4 at gap 10 (16 in period 1, behind its twelve loads and two pieces) and, for the second one, gap 16;
+// the lgkmcnt immediates below count them.  P1S: see x6_period_wait.
+template <int J, int DP, bool FIRST, int SI, int NS, int P1S>
 __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f32x4 (&dd)[2][2], x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6], x6_i32x4 (&vf)[2][6], X6Split& sp,
                                           unsigned d_a, unsigned d_b, float sgn, const char* us, unsigned voff0, unsigned voff1,
-                                          const float* (&dptr)[6], unsigned lds_w, long long (&tl)[16]) {
+                                          const float* (&dptr)[6], unsigned lds_w, const X6Pending& pend, unsigned tr_lane, long long (&tl)[16]) {
+    static_assert(NS == 0 || (NS == 1 && SI >= 0) || (NS == 2 && J == 2 && SI >= 0), "one deferred store per period, two in period 2");
+    constexpr int GS = J == 1 ? 16 : 10;                         // the gap of the (first) deferred store
+    f32x4 sv, sv2;
     constexpr int CB = J & 1, NB = CB ^ 1;
     // weight fragments: u(0), u(2) live in uf[0], u(1) in uf[1], u(3) in ue.  Period 0 loads u(1); period 1 loads u(2) AND u(3); period 2
     // loads nothing; period 3 loads the next chunk's u(0).  So no weight load is issued in the period behind the chunk's first-touch DMA
@@ -216,9 +251,25 @@ __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f
         }
         if (ND && n == (J == 1 ? 12 : 6) && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ], lds_w, DP * kX6DB + DJ * 4096);
         if (ND && n == (J == 1 ? 14 : 8) && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ + 1], lds_w, DP * kX6DB + (DJ + 1) * 4096);
+        if (NS >= 1 && n == 2) X6_RD128(sv, tr_lane, (SI < 0 ? 0 : SI) * 2 * kX6TileB);
+        if (NS == 2 && n == 3) X6_RD128(sv2, tr_lane, (SI < 0 ? 0 : SI + 1) * 2 * kX6TileB);
+        // LDS operations retire in order; per period: row pairs at gaps 0, 1, the deferred reads at 2 (, 3), row pairs at 7, 13.  Every wait
+        // names what may still be in flight BEHIND the read it needs.
+        if (NS >= 1 && n == GS) {
+            if (J == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(sv));                       // behind it: pairs 2, 3
+            else if (NS == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(sv));                 // the second deferred read, pair 2
+            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(sv));                              // pair 2
+            const unsigned so = pend.off + (unsigned)(SI >> 2) * pend.rowstep + (unsigned)(SI & 3) * pend.colstep;
+            if (!(UNET_X6_ABLATE & 1024)) X6_STORE(so, sv, pend.base);
+        }
+        if (NS == 2 && n == 16) {
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(sv2));                                  // pairs 2, 3
+            const unsigned so = pend.off + (unsigned)((SI + 1) >> 2) * pend.rowstep + (unsigned)((SI + 1) & 3) * pend.colstep;
+            if (!(UNET_X6_ABLATE & 1024)) X6_STORE(so, sv2, pend.base);
+        }
         if (n % 6 == 5) {
-            if (n == 5) x6_row_stage<2>(T[PC][0], dd[0], sgn);            // (LDS reads retire in order: 2 = the other pair may still be in flight)
-            if (n == 11) x6_row_stage<2>(T[PC][1], dd[1], sgn);
+            if (n == 5) x6_row_stage<2 + NS>(T[PC][0], dd[0], sgn);                            // behind pair 0: pair 1 and the deferred reads
+            if (n == 11) x6_row_stage<((NS >= 1 && J == 1) ? 3 : NS == 2 ? 3 : 2)>(T[PC][1], dd[1], sgn);     // behind pair 1: pair 2 (+ a deferred read not yet waited for)
             if (n == 17) x6_row_stage<2>(T[PC][2], dd[0], sgn);
             if (n == 23) x6_row_stage<0>(T[PC][3], dd[1], sgn);
             if (ND && n == 17) { dptr[DJ] += 16; dptr[DJ + 1] += 16; X6_PIN("+v"(dptr[DJ]), "+v"(dptr[DJ + 1])); }     // the two pointers move on by one chunk
@@ -233,12 +284,12 @@ __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f
     }
 #if (UNET_X6_ABLATE & 8)
     X6_STAMP(q1);
-    x6_period_wait<J>(uf, ue);
+    x6_period_wait<J, NS, P1S>(uf, ue);
     X6_STAMP(q2);
     tl[2 * J] += q1 - q0; tl[2 * J + 1] += q2 - q1;
     if (J == 0) { asm volatile("s_barrier" ::: "memory"); long long q3; X6_STAMP(q3); tl[8] += q3 - q2; tl[9] += 1; }
 #else
-    x6_period_wait<J>(uf, ue);
+    x6_period_wait<J, NS, P1S>(uf, ue);
     if (J == 0) asm volatile("s_barrier" ::: "memory");
 #endif
     asm volatile("" : X6_TIE6(vf[NB]));
@@ -256,33 +307,39 @@ struct X6Args {
 // lane = (pixel L / 8, channel quad L % 8): a store instruction then covers 8 pixels x 128 contiguous bytes, the lane's channel quad is
 // the same in all 16 passes (bias: 4 values; BatchNorm sums: 2 x 4 registers instead of 2 x 16), and the STATS 2 reads of the producer's
 // activation are coalesced the same way.  STATS 1: sum, sum of squares of the stored values; STATS 2: sum dy, sum dy r.
-constexpr int kX6TileB = 528;
+// -> the pending-store state of this tile (x6_period issues the stores); a tile block that sticks out of the image is stored here instead
+// (per-lane masks) and leaves nothing pending.  bias16: the lane's 16 channels of the accumulator layout.
 template <int STATS>
-__device__ __forceinline__ void x6_finish(float (&y)[2][2][16], const WinoFusedArgs& p, int img, int by, int bx, int n0, int tb, int cb, int lane_in,
-                                          unsigned t_area, f32x4 b4, f32x4& s1, f32x4& s2) {
+__device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoFusedArgs& p, int img, int by, int bx, int n0, int tb, int cb, int lane_in,
+                                               unsigned t_area, const f32x4 (&bias16)[4], f32x4& s1, f32x4& s2) {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));                                // (everything per-lane below is re-derived here: kept live across the chunk loop it is spilled)
     const int li = lane & 31, lh = lane >> 5;
     const unsigned tw = t_area + (unsigned)(li * kX6TileB + lh * 64);
+    const float lo = p.relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                X6_WR128(tw, (2 * a + b) * 128 + g * 16, (f32x4{y[a][b][4 * g], y[a][b][4 * g + 1], y[a][b][4 * g + 2], y[a][b][4 * g + 3]}));
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(y[a][b][4 * g + e] + bias16[g][e], lo);
+                X6_WR128(tw, (2 * a + b) * 128 + g * 16, v);
+            }
     const int cq = lane & 7, pl = lane >> 3;                     // reader: channel quad, pixel of a pass (tile pl >> 2 of the pass, pixel pl & 3)
     const unsigned tr = t_area + (unsigned)((pl >> 2) * kX6TileB + (pl & 3) * 128 + cq * 16);
-    const float lo = p.relu ? 0.f : -__builtin_inff();
     const bool rok = STATS == 2 && n0 >= p.bn_c0 && n0 < p.bn_c1;
     const int oa = (pl >> 1) & 1, ob = pl & 1;
-    // addresses: a wave-uniform 64-bit base (the tile block's first pixel, the quarter's first channel) + a 32-bit lane offset in elements
-    // (16 rows x W x ld of the tensor: far below 2^31 for every shape the entry points admit)
+    // addresses: a wave-uniform 64-bit base (the tile block's first pixel, the output tile's first channel) + a 32-bit lane offset
+    // (16 rows x W x ld of the tensor: far below 2^31 elements for every shape the entry points admit)
     const int ch = 32 * cb + 4 * cq;
     const int gy = 16 * by + 8 * tb + oa, gx = 16 * bx + 2 * (pl >> 2) + ob;       // the lane's pixel in pass (hp = 0, k = 0)
     float* const ob_ = p.out + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.ldo + n0;
     const float* const rb_ = STATS == 2 ? p.bn_r + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.bn_ldr + (n0 - p.bn_c0) : nullptr;
     const int pix0 = (8 * tb + oa) * p.W + 2 * (pl >> 2) + ob;                     // pixel offset of that pixel from the block's first pixel
+    const bool edge = 16 * by + 16 > p.H || 16 * bx + 16 > p.W;                    // wave-uniform
     // STATS 2: the producer's saved activation at the lane's 16 pixels, ALL loaded here (y is dead behind the LDS writes: the registers are
     // there) -- loaded pass by pass, every pass paid a global-memory round trip
     f32x4 rall[16];
@@ -294,30 +351,29 @@ __device__ __forceinline__ void x6_finish(float (&y)[2][2][16], const WinoFusedA
             if (rok && okq) rall[q] = *reinterpret_cast<const f32x4*>(rb_ + (unsigned)((pix0 + 2 * (q >> 2) * p.W + 4 * (q & 3)) * p.bn_ldr + ch));
         }
     }
+    if (STATS != 0 || edge) {
 #pragma unroll
-    for (int h2 = 0; h2 < 8; ++h2) {                             // two passes at a time: half of tile row h2 / 2 of the block
-        const int hp = h2 >> 1, k0 = 2 * (h2 & 1);
-        f32x4 v[2];
+        for (int h2 = 0; h2 < 8; ++h2) {                         // two passes at a time: half of tile row h2 / 2 of the block
+            const int hp = h2 >> 1, k0 = 2 * (h2 & 1);
+            f32x4 v[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) X6_RD128(v[k], tr, (4 * hp + k0 + k) * 2 * kX6TileB);
-        bool ok[2];
-        int pix[2];
+            for (int k = 0; k < 2; ++k) X6_RD128(v[k], tr, (4 * hp + k0 + k) * 2 * kX6TileB);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            ok[k] = gy + 2 * hp < p.H && gx + 4 * (k0 + k) < p.W;
-            pix[k] = pix0 + 2 * hp * p.W + 4 * (k0 + k);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (!ok[k]) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[k][e] = fmaxf(v[k][e] + b4[e], lo);
-            if (!(UNET_X6_ABLATE & 1024)) *reinterpret_cast<f32x4*>(ob_ + (unsigned)(pix[k] * p.ldo + ch)) = v[k];
-            if (STATS == 1) { s1 += v[k]; s2 += v[k] * v[k]; }
-            if (STATS == 2) { s1 += v[k]; s2 += v[k] * rall[4 * hp + k0 + k]; }
+            for (int k = 0; k < 2; ++k) {
+                if (!(gy + 2 * hp < p.H && gx + 4 * (k0 + k) < p.W)) continue;
+                if (edge && !(UNET_X6_ABLATE & 1024)) *reinterpret_cast<f32x4*>(ob_ + (unsigned)((pix0 + 2 * hp * p.W + 4 * (k0 + k)) * p.ldo + ch)) = v[k];
+                if (STATS == 1) { s1 += v[k]; s2 += v[k] * v[k]; }
+                if (STATS == 2) { s1 += v[k]; s2 += v[k] * rall[4 * hp + k0 + k]; }
+            }
         }
     }
+    X6Pending pd;
+    pd.base = edge ? g_x6_sink : ob_;
+    pd.off = edge ? (unsigned)lane * 16u : (unsigned)(pix0 * p.ldo + ch) * 4u;
+    pd.rowstep = edge ? 0u : (unsigned)(2 * p.W * p.ldo) * 4u;
+    pd.colstep = edge ? 0u : (unsigned)(4 * p.ldo) * 4u;
+    return pd;
 }
 // Per-lane running sums -> one row of partials per wave (the layout of wf_write_stats: stat_part[tn][row][64 channels][2],
 // row = 2 * (first tile / nt) + tile block): the lanes with one channel quad (lane % 8) are reduced, lanes 0..7 write.
@@ -396,6 +452,10 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
     if ((gridDim.x & 7) == 0 && (p.nt & 7) != 0) t = (t & 7) * (int)(gridDim.x >> 3) + (t >> 3);       // XCD-aware renumbering, as winograd.hip
     const int t_first = t;
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    X6Pending pend;                                                // nothing pending yet: the sixteen store slots of the first tile write the lane's sink slot
+    pend.base = g_x6_sink; pend.off = (unsigned)lane * 16u; pend.rowstep = 0u; pend.colstep = 0u;
+    const unsigned t_area = lds0 + kX6X + (unsigned)(wv * kX6XW);
+    const unsigned tr_lane = t_area + (unsigned)(((lane >> 3) >> 2) * kX6TileB + ((lane >> 3) & 3) * 128 + (lane & 7) * 16);
     TileCoord tc = decode(t);
     tile_sources(tc, dptr);
     ucur = u_source(tc);
@@ -433,17 +493,27 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         unxt = u_source(tcn);
         // weight fragments of point J + 1 (period J of chunk c): this chunk's next point, the next chunk's point 0, or the next tile's
 #define X6_US(c, J) ((J) < 3 ? ucur + (size_t)(c) * kX6UChunk + ((J) + 1) * kX6UPoint : ((c) + 1 < nchunks ? ucur + (size_t)((c) + 1) * kX6UChunk : unxt))
-#define X6_PERIOD(J, DP, FIRST, c) x6_period<J, DP, FIRST>(acc, T, dd, uf, ue, vf, sp, d_a, d_b, sgn, X6_US(c, J), voff0, voff1, dptr, lds_w, tl)
+#define X6_PERIOD(J, DP, FIRST, c, SI, NS, P1S) x6_period<J, DP, FIRST, SI, NS, P1S>(acc, T, dd, uf, ue, vf, sp, d_a, d_b, sgn, X6_US(c, J), voff0, voff1, dptr, lds_w, pend, tr_lane, tl)
         // (the patch pieces issued from chunk nchunks - 2 on belong to the next tile: its pointers are formed in the one period without DMA)
-#define X6_CHUNK(DP, FIRST, c) \
-        if ((c) == nchunks - 2) tile_sources(tcn, dptr); \
-        X6_PERIOD(0, DP, FIRST, c); X6_PERIOD(1, DP, FIRST, c); X6_PERIOD(2, DP, FIRST, c); X6_PERIOD(3, DP, FIRST, c);
-        X6_CHUNK(0, true, 0)
-        X6_CHUNK(1, false, 1)
-        for (int c = 2; c < nchunks; c += 2) {
-            X6_CHUNK(0, false, c)
-            X6_CHUNK(1, false, c + 1)
+        // X6_CHUNK_S: the chunk issues the previous tile's deferred stores S0 .. S0 + 4 (periods 0, 1, 2 twice, 3); X6_CHUNK_L: only store 15, in period 0
+#define X6_SWITCH(c) if ((c) == nchunks - 2) tile_sources(tcn, dptr);
+#define X6_CHUNK_S(DP, FIRST, c, S0) X6_SWITCH(c) \
+        X6_PERIOD(0, DP, FIRST, c, S0, 1, 1); X6_PERIOD(1, DP, FIRST, c, S0 + 1, 1, 1); X6_PERIOD(2, DP, FIRST, c, S0 + 2, 2, 1); X6_PERIOD(3, DP, FIRST, c, S0 + 4, 1, 1);
+#define X6_CHUNK_L(DP, c) X6_SWITCH(c) \
+        X6_PERIOD(0, DP, false, c, 15, 1, 0); X6_PERIOD(1, DP, false, c, -1, 0, 0); X6_PERIOD(2, DP, false, c, -1, 0, 0); X6_PERIOD(3, DP, false, c, -1, 0, 0);
+#define X6_CHUNK(DP, c) X6_SWITCH(c) \
+        X6_PERIOD(0, DP, false, c, -1, 0, 0); X6_PERIOD(1, DP, false, c, -1, 0, 0); X6_PERIOD(2, DP, false, c, -1, 0, 0); X6_PERIOD(3, DP, false, c, -1, 0, 0);
+        X6_CHUNK_S(0, true, 0, 0)
+        X6_CHUNK_S(1, false, 1, 5)
+        X6_CHUNK_S(0, false, 2, 10)
+        X6_CHUNK_L(1, 3)
+        for (int c = 4; c < nchunks; c += 2) {
+            X6_CHUNK(0, c)
+            X6_CHUNK(1, c + 1)
         }
+#undef X6_CHUNK_S
+#undef X6_CHUNK_L
+#undef X6_SWITCH
 #undef X6_CHUNK
 #undef X6_PERIOD
 #undef X6_US
@@ -452,8 +522,12 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         long long e1; X6_STAMP(e1);
 #endif
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMAs are invisible to the compiler's hazard recogniser
-        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};                    // the bias of the lane's channel quad in the finish (latency behind the column stage)
-        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + tc.tn * 64 + 32 * (wv >> 1) + 4 * (lane & 7));
+        f32x4 bias16[4];                                         // the bias of the lane's 16 channels (accumulator layout); its latency passes behind the column stage
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bias16[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bias16[g] = *reinterpret_cast<const f32x4*>(p.bias + tc.tn * 64 + 32 * (wv >> 1) + 16 * lh + 4 * g);
+        }
         float zown[2][16];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {                        // quarter (channel block qd >> 1, tile block qd & 1), owner = wave qd
@@ -523,7 +597,7 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
 #if (UNET_X6_ABLATE & 8)
         X6_STAMP(e5);
 #endif
-        x6_finish<STATS>(y, p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane, lds0 + kX6X + (unsigned)(wv * kX6XW), b4, s1, s2);
+        pend = x6_finish<STATS>(y, p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane, t_area, bias16, s1, s2);
         ucur = unxt; tc = tcn;
 #if (UNET_X6_ABLATE & 8)
         { long long e2; X6_STAMP(e2); tl[10] += e1 - e0; tl[11] += e2 - e1; tl[12] += 1; tl[13] += e3 - e1; tl[14] += e4 - e3; tl[15] += e5 - e4; }
@@ -532,8 +606,16 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
 #if (UNET_X6_ABLATE & 8)
     if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 16; ++i) g_x6_timeline[i] = tl[i];
 #endif
-    // retire the prefetches of the tile that never runs (weight fragments, DMA pieces) before the wave ends
+    // retire the prefetches of the tile that never runs (weight fragments, DMA pieces), then the last tile's deferred stores
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : X6_TIE6(uf[0]) :: "memory");
+#pragma unroll
+    for (int si = 0; si < 16; ++si) {
+        f32x4 sv;
+        X6_RD128(sv, tr_lane, si * 2 * kX6TileB);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sv));
+        const unsigned so = pend.off + (unsigned)(si >> 2) * pend.rowstep + (unsigned)(si & 3) * pend.colstep;
+        if (!(UNET_X6_ABLATE & 1024)) X6_STORE(so, sv, pend.base);
+    }
     if (STATS) x6_write_stats(p, t_first, 2 * ((int)gridDim.x / p.nt), wv & 1, wv >> 1, lane, s1, s2);
 }
 __global__ __launch_bounds__(256, 1) void wino_x6_stream_kernel(X6Args q, int ntiles) { x6_stream_body<0>(q, ntiles); }
