@@ -46,7 +46,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything i
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, chip table (dense, spec)
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table: ~2.5 PF dense bf16 (spec)
-TRAFFIC_TAG = "r04"                  # profiles/<tag>_*_pmc_traffic.json of the current round
+TRAFFIC_TAG = "r05"                  # profiles/<tag>_*_pmc_traffic.json of the current round
 WINOGRAD_MULT_RATIO = 2.25           # F(2x2,3x3): 36 direct multiplies per tile and channel pair -> 16
 
 X6_PRODUCTS = 6                      # BF16x6: six bf16 piece products per fp32-grade product (hh hm mh hl lh mm)
@@ -55,7 +55,7 @@ ARITHMETIC = {"bf16x6": "fp32 operands as 3 bf16 pieces, 6 products, fp32 accumu
               "native": "fp32 (v_mfma_f32_32x32x2_f32 for every contraction)"}
 
 FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16 matrix pipe?, offline PMC traffic file)
-    "conv3x3_fwd_winograd_x6": ("wino_x6_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3), fp32-grade products as 6 x v_mfma_f32_32x32x16_bf16 on three-piece operands)", True, True, "x6_fwd_pmc_traffic.json"),
+    "conv3x3_fwd_winograd_x6": ("wino_x6_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3), fp32-grade products as 6 x v_mfma_f32_32x32x16_bf16 on three-piece operands; one point row per wave, both operands from registers)", True, True, "x6_fwd_pmc_traffic.json"),
     "conv3x3_dgrad_winograd_x6": ("wino_x6_stream_kernel / _bnbwd (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3), fp32-grade products as 6 x v_mfma_f32_32x32x16_bf16)", True, True, "x6_dgrad_pmc_traffic.json"),
     "conv3x3_fwd_winograd_fused": ("wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "wino_fwd_pmc_traffic.json"),
     "conv3x3_dgrad_winograd_fused": ("wino_fused_stream_kernel / _bnstats (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "wino_dgrad_pmc_traffic.json"),

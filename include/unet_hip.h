@@ -28,8 +28,10 @@ extern "C" {
 #define UNET_ENOSPC (-2)
 
 /* Bumped whenever an exported signature changes; a loader must refuse a library whose unet_hip_abi_version() differs
- * (6: round 4 -- unet_convT2x2_*_x6; 5: round 4 -- the `_wg` (max_workgroups) entry points of every persistent kernel, unet_standin_collective; 4: round 4 -- the BF16x6 Winograd route: unet_*_x6; 3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
-#define UNET_HIP_ABI_VERSION 6
+ * (7: round 5 -- no signature changed, but the operand unet_winograd_weight_transform_x6 / _fold_x6 write is laid out for the round-5 kernel
+ *  (MFMA A-operand order per 64-channel tile, chunk and point row): an operand and the conv entry point that reads it must come from one library;
+ *  6: round 4 -- unet_convT2x2_*_x6; 5: round 4 -- the `_wg` (max_workgroups) entry points of every persistent kernel, unet_standin_collective; 4: round 4 -- the BF16x6 Winograd route: unet_*_x6; 3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
+#define UNET_HIP_ABI_VERSION 7
 int unet_hip_abi_version(void);
 
 /* ---- Conv2D(3x3, 'same', relu) of UNet._conv_layer, UNet/model.py:28-35 (18 instances, :88-134) ------------------ */
@@ -91,7 +93,7 @@ int unet_conv3x3_wgrad_fold_fix(float* dw, const float* scale, const float* shif
  * and accumulate in fp32 (v_mfma_f32_32x32x16_bf16); the three dropped products sum to at most 2^-21, on average 2^-24.5 of the product, i.e. one fp32 multiply's
  * rounding, so the error against an fp64 evaluation equals that of the fp32 matrix instruction (tests/test_gpu_x6.py asserts <= 1.25 x).
  * The transforms stay fp32.  Shapes: H, W even, reduce channels % 32 == 0 and >= 64, output channels % 64 == 0 (unet_winograd_x6_supported).
- * Weight operands (16 * 3 * Cin * Cout bf16 = unet_winograd_x6_weight_bytes): _x6(w, mode 0 forward / 1 data gradient), every layer and
+ * Weight operands (16 * 3 * Cin * Cout bf16 = unet_winograd_x6_weight_bytes; opaque: made and read by the same library): _x6(w, mode 0 forward / 1 data gradient), every layer and
  * direction in one launch with _x6_batch (jobs: njobs x 6 int64 = { w, U6, Cin | Cout << 32, first_block, mode, 0 }, first_block = running
  * sum of ceil(Cin * Cout / 2048)), or _fold_x6 = unet_winograd_weight_fold for this route.  The two conv entry points take the arguments of
  * unet_conv3x3_fwd_winograd_fused / unet_conv3x3_dgrad_winograd_fused with U6 in place of Uc; stat_part rows are the same function. */
