@@ -837,3 +837,25 @@ def test_inference_fold_cache_follows_the_parameters():
     assert not torch.equal(p1, p0)
     e.load_parameters(prm)
     assert len(e._eval_folded) == 0 and torch.equal(e.forward(x), p0)
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, 2, 128), (1, 1, 2, (48, 80))])
+def test_the_two_fp32_routes_agree_on_inference_tiles(cfg):
+    # An inference run may evaluate interior tiles on the BF16x6 transposed-conv GEMMs (pixel counts that are multiples of 128) and edge
+    # tiles on the native kernels (any other shape), and a user may switch routes between runs: the two fp32-grade evaluations of the same
+    # tile must agree to the forward tolerance each is held to against the oracle, and give the same mask wherever the decision is not
+    # inside that tolerance.  (2 x 128 x 128: all four transposed convs on BF16x6; 48 x 80: none of them, odd bottleneck tile.)
+    n, c, k, hw = cfg
+    img, lab, prm, masks = make_case(29, n, c, k, hw)
+    out = {}
+    for route in ROUTES:
+        net = make_net(route, k, n, c)
+        net.engine.load_parameters(prm)
+        out[route], counts = recorded(net.engine, lambda: net.get_keras_model()(img))
+        assert_route_taken(counts, route, hw, training=False)
+        if cfg == (2, 1, 2, 128):
+            assert (counts.get("convt_fwd_x6") == 4) == (route == "bf16x6"), counts
+    a, b = out["bf16x6"], out["native"]
+    assert np.abs(a - b).max() < 4e-5                       # each is within 2e-5 of the fp64 oracle
+    ok, undecided, differ = argmax_agreement(a, b)
+    assert ok and differ <= undecided, (undecided, differ)
