@@ -609,6 +609,8 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
         // ONE piece per MFMA group: a global_load_lds costs the issuing wave ~15 cycles behind an MFMA but ~64 directly behind another one (3.1);
         // three per group (patch + two weight pieces in groups 0..4) made the patch pieces 3.5 x as expensive as the weight pieces per instruction
         static_assert(KW + KX <= 18, "one DMA instruction per MFMA group");
+        // (round 5, A/B: the patch pieces -- the first touch of their cache lines, ~1900 cycles from HBM -- in the chunk's FIRST groups instead
+        // of its last: forward -1 .. -3 % on most layers, bott_b's data gradient +4 %: within noise of zero over the step, not kept)
         if (g < KW) { if (!(UNET_CBS_ABLATE & 16)) issue_w1(s, chunk, stage, g); }
         else if (g - KW < KX) { if (!(UNET_CBS_ABLATE & 8)) issue_x1(s, chunk, stage, g - KW); }
     };
