@@ -9,6 +9,7 @@
 // saved matrix work to dominate.  dgrad is the same pipeline on dz with the 180-degree rotated, in/out-swapped kernel.
 //
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+#include <utility>
 #include "common.h"
 #include "wino_epilogue.h"
 #include <cstdlib>
@@ -542,13 +543,18 @@ __global__ __launch_bounds__(256, 1) void wino_fused_stream_bnbwd_kernel(WinoFus
 // and every lane transforms ITS OWN 4 tiles in registers (lane = channel, lane half = tile quad): no transformed LDS
 // images, no transform waves, one barrier per chunk.  Tile s of the chunk feeds 16 independent MFMAs (one per point).
 // Epilogue: G^T dU G is lane-local; split partials go to the workspace [split][9][Ci][Co] and are reduced in fixed order.
+template <int... I, class F> __device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(step) for step = 0 .. N-1 with decltype(step)::value a compile-time constant (an unrolled loop whose index can pick registers,
+// immediates and `if constexpr` branches without depending on the unroller)
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_seq(std::make_integer_sequence<int, N>{}, f); }
 struct WinoWgradArgs {
     const float* x; const float* dz; float* ws;
     int ldx, lddz, N, H, W, Ci, Co;
     int mt, nt, splits, tbx, nchunks;
 };
 typedef __attribute__((address_space(3))) void lds_void_g;
-__device__ __attribute__((aligned(256))) float g_zero_page_g[64];
 
 __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs p) {
     constexpr int XP = 4 * 18, ZP = 2 * 16;                 // raw pixels per chunk
@@ -581,73 +587,97 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
 
     // DMA geometry, chunk-invariant: piece 4k+wv of wave wv; pieces 0..17 are x rows (pixels (-1,-1)..(2,16) relative to
     // the chunk's first output pixel), 18..25 dz rows, 26..27 dummies that re-read an always-valid x pixel into an unused LDS
-    // piece (so every wave issues exactly KPW DMAs per chunk).  Per lane and piece only a byte offset from a per-chunk
-    // scalar base and a 4-bit border code (top / bottom / left / right pixel of the halo) are kept; the per-chunk part is
-    // scalar arithmetic.  Address generation is ~4 VALU instructions per piece: with one wave per SIMD every VALU
-    // instruction is matrix-pipe time.
+    // piece (so every wave issues exactly KPW DMAs per chunk).  The loads are buffer loads (`buffer_load_dwordx4 ... offen lds`):
+    // the chunk's base address is SCALAR (two descriptors per chunk, x and dz), a lane keeps one 32-bit byte offset per piece,
+    // and a halo pixel outside the image is given an offset the descriptor's range check rejects -- the hardware then writes
+    // zeros into LDS (checked on gfx950), so no zero page, no 64-bit per-lane address and no select between two pointers.
+    // Per lane and piece that leaves a 4-bit border code (top / bottom / left / right pixel of the halo) and three VALU
+    // instructions per chunk; with one wave per SIMD every VALU instruction is matrix-pipe time (round 5: 45 -> 22 here).
     const int dq = lane & 15, dp = lane >> 4;
     const int wlast = p.W - 16 * (p.tbx - 1);      // image columns covered by the last chunk of a tile row (16 unless W is ragged)
     unsigned g_off[KPW];                 // byte offset from the chunk base (x: pixel (-1,-1); dz: pixel (0,0))
-    unsigned g_codes = 0;                // 4 bits per piece: pixel lies in the top row / bottom row / left column / beyond the last image column (1, 2, 4, 8)
-                                         // of a chunk at the corresponding image border
-    bool g_isx[KPW];                     // wave-uniform
+    unsigned g_codes = 0;                // 4 bits per piece, from bit 4k+1: pixel lies in the top row / bottom row / left column / beyond the last image
+                                         // column (2, 4, 8, 16) of a chunk at the corresponding image border.  (From bit 1, not 0: the scalar
+                                         // side's `cond ? 1 : 0` is turned into a vector-ALU zero-extension by the compiler, `cond ? 2 : 0` is not.)
 #pragma unroll
     for (int k = 0; k < KPW; ++k) {
         const int piece = 4 * k + wv;
-        g_isx[k] = piece < XPIECES || piece >= XPIECES + ZPIECES;
         if (piece < XPIECES) {
             const int px = 4 * piece + dp, row = px / 18, col = px % 18;          // halo coordinates 0..3 x 0..17
             g_off[k] = (unsigned)(((row * p.W + col) * p.ldx + 4 * dq) * 4);
-            g_codes |= (unsigned)((row == 0) | ((row == 3) << 1) | ((col == 0) << 2) | ((col > wlast) << 3)) << (4 * k);
+            g_codes |= (unsigned)((row == 0) | ((row == 3) << 1) | ((col == 0) << 2) | ((col > wlast) << 3)) << (4 * k + 1);
         } else if (piece < XPIECES + ZPIECES) {
             const int px = 4 * (piece - XPIECES) + dp;
             g_off[k] = (unsigned)((((px >> 4) * p.W + (px & 15)) * p.lddz + 4 * dq) * 4);
-            g_codes |= (unsigned)(((px & 15) >= wlast) << 3) << (4 * k);
+            g_codes |= (unsigned)(((px & 15) >= wlast) << 3) << (4 * k + 1);
         } else {
             g_off[k] = (unsigned)(((p.W + 1) * p.ldx + 4 * dq) * 4);              // halo pixel (1,1): never out of bounds
         }
     }
-    const float* zpage = g_zero_page_g + 4 * dq;
-    // chunk coordinates of the next batch to issue, advanced by `splits` chunks at a time without divisions
-    int ic = split, i_txb, i_ty, i_img;
-    { int t = ic; i_txb = t % p.tbx; t /= p.tbx; i_ty = t % Th; i_img = t / Th; }
-    const int d_txb = p.splits % p.tbx, d_ty = (p.splits / p.tbx) % Th, d_img = p.splits / (p.tbx * Th);
-    const float* dsrc[KPW];              // this lane's sources for the next batch
-    auto next_sources = [&]() {
-        const bool cv = ic < p.nchunks;                                           // past the end: re-read chunk 0, never used
-        const int txb = cv ? i_txb : 0, ty = cv ? i_ty : 0, img = cv ? i_img : 0;
-#if UNET_ABLATE == 5        /* diagnostics only: every DMA reads the same few KB (always an L2 hit) */
-        const long long pixz = 0;
-#else
-        const long long pixz = (long long)(img * p.H + 2 * ty) * p.W + 16 * txb;
-#endif
-        const char* bx = reinterpret_cast<const char*>(p.x + m0) + (pixz - p.W - 1) * p.ldx * 4;
-        const char* bz = reinterpret_cast<const char*>(p.dz + n0) + pixz * p.lddz * 4;
-        const unsigned scode = (unsigned)((ty == 0) | ((ty == Th - 1) << 1) | ((txb == 0) << 2) | ((txb == p.tbx - 1) << 3));
-        const unsigned hit = g_codes & (scode * 0x01111111u);
-#pragma unroll
-        for (int k = 0; k < KPW; ++k) {
-            const char* src = (g_isx[k] ? bx : bz) + g_off[k];
-            src = (hit & (0xFu << (4 * k))) ? reinterpret_cast<const char*>(zpage) : src;
-            dsrc[k] = reinterpret_cast<const float*>(src);
-        }
-        asm volatile("" : "+v"(dsrc[0]), "+v"(dsrc[1]), "+v"(dsrc[2]), "+v"(dsrc[3]), "+v"(dsrc[4]), "+v"(dsrc[5]), "+v"(dsrc[6]));
+    // Chunk bases, all scalar.  A workgroup takes chunks split, split + splits, ...; the chunk's first output pixel is
+    //     pix = (img H + 2 ty) W + 16 txb,
+    // and going `splits` chunks on adds a constant number of pixels plus (2 W - 16 tbx) each time the column-block digit wraps
+    // (the wrap of the tile-row digit into the image digit adds H W - 2 Th W = 0): one running pixel index, two 32 x 32 -> 64
+    // bit multiplications per chunk for the byte offsets, no division.  Past the last chunk the bases fall back to chunk 0 with every border
+    // code raised: only pixels certainly inside image 0 are read, and the data is never used.
+    const int d_txb = p.splits % p.tbx, d_ty = (p.splits / p.tbx) % Th;
+    const unsigned xpix = (unsigned)p.ldx * 4u, zpix = (unsigned)p.lddz * 4u;      // bytes per pixel
+    const int dpix0 = ((p.splits / (p.tbx * Th)) * p.H + 2 * d_ty) * p.W + 16 * d_txb;
+    const int dpix1 = 2 * p.W - 16 * p.tbx;
+    const char* const x0 = reinterpret_cast<const char*>(p.x + m0) - (long long)(p.W + 1) * xpix;   // chunk 0's halo pixel (-1,-1)
+    const char* const z0 = reinterpret_cast<const char*>(p.dz + n0);
+    // (the initial digits come out of integer divisions, which the compiler expands on the vector ALU: readfirstlane keeps the
+    // loop-carried state in scalar registers)
+    int ic = split, i_txb, i_ty, pix;
+    {
+        int t = ic; i_txb = __builtin_amdgcn_readfirstlane(t % p.tbx); t /= p.tbx; i_ty = __builtin_amdgcn_readfirstlane(t % Th);
+        const int img = __builtin_amdgcn_readfirstlane(t / Th);
+        pix = (img * p.H + 2 * i_ty) * p.W + 16 * i_txb;          // < N H W, which the host keeps below 2^31
+    }
+    constexpr unsigned kRecords = 0x40000000u, kRejected = 0x80000000u;   // every real offset is far below 1 GB (host-checked)
+    // what the vector part of the NEXT batch needs: the bases of its x and dz rows, the two mixed pieces' bases, its border mask
+    const char *b_x, *b_z, *b_4, *b_6;
+    unsigned b_mask;
+    auto next_scalars = [&]() {
+        const bool cv = ic < p.nchunks;
+        const unsigned scode = (i_ty == 0 ? 2u : 0u) | (i_ty == Th - 1 ? 4u : 0u) | (i_txb == 0 ? 8u : 0u) | (i_txb == p.tbx - 1 ? 16u : 0u);
+        b_mask = (cv ? scode : 0x1Eu) * 0x01111111u;
+        const unsigned cp = cv ? (unsigned)pix : 0u;
+        b_x = x0 + (unsigned long long)cp * xpix;
+        b_z = z0 + (unsigned long long)cp * zpix;
+        b_4 = wv < 2 ? b_x : b_z;                     // pieces 16, 17 are x rows, 18, 19 dz rows
+        b_6 = wv < 2 ? b_z : b_x;                     // pieces 24, 25 are dz rows, 26, 27 the dummies
         ic += p.splits;
-        i_txb += d_txb; const int c1 = i_txb >= p.tbx; i_txb -= c1 ? p.tbx : 0;
-        i_ty += d_ty + c1; const int c2 = i_ty >= Th; i_ty -= c2 ? Th : 0;
-        i_img += d_img + c2;
+        i_txb += d_txb; const bool c1 = i_txb >= p.tbx; i_txb -= c1 ? p.tbx : 0;
+        i_ty += d_ty + (c1 ? 1 : 0); i_ty -= i_ty >= Th ? Th : 0;
+        pix += dpix0 + (c1 ? dpix1 : 0);
+    };
+    unsigned voff[KPW];                  // this lane's offsets for the next batch
+    __amdgpu_buffer_rsrc_t r_x, r_z, r_4, r_6;
+    auto next_offsets = [&]() {
+        unsigned hit;                                 // (asm: takes the mask as a scalar operand where it is; the compiler's own `and` first copies it to a vector register in the MFMA block)
+        asm("v_and_b32 %0, %1, %2" : "=v"(hit) : "s"(b_mask), "v"(g_codes));
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) voff[k] = (hit & (0xFu << (4 * k + 1))) ? kRejected : g_off[k];
+        asm volatile("" : "+v"(voff[0]), "+v"(voff[1]), "+v"(voff[2]), "+v"(voff[3]), "+v"(voff[4]), "+v"(voff[5]), "+v"(voff[6]));
+        r_x = __builtin_amdgcn_make_buffer_rsrc((void*)b_x, 0, kRecords, 0x00020000);
+        r_z = __builtin_amdgcn_make_buffer_rsrc((void*)b_z, 0, kRecords, 0x00020000);
+        r_4 = __builtin_amdgcn_make_buffer_rsrc((void*)b_4, 0, kRecords, 0x00020000);
+        r_6 = __builtin_amdgcn_make_buffer_rsrc((void*)b_6, 0, kRecords, 0x00020000);
     };
     auto dma = [&](int k, float* dst) {
-        __builtin_amdgcn_global_load_lds(dsrc[k], (lds_void_g*)(dst + (4 * k + wv) * 256), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k < 4 ? r_x : k == 4 ? r_4 : k == 5 ? r_z : r_6,
+                                                 (lds_void_g*)(dst + (4 * k + wv) * 256), 16, voff[k], 0, 0, 0);
     };
 
     int c = split;
 #pragma unroll
     for (int k = 0; k < LEAD; ++k) {
-        next_sources();
+        next_scalars(); next_offsets();
 #pragma unroll
         for (int j = 0; j < KPW; ++j) dma(j, smem + k * BUF);
     }
+    next_scalars();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int xa = (8 * lh) * 64 + 32 * mi + li;                    // + (row*18 + cc)*64
@@ -725,7 +755,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
                 }
             }
         }
-        next_sources();                               // 7 DMA sources for the chunk LEAD ahead: VALU work, so it belongs here
+        next_offsets();                               // 7 DMA offsets for the chunk LEAD ahead: VALU work, so it belongs here
         __builtin_amdgcn_sched_barrier(0);            // keep the VALU block out of the MFMA block
         STAMP(ts2);
         asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
@@ -737,16 +767,56 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
 #endif
         slot = (slot + 1) % NSLOT;
         // 64 MFMAs as an explicit stream.  Behind each of the first 28: one LDS read of the next chunk's raw rows (stale data
-        // past the last chunk, never used; a burst of 28 would stall on the 15-deep LDS counter).  Behind every 8th: one DMA
-        // (a global_load_lds holds the vector-memory issue path ~64 cycles: back to back they stall, spread out they are free).
+        // past the last chunk, never used; a burst of 28 would stall on the 15-deep LDS counter).  Behind every 4th from the
+        // 31st on: one DMA (an LDS-DMA load holds the vector-memory issue path ~64 cycles: back to back they stall, spread out
+        // they cost ~15 cycles each, scripts/micro/mfma_issue_cost).
+        // Order: points 0, 3, 12, 15 of the dz transform ARE raw dz values (corners of A dY A^T), i.e. the registers the dz reads
+        // overwrite; their 16 MFMAs go first and the dz reads behind them, so no register copy has to keep them alive (the
+        // compiler otherwise puts 2-10 v_mov_b64 into this block at ~14 cycles each).  The other 48 follow tile by tile.
         const unsigned xb = xa_b + (unsigned)slot * (BUF * 4u), zb = za_b + (unsigned)slot * (BUF * 4u);
         float* const dst = smem + ((slot + LEAD - 1) % NSLOT) * BUF;
-#pragma unroll
-        for (int n = 0; n < 64; ++n) {
-            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[n & 15]) : "v"(V[n >> 4][n & 15]), "v"(M[n >> 4][n & 15]) : "memory");
-            if (n < 28) READ_K(n, xb, zb);
-            if (n >= 30 && ((n - 30) & 3) == 0 && ((n - 30) >> 2) < KPW) dma((n - 30) >> 2, dst);
-        }
+        static_for<64>([&](auto step) {
+            constexpr int n = decltype(step)::value;
+            constexpr int r16 = n & 3, r48 = (n + 32) % 12;        // (n + 32 = n - 16 mod 12, non-negative)
+            constexpr int ms = n < 16 ? n >> 2 : (n - 16) / 12;
+            constexpr int mp = n < 16 ? (r16 == 0 ? 0 : r16 == 1 ? 3 : r16 == 2 ? 12 : 15) : (r48 < 2 ? r48 + 1 : r48 < 10 ? r48 + 2 : r48 + 3);
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[mp]) : "v"(V[ms][mp]), "v"(M[ms][mp]) : "memory");
+            if constexpr (n < 16) READ_K(n, xb, zb);                        // x pairs 0..15
+            else if constexpr (n < 24) READ_K(n + 4, xb, zb);               // the 8 dz pairs
+            else if constexpr (n < 28) READ_K(n - 8, xb, zb);               // x pairs 16..19
+            if constexpr (n >= 30 && ((n - 30) & 3) == 0 && ((n - 30) >> 2) < KPW) dma((n - 30) >> 2, dst);
+            // The scalar bases of the batch after that one, in five gaps behind the last DMA: ~60 scalar instructions that a
+            // single wave per SIMD would otherwise issue one at a time in front of the transforms (round 4: 105 scalar
+            // instructions per chunk outside the MFMA block, ~400 cycles of 5 900).  Each stage is fenced by empty asm
+            // statements on its inputs and outputs, which keeps it between the two neighbouring MFMAs.
+            if constexpr (n == 55) {
+                asm volatile("" : "+s"(ic), "+s"(i_txb), "+s"(i_ty));
+                const unsigned scode = (i_ty == 0 ? 2u : 0u) | (i_ty == Th - 1 ? 4u : 0u) | (i_txb == 0 ? 8u : 0u) | (i_txb == p.tbx - 1 ? 16u : 0u);
+                b_mask = (ic < p.nchunks ? scode : 0x1Eu) * 0x01111111u;
+                asm volatile("" : "+s"(b_mask));
+            }
+            if constexpr (n == 56) {
+                asm volatile("" : "+s"(ic), "+s"(pix));
+                const unsigned cp = ic < p.nchunks ? (unsigned)pix : 0u;
+                b_x = x0 + (unsigned long long)cp * xpix;
+                b_z = z0 + (unsigned long long)cp * zpix;
+                asm volatile("" : "+s"(b_x), "+s"(b_z));
+            }
+            if constexpr (n == 57) {
+                asm volatile("" : "+s"(b_x), "+s"(b_z));
+                b_4 = wv < 2 ? b_x : b_z;
+                b_6 = wv < 2 ? b_z : b_x;
+                asm volatile("" : "+s"(b_4), "+s"(b_6));
+            }
+            if constexpr (n == 58) {
+                asm volatile("" : "+s"(ic), "+s"(i_txb), "+s"(i_ty), "+s"(pix));
+                ic += p.splits;
+                i_txb += d_txb; const bool c1 = i_txb >= p.tbx; i_txb -= c1 ? p.tbx : 0;
+                i_ty += d_ty + (c1 ? 1 : 0); i_ty -= i_ty >= Th ? Th : 0;
+                pix += dpix0 + (c1 ? dpix1 : 0);
+                asm volatile("" : "+s"(ic), "+s"(i_txb), "+s"(i_ty), "+s"(pix));
+            }
+        });
     }
     // retire the last read batch (its registers are dead to the compiler, not to the LDS) and the dummy tail DMAs
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" : ALL_PAIRS :: "memory");       // (+ MFMA -> accumulator read distance:
@@ -1096,6 +1166,9 @@ extern "C" int unet_conv3x3_wgrad_winograd_fused(const float* xin, int ldx, cons
     UNET_CHECK_ARG(xin && dz && dw && ws && unet_winograd_wgrad_fused_supported(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(ldx >= Cin && lddz >= Cout && ldx % 4 == 0 && lddz % 4 == 0);
     UNET_CHECK_ARG(unet_aligned16(xin) && unet_aligned16(dz) && unet_aligned16(dw) && unet_aligned16(ws));
+    // the kernel's addressing: a 32-bit pixel index, and per-lane byte offsets inside one chunk's halo (4 image rows) that must stay
+    // below the 1 GB its buffer descriptors admit
+    UNET_CHECK_ARG((long long)N * H * W < (1ll << 31) && (3ll * W + 18) * (ldx > lddz ? ldx : lddz) * 4 < (1ll << 30));
     if (ws_bytes < unet_conv3x3_wgrad_winograd_fused_workspace(N, H, W, Cin, Cout, max_workgroups)) return UNET_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     WinoWgradArgs a{};
