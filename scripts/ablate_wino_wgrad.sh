@@ -1,13 +1,11 @@
 #!/bin/bash
-# Diagnostic: ablation variants of the fused Winograd weight-gradient kernel, same box.
-#   0: product build   5: every DMA reads the same few KB (wrong results; removes fabric/HBM traffic)   6: no XCD renumbering
+# Diagnostic: variants of the fused Winograd weight-gradient kernel on the same box.
+#   product build | 6: no XCD renumbering | 7: s_memtime phase timeline (scripts/wgrad_timeline.py)
 set -e
 cd "$(dirname "$0")/.."
 C=semantic-segmentation-unet_amd/csrc
-for a in 0 5 6; do
-  hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -DUNET_ABLATE=$a -shared -o /tmp/libunet_wgabl$a.so $C/conv_igemm.hip $C/conv_wgrad.hip $C/conv_direct.hip $C/winograd.hip $C/norm.hip $C/misc.hip 2>/dev/null
-done
-for a in 0 5 6 0; do
-  echo "== ablate $a"
-  UNET_HIP_LIB=/tmp/libunet_wgabl$a.so python scripts/bench_conv.py fwgrad 2>/dev/null | grep -E "fwgrad"
-done
+bash scripts/build_variant.sh wg6 winograd.hip "-DUNET_ABLATE=6" > /dev/null
+bash scripts/build_variant.sh wg7 winograd.hip "-DUNET_ABLATE=7" > /dev/null
+echo "== product"; python scripts/bench_conv.py fwgrad 2>/dev/null | grep -E "fwgrad"
+echo "== no XCD renumbering"; UNET_HIP_LIB=$C/libunet_hip_wg6.so python scripts/bench_conv.py fwgrad 2>/dev/null | grep -E "fwgrad"
+echo "== phase timeline (cycles per chunk, workgroup 0 wave 0)"; UNET_HIP_LIB=$C/libunet_hip_wg7.so python scripts/wgrad_timeline.py 2>/dev/null

@@ -16,5 +16,5 @@ for name, h, ci, co in [("bott_b", 32, 1024, 1024), ("4b", 64, 512, 512), ("2b",
     torch.cuda.synchronize()
     t = ws[nb:nb + 40].view(torch.int64).tolist()
     n = max(t[4], 1)
-    print("%-7s iterations %4d | cycles per iteration: LDS-wait %6.0f  body(3 groups+transforms+DMA issue) %6.0f  vmcnt+barrier %6.0f  reads+last 16 MFMAs %6.0f | total %6.0f"
+    print("%-7s iterations %4d | cycles per iteration: LDS-wait %6.0f  transforms + DMA offsets (VALU block) %6.0f  vmcnt+barrier %6.0f  64 MFMAs with reads, DMAs and scalar stages behind them %6.0f | total %6.0f"
           % (name, n, t[0] / n, t[1] / n, t[2] / n, t[3] / max(n - 1, 1), (t[0] + t[1] + t[2]) / n + t[3] / max(n - 1, 1)))

@@ -635,47 +635,52 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
         pix = (img * p.H + 2 * i_ty) * p.W + 16 * i_txb;          // < N H W, which the host keeps below 2^31
     }
     constexpr unsigned kRecords = 0x40000000u, kRejected = 0x80000000u;   // every real offset is far below 1 GB (host-checked)
-    // what the vector part of the NEXT batch needs: the bases of its x and dz rows, the two mixed pieces' bases, its border mask
-    const char *b_x, *b_z, *b_4, *b_6;
+    // what the NEXT batch needs: the descriptors of its x and dz rows and of the two pieces that are x rows in two waves and dz
+    // rows in the other two, and its border mask.  A descriptor is four scalar registers: base[31:0], base[47:32] (stride 0),
+    // the record count, the gfx9 raw-buffer format word.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 r_x, r_z, r_4, r_6;
     unsigned b_mask;
+    auto descriptor = [&](const char* base) {
+        const unsigned long long a = (unsigned long long)(uintptr_t)base;
+        return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, kRecords, 0x00020000u};
+    };
     auto next_scalars = [&]() {
         const bool cv = ic < p.nchunks;
         const unsigned scode = (i_ty == 0 ? 2u : 0u) | (i_ty == Th - 1 ? 4u : 0u) | (i_txb == 0 ? 8u : 0u) | (i_txb == p.tbx - 1 ? 16u : 0u);
         b_mask = (cv ? scode : 0x1Eu) * 0x01111111u;
         const unsigned cp = cv ? (unsigned)pix : 0u;
-        b_x = x0 + (unsigned long long)cp * xpix;
-        b_z = z0 + (unsigned long long)cp * zpix;
-        b_4 = wv < 2 ? b_x : b_z;                     // pieces 16, 17 are x rows, 18, 19 dz rows
-        b_6 = wv < 2 ? b_z : b_x;                     // pieces 24, 25 are dz rows, 26, 27 the dummies
+        r_x = descriptor(x0 + (unsigned long long)cp * xpix);
+        r_z = descriptor(z0 + (unsigned long long)cp * zpix);
+        r_4 = wv < 2 ? r_x : r_z;                     // pieces 16, 17 are x rows, 18, 19 dz rows
+        r_6 = wv < 2 ? r_z : r_x;                     // pieces 24, 25 are dz rows, 26, 27 the dummies
         ic += p.splits;
         i_txb += d_txb; const bool c1 = i_txb >= p.tbx; i_txb -= c1 ? p.tbx : 0;
         i_ty += d_ty + (c1 ? 1 : 0); i_ty -= i_ty >= Th ? Th : 0;
         pix += dpix0 + (c1 ? dpix1 : 0);
     };
     unsigned voff[KPW];                  // this lane's offsets for the next batch
-    __amdgpu_buffer_rsrc_t r_x, r_z, r_4, r_6;
     auto next_offsets = [&]() {
         unsigned hit;                                 // (asm: takes the mask as a scalar operand where it is; the compiler's own `and` first copies it to a vector register in the MFMA block)
         asm("v_and_b32 %0, %1, %2" : "=v"(hit) : "s"(b_mask), "v"(g_codes));
 #pragma unroll
         for (int k = 0; k < KPW; ++k) voff[k] = (hit & (0xFu << (4 * k + 1))) ? kRejected : g_off[k];
         asm volatile("" : "+v"(voff[0]), "+v"(voff[1]), "+v"(voff[2]), "+v"(voff[3]), "+v"(voff[4]), "+v"(voff[5]), "+v"(voff[6]));
-        r_x = __builtin_amdgcn_make_buffer_rsrc((void*)b_x, 0, kRecords, 0x00020000);
-        r_z = __builtin_amdgcn_make_buffer_rsrc((void*)b_z, 0, kRecords, 0x00020000);
-        r_4 = __builtin_amdgcn_make_buffer_rsrc((void*)b_4, 0, kRecords, 0x00020000);
-        r_6 = __builtin_amdgcn_make_buffer_rsrc((void*)b_6, 0, kRecords, 0x00020000);
     };
-    auto dma = [&](int k, float* dst) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k < 4 ? r_x : k == 4 ? r_4 : k == 5 ? r_z : r_6,
-                                                 (lds_void_g*)(dst + (4 * k + wv) * 256), 16, voff[k], 0, 0, 0);
-    };
+    // piece k of this wave into the ring slot whose LDS byte address (+ this wave's 1 KB) is ldsw.  M0 is written in the same statement
+    // that uses it (nothing else in this kernel needs M0); asm so that the descriptor quads stay exactly where the scalar stages below
+    // left them -- the builtin rebuilds each descriptor from a pointer in front of the transforms (10 scalar instructions per chunk).
+#define WG_DMA(k, ldsw) asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" \
+        :: "v"(voff[k]), "s"((k) < 4 ? r_x : (k) == 4 ? r_4 : (k) == 5 ? r_z : r_6), "s"(ldsw), "n"(4096 * (k)) : "memory", "scc")
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_g*)smem;
+    const unsigned lds_wv = lds0 + 1024u * (unsigned)wv;
 
     int c = split;
 #pragma unroll
     for (int k = 0; k < LEAD; ++k) {
         next_scalars(); next_offsets();
-#pragma unroll
-        for (int j = 0; j < KPW; ++j) dma(j, smem + k * BUF);
+        const unsigned ldsw = lds_wv + (unsigned)k * (BUF * 4u);
+        WG_DMA(0, ldsw); WG_DMA(1, ldsw); WG_DMA(2, ldsw); WG_DMA(3, ldsw); WG_DMA(4, ldsw); WG_DMA(5, ldsw); WG_DMA(6, ldsw);
     }
     next_scalars();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -689,7 +694,6 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
     // transform and lands under its last 16 MFMAs; READ_PAIR ties one MFMA operand to each read so those MFMAs stay behind it,
     // and the single lgkmcnt(0) at the top of the next iteration carries every pair as an operand so no use can move above it.
     f32x2 xp[4][5], zp[2][4];
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_g*)smem;
     const unsigned xa_b = lds0 + 4u * xa, za_b = lds0 + 4u * za;
 #define READ_PAIR(dst, base, off) \
     asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(dst) : "v"(base), "n"(off), "n"((off) + 1))
@@ -710,7 +714,14 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
 #pragma unroll
         for (int k = 0; k < 28; ++k) READ_K(k, xa_b, za_b);
     }
-    int slot = 0;
+    // ring positions as scalar byte offsets: the slot the next chunk's raw rows are read from and the slot the next batch of DMAs
+    // fills (LEAD - 1 slots further on), both advanced behind the MFMAs
+    unsigned rd_off = 0, wr_ldsw = lds_wv + (unsigned)(LEAD - 1) * (BUF * 4u);
+    auto ring_step = [&]() {
+        rd_off = rd_off + BUF * 4u == NSLOT * BUF * 4u ? 0u : rd_off + BUF * 4u;
+        wr_ldsw = wr_ldsw + BUF * 4u == lds_wv + NSLOT * BUF * 4u ? lds_wv : wr_ldsw + BUF * 4u;
+    };
+    ring_step();
 #if UNET_ABLATE == 7        /* diagnostics only: s_memtime stamps around the phases of one iteration (block 0, wave 0) */
     long long tl[5] = {0, 0, 0, 0, 0}, ts0, ts1, ts2, ts3, ts4 = 0;
 #define STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
@@ -756,6 +767,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
             }
         }
         next_offsets();                               // 7 DMA offsets for the chunk LEAD ahead: VALU work, so it belongs here
+        unsigned xb = xa_b + rd_off, zb = za_b + rd_off;      // and the two read bases
+        asm volatile("" : "+v"(xb), "+v"(zb));
         __builtin_amdgcn_sched_barrier(0);            // keep the VALU block out of the MFMA block
         STAMP(ts2);
         asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
@@ -765,7 +778,6 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
         if (ts4) tl[3] += ts0 - ts4;
         tl[0] += ts1 - ts0; tl[1] += ts2 - ts1; tl[2] += ts3 - ts2; tl[4] += 1; ts4 = ts3;
 #endif
-        slot = (slot + 1) % NSLOT;
         // 64 MFMAs as an explicit stream.  Behind each of the first 28: one LDS read of the next chunk's raw rows (stale data
         // past the last chunk, never used; a burst of 28 would stall on the 15-deep LDS counter).  Behind every 4th from the
         // 31st on: one DMA (an LDS-DMA load holds the vector-memory issue path ~64 cycles: back to back they stall, spread out
@@ -773,8 +785,6 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
         // Order: points 0, 3, 12, 15 of the dz transform ARE raw dz values (corners of A dY A^T), i.e. the registers the dz reads
         // overwrite; their 16 MFMAs go first and the dz reads behind them, so no register copy has to keep them alive (the
         // compiler otherwise puts 2-10 v_mov_b64 into this block at ~14 cycles each).  The other 48 follow tile by tile.
-        const unsigned xb = xa_b + (unsigned)slot * (BUF * 4u), zb = za_b + (unsigned)slot * (BUF * 4u);
-        float* const dst = smem + ((slot + LEAD - 1) % NSLOT) * BUF;
         static_for<64>([&](auto step) {
             constexpr int n = decltype(step)::value;
             constexpr int r16 = n & 3, r48 = (n + 32) % 12;        // (n + 32 = n - 16 mod 12, non-negative)
@@ -784,7 +794,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
             if constexpr (n < 16) READ_K(n, xb, zb);                        // x pairs 0..15
             else if constexpr (n < 24) READ_K(n + 4, xb, zb);               // the 8 dz pairs
             else if constexpr (n < 28) READ_K(n - 8, xb, zb);               // x pairs 16..19
-            if constexpr (n >= 30 && ((n - 30) & 3) == 0 && ((n - 30) >> 2) < KPW) dma((n - 30) >> 2, dst);
+            if constexpr (n >= 30 && ((n - 30) & 3) == 0 && ((n - 30) >> 2) < KPW) WG_DMA((n - 30) >> 2, wr_ldsw);
             // The scalar bases of the batch after that one, in five gaps behind the last DMA: ~60 scalar instructions that a
             // single wave per SIMD would otherwise issue one at a time in front of the transforms (round 4: 105 scalar
             // instructions per chunk outside the MFMA block, ~400 cycles of 5 900).  Each stage is fenced by empty asm
@@ -798,15 +808,15 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
             if constexpr (n == 56) {
                 asm volatile("" : "+s"(ic), "+s"(pix));
                 const unsigned cp = ic < p.nchunks ? (unsigned)pix : 0u;
-                b_x = x0 + (unsigned long long)cp * xpix;
-                b_z = z0 + (unsigned long long)cp * zpix;
-                asm volatile("" : "+s"(b_x), "+s"(b_z));
+                r_x = descriptor(x0 + (unsigned long long)cp * xpix);
+                r_z = descriptor(z0 + (unsigned long long)cp * zpix);
+                asm volatile("" : "+s"(r_x), "+s"(r_z));
             }
             if constexpr (n == 57) {
-                asm volatile("" : "+s"(b_x), "+s"(b_z));
-                b_4 = wv < 2 ? b_x : b_z;
-                b_6 = wv < 2 ? b_z : b_x;
-                asm volatile("" : "+s"(b_4), "+s"(b_6));
+                asm volatile("" : "+s"(r_x), "+s"(r_z));
+                r_4 = wv < 2 ? r_x : r_z;
+                r_6 = wv < 2 ? r_z : r_x;
+                asm volatile("" : "+s"(r_4), "+s"(r_6));
             }
             if constexpr (n == 58) {
                 asm volatile("" : "+s"(ic), "+s"(i_txb), "+s"(i_ty), "+s"(pix));
@@ -815,6 +825,11 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_fused_kernel(WinoWgradArgs 
                 i_ty += d_ty + (c1 ? 1 : 0); i_ty -= i_ty >= Th ? Th : 0;
                 pix += dpix0 + (c1 ? dpix1 : 0);
                 asm volatile("" : "+s"(ic), "+s"(i_txb), "+s"(i_ty), "+s"(pix));
+            }
+            if constexpr (n == 59) {
+                asm volatile("" : "+s"(rd_off), "+s"(wr_ldsw));
+                ring_step();
+                asm volatile("" : "+s"(rd_off), "+s"(wr_ldsw));
             }
         });
     }
