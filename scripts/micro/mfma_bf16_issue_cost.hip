@@ -7,7 +7,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-enum { OP_NONE, OP_VADD, OP_PKADD, OP_ACCREAD, OP_CVT, OP_STORE, OP_DSB128, OP_EPI };
+enum { OP_NONE, OP_VADD, OP_PKADD, OP_ACCREAD, OP_CVT, OP_STORE, OP_DSB128, OP_EPI, OP_AND, OP_PERM, OP_PKFMA, OP_MIX5, OP_MIX4PK, OP_GLOAD, OP_ANDS, OP_FMAC, OP_FMA, OP_MIX5S, OP_AND8, OP_OR8, OP_ADD4D, OP_SUBNEW };
 template <int OP, int N>
 __global__ __launch_bounds__(256, 1) void k(float* out, long long* clk, int iters, float a0) {
     f32x16 acc[8], old[8];
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* clk, int iter
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 l4[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     float* dst = out + 65536 + (size_t)blockIdx.x * 4096 + threadIdx.x;
+    const char* gsrc = reinterpret_cast<const char*>(out) + (size_t)(blockIdx.x & 63) * 16384 + (threadIdx.x & 63) * 16;
     const long long c0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -37,6 +38,40 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* clk, int iter
                 if (OP == OP_CVT) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[v & 3]) : "v"(t[v & 7]), "v"(t[(v + 1) & 7]));
                 if (OP == OP_STORE) asm volatile("global_store_dword %0, %1, off" :: "v"(dst + 256 * (v & 7)), "v"(t[v & 7]) : "memory");
                 if (OP == OP_DSB128) asm volatile("ds_read_b128 %0, %1" : "=v"(l4[v & 1]) : "v"(laddr4));
+                if (OP == OP_AND) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(pk[v & 3]) : "v"(t[v & 7]));
+                if (OP == OP_PERM) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(pk[v & 3]) : "v"(t[v & 7]), "v"(t[(v + 1) & 7]), "s"(0x07060302));
+                if (OP == OP_PKFMA) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(t2[v & 3]) : "v"(u2));
+                if (OP == OP_MIX5) {     // the BF16x6 split step of one value pair: 2 and, 2 sub, 1 perm
+                    float h0, h1;
+                    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(h0) : "v"(t[(2 * v) & 7]));
+                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(t[(2 * v) & 7]) : "v"(t[(2 * v) & 7]), "v"(h0));
+                    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(h1) : "v"(t[(2 * v + 1) & 7]));
+                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(t[(2 * v + 1) & 7]) : "v"(t[(2 * v + 1) & 7]), "v"(h1));
+                    asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(pk[v & 3]) : "v"(h1), "v"(h0), "s"(0x07060302));
+                }
+                if (OP == OP_MIX4PK) {   // the same with one packed subtraction: 2 and, 1 pk_add (neg), 1 perm
+                    f32x2 hh;
+                    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(hh[0]) : "v"(t2[v & 3][0]));
+                    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(hh[1]) : "v"(t2[v & 3][1]));
+                    asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(t2[v & 3]) : "v"(hh));
+                    asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(pk[v & 3]) : "v"(hh[1]), "v"(hh[0]), "s"(0x07060302));
+                }
+                if (OP == OP_ANDS) asm volatile("v_and_b32_e32 %0, %1, %2" : "=v"(pk[v & 3]) : "s"(0xffff0000u), "v"(t[v & 7]));
+                if (OP == OP_FMAC) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(t[v & 7]) : "s"(a0), "v"(u));
+                if (OP == OP_FMA) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t[v & 7]) : "v"(a0), "v"(u));
+                if (OP == OP_MIX5S) {    // the split step with the mask in a scalar register (4-byte encodings except the perm)
+                    float h0, h1;
+                    asm volatile("v_and_b32_e32 %0, %1, %2" : "=v"(h0) : "s"(0xffff0000u), "v"(t[(2 * v) & 7]));
+                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(t[(2 * v) & 7]) : "v"(t[(2 * v) & 7]), "v"(h0));
+                    asm volatile("v_and_b32_e32 %0, %1, %2" : "=v"(h1) : "s"(0xffff0000u), "v"(t[(2 * v + 1) & 7]));
+                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(t[(2 * v + 1) & 7]) : "v"(t[(2 * v + 1) & 7]), "v"(h1));
+                    asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(pk[v & 3]) : "v"(h1), "v"(h0), "s"(0x07060302));
+                }
+                if (OP == OP_AND8) asm volatile("v_and_b32_e32 %0, %1, %0" : "+v"(t[v & 7]) : "s"(0xffffff00u));          // eight independent chains, like v_add_f32 above
+                if (OP == OP_OR8) asm volatile("v_or_b32_e32 %0, %1, %0" : "+v"(t[v & 7]) : "s"(0x1u));
+                if (OP == OP_ADD4D) asm volatile("v_add_f32 %0, %1, %2" : "=v"(rd[v & 3]) : "v"(t[v & 7]), "v"(u));        // four destinations, sources never written: like v_and_b32 above
+                if (OP == OP_SUBNEW) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(rd[v & 3]) : "v"(t[v & 7]), "v"(t[(v + 1) & 7]));
+                if (OP == OP_GLOAD) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(l4[v & 1]) : "v"(gsrc + 1024 * (v & 7)) : "memory");
                 if (OP == OP_EPI) {      // one epilogue item: 2 acc reads, pk add bias, pk max, 2 pk fma-ish stats, cvt, (store every item)
                     float v0, v1;
                     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v0) : "a"(old[x][(2 * v) & 15]));
@@ -52,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* clk, int iter
                     asm volatile("global_store_dword %0, %1, off" :: "v"(dst + 256 * (v & 7)), "v"(p) : "memory");
                 }
             }
-            if (OP == OP_STORE || OP == OP_EPI) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            if (OP == OP_STORE || OP == OP_EPI || OP == OP_GLOAD) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         }
         if (OP == OP_DSB128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -83,6 +118,10 @@ int main() {
     printf("bare bf16 MFMA stream (32x32x16): %.1f cycles per MFMA\n", run1<OP_NONE, 0>());
     run<OP_VADD>("v_add_f32"); run<OP_PKADD>("v_pk_add_f32"); run<OP_ACCREAD>("v_accvgpr_read_b32"); run<OP_CVT>("v_cvt_pk_bf16_f32");
     run<OP_DSB128>("ds_read_b128"); run<OP_STORE>("global_store_dword");
+    run<OP_AND>("v_and_b32"); run<OP_PERM>("v_perm_b32"); run<OP_PKFMA>("v_pk_fma_f32"); run<OP_GLOAD>("global_load_dwordx4");
+    run<OP_AND8>("v_and_b32 in place, 8 chains"); run<OP_OR8>("v_or_b32 in place, 8 chains"); run<OP_ADD4D>("v_add_f32 into 4 registers"); run<OP_SUBNEW>("v_sub_f32 into 4 registers");
+    run<OP_ANDS>("v_and_b32_e32 (scalar mask)"); run<OP_FMA>("v_fma_f32 (VOP3)"); run<OP_FMAC>("v_fmac_f32_e32"); run<OP_MIX5S>("split pair, 4-byte ands");
+    run<OP_MIX5>("split pair: 2 and 2 sub 1 perm"); run<OP_MIX4PK>("split pair: 2 and 1 pk_sub 1 perm");
     printf("epilogue item (2 accvgpr_read + 3 packed VALU + 2 max + cvt + 4-byte store):\n");
     run<OP_EPI>("  items per MFMA");
     return 0;

@@ -68,6 +68,9 @@ constexpr int kX6TileB = 528;                     // bytes per tile in a wave's 
 #define X6_MFMA0(accv, av, bv) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(accv) : "v"(av), "v"(bv) : "memory")
 // LDS-DMA of one 1-KB piece (16 B per lane) to LDS byte address ldsw + ldsoff (wave-uniform): M0 carries the LDS address.
 #define X6_DMA_V(vptr, ldsw, ldsoff) asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vptr), "s"(ldsw), "n"(ldsoff) : "memory", "scc")
+// the same in two statements, for a stream that has an instruction of its own to put between them (nothing else in these kernels uses M0)
+#define X6_DMA_M0(ldsw, ldsoff) asm volatile("s_add_u32 m0, %0, %1" :: "s"(ldsw), "n"(ldsoff) : "memory", "scc")
+#define X6_DMA_GO(vptr) asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(vptr) : "memory")
 // one weight fragment: 16 B per lane at sbase + voff + imm (sbase wave-uniform)
 #define X6_LDU(dst, voff, sbase, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
 
@@ -87,36 +90,40 @@ __device__ __forceinline__ float x6_trunc(float v) { return __builtin_bit_cast(f
 // X6_PIN: an empty volatile asm over a step's inputs / results.  Instruction selection orders pure arithmetic freely between the volatile
 // MFMAs (sched_barrier only binds the machine scheduler); tied to a volatile statement on both sides a step stays in its gap.
 #define X6_PIN(...) asm volatile("" : __VA_ARGS__)
+#define X6_USE(...) asm volatile("" :: __VA_ARGS__)
 template <int K, int J, int G> __device__ __forceinline__ void x6_split_step(X6Split& s, f32x4 (&T)[4][4]) {
 #if (UNET_X6_ABLATE & 16)        /* diagnostics: no column stage / split (results wrong) */
     return;
 #endif
     if constexpr (K == 0) {
         constexpr int TA = J == 0 ? 0 : J == 2 ? 2 : 1, TB = J == 0 ? 2 : J == 1 ? 2 : J == 2 ? 1 : 3;
-        X6_PIN("+v"(T[TA][G]), "+v"(T[TB][G]));
-        if constexpr (J == 1) {          // (as above: no v_pk_add_f32)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) asm("v_add_f32 %0, %1, %2" : "=v"(s.v[e]) : "v"(T[TA][G][e]), "v"(T[TB][G][e]));
-        } else {
-            const f32x4 vv = T[TA][G] - T[TB][G];
-            s.v[0] = vv[0]; s.v[1] = vv[1]; s.v[2] = vv[2]; s.v[3] = vv[3];
-        }
+        // (no X6_PIN over the two quads and no asm here: a vector instruction that reads a register an asm statement has just defined -- an empty
+        //  "+v" pin included -- is padded with an s_nop by the compiler unless an instruction of its own lies in between, and with ~7 instructions
+        //  in every MFMA gap each s_nop is ~4 cycles of matrix time (scripts/micro/valu_dep_cost.hip); X6_USE below keeps the step in its gap)
+        // (this group's two quads were pinned in the middle of the previous group's last step)
+        if constexpr (J == 1) { const f32x4 vv = T[TA][G] + T[TB][G]; s.v[0] = vv[0]; s.v[1] = vv[1]; s.v[2] = vv[2]; s.v[3] = vv[3]; }
+        else { const f32x4 vv = T[TA][G] - T[TB][G]; s.v[0] = vv[0]; s.v[1] = vv[1]; s.v[2] = vv[2]; s.v[3] = vv[3]; }
         s.h[0] = x6_hi2(s.v[0], s.v[1]);
-        X6_PIN("+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.h[0]));
+        X6_USE("v"(s.v[0]), "v"(s.v[1]), "v"(s.v[2]), "v"(s.v[3]), "v"(s.h[0]));
     } else if constexpr (K == 1) {
         s.a[0] = s.v[0] - x6_trunc(s.v[0]); s.a[1] = s.v[1] - x6_trunc(s.v[1]);
         s.h[1] = x6_hi2(s.v[2], s.v[3]);
-        X6_PIN("+v"(s.a[0]), "+v"(s.a[1]), "+v"(s.h[1]));
+        X6_USE("v"(s.a[0]), "v"(s.a[1]), "v"(s.h[1]));
     } else if constexpr (K == 2) {
         s.a[2] = s.v[2] - x6_trunc(s.v[2]); s.a[3] = s.v[3] - x6_trunc(s.v[3]);
         s.m[0] = x6_hi2(s.a[0], s.a[1]);
-        X6_PIN("+v"(s.a[2]), "+v"(s.a[3]), "+v"(s.m[0]));
+        X6_USE("v"(s.a[2]), "v"(s.a[3]), "v"(s.m[0]));
     } else if constexpr (K == 3) {
         s.b[0] = s.a[0] - x6_trunc(s.a[0]); s.b[1] = s.a[1] - x6_trunc(s.a[1]);
         s.m[1] = x6_hi2(s.a[2], s.a[3]);
-        X6_PIN("+v"(s.b[0]), "+v"(s.b[1]), "+v"(s.m[1]));
+        X6_USE("v"(s.b[0]), "v"(s.b[1]), "v"(s.m[1]));
     } else {
         s.b[2] = s.a[2] - x6_trunc(s.a[2]); s.b[3] = s.a[3] - x6_trunc(s.a[3]);
+        {                                // the next group's column stage may not start before this point; the two packs below separate the pin from it
+            constexpr int JX = G < 3 ? J : ((J + 1) & 3), GX = G < 3 ? G + 1 : 0;      // (behind group 3: group 0 of the next point, built in the next period)
+            constexpr int TA = JX == 0 ? 0 : JX == 2 ? 2 : 1, TB = JX == 0 ? 2 : JX == 1 ? 2 : JX == 2 ? 1 : 3;
+            X6_PIN("+v"(T[TA][GX]), "+v"(T[TB][GX]), "+v"(s.b[2]), "+v"(s.b[3]));
+        }
         s.l[0] = x6_hi2(s.b[0], s.b[1]); s.l[1] = x6_hi2(s.b[2], s.b[3]);
     }
 }
@@ -138,16 +145,25 @@ template <int DPR, int C, int G> __device__ __forceinline__ void x6_read_rows(f3
     X6_RD128(dd[0], d_a, OFF);
     X6_RD128(dd[1], d_b, OFF);
 }
-// row stage of the wave's point row: d[ra] + sgn d[rb]  (r = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3; an fma by +-1 is exact)
-template <int PENDING> __device__ __forceinline__ void x6_row_stage(f32x4& t, f32x4 (&dd)[2], float sgn) {
+// row stage of the wave's point row: d[ra] + sgn d[rb]  (r = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3; an fma by +-1 is exact).
+// In two parts: the counted wait for the pair goes in FRONT of the MFMA whose shadow holds the four fmas -- the wait statement carries the two
+// 128-bit quads as operands, and a vector instruction that writes into such an operand directly behind the statement gets an s_nop from the
+// compiler; with the MFMA in between none is owed.
+template <int PENDING> __device__ __forceinline__ void x6_row_wait(f32x4 (&dd)[2]) {
     if constexpr (PENDING == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dd[0]), "+v"(dd[1]));
     else if constexpr (PENDING == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(dd[0]), "+v"(dd[1]));
     else if constexpr (PENDING == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(dd[0]), "+v"(dd[1]));
     else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(dd[0]), "+v"(dd[1]));
-    // (scalar fmas written out: left to the compiler they become v_pk_fma_f32, which costs an MFMA-paced stream more than two plain ones)
+}
+__device__ __forceinline__ void x6_row_fma(f32x4& t, f32x4 (&dd)[2], float sgn) {
+    // (scalar fmas written out: left to the compiler they become v_pk_fma_f32, which costs an MFMA-paced stream more than two plain ones;
+    //  volatile: they stay in this gap without an X6_PIN over the 128-bit result)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(dd[1][e]), "v"(sgn), "v"(dd[0][e])); t[e] = r; }
-    X6_PIN("+v"(t));
+    for (int e = 0; e < 4; ++e) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(dd[1][e]), "v"(sgn), "v"(dd[0][e])); t[e] = r; }
+}
+template <int PENDING> __device__ __forceinline__ void x6_row_stage(f32x4& t, f32x4 (&dd)[2], float sgn) {
+    x6_row_wait<PENDING>(dd);
+    x6_row_fma(t, dd, sgn);
 }
 #define X6_TIE6(f) "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5])
 
@@ -249,8 +265,11 @@ __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f
             if (n == 7) x6_read_rows<DPR, PC, 2>(dd[0], d_a, d_b);
             if (n == 13) x6_read_rows<DPR, PC, 3>(dd[1], d_a, d_b);
         }
-        if (ND && n == (J == 1 ? 12 : 6) && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ], lds_w, DP * kX6DB + DJ * 4096);
-        if (ND && n == (J == 1 ? 14 : 8) && !(UNET_X6_ABLATE & 64)) X6_DMA_V(dptr[DJ + 1], lds_w, DP * kX6DB + (DJ + 1) * 4096);
+        // (M0 is written one gap ahead of the piece that uses it: the MFMA in between is the wait state the hardware asks for, instead of an s_nop)
+        if (ND && n == (J == 1 ? 11 : 5) && !(UNET_X6_ABLATE & 64)) X6_DMA_M0(lds_w, DP * kX6DB + DJ * 4096);
+        if (ND && n == (J == 1 ? 12 : 6) && !(UNET_X6_ABLATE & 64)) X6_DMA_GO(dptr[DJ]);
+        if (ND && n == (J == 1 ? 13 : 7) && !(UNET_X6_ABLATE & 64)) X6_DMA_M0(lds_w, DP * kX6DB + (DJ + 1) * 4096);
+        if (ND && n == (J == 1 ? 14 : 8) && !(UNET_X6_ABLATE & 64)) X6_DMA_GO(dptr[DJ + 1]);
         if (NS >= 1 && n == 2) X6_RD128(sv, tr_lane, (SI < 0 ? 0 : SI) * 2 * kX6TileB);
         if (NS == 2 && n == 3) X6_RD128(sv2, tr_lane, (SI < 0 ? 0 : SI + 1) * 2 * kX6TileB);
         // LDS operations retire in order; per period: row pairs at gaps 0, 1, the deferred reads at 2 (, 3), row pairs at 7, 13.  Every wait
@@ -267,11 +286,17 @@ __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f
             const unsigned so = pend.off + (unsigned)((SI + 1) >> 2) * pend.rowstep + (unsigned)((SI + 1) & 3) * pend.colstep;
             if (!(UNET_X6_ABLATE & 1024)) X6_STORE(so, sv2, pend.base);
         }
+        // the waits of the row stages in the NEXT gap (x6_row_wait), at the head of this one: the split step's instructions separate the statement
+        // from the fmas; no LDS operation is issued in between, so the counts are the next gap's
+        if (n == 4) x6_row_wait<2 + NS>(dd[0]);                                            // behind pair 0: pair 1 and the deferred reads
+        if (n == 10) x6_row_wait<((NS >= 1 && J == 1) ? 3 : NS == 2 ? 3 : 2)>(dd[1]);      // behind pair 1: pair 2 (+ a deferred read not yet waited for)
+        if (n == 16) x6_row_wait<2>(dd[0]);
+        if (n == 22) x6_row_wait<0>(dd[1]);
         if (n % 6 == 5) {
-            if (n == 5) x6_row_stage<2 + NS>(T[PC][0], dd[0], sgn);                            // behind pair 0: pair 1 and the deferred reads
-            if (n == 11) x6_row_stage<((NS >= 1 && J == 1) ? 3 : NS == 2 ? 3 : 2)>(T[PC][1], dd[1], sgn);     // behind pair 1: pair 2 (+ a deferred read not yet waited for)
-            if (n == 17) x6_row_stage<2>(T[PC][2], dd[0], sgn);
-            if (n == 23) x6_row_stage<0>(T[PC][3], dd[1], sgn);
+            if (n == 5) x6_row_fma(T[PC][0], dd[0], sgn);
+            if (n == 11) x6_row_fma(T[PC][1], dd[1], sgn);
+            if (n == 17) x6_row_fma(T[PC][2], dd[0], sgn);
+            if (n == 23) x6_row_fma(T[PC][3], dd[1], sgn);
             if (ND && n == 17) { dptr[DJ] += 16; dptr[DJ + 1] += 16; X6_PIN("+v"(dptr[DJ]), "+v"(dptr[DJ + 1])); }     // the two pointers move on by one chunk
         } else {
             const int sidx = n - n / 6;                                  // 0..19: group sidx / 5, step sidx % 5
@@ -316,7 +341,9 @@ __device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoF
     asm volatile("" : "+v"(lane));                                // (everything per-lane below is re-derived here: kept live across the chunk loop it is spilled)
     const int li = lane & 31, lh = lane >> 5;
     const unsigned tw = t_area + (unsigned)(li * kX6TileB + lh * 64);
-    const float lo = p.relu ? 0.f : -__builtin_inff();
+    int relu = p.relu;
+    asm volatile("" : "+s"(relu));                                // (a scalar select here; hoisted out of the tile loop the floor became a spilled vector register)
+    const float lo = relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -523,10 +550,12 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
 #endif
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMAs are invisible to the compiler's hazard recogniser
         f32x4 bias16[4];                                         // the bias of the lane's 16 channels (accumulator layout); its latency passes behind the column stage
+        int lnb = lane;
+        asm volatile("" : "+v"(lnb));                            // (the lane's part of the address is formed here: hoisted out of the tile loop it was spilled)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             bias16[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bias16[g] = *reinterpret_cast<const f32x4*>(p.bias + tc.tn * 64 + 32 * (wv >> 1) + 16 * lh + 4 * g);
+            if (p.bias) bias16[g] = *reinterpret_cast<const f32x4*>(p.bias + tc.tn * 64 + 32 * (wv >> 1) + 16 * (lnb >> 5) + 4 * g);
         }
         float zown[2][16];
 #pragma unroll
