@@ -168,22 +168,22 @@ template <int PENDING> __device__ __forceinline__ void x6_row_stage(f32x4& t, f3
 #define X6_TIE6(f) "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5])
 
 // End of period J: the weight fragments the NEXT period multiplies with have landed.  Vector-memory operations return in order, so
-// vmcnt(n) = "all but the n youngest": period 0 (loaded u(1), no DMA; the barrier behind it needs every DMA piece of the wave): 0;
-// period 1 (u(2), then u(3), then 2 DMA pieces): u(2) -> 6 + 2 younger; period 2 (2 DMA pieces): u(3) -> period 1's and period 2's pieces
-// younger = 4, so the first-touch pieces of period 1 may still be in flight; period 3 (u(0'), 2 pieces): 2.
-// NS = deferred output stores this period issued behind its loads and DMA pieces (x6_period), P1S = period 1 of this chunk issued one: they
-// may stay in flight -- period 0: NS (the barrier needs the wave's DMA pieces, which are older); period 1: 8 + NS; period 2: period 1's
-// store and pieces and its own = 4 + P1S + NS; period 3: 2 + NS.  A store issued in period X is older than the loads of period X + 1 (X + 2
-// for period 1's), so it has until the end of that period to leave the CU: one or two stores per wave and period are well inside the ~75
-// cycles per KB a CU's store path sustains.
-template <int J, int NS, int P1S> __device__ __forceinline__ void x6_period_wait(x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6]) {
+// vmcnt(n) = "all but the n youngest".  NS = deferred output stores this period issued behind its loads (x6_period); they may stay in flight.
+//   period 0 (loads u(1), then u(3), then the store; no DMA): u(1) -> 6 + NS younger.  The barrier behind it needs every DMA piece of the wave:
+//            they are older than the loads, so they have landed too.
+//   period 1 (u(2), 2 pieces, store): 2 + NS; u(3) is older and has landed with it.
+//   period 2 (2 pieces): nothing to wait for -- period 3 multiplies with u(3).
+//   period 3 (the next chunk's u(0), 2 pieces, store): 2 + NS.
+// A store issued in period X is older than the loads of period X + 1, so it has until the end of that period to leave the CU: one or two stores
+// per wave and period are well inside the ~75 cycles per KB a CU's store path sustains.
+template <int J, int NS> __device__ __forceinline__ void x6_period_wait(x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6]) {
 #define X6_VMW(N, F) asm volatile("s_waitcnt vmcnt(" #N ")" : X6_TIE6(F) :: "memory")
-    if constexpr (J == 0) { if constexpr (NS == 0) X6_VMW(0, uf[1]); else X6_VMW(1, uf[1]); }
-    else if constexpr (J == 1) { if constexpr (NS == 0) X6_VMW(8, uf[0]); else X6_VMW(9, uf[0]); }
-    else if constexpr (J == 2) {
-        if constexpr (NS + P1S == 0) X6_VMW(4, ue); else if constexpr (NS + P1S == 1) X6_VMW(5, ue); else if constexpr (NS + P1S == 2) X6_VMW(6, ue); else X6_VMW(7, ue);
+    if constexpr (J == 0) { if constexpr (NS == 0) X6_VMW(6, uf[1]); else X6_VMW(7, uf[1]); }
+    else if constexpr (J == 1) {
+        if constexpr (NS == 0) asm volatile("s_waitcnt vmcnt(2)" : X6_TIE6(uf[0]), X6_TIE6(ue) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" : X6_TIE6(uf[0]), X6_TIE6(ue) :: "memory");
     }
-    else { if constexpr (NS == 0) X6_VMW(2, uf[0]); else X6_VMW(3, uf[0]); }
+    else if constexpr (J == 3) { if constexpr (NS == 0) X6_VMW(2, uf[0]); else X6_VMW(3, uf[0]); }
 #undef X6_VMW
 }
 
@@ -209,29 +209,31 @@ __device__ float g_x6_sink[256];
 //   * the row stage of ONE patch column (PC: 3, 0, 2, 1 for J = 0..3; column 3 belongs to this chunk, the others to the next one) in the
 //     gaps n % 6 == 5, its two ds_read_b128 issued four gaps earlier -- so that every column register set is written right after its last
 //     reader: no double buffering of the 64 row-stage registers;
-//   * the six weight fragments of point JN (global loads, gaps 0..5) and, for J >= 1, two LDS-DMA pieces of the patch of chunk
-//     c + 2 into the buffer chunk c left behind at the barrier after period 0 (gaps 6, 8: right behind the weight loads -- a piece that is the
-//     first touch of its cache lines holds up every later vector-memory instruction of the wave until it returns).
+//   * weight fragments (global loads from gap 0 on: point 1 and point 3 in period 0, point 2 in period 1, the next chunk's point 0 in period 3)
+//     and, for J >= 1, two LDS-DMA pieces of the patch of chunk c + 2 into the buffer chunk c left behind at the barrier after period 0 (gaps
+//     6, 8; 12, 14 in period 1: right behind the weight loads -- a piece that is the first touch of its cache lines holds up every later
+//     vector-memory instruction of the wave until it returns).
 // At the end the wave waits for the fragments it loaded (vector-memory operations return in order: everything older has landed too,
 // in particular the wave's DMA pieces of earlier periods), and after period 0 all waves meet: D(c) is dead, D(c + 1) complete.
 // SI >= 0: this period also issues NS deferred stores SI, SI + 1 (passes of the previous tile's quarter): ds_read_b128 from the transposed
-// area at gaps 2, 3, global_store_dwordx4 at gap 10 (16 in period 1, behind its twelve loads and two pieces) and, for the second one, gap 16;
-// the lgkmcnt immediates below count them.  P1S: see x6_period_wait.
-template <int J, int DP, bool FIRST, int SI, int NS, int P1S>
+// area at gaps 2, 3, global_store_dwordx4 at gap 10 (16 in periods 0 and 1, behind their loads and pieces) and, for the second one, gap 16;
+// the lgkmcnt immediates below count them.
+template <int J, int DP, bool FIRST, int SI, int NS>
 __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f32x4 (&dd)[2][2], x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6], x6_i32x4 (&vf)[2][6], X6Split& sp,
                                           unsigned d_a, unsigned d_b, float sgn, const char* us, unsigned voff0, unsigned voff1,
                                           const float* (&dptr)[6], unsigned lds_w, const X6Pending& pend, unsigned tr_lane, long long (&tl)[16]) {
     static_assert(NS == 0 || (NS == 1 && SI >= 0) || (NS == 2 && J == 2 && SI >= 0), "one deferred store per period, two in period 2");
-    constexpr int GS = J == 1 ? 16 : 10;                         // the gap of the (first) deferred store
+    constexpr int GS = J <= 1 ? 16 : 10;                         // the gap of the (first) deferred store: behind the period's loads and pieces
     f32x4 sv, sv2;
     constexpr int CB = J & 1, NB = CB ^ 1;
-    // weight fragments: u(0), u(2) live in uf[0], u(1) in uf[1], u(3) in ue.  Period 0 loads u(1); period 1 loads u(2) AND u(3); period 2
-    // loads nothing; period 3 loads the next chunk's u(0).  So no weight load is issued in the period behind the chunk's first-touch DMA
-    // pieces (period 1's: they return after ~1900 cycles from HBM and hold up every vector-memory instruction issued meanwhile --
-    // profiles/r05_x6_timeline.txt), and nothing has to wait for those pieces before the end of period 3.
+    // weight fragments: u(0), u(2) live in uf[0], u(1) in uf[1], u(3) in ue.  Period 0 loads u(1) AND u(3) (twelve loads, no DMA piece); period 1
+    // loads u(2); period 2 loads nothing; period 3 loads the next chunk's u(0).  So no weight load is issued in the period behind the chunk's
+    // first-touch DMA pieces (period 1's: they return after ~1900 cycles from HBM and hold up every vector-memory instruction issued meanwhile --
+    // profiles/r05_x6_timeline.txt), and the heaviest period for the CU's 64 B/clk vector-memory path carries 48 KB instead of 56 (u(3) used to ride
+    // in period 1 with u(2) and two pieces: moving it is worth 1-3.5 % per layer, profiles/r05_x6_load_plan.txt).
     x6_i32x4 (&ucur)[6] = J == 3 ? ue : uf[CB];
     x6_i32x4 (&unew)[6] = J == 0 ? uf[1] : uf[0];
-    constexpr int NLOAD = J == 1 ? 12 : J == 2 ? 0 : 6;
+    constexpr int NLOAD = J == 0 ? 12 : J == 2 ? 0 : 6;
 #if (UNET_X6_ABLATE & 8)
     long long q0, q1, q2;
     X6_STAMP(q0);
@@ -256,8 +258,8 @@ __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f
         if (n >= L0 && n < L0 + NLOAD && !(UNET_X6_ABLATE & 128)) {      // weight fragments [piece][channel block], 1 KB each
             if (n - L0 < 4) X6_LDU(unew[n - L0], voff0, us, (n - L0) * 1024);
             else if (n - L0 < 6) X6_LDU(unew[n - L0], voff1, us, (n - L0 - 4) * 1024);
-            else if (n < 8) X6_LDU(ue[n - 6], voff1, us, (n - 4) * 1024);         // (period 1: point 3 follows point 2 in memory)
-            else X6_LDU(ue[n - 6], voff1 + 4096u, us, (n - 8) * 1024);
+            else if (n < 10) X6_LDU(ue[n - 6], voff0, us + 2 * kX6UPoint, (n - 6) * 1024);     // (period 0: point 3 lies two points behind point 1; a scalar add,
+            else X6_LDU(ue[n - 6], voff1, us + 2 * kX6UPoint, (n - 10) * 1024);                //  not two more per-lane offsets kept live across the loop)
         }
         if (!(UNET_X6_ABLATE & 512)) {                                   // raw rows of the four groups of column PC: 5 / 10 gaps ahead of their row stage
             if (n == 0) x6_read_rows<DPR, PC, 0>(dd[0], d_a, d_b);
@@ -275,7 +277,7 @@ __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f
         // LDS operations retire in order; per period: row pairs at gaps 0, 1, the deferred reads at 2 (, 3), row pairs at 7, 13.  Every wait
         // names what may still be in flight BEHIND the read it needs.
         if (NS >= 1 && n == GS) {
-            if (J == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(sv));                       // behind it: pairs 2, 3
+            if (GS == 16) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(sv));                     // behind it: pairs 2, 3
             else if (NS == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(sv));                 // the second deferred read, pair 2
             else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(sv));                              // pair 2
             const unsigned so = pend.off + (unsigned)(SI >> 2) * pend.rowstep + (unsigned)(SI & 3) * pend.colstep;
@@ -289,7 +291,7 @@ __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f
         // the waits of the row stages in the NEXT gap (x6_row_wait), at the head of this one: the split step's instructions separate the statement
         // from the fmas; no LDS operation is issued in between, so the counts are the next gap's
         if (n == 4) x6_row_wait<2 + NS>(dd[0]);                                            // behind pair 0: pair 1 and the deferred reads
-        if (n == 10) x6_row_wait<((NS >= 1 && J == 1) ? 3 : NS == 2 ? 3 : 2)>(dd[1]);      // behind pair 1: pair 2 (+ a deferred read not yet waited for)
+        if (n == 10) x6_row_wait<((NS >= 1 && GS == 16) ? 3 : NS == 2 ? 3 : 2)>(dd[1]);      // behind pair 1: pair 2 (+ a deferred read not yet waited for)
         if (n == 16) x6_row_wait<2>(dd[0]);
         if (n == 22) x6_row_wait<0>(dd[1]);
         if (n % 6 == 5) {
@@ -309,12 +311,12 @@ __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f
     }
 #if (UNET_X6_ABLATE & 8)
     X6_STAMP(q1);
-    x6_period_wait<J, NS, P1S>(uf, ue);
+    x6_period_wait<J, NS>(uf, ue);
     X6_STAMP(q2);
     tl[2 * J] += q1 - q0; tl[2 * J + 1] += q2 - q1;
     if (J == 0) { asm volatile("s_barrier" ::: "memory"); long long q3; X6_STAMP(q3); tl[8] += q3 - q2; tl[9] += 1; }
 #else
-    x6_period_wait<J, NS, P1S>(uf, ue);
+    x6_period_wait<J, NS>(uf, ue);
     if (J == 0) asm volatile("s_barrier" ::: "memory");
 #endif
     asm volatile("" : X6_TIE6(vf[NB]));
@@ -520,16 +522,16 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         unxt = u_source(tcn);
         // weight fragments of point J + 1 (period J of chunk c): this chunk's next point, the next chunk's point 0, or the next tile's
 #define X6_US(c, J) ((J) < 3 ? ucur + (size_t)(c) * kX6UChunk + ((J) + 1) * kX6UPoint : ((c) + 1 < nchunks ? ucur + (size_t)((c) + 1) * kX6UChunk : unxt))
-#define X6_PERIOD(J, DP, FIRST, c, SI, NS, P1S) x6_period<J, DP, FIRST, SI, NS, P1S>(acc, T, dd, uf, ue, vf, sp, d_a, d_b, sgn, X6_US(c, J), voff0, voff1, dptr, lds_w, pend, tr_lane, tl)
+#define X6_PERIOD(J, DP, FIRST, c, SI, NS) x6_period<J, DP, FIRST, SI, NS>(acc, T, dd, uf, ue, vf, sp, d_a, d_b, sgn, X6_US(c, J), voff0, voff1, dptr, lds_w, pend, tr_lane, tl)
         // (the patch pieces issued from chunk nchunks - 2 on belong to the next tile: its pointers are formed in the one period without DMA)
         // X6_CHUNK_S: the chunk issues the previous tile's deferred stores S0 .. S0 + 4 (periods 0, 1, 2 twice, 3); X6_CHUNK_L: only store 15, in period 0
 #define X6_SWITCH(c) if ((c) == nchunks - 2) tile_sources(tcn, dptr);
 #define X6_CHUNK_S(DP, FIRST, c, S0) X6_SWITCH(c) \
-        X6_PERIOD(0, DP, FIRST, c, S0, 1, 1); X6_PERIOD(1, DP, FIRST, c, S0 + 1, 1, 1); X6_PERIOD(2, DP, FIRST, c, S0 + 2, 2, 1); X6_PERIOD(3, DP, FIRST, c, S0 + 4, 1, 1);
+        X6_PERIOD(0, DP, FIRST, c, S0, 1); X6_PERIOD(1, DP, FIRST, c, S0 + 1, 1); X6_PERIOD(2, DP, FIRST, c, S0 + 2, 2); X6_PERIOD(3, DP, FIRST, c, S0 + 4, 1);
 #define X6_CHUNK_L(DP, c) X6_SWITCH(c) \
-        X6_PERIOD(0, DP, false, c, 15, 1, 0); X6_PERIOD(1, DP, false, c, -1, 0, 0); X6_PERIOD(2, DP, false, c, -1, 0, 0); X6_PERIOD(3, DP, false, c, -1, 0, 0);
+        X6_PERIOD(0, DP, false, c, 15, 1); X6_PERIOD(1, DP, false, c, -1, 0); X6_PERIOD(2, DP, false, c, -1, 0); X6_PERIOD(3, DP, false, c, -1, 0);
 #define X6_CHUNK(DP, c) X6_SWITCH(c) \
-        X6_PERIOD(0, DP, false, c, -1, 0, 0); X6_PERIOD(1, DP, false, c, -1, 0, 0); X6_PERIOD(2, DP, false, c, -1, 0, 0); X6_PERIOD(3, DP, false, c, -1, 0, 0);
+        X6_PERIOD(0, DP, false, c, -1, 0); X6_PERIOD(1, DP, false, c, -1, 0); X6_PERIOD(2, DP, false, c, -1, 0); X6_PERIOD(3, DP, false, c, -1, 0);
         X6_CHUNK_S(0, true, 0, 0)
         X6_CHUNK_S(1, false, 1, 5)
         X6_CHUNK_S(0, false, 2, 10)
