@@ -679,7 +679,10 @@ def test_dgrad_bn_backward_sums_match_reduction(hip, shape, crange):
         assert (a_ - b_).abs().max().item() < 2e-5 * scale + 1e-6, (a_ - b_).abs().max().item() / scale
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 64), (3, 8, 24, 64, 192), (1, 6, 10, 64, 64), (2, 32, 48, 128, 128)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 64), (3, 8, 24, 64, 192), (1, 6, 10, 64, 64), (2, 32, 48, 128, 128),
+                                   # (round 5: buffer loads with range-check zeros and scalar chunk bases) one tile row = top AND bottom border in every chunk;
+                                   # one 2-pixel column; a chunk row of 16 + 2 columns; more workgroups than chunks; one split over 256 channel blocks
+                                   (1, 2, 2, 64, 64), (1, 2, 34, 64, 64), (2, 4, 18, 64, 128), (1, 4, 4, 128, 128), (1, 8, 8, 1024, 1024)])
 def test_conv3x3_winograd_fused_wgrad(hip, shape):
     # raw rows through LDS, per-lane Winograd transforms in registers, G^T dU G in the epilogue; ragged tile rows included
     n, h, w, ci, co = shape
