@@ -336,6 +336,31 @@ struct X6Args {
 // activation are coalesced the same way.  STATS 1: sum, sum of squares of the stored values; STATS 2: sum dy, sum dy r.
 // -> the pending-store state of this tile (x6_period issues the stores); a tile block that sticks out of the image is stored here instead
 // (per-lane masks) and leaves nothing pending.  bias16: the lane's 16 channels of the accumulator layout.
+// STATS 2 reads the producer's saved activation at the finished quarter's pixels (x6_finish), lines written a whole forward pass ago: loaded where
+// they are used, every tile waited ~2.3 us for them (the data gradient ran 4-16 % slower than the forward kernel on the same shape, most on the
+// full-resolution layers with their many short tiles), and the 64 registers they fill are not free before the exchange is over.  So the same 16
+// addresses are TOUCHED at the start of the end-of-tile work -- 16 loads into one scratch quad, never read -- and the round trip to HBM passes behind
+// the column stage and the exchange; x6_finish's own loads then hit the L2.  `scratch` must stay allocated until those loads have landed: the
+// caller ties it to a statement behind x6_finish (vector-memory operations return in order: x6_finish's loads are younger).
+__device__ __forceinline__ void x6_touch_saved(f32x4& scratch, const WinoFusedArgs& p, int img, int by, int bx, int n0, int tb, int cb, int lane_in) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int cq = lane & 7, pl = lane >> 3;
+    if (!(n0 >= p.bn_c0 && n0 < p.bn_c1)) return;
+    const int oa = (pl >> 1) & 1, ob = pl & 1;
+    const int ch = 32 * cb + 4 * cq;
+    const int gy = 16 * by + 8 * tb + oa, gx = 16 * bx + 2 * (pl >> 2) + ob;
+    const float* const rb_ = p.bn_r + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.bn_ldr + (n0 - p.bn_c0);
+    const int pix0 = (8 * tb + oa) * p.W + 2 * (pl >> 2) + ob;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        // (lanes whose pixel lies outside the image re-read the block's first pixel: always inside)
+        const bool okq = gy + 2 * (q >> 2) < p.H && gx + 4 * (q & 3) < p.W;
+        const float* src = rb_ + (okq ? (unsigned)((pix0 + 2 * (q >> 2) * p.W + 4 * (q & 3)) * p.bn_ldr + ch) : 0u);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(scratch) : "v"(src) : "memory");
+    }
+}
+
 template <int STATS>
 __device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoFusedArgs& p, int img, int by, int bx, int n0, int tb, int cb, int lane_in,
                                                unsigned t_area, const f32x4 (&bias16)[4], f32x4& s1, f32x4& s2) {
@@ -559,6 +584,8 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
             bias16[g] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias) bias16[g] = *reinterpret_cast<const f32x4*>(p.bias + tc.tn * 64 + 32 * (wv >> 1) + 16 * (lnb >> 5) + 4 * g);
         }
+        f32x4 touched = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (STATS == 2) x6_touch_saved(touched, p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane);
         float zown[2][16];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {                        // quarter (channel block qd >> 1, tile block qd & 1), owner = wave qd
@@ -629,6 +656,7 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         X6_STAMP(e5);
 #endif
         pend = x6_finish<STATS>(y, p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane, t_area, bias16, s1, s2);
+        if constexpr (STATS == 2) asm volatile("" : "+v"(touched));          // (x6_touch_saved: the scratch quad lives until here)
         ucur = unxt; tc = tcn;
 #if (UNET_X6_ABLATE & 8)
         { long long e2; X6_STAMP(e2); tl[10] += e1 - e0; tl[11] += e2 - e1; tl[12] += 1; tl[13] += e3 - e1; tl[14] += e4 - e3; tl[15] += e5 - e4; }
