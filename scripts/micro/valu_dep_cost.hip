@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* clk, int iter
             if (PAT == 11) asm volatile("v_add_f32 v48, v40, v56\n s_add_u32 s40, s41, 0x1000\n v_add_f32 v49, v41, v56\n v_add_f32 v50, v42, v56\n s_add_u32 s42, s41, 0x2000\n v_add_f32 v51, v43, v56\n v_add_f32 v52, v44, v56" ::: "memory", "s40", "s41", "s42", "scc");
             if (PAT == 12) asm volatile("v_add_f32 v48, v40, v56\n v_add_f32 v49, v41, v56\n v_add_f32 v50, v42, v56\n v_add_f32 v51, v43, v56" ::: "memory");
             if (PAT == 13) asm volatile("v_add_f32 v48, v40, v56\n v_add_f32 v49, v41, v56\n v_add_f32 v50, v42, v56\n v_add_f32 v51, v43, v56\n v_add_f32 v52, v44, v56\n v_add_f32 v53, v45, v56" ::: "memory");
+            if (PAT == 14) asm volatile("v_accvgpr_read_b32 v48, a240\n v_accvgpr_read_b32 v49, a241\n v_accvgpr_read_b32 v50, a242\n v_accvgpr_read_b32 v51, a243\n v_accvgpr_read_b32 v52, a244\n v_accvgpr_read_b32 v53, a245\n v_accvgpr_read_b32 v54, a246\n v_accvgpr_read_b32 v55, a247" ::: "memory");
             if (PAT == 7) asm volatile("v_and_b32 v48, %0, v40\n v_and_b32 v49, %0, v41\n v_and_b32 v50, %0, v42\n v_and_b32 v51, %0, v43\n v_sub_f32 v40, v40, v48\n v_sub_f32 v41, v41, v49\n"
                                        "v_sub_f32 v42, v42, v50\n v_sub_f32 v43, v43, v51\n v_perm_b32 v52, v49, v48, %1\n v_perm_b32 v53, v51, v50, %1" :: "s"(mask), "s"(sel) : "memory");
             }
@@ -73,6 +74,7 @@ int main() {
     run<5>("F  8 in-place chains (distance 8 + one MFMA)");
     run<6>("G  split of two value pairs, as compiled (10 instructions)");
     run<7>("H  the same, ands first then subs then perms");
+    run<14>("M  8 v_accvgpr_read_b32 (registers no MFMA of the loop writes)");
     run<12>("I4 4 independent adds");
     run<8>("I  5 independent adds");
     run<13>("I6 6 independent adds");
