@@ -494,7 +494,6 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
     const unsigned d_a = d_lane + (unsigned)(ra * kX6RowB), d_b = d_lane + (unsigned)(rb * kX6RowB);
     const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wv * 1024));       // this wave's first DMA piece, as an M0 value
     const unsigned voff0 = (unsigned)lane * 16u, voff1 = voff0 + 4096u;
-    const unsigned x_lane = lds0 + kX6X + (unsigned)lane * 16u;
 
     f32x16 acc[16];
     f32x4 T[4][4];
@@ -550,19 +549,24 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
 #define X6_PERIOD(J, DP, FIRST, c, SI, NS) x6_period<J, DP, FIRST, SI, NS>(acc, T, dd, uf, ue, vf, sp, d_a, d_b, sgn, X6_US(c, J), voff0, voff1, dptr, lds_w, pend, tr_lane, tl)
         // (the patch pieces issued from chunk nchunks - 2 on belong to the next tile: its pointers are formed in the one period without DMA)
         // X6_CHUNK_S: the chunk issues the previous tile's deferred stores S0 .. S0 + 4 (periods 0, 1, 2 twice, 3); X6_CHUNK_L: only store 15, in period 0
+        // The switch sits in front of chunk nchunks - 2, an EVEN chunk (K % 32 == 0: x6_shape_ok): only chunk 2 and the loop's even chunk carry its
+        // ~150 instructions.  (Code size is performance here: the kernel is ~66 KB against a 64 KB instruction cache, and everything a tile runs once
+        // -- the four store chunks, the switch, the end-of-tile work -- is re-fetched every tile when the tile's footprint does not fit: with the switch
+        // inlined in all six chunk copies the column stage of the kernels with BatchNorm sums took 6 500 cycles against 4 000 in the plain kernel, the
+        // same instructions; profiles/r05_x6_timeline.txt section 5.)
 #define X6_SWITCH(c) if ((c) == nchunks - 2) tile_sources(tcn, dptr);
-#define X6_CHUNK_S(DP, FIRST, c, S0) X6_SWITCH(c) \
+#define X6_CHUNK_S(DP, FIRST, c, S0) \
         X6_PERIOD(0, DP, FIRST, c, S0, 1); X6_PERIOD(1, DP, FIRST, c, S0 + 1, 1); X6_PERIOD(2, DP, FIRST, c, S0 + 2, 2); X6_PERIOD(3, DP, FIRST, c, S0 + 4, 1);
-#define X6_CHUNK_L(DP, c) X6_SWITCH(c) \
+#define X6_CHUNK_L(DP, c) \
         X6_PERIOD(0, DP, false, c, 15, 1); X6_PERIOD(1, DP, false, c, -1, 0); X6_PERIOD(2, DP, false, c, -1, 0); X6_PERIOD(3, DP, false, c, -1, 0);
-#define X6_CHUNK(DP, c) X6_SWITCH(c) \
+#define X6_CHUNK(DP, c) \
         X6_PERIOD(0, DP, false, c, -1, 0); X6_PERIOD(1, DP, false, c, -1, 0); X6_PERIOD(2, DP, false, c, -1, 0); X6_PERIOD(3, DP, false, c, -1, 0);
         X6_CHUNK_S(0, true, 0, 0)
         X6_CHUNK_S(1, false, 1, 5)
-        X6_CHUNK_S(0, false, 2, 10)
+        X6_SWITCH(2) X6_CHUNK_S(0, false, 2, 10)
         X6_CHUNK_L(1, 3)
         for (int c = 4; c < nchunks; c += 2) {
-            X6_CHUNK(0, c)
+            X6_SWITCH(c) X6_CHUNK(0, c)
             X6_CHUNK(1, c + 1)
         }
 #undef X6_CHUNK_S
@@ -584,6 +588,9 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
             bias16[g] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias) bias16[g] = *reinterpret_cast<const f32x4*>(p.bias + tc.tn * 64 + 32 * (wv >> 1) + 16 * (lnb >> 5) + 4 * g);
         }
+        int lnx = lane;
+        asm volatile("" : "+v"(lnx));                            // (the exchange addresses are formed here: hoisted out of the tile loop they were spilled)
+        const unsigned x_lane = lds0 + kX6X + (unsigned)lnx * 16u;
         f32x4 touched = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (STATS == 2) x6_touch_saved(touched, p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane);
         float zown[2][16];
