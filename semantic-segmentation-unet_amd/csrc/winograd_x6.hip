@@ -177,21 +177,24 @@ template <int PENDING> __device__ __forceinline__ void x6_row_stage(f32x4& t, f3
 // A store issued in period X is older than the loads of period X + 1, so it has until the end of that period to leave the CU: one or two stores
 // per wave and period are well inside the ~75 cycles per KB a CU's store path sustains.
 template <int J, int NS> __device__ __forceinline__ void x6_period_wait(x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6]) {
+    static_assert(NS >= 0 && NS <= 2, "");
 #define X6_VMW(N, F) asm volatile("s_waitcnt vmcnt(" #N ")" : X6_TIE6(F) :: "memory")
-    if constexpr (J == 0) { if constexpr (NS == 0) X6_VMW(6, uf[1]); else X6_VMW(7, uf[1]); }
+    if constexpr (J == 0) { if constexpr (NS == 0) X6_VMW(6, uf[1]); else if constexpr (NS == 1) X6_VMW(7, uf[1]); else X6_VMW(8, uf[1]); }
     else if constexpr (J == 1) {
         if constexpr (NS == 0) asm volatile("s_waitcnt vmcnt(2)" : X6_TIE6(uf[0]), X6_TIE6(ue) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" : X6_TIE6(uf[0]), X6_TIE6(ue) :: "memory");
+        else if constexpr (NS == 1) asm volatile("s_waitcnt vmcnt(3)" : X6_TIE6(uf[0]), X6_TIE6(ue) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" : X6_TIE6(uf[0]), X6_TIE6(ue) :: "memory");
     }
-    else if constexpr (J == 3) { if constexpr (NS == 0) X6_VMW(2, uf[0]); else X6_VMW(3, uf[0]); }
+    else if constexpr (J == 3) { if constexpr (NS == 0) X6_VMW(2, uf[0]); else if constexpr (NS == 1) X6_VMW(3, uf[0]); else X6_VMW(4, uf[0]); }
 #undef X6_VMW
 }
 
 // The output stores of a tile are DEFERRED into the first four chunks of the next one (every tile has at least four): a CU's store path takes
 // ~75 cycles per 1-KB store instruction, so the 64 stores of a tile issued back to back held the four waves for ~4,700 cycles with the
 // matrix pipe idle (profiles/r05_x6_timeline.txt); one store per wave and period (two in period 2, which loads nothing) disappears behind the
-// MFMAs: five per chunk in chunks 0..2, the sixteenth in period 0 of chunk 3 -- in front of that chunk's barrier, so that every read of the
-// transposed area is over before another wave can reach the next end-of-tile exchange, which writes there.  The finished values wait in
+// MFMAs.  Round 5, late: TWO per wave and period, all sixteen in chunks 0 and 1 (two chunk copies with stores instead of four: 20 KB less code, the
+// same speed); every read of the transposed area is over long before another wave can reach the next end-of-tile exchange, which writes there.
+// The finished values wait in
 // the wave's transposed area (x6_finish); state of the wave's pending tile:
 struct X6Pending {
     float* base;             // wave-uniform: the tile block's first pixel, the output tile's first channel -- or the sink when nothing is pending
@@ -222,7 +225,7 @@ template <int J, int DP, bool FIRST, int SI, int NS>
 __device__ __forceinline__ void x6_period(f32x16 (&acc)[16], f32x4 (&T)[4][4], f32x4 (&dd)[2][2], x6_i32x4 (&uf)[2][6], x6_i32x4 (&ue)[6], x6_i32x4 (&vf)[2][6], X6Split& sp,
                                           unsigned d_a, unsigned d_b, float sgn, const char* us, unsigned voff0, unsigned voff1,
                                           const float* (&dptr)[6], unsigned lds_w, const X6Pending& pend, unsigned tr_lane, long long (&tl)[16]) {
-    static_assert(NS == 0 || (NS == 1 && SI >= 0) || (NS == 2 && J == 2 && SI >= 0), "one deferred store per period, two in period 2");
+    static_assert(NS == 0 || ((NS == 1 || NS == 2) && SI >= 0), "up to two deferred stores per period");
     constexpr int GS = J <= 1 ? 16 : 10;                         // the gap of the (first) deferred store: behind the period's loads and pieces
     f32x4 sv, sv2;
     constexpr int CB = J & 1, NB = CB ^ 1;
@@ -342,23 +345,30 @@ struct X6Args {
 // addresses are TOUCHED at the start of the end-of-tile work -- 16 loads into one scratch quad, never read -- and the round trip to HBM passes behind
 // the column stage and the exchange; x6_finish's own loads then hit the L2.  `scratch` must stay allocated until those loads have landed: the
 // caller ties it to a statement behind x6_finish (vector-memory operations return in order: x6_finish's loads are younger).
-__device__ __forceinline__ void x6_touch_saved(f32x4& scratch, const WinoFusedArgs& p, int img, int by, int bx, int n0, int tb, int cb, int lane_in) {
+// Both go through ONE buffer descriptor over the saved activation with the tile block's first pixel in the scalar offset and a single per-lane offset:
+// a load is a scalar add and the instruction (an address with bounds checks and a select per load was 250 instructions for the sixteen touches and as
+// many again in x6_finish -- kernel size is performance here, see the chunk macros in x6_stream_body).  Pixels outside the image but inside the tensor
+// read their neighbours' values (x6_finish skips those passes), offsets past the tensor's end are rejected by the range check; no channel of
+// [c0, c1) -> zero records, every load returns zeros.
+struct X6Saved { __amdgpu_buffer_rsrc_t srd; unsigned soff, vlane, rowstep, colstep; };
+__device__ __forceinline__ X6Saved x6_saved(const WinoFusedArgs& p, int img, int by, int bx, int n0, int tb, int cb, int lane_in) {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int cq = lane & 7, pl = lane >> 3;
-    if (!(n0 >= p.bn_c0 && n0 < p.bn_c1)) return;
+    const bool rok = n0 >= p.bn_c0 && n0 < p.bn_c1;
     const int oa = (pl >> 1) & 1, ob = pl & 1;
-    const int ch = 32 * cb + 4 * cq;
-    const int gy = 16 * by + 8 * tb + oa, gx = 16 * bx + 2 * (pl >> 2) + ob;
-    const float* const rb_ = p.bn_r + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.bn_ldr + (n0 - p.bn_c0);
-    const int pix0 = (8 * tb + oa) * p.W + 2 * (pl >> 2) + ob;
+    X6Saved r;
+    const unsigned bytes = (unsigned)((((size_t)p.N * p.H * p.W - 1) * p.bn_ldr + (p.bn_c1 - p.bn_c0)) * 4);      // (< 4 GB: checked on the host)
+    r.srd = __builtin_amdgcn_make_buffer_rsrc((void*)p.bn_r, 0, rok ? (int)bytes : 0, 0x00020000);
+    r.soff = (unsigned)((((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.bn_ldr + (rok ? n0 - p.bn_c0 : 0)) * 4);
+    r.vlane = (unsigned)((((8 * tb + oa) * p.W + 2 * (pl >> 2) + ob) * p.bn_ldr + 32 * cb + 4 * cq) * 4);
+    r.rowstep = (unsigned)(2 * p.W * p.bn_ldr) * 4u; r.colstep = (unsigned)(4 * p.bn_ldr) * 4u;
+    return r;
+}
+__device__ __forceinline__ void x6_touch_saved(f32x4& scratch, const X6Saved& r) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        // (lanes whose pixel lies outside the image re-read the block's first pixel: always inside)
-        const bool okq = gy + 2 * (q >> 2) < p.H && gx + 4 * (q & 3) < p.W;
-        const float* src = rb_ + (okq ? (unsigned)((pix0 + 2 * (q >> 2) * p.W + 4 * (q & 3)) * p.bn_ldr + ch) : 0u);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(scratch) : "v"(src) : "memory");
-    }
+    for (int q = 0; q < 16; ++q)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(scratch) : "v"(r.vlane), "s"(r.srd), "s"(r.soff + (unsigned)(q >> 2) * r.rowstep + (unsigned)(q & 3) * r.colstep) : "memory");
 }
 
 template <int STATS>
@@ -384,26 +394,22 @@ __device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoF
             }
     const int cq = lane & 7, pl = lane >> 3;                     // reader: channel quad, pixel of a pass (tile pl >> 2 of the pass, pixel pl & 3)
     const unsigned tr = t_area + (unsigned)((pl >> 2) * kX6TileB + (pl & 3) * 128 + cq * 16);
-    const bool rok = STATS == 2 && n0 >= p.bn_c0 && n0 < p.bn_c1;
     const int oa = (pl >> 1) & 1, ob = pl & 1;
     // addresses: a wave-uniform 64-bit base (the tile block's first pixel, the output tile's first channel) + a 32-bit lane offset
     // (16 rows x W x ld of the tensor: far below 2^31 elements for every shape the entry points admit)
     const int ch = 32 * cb + 4 * cq;
     const int gy = 16 * by + 8 * tb + oa, gx = 16 * bx + 2 * (pl >> 2) + ob;       // the lane's pixel in pass (hp = 0, k = 0)
     float* const ob_ = p.out + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.ldo + n0;
-    const float* const rb_ = STATS == 2 ? p.bn_r + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.bn_ldr + (n0 - p.bn_c0) : nullptr;
     const int pix0 = (8 * tb + oa) * p.W + 2 * (pl >> 2) + ob;                     // pixel offset of that pixel from the block's first pixel
     const bool edge = 16 * by + 16 > p.H || 16 * bx + 16 > p.W;                    // wave-uniform
     // STATS 2: the producer's saved activation at the lane's 16 pixels, ALL loaded here (y is dead behind the LDS writes: the registers are
     // there) -- loaded pass by pass, every pass paid a global-memory round trip
     f32x4 rall[16];
     if (STATS == 2) {
+        const X6Saved r = x6_saved(p, img, by, bx, n0, tb, cb, lane_in);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const bool okq = gy + 2 * (q >> 2) < p.H && gx + 4 * (q & 3) < p.W;
-            rall[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rok && okq) rall[q] = *reinterpret_cast<const f32x4*>(rb_ + (unsigned)((pix0 + 2 * (q >> 2) * p.W + 4 * (q & 3)) * p.bn_ldr + ch));
-        }
+        for (int q = 0; q < 16; ++q)
+            rall[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r.srd, (int)r.vlane, (int)(r.soff + (unsigned)(q >> 2) * r.rowstep + (unsigned)(q & 3) * r.colstep), 0));
     }
     if (STATS != 0 || edge) {
 #pragma unroll
@@ -548,29 +554,25 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
 #define X6_US(c, J) ((J) < 3 ? ucur + (size_t)(c) * kX6UChunk + ((J) + 1) * kX6UPoint : ((c) + 1 < nchunks ? ucur + (size_t)((c) + 1) * kX6UChunk : unxt))
 #define X6_PERIOD(J, DP, FIRST, c, SI, NS) x6_period<J, DP, FIRST, SI, NS>(acc, T, dd, uf, ue, vf, sp, d_a, d_b, sgn, X6_US(c, J), voff0, voff1, dptr, lds_w, pend, tr_lane, tl)
         // (the patch pieces issued from chunk nchunks - 2 on belong to the next tile: its pointers are formed in the one period without DMA)
-        // X6_CHUNK_S: the chunk issues the previous tile's deferred stores S0 .. S0 + 4 (periods 0, 1, 2 twice, 3); X6_CHUNK_L: only store 15, in period 0
-        // The switch sits in front of chunk nchunks - 2, an EVEN chunk (K % 32 == 0: x6_shape_ok): only chunk 2 and the loop's even chunk carry its
-        // ~150 instructions.  (Code size is performance here: the kernel is ~66 KB against a 64 KB instruction cache, and everything a tile runs once
-        // -- the four store chunks, the switch, the end-of-tile work -- is re-fetched every tile when the tile's footprint does not fit: with the switch
-        // inlined in all six chunk copies the column stage of the kernels with BatchNorm sums took 6 500 cycles against 4 000 in the plain kernel, the
-        // same instructions; profiles/r05_x6_timeline.txt section 5.)
+        // X6_CHUNK_S: the chunk issues the previous tile's deferred stores S0 .. S0 + 7, two per period
+        // The switch sits in front of chunk nchunks - 2, an EVEN chunk (K % 32 == 0: x6_shape_ok): only the loop's even chunk carries its ~150
+        // instructions.  A chunk is ~7 KB of code; with six chunk copies (three with five stores, one with the sixteenth, two generic) and the switch
+        // inlined in all of them the kernels were 68-72 KB.  In the INSTRUMENTED build (s_memtime stamps, ~3 KB more) that showed as a column stage of
+        // 6 500 cycles in the kernels with BatchNorm sums against 4 000 in the plain kernel for the same instructions -- code that runs once per tile
+        // re-fetched every tile -- and went away below ~67 KB; the product kernels measure the same at 69 KB and at 49 KB (same-box bench.py runs,
+        // profiles/r05_x6_timeline.txt section 5), so the smaller form is kept for what it is: two store chunks, two generic ones, 48-51 KB.
 #define X6_SWITCH(c) if ((c) == nchunks - 2) tile_sources(tcn, dptr);
 #define X6_CHUNK_S(DP, FIRST, c, S0) \
-        X6_PERIOD(0, DP, FIRST, c, S0, 1); X6_PERIOD(1, DP, FIRST, c, S0 + 1, 1); X6_PERIOD(2, DP, FIRST, c, S0 + 2, 2); X6_PERIOD(3, DP, FIRST, c, S0 + 4, 1);
-#define X6_CHUNK_L(DP, c) \
-        X6_PERIOD(0, DP, false, c, 15, 1); X6_PERIOD(1, DP, false, c, -1, 0); X6_PERIOD(2, DP, false, c, -1, 0); X6_PERIOD(3, DP, false, c, -1, 0);
+        X6_PERIOD(0, DP, FIRST, c, S0, 2); X6_PERIOD(1, DP, FIRST, c, S0 + 2, 2); X6_PERIOD(2, DP, FIRST, c, S0 + 4, 2); X6_PERIOD(3, DP, FIRST, c, S0 + 6, 2);
 #define X6_CHUNK(DP, c) \
         X6_PERIOD(0, DP, false, c, -1, 0); X6_PERIOD(1, DP, false, c, -1, 0); X6_PERIOD(2, DP, false, c, -1, 0); X6_PERIOD(3, DP, false, c, -1, 0);
         X6_CHUNK_S(0, true, 0, 0)
-        X6_CHUNK_S(1, false, 1, 5)
-        X6_SWITCH(2) X6_CHUNK_S(0, false, 2, 10)
-        X6_CHUNK_L(1, 3)
-        for (int c = 4; c < nchunks; c += 2) {
+        X6_CHUNK_S(1, false, 1, 8)
+        for (int c = 2; c < nchunks; c += 2) {
             X6_SWITCH(c) X6_CHUNK(0, c)
             X6_CHUNK(1, c + 1)
         }
 #undef X6_CHUNK_S
-#undef X6_CHUNK_L
 #undef X6_SWITCH
 #undef X6_CHUNK
 #undef X6_PERIOD
@@ -592,7 +594,7 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         asm volatile("" : "+v"(lnx));                            // (the exchange addresses are formed here: hoisted out of the tile loop they were spilled)
         const unsigned x_lane = lds0 + kX6X + (unsigned)lnx * 16u;
         f32x4 touched = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (STATS == 2) x6_touch_saved(touched, p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane);
+        if constexpr (STATS == 2) x6_touch_saved(touched, x6_saved(p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane));
         float zown[2][16];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {                        // quarter (channel block qd >> 1, tile block qd & 1), owner = wave qd
