@@ -412,19 +412,26 @@ __device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoF
             rall[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r.srd, (int)r.vlane, (int)(r.soff + (unsigned)(q >> 2) * r.rowstep + (unsigned)(q & 3) * r.colstep), 0));
     }
     if (STATS != 0 || edge) {
+        // two passes at a time (half of tile row h2 / 2 of the block), the next pair's reads in flight while this pair is summed: one LDS round
+        // trip per tile instead of eight (no MFMA runs here: every cycle of this loop is matrix-pipe time)
+        f32x4 v[2][2];
+        X6_RD128(v[0][0], tr, 0); X6_RD128(v[0][1], tr, 2 * kX6TileB);
 #pragma unroll
-        for (int h2 = 0; h2 < 8; ++h2) {                         // two passes at a time: half of tile row h2 / 2 of the block
-            const int hp = h2 >> 1, k0 = 2 * (h2 & 1);
-            f32x4 v[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) X6_RD128(v[k], tr, (4 * hp + k0 + k) * 2 * kX6TileB);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
+        for (int h2 = 0; h2 < 8; ++h2) {
+            const int hp = h2 >> 1, k0 = 2 * (h2 & 1), cur = h2 & 1;
+            if (h2 < 7) {
+                const int hn = (h2 + 1) >> 1, kn = 2 * ((h2 + 1) & 1);
+                X6_RD128(v[cur ^ 1][0], tr, (4 * hn + kn) * 2 * kX6TileB); X6_RD128(v[cur ^ 1][1], tr, (4 * hn + kn + 1) * 2 * kX6TileB);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(v[cur][0]), "+v"(v[cur][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[cur][0]), "+v"(v[cur][1]));
+            }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (!(gy + 2 * hp < p.H && gx + 4 * (k0 + k) < p.W)) continue;
-                if (edge && !(UNET_X6_ABLATE & 1024)) *reinterpret_cast<f32x4*>(ob_ + (unsigned)((pix0 + 2 * hp * p.W + 4 * (k0 + k)) * p.ldo + ch)) = v[k];
-                if (STATS == 1) { s1 += v[k]; s2 += v[k] * v[k]; }
-                if (STATS == 2) { s1 += v[k]; s2 += v[k] * rall[4 * hp + k0 + k]; }
+                if (edge && !(UNET_X6_ABLATE & 1024)) *reinterpret_cast<f32x4*>(ob_ + (unsigned)((pix0 + 2 * hp * p.W + 4 * (k0 + k)) * p.ldo + ch)) = v[cur][k];
+                if (STATS == 1) { s1 += v[cur][k]; s2 += v[cur][k] * v[cur][k]; }
+                if (STATS == 2) { s1 += v[cur][k]; s2 += v[cur][k] * rall[4 * hp + k0 + k]; }
             }
         }
     }
