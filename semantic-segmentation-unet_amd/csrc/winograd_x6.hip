@@ -342,7 +342,7 @@ struct X6Args {
 // STATS 2 reads the producer's saved activation at the finished quarter's pixels (x6_finish), lines written a whole forward pass ago: loaded where
 // they are used, every tile waited ~2.3 us for them (the data gradient ran 4-16 % slower than the forward kernel on the same shape, most on the
 // full-resolution layers with their many short tiles), and the 64 registers they fill are not free before the exchange is over.  So the same 16
-// addresses are TOUCHED at the start of the end-of-tile work -- 16 loads into one scratch quad, never read -- and the round trip to HBM passes behind
+// addresses are TOUCHED at the start of the end-of-tile work -- 16 loads into one scratch register, never read -- and the round trip to HBM passes behind
 // the column stage and the exchange; x6_finish's own loads then hit the L2.  `scratch` must stay allocated until those loads have landed: the
 // caller ties it to a statement behind x6_finish (vector-memory operations return in order: x6_finish's loads are younger).
 // Both go through ONE buffer descriptor over the saved activation with the tile block's first pixel in the scalar offset and a single per-lane offset:
@@ -365,10 +365,12 @@ __device__ __forceinline__ X6Saved x6_saved(const WinoFusedArgs& p, int img, int
     r.rowstep = (unsigned)(2 * p.W * p.bn_ldr) * 4u; r.colstep = (unsigned)(4 * p.bn_ldr) * 4u;
     return r;
 }
-__device__ __forceinline__ void x6_touch_saved(f32x4& scratch, const X6Saved& r) {
+// (one dword per lane: eight lanes still cover each 128-byte line, and a quarter of the bytes crosses the CU's 64 B/clk vector-memory path --
+//  sixteen 16-byte touches held the wave's instruction stream for ~1 300 cycles)
+__device__ __forceinline__ void x6_touch_saved(float& scratch, const X6Saved& r) {
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(scratch) : "v"(r.vlane), "s"(r.srd), "s"(r.soff + (unsigned)(q >> 2) * r.rowstep + (unsigned)(q & 3) * r.colstep) : "memory");
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(scratch) : "v"(r.vlane), "s"(r.srd), "s"(r.soff + (unsigned)(q >> 2) * r.rowstep + (unsigned)(q & 3) * r.colstep) : "memory");
 }
 
 template <int STATS>
@@ -600,7 +602,7 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         int lnx = lane;
         asm volatile("" : "+v"(lnx));                            // (the exchange addresses are formed here: hoisted out of the tile loop they were spilled)
         const unsigned x_lane = lds0 + kX6X + (unsigned)lnx * 16u;
-        f32x4 touched = f32x4{0.f, 0.f, 0.f, 0.f};
+        float touched = 0.f;
         if constexpr (STATS == 2) x6_touch_saved(touched, x6_saved(p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane));
         float zown[2][16];
 #pragma unroll
@@ -672,7 +674,7 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         X6_STAMP(e5);
 #endif
         pend = x6_finish<STATS>(y, p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane, t_area, bias16, s1, s2);
-        if constexpr (STATS == 2) asm volatile("" : "+v"(touched));          // (x6_touch_saved: the scratch quad lives until here)
+        if constexpr (STATS == 2) asm volatile("" : "+v"(touched));          // (x6_touch_saved: the scratch register lives until here)
         ucur = unxt; tc = tcn;
 #if (UNET_X6_ABLATE & 8)
         { long long e2; X6_STAMP(e2); tl[10] += e1 - e0; tl[11] += e2 - e1; tl[12] += 1; tl[13] += e3 - e1; tl[14] += e4 - e3; tl[15] += e5 - e4; }
