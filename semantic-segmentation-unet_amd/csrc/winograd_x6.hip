@@ -383,10 +383,15 @@ __device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoF
     int relu = p.relu;
     asm volatile("" : "+s"(relu));                                // (a scalar select here; hoisted out of the tile loop the floor became a spilled vector register)
     const float lo = relu ? 0.f : -__builtin_inff();
+    // STATS 2: the producer's saved activation at the lane's 16 pixels (reader layout below), four loads behind each quarter of the transposed
+    // writes -- that quarter's 16 registers of y are free by then, and the L2 round trip of the loads passes behind the remaining writes
+    f32x4 rall[16];
+    X6Saved rs;
+    if constexpr (STATS == 2) rs = x6_saved(p, img, by, bx, n0, tb, cb, lane_in);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
@@ -394,6 +399,14 @@ __device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoF
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(y[a][b][4 * g + e] + bias16[g][e], lo);
                 X6_WR128(tw, (2 * a + b) * 128 + g * 16, v);
             }
+            if constexpr (STATS == 2) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int q = 4 * (2 * a + b) + q4;
+                    rall[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs.srd, (int)rs.vlane, (int)(rs.soff + (unsigned)(q >> 2) * rs.rowstep + (unsigned)(q & 3) * rs.colstep), 0));
+                }
+            }
+        }
     const int cq = lane & 7, pl = lane >> 3;                     // reader: channel quad, pixel of a pass (tile pl >> 2 of the pass, pixel pl & 3)
     const unsigned tr = t_area + (unsigned)((pl >> 2) * kX6TileB + (pl & 3) * 128 + cq * 16);
     const int oa = (pl >> 1) & 1, ob = pl & 1;
@@ -404,15 +417,6 @@ __device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoF
     float* const ob_ = p.out + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.ldo + n0;
     const int pix0 = (8 * tb + oa) * p.W + 2 * (pl >> 2) + ob;                     // pixel offset of that pixel from the block's first pixel
     const bool edge = 16 * by + 16 > p.H || 16 * bx + 16 > p.W;                    // wave-uniform
-    // STATS 2: the producer's saved activation at the lane's 16 pixels, ALL loaded here (y is dead behind the LDS writes: the registers are
-    // there) -- loaded pass by pass, every pass paid a global-memory round trip
-    f32x4 rall[16];
-    if (STATS == 2) {
-        const X6Saved r = x6_saved(p, img, by, bx, n0, tb, cb, lane_in);
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            rall[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r.srd, (int)r.vlane, (int)(r.soff + (unsigned)(q >> 2) * r.rowstep + (unsigned)(q & 3) * r.colstep), 0));
-    }
     if (STATS != 0 || edge) {
         // two passes at a time (half of tile row h2 / 2 of the block), the next pair's reads in flight while this pair is summed: one LDS round
         // trip per tile instead of eight (no MFMA runs here: every cycle of this loop is matrix-pipe time)
