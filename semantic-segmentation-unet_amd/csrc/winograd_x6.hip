@@ -462,6 +462,38 @@ __device__ __forceinline__ void x6_write_stats(const WinoFusedArgs& p, int t0, i
     for (int e = 0; e < 4; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
 }
 
+// Column stage of wave WV's point row at the end of a tile: z0 = m0 + m1 + m2, z1 = m1 - m2 - m3 over the row's four points, per quarter (channel
+// block qd >> 1, tile block qd & 1) of the 64 x 64 tile; the quarter this wave owns stays in registers (zown), the others go to their owners' exchange areas.
+template <int WV>
+__device__ __forceinline__ void x6_column_stage(f32x16 (&acc)[16], unsigned x_lane, float (&zown)[2][16]) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {                            // owner = wave qd
+        const unsigned xw = x_lane + (unsigned)(qd * kX6XW) + (unsigned)((WV - (WV > qd ? 1 : 0)) * 8192);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 z0, z1;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {                     // two elements at a time: packed adds on aligned register pairs (no MFMA runs here)
+                f32x2 m0, m1, m2, m3;
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(m0.x) : "a"(acc[0 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m0.y) : "a"(acc[0 + qd][4 * e4 + i + 1]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(m1.x) : "a"(acc[4 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m1.y) : "a"(acc[4 + qd][4 * e4 + i + 1]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(m2.x) : "a"(acc[8 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m2.y) : "a"(acc[8 + qd][4 * e4 + i + 1]));
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(m3.x) : "a"(acc[12 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m3.y) : "a"(acc[12 + qd][4 * e4 + i + 1]));
+                const f32x2 r0 = (m0 + m1) + m2, r1 = wf_pk_sub(wf_pk_sub(m1, m2), m3);
+                z0[i] = r0.x; z0[i + 1] = r0.y; z1[i] = r1.x; z1[i + 1] = r1.y;
+            }
+            if (qd == WV) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { zown[0][4 * e4 + i] = z0[i]; zown[1][4 * e4 + i] = z1[i]; }
+            } else {
+                X6_WR128(xw, (2 * e4) * 1024, z0);
+                X6_WR128(xw, (2 * e4 + 1) * 1024, z1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int STATS>
 __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
     const WinoFusedArgs& p = q.f;
@@ -609,31 +641,13 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         float touched = 0.f;
         if constexpr (STATS == 2) x6_touch_saved(touched, x6_saved(p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane));
         float zown[2][16];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {                        // quarter (channel block qd >> 1, tile block qd & 1), owner = wave qd
-            const unsigned xw = x_lane + (unsigned)(qd * kX6XW) + (unsigned)((wv - (wv > qd ? 1 : 0)) * 8192);
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                f32x4 z0, z1;
-#pragma unroll
-                for (int i = 0; i < 4; i += 2) {                 // two elements at a time: packed adds on aligned register pairs (no MFMA runs here)
-                    f32x2 m0, m1, m2, m3;
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(m0.x) : "a"(acc[0 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m0.y) : "a"(acc[0 + qd][4 * e4 + i + 1]));
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(m1.x) : "a"(acc[4 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m1.y) : "a"(acc[4 + qd][4 * e4 + i + 1]));
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(m2.x) : "a"(acc[8 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m2.y) : "a"(acc[8 + qd][4 * e4 + i + 1]));
-                    asm("v_accvgpr_read_b32 %0, %1" : "=v"(m3.x) : "a"(acc[12 + qd][4 * e4 + i])); asm("v_accvgpr_read_b32 %0, %1" : "=v"(m3.y) : "a"(acc[12 + qd][4 * e4 + i + 1]));
-                    const f32x2 r0 = (m0 + m1) + m2, r1 = wf_pk_sub(wf_pk_sub(m1, m2), m3);
-                    z0[i] = r0.x; z0[i + 1] = r0.y; z1[i] = r1.x; z1[i + 1] = r1.y;
-                }
-                if (qd == wv) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { zown[0][4 * e4 + i] = z0[i]; zown[1][4 * e4 + i] = z1[i]; }
-                } else {
-                    X6_WR128(xw, (2 * e4) * 1024, z0);
-                    X6_WR128(xw, (2 * e4 + 1) * 1024, z1);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        // (one straight-line copy per wave: with the owner test inside the loop every quarter cost two taken branches and the own quarter 32 register
+        //  copies -- the accumulators are only READ here, so the four copies do not disturb their allocation)
+        switch (wv) {
+            case 0: x6_column_stage<0>(acc, x_lane, zown); break;
+            case 1: x6_column_stage<1>(acc, x_lane, zown); break;
+            case 2: x6_column_stage<2>(acc, x_lane, zown); break;
+            default: x6_column_stage<3>(acc, x_lane, zown); break;
         }
 #if (UNET_X6_ABLATE & 8)
         long long e3, e4, e5; X6_STAMP(e3);
