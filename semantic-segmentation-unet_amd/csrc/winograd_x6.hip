@@ -32,6 +32,7 @@
 // The price: the output transform needs all four point rows of a (tile, channel): the waves reduce their rows' column stage
 // (m0 + m1 + m2, m1 - m2 - m3) locally and exchange the halves through LDS once per tile (96 KB), each wave finishing one
 // [32 channels x 32 tiles] quarter with the epilogue element order of the other Winograd kernels (bias, ReLU, BatchNorm sums).
+#include <type_traits>
 #include "common.h"
 #include "wino_epilogue.h"
 #include <cstdlib>
@@ -417,9 +418,12 @@ __device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoF
     float* const ob_ = p.out + ((size_t)(img * p.H + 16 * by) * p.W + 16 * bx) * p.ldo + n0;
     const int pix0 = (8 * tb + oa) * p.W + 2 * (pl >> 2) + ob;                     // pixel offset of that pixel from the block's first pixel
     const bool edge = 16 * by + 16 > p.H || 16 * bx + 16 > p.W;                    // wave-uniform
-    if (STATS != 0 || edge) {
-        // two passes at a time (half of tile row h2 / 2 of the block), the next pair's reads in flight while this pair is summed: one LDS round
-        // trip per tile instead of eight (no MFMA runs here: every cycle of this loop is matrix-pipe time)
+    // two passes at a time (half of tile row h2 / 2 of the block), the next pair's reads in flight while this pair is summed: one LDS round
+    // trip per tile instead of eight (no MFMA runs here: every cycle of this loop is matrix-pipe time).  EDGE = the tile block sticks out of the
+    // image (wave-uniform): only then are the per-lane in-image tests and the direct stores compiled in -- as one loop they cost every tile sixteen
+    // exec-mask branches.
+    auto sums = [&](auto edge_c) {
+        constexpr bool EDGE = decltype(edge_c)::value;
         f32x4 v[2][2];
         X6_RD128(v[0][0], tr, 0); X6_RD128(v[0][1], tr, 2 * kX6TileB);
 #pragma unroll
@@ -434,13 +438,17 @@ __device__ __forceinline__ X6Pending x6_finish(float (&y)[2][2][16], const WinoF
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                if (!(gy + 2 * hp < p.H && gx + 4 * (k0 + k) < p.W)) continue;
-                if (edge && !(UNET_X6_ABLATE & 1024)) *reinterpret_cast<f32x4*>(ob_ + (unsigned)((pix0 + 2 * hp * p.W + 4 * (k0 + k)) * p.ldo + ch)) = v[cur][k];
+                if constexpr (EDGE) {
+                    if (!(gy + 2 * hp < p.H && gx + 4 * (k0 + k) < p.W)) continue;
+                    if (!(UNET_X6_ABLATE & 1024)) *reinterpret_cast<f32x4*>(ob_ + (unsigned)((pix0 + 2 * hp * p.W + 4 * (k0 + k)) * p.ldo + ch)) = v[cur][k];
+                }
                 if (STATS == 1) { s1 += v[cur][k]; s2 += v[cur][k] * v[cur][k]; }
                 if (STATS == 2) { s1 += v[cur][k]; s2 += v[cur][k] * rall[4 * hp + k0 + k]; }
             }
         }
-    }
+    };
+    if (edge) sums(std::true_type{});
+    else if (STATS != 0) sums(std::false_type{});
     X6Pending pd;
     pd.base = edge ? g_x6_sink : ob_;
     pd.off = edge ? (unsigned)lane * 16u : (unsigned)(pix0 * p.ldo + ch) * 4u;
