@@ -368,10 +368,8 @@ __device__ __forceinline__ X6Saved x6_saved(const WinoFusedArgs& p, int img, int
 }
 // (one dword per lane: eight lanes still cover each 128-byte line, and a quarter of the bytes crosses the CU's 64 B/clk vector-memory path --
 //  sixteen 16-byte touches held the wave's instruction stream for ~1 300 cycles)
-__device__ __forceinline__ void x6_touch_saved(float& scratch, const X6Saved& r) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(scratch) : "v"(r.vlane), "s"(r.srd), "s"(r.soff + (unsigned)(q >> 2) * r.rowstep + (unsigned)(q & 3) * r.colstep) : "memory");
+__device__ __forceinline__ void x6_touch_one(float& scratch, const X6Saved& r, int q) {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(scratch) : "v"(r.vlane), "s"(r.srd), "s"(r.soff + (unsigned)(q >> 2) * r.rowstep + (unsigned)(q & 3) * r.colstep) : "memory");
 }
 
 template <int STATS>
@@ -472,8 +470,10 @@ __device__ __forceinline__ void x6_write_stats(const WinoFusedArgs& p, int t0, i
 
 // Column stage of wave WV's point row at the end of a tile: z0 = m0 + m1 + m2, z1 = m1 - m2 - m3 over the row's four points, per quarter (channel
 // block qd >> 1, tile block qd & 1) of the 64 x 64 tile; the quarter this wave owns stays in registers (zown), the others go to their owners' exchange areas.
-template <int WV>
-__device__ __forceinline__ void x6_column_stage(f32x16 (&acc)[16], unsigned x_lane, float (&zown)[2][16]) {
+// TOUCH: two of the sixteen saved-activation touches go behind each of the first eight groups of sixteen accumulator reads -- issued back to back in front
+// of the stage they held the wave's instruction stream for 1 000 - 1 600 cycles.
+template <int WV, bool TOUCH>
+__device__ __forceinline__ void x6_column_stage(f32x16 (&acc)[16], unsigned x_lane, float (&zown)[2][16], float& scratch, const X6Saved& sv) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {                            // owner = wave qd
         const unsigned xw = x_lane + (unsigned)(qd * kX6XW) + (unsigned)((WV - (WV > qd ? 1 : 0)) * 8192);
@@ -497,6 +497,7 @@ __device__ __forceinline__ void x6_column_stage(f32x16 (&acc)[16], unsigned x_la
                 X6_WR128(xw, (2 * e4) * 1024, z0);
                 X6_WR128(xw, (2 * e4 + 1) * 1024, z1);
             }
+            if constexpr (TOUCH) { if (qd < 2) { x6_touch_one(scratch, sv, 2 * (4 * qd + e4)); x6_touch_one(scratch, sv, 2 * (4 * qd + e4) + 1); } }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -647,15 +648,16 @@ __device__ __forceinline__ void x6_stream_body(const X6Args& q, int ntiles) {
         asm volatile("" : "+v"(lnx));                            // (the exchange addresses are formed here: hoisted out of the tile loop they were spilled)
         const unsigned x_lane = lds0 + kX6X + (unsigned)lnx * 16u;
         float touched = 0.f;
-        if constexpr (STATS == 2) x6_touch_saved(touched, x6_saved(p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane));
+        X6Saved saved{};
+        if constexpr (STATS == 2) saved = x6_saved(p, tc.img, tc.by, tc.bx, tc.tn * 64, wv & 1, wv >> 1, lane);
         float zown[2][16];
         // (one straight-line copy per wave: with the owner test inside the loop every quarter cost two taken branches and the own quarter 32 register
         //  copies -- the accumulators are only READ here, so the four copies do not disturb their allocation)
         switch (wv) {
-            case 0: x6_column_stage<0>(acc, x_lane, zown); break;
-            case 1: x6_column_stage<1>(acc, x_lane, zown); break;
-            case 2: x6_column_stage<2>(acc, x_lane, zown); break;
-            default: x6_column_stage<3>(acc, x_lane, zown); break;
+            case 0: x6_column_stage<0, STATS == 2>(acc, x_lane, zown, touched, saved); break;
+            case 1: x6_column_stage<1, STATS == 2>(acc, x_lane, zown, touched, saved); break;
+            case 2: x6_column_stage<2, STATS == 2>(acc, x_lane, zown, touched, saved); break;
+            default: x6_column_stage<3, STATS == 2>(acc, x_lane, zown, touched, saved); break;
         }
 #if (UNET_X6_ABLATE & 8)
         long long e3, e4, e5; X6_STAMP(e3);
