@@ -26,7 +26,9 @@ apply / backward / statistics, pool, dropout, softmax-CE, Adam, first layer, cla
 tensor the pass reads or writes, once) / exclusive HIP-event time, against the guide's measured copy bandwidth (6.29 TB/s) and the 8 TB/s
 spec.  With N > 1, `distributed` carries world size, backend and -- from one traced, untimed step -- when each gradient bucket's
 all-reduce was issued and passed.  The sampled single-stream steps (one in eight) are INSIDE the timed region (they cost ~0.2 % of `value`).
-`step_executed_frac` = executed FLOPs of the whole step (3x3 Winograd layers / 2.25 + everything else) / step time / peak.
+`roofline.by_family` = [{family, ms, frac, pipe}] for every instrumented family (largest first) and `matrix_time_frac` = per matrix pipe
+the time-weighted fraction of that pipe's peak (sum of family ms x frac / sum of family ms): the whole step, not only the dominant kernel.
+The dominant kernel counts the forward and data-gradient launches of one kernel body as ONE family.
 `cpu_baseline` times the oracle's torch-CPU fp32 restatement of the same train step on the host cores (rank 0, N=1 only):
 config 2 at batch 8, 1 warm-up + 3 timed steps -- a reported baseline, not the target.
 `extra_configs` (N=1 only): short driver-visible runs of BASELINE configs 4 and 5's per-GPU workloads (bf16 512x512x3 / 4
@@ -46,7 +48,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything i
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, chip table (dense, spec)
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table: ~2.5 PF dense bf16 (spec)
-TRAFFIC_TAG = "r05"                  # profiles/<tag>_*_pmc_traffic.json of the current round
+TRAFFIC_TAGS = ("r06", "r05")        # profiles/<tag>_*_pmc_traffic.json: this round's passes, else the last round's (the file name is reported)
 WINOGRAD_MULT_RATIO = 2.25           # F(2x2,3x3): 36 direct multiplies per tile and channel pair -> 16
 
 X6_PRODUCTS = 6                      # BF16x6: six bf16 piece products per fp32-grade product (hh hm mh hl lh mm)
@@ -310,7 +312,8 @@ def run_workload(model, dev, world, rank, size, channels, classes, batch, dtype,
             peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
             kernels[key] = {"kernel": desc, "launches_per_step": len(evs) // sampled, "ms_per_step": round(ms / sampled, 3),
                             "avg_launch_ms": round(ms / len(evs), 4), "effective_tflops": round(eff, 2),
-                            "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4), "exclusive": True}
+                            "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4), "exclusive": True,
+                            "pipe": "bf16 mfma" if bf16 else "fp32 mfma"}
             if x6:
                 kernels[key]["fp32_grade_tflops"] = round(grade, 2)
                 kernels[key]["fp32_grade_vs_fp32_mfma_peak"] = round(grade / PEAK_FP32_MFMA_TFLOPS, 4)
@@ -327,41 +330,99 @@ def baseline_config_id(args, world):
     return {(512, 3, 4, 8, "bf16"): "4", (1024, 3, 6, 2, "f32"): "5"}.get(key, "custom")
 
 
-def roofline_of(kernels, workload_key):
-    """The 3x3 family with the most exclusive ms per step."""
-    cands = {k: v for k, v in kernels.items() if k in FAMILY}
-    if not cands:
-        return None
-    key = max(cands, key=lambda k: cands[k]["ms_per_step"])
-    v = cands[key]
-    desc, wino, bf16, tfile = FAMILY[key]
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    x6 = key.endswith("_x6")
-    r = {"bound": "mfma", "kernel": desc, "family": key, "achieved": v["executed_tflops"], "peak": peak, "unit": "TFLOP/s",
-         "frac": v["executed_frac"], "effective": v["effective_tflops"],
-         "flop_accounting": ("executed = 6 x algorithmic / 2.25 bf16-MFMA FLOP (Winograd F(2x2,3x3), six piece products per fp32-grade product) against the bf16 peak"
-                             if x6 else "executed = algorithmic / 2.25 (Winograd F(2x2,3x3))" if wino else "executed = algorithmic (implicit GEMM)"),
-         "launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"], "ms_per_step": v["ms_per_step"],
-         "timing": "HIP events on the launch stream, sampled timed steps, single-stream backward (exclusive)",
-         "traffic": None, "traffic_source": None}
-    if x6:
-        r["fp32_grade_tflops"] = v["fp32_grade_tflops"]
-        r["fp32_grade_vs_fp32_mfma_peak"] = v["fp32_grade_vs_fp32_mfma_peak"]
-    # offline PMC passes of this round (scripts/collect_profiles.sh): config 2 / 4 files and the config-5 ones; the file must be FOR this workload
-    for tname in (TRAFFIC_TAG + "_" + tfile, TRAFFIC_TAG + "_config5_" + tfile):
+# forward and data gradient of a route are ONE kernel body (x6_stream_body<0|1|2>, wino_fused_stream_body, conv_bf16_stream_body) launched on
+# different operands: they count as one family when the dominant kernel is chosen, so the `roofline` block cannot skip the larger half of the step
+STREAM_PAIRS = {
+    "conv3x3_stream_winograd_x6": ("conv3x3_fwd_winograd_x6", "conv3x3_dgrad_winograd_x6"),
+    "conv3x3_stream_winograd_fused": ("conv3x3_fwd_winograd_fused", "conv3x3_dgrad_winograd_fused"),
+    "conv3x3_stream_bf16": ("conv3x3_fwd_bf16", "conv3x3_dgrad_bf16"),
+}
+
+
+def _traffic_of(tfile, workload_key, launches):
+    """offline PMC passes of this round (scripts/collect_profiles.sh): config 2 / 4 files and the config-5 ones; the file must be FOR this workload"""
+    for tname in [tag + mid + tfile for tag in TRAFFIC_TAGS for mid in ("_", "_config5_")]:
         tf = os.path.join(ROOT, "profiles", tname)
         if not os.path.exists(tf):
             continue
         t = json.load(open(tf))
-        if t.get("workload") == workload_key and t.get("launches_per_step") == v["launches_per_step"]:
-            r["traffic"] = round(t["hbm_bytes_per_launch"])
-            ff = t.get("fetch_size_factor", 2.0)
-            r["traffic_source"] = "offline PMC (profiles/%s; FETCH_SIZE x%g%s + WRITE_SIZE, separate passes)" % (
-                tname, ff, " gfx950 correction" if ff == 2.0 else " (calibrated for this kernel's 16-byte gathers; the x2 reading is in the file)")
-            r["algorithmic_bytes_per_launch"] = round(t["algorithmic_bytes_per_launch"])
-            if "hbm_bytes_per_launch_fetch_x2" in t:
-                r["traffic_fetch_x2"] = round(t["hbm_bytes_per_launch_fetch_x2"])
-            break
+        if str(t.get("workload", "")).startswith(workload_key) and t.get("launches_per_step") == launches:
+            return tname, t
+    return None, None
+
+
+def family_table(kernels):
+    """[{family, ms, frac, pipe}] over every instrumented family, largest first: matrix-core families as executed FLOP/s over the dense peak
+    of THEIR pipe, HBM-bound passes as algorithmic bytes over the measured copy bandwidth."""
+    rows = []
+    for k, v in kernels.items():
+        if v.get("bound") == "hbm":
+            rows.append({"family": k, "ms": v["ms_per_step"], "frac": v["frac_of_copy_bw"], "pipe": "hbm (6.29 TB/s copy)"})
+        else:
+            rows.append({"family": k, "ms": v["ms_per_step"], "frac": round(v["executed_frac"], 4), "pipe": v.get("pipe")})
+    rows.sort(key=lambda r: -r["ms"])
+    return rows
+
+
+def matrix_time_frac(kernels):
+    """per pipe: sum(family ms x family fraction of that pipe's peak) / sum(family ms) -- the time-weighted fraction of peak over the launches
+    that run on the pipe (replaces round 5's mixed-pipe step_executed_frac, which priced bf16-pipe work against the fp32 peak)."""
+    acc = {}
+    for v in kernels.values():
+        if v.get("bound") == "hbm":
+            continue
+        a = acc.setdefault(v.get("pipe"), [0.0, 0.0])
+        a[0] += v["ms_per_step"] * v["executed_frac"]; a[1] += v["ms_per_step"]
+    return {p: {"frac": round(a[0] / a[1], 4), "ms_per_step": round(a[1], 3)} for p, a in acc.items() if a[1] > 0}
+
+
+def roofline_of(kernels, workload_key):
+    """The 3x3 KERNEL with the most exclusive ms per step; the forward and data-gradient launches of one kernel body are one candidate."""
+    cands = {}
+    for k, v in kernels.items():
+        if k not in FAMILY:
+            continue
+        pair = next((p for p, members in STREAM_PAIRS.items() if k in members), None)
+        cands.setdefault(pair or k, []).append(k)
+    if not cands:
+        return None
+    key = max(cands, key=lambda c: sum(kernels[k]["ms_per_step"] for k in cands[c]))
+    members = sorted(cands[key])
+    vs = [kernels[k] for k in members]
+    desc, wino, bf16, _ = FAMILY[members[0]]
+    if len(members) > 1:
+        desc = " + ".join(FAMILY[k][0] for k in members)
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    x6 = members[0].endswith("_x6")
+    ms = sum(v["ms_per_step"] for v in vs)
+    launches = sum(v["launches_per_step"] for v in vs)
+    wsum = lambda f: sum(v[f] * v["ms_per_step"] for v in vs) / ms          # time-weighted rate = total work / total time
+    r = {"bound": "mfma", "kernel": desc, "family": key if len(members) > 1 else members[0], "members": members,
+         "achieved": round(wsum("executed_tflops"), 2), "peak": peak, "unit": "TFLOP/s",
+         "frac": round(wsum("executed_tflops") / peak, 4), "effective": round(wsum("effective_tflops"), 2),
+         "flop_accounting": ("executed = 6 x algorithmic / 2.25 bf16-MFMA FLOP (Winograd F(2x2,3x3), six piece products per fp32-grade product) against the bf16 peak"
+                             if x6 else "executed = algorithmic / 2.25 (Winograd F(2x2,3x3))" if wino else "executed = algorithmic (implicit GEMM)"),
+         "launches_per_step": launches, "avg_launch_ms": round(ms / launches, 4), "ms_per_step": round(ms, 3),
+         "timing": "HIP events on the launch stream, sampled timed steps, single-stream backward (exclusive)",
+         "traffic": None, "traffic_source": None}
+    if x6:
+        r["fp32_grade_tflops"] = round(wsum("fp32_grade_tflops"), 2)
+        r["fp32_grade_vs_fp32_mfma_peak"] = round(wsum("fp32_grade_tflops") / PEAK_FP32_MFMA_TFLOPS, 4)
+    # HBM bytes per launch: the launch-weighted mean over the members' offline PMC files (every member needs one)
+    found = [(_traffic_of(FAMILY[k][3], workload_key, kernels[k]["launches_per_step"]), kernels[k]["launches_per_step"]) for k in members]
+    if all(t is not None for (_, t), _ in found):
+        mean = lambda f: sum(t[f] * n for (_, t), n in found) / launches
+        r["traffic"] = round(mean("hbm_bytes_per_launch"))
+        r["algorithmic_bytes_per_launch"] = round(mean("algorithmic_bytes_per_launch"))
+        ff = sorted({t.get("fetch_size_factor", 2.0) for (_, t), _ in found})
+        r["traffic_source"] = "offline PMC (%s; FETCH_SIZE x%s + WRITE_SIZE, separate passes%s)" % (
+            ", ".join("profiles/" + n for (n, _), _ in found), "/".join("%g" % f for f in ff),
+            "; gfx950 correction" if ff == [2.0] else "; x1 = calibrated for these kernels' 16-byte gathers, the x2 reading is traffic_fetch_x2")
+        if all("hbm_bytes_per_launch_fetch_x2" in t for (_, t), _ in found):
+            r["traffic_fetch_x2"] = round(mean("hbm_bytes_per_launch_fetch_x2"))
+        r["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
+    r["by_family"] = family_table(kernels)
+    r["matrix_time_frac"] = matrix_time_frac(kernels)
     return r
 
 
@@ -446,7 +507,7 @@ def main():
             "roofline": roofline_of(r["kernels"], wk), "kernels": r["kernels"],
             "step_effective_tflops_per_gpu": round(ips / nworld * total / 1e12, 2),
             "step_executed_tflops_per_gpu": round(ips / nworld * executed / 1e12, 2),
-            "step_executed_frac": round(ips / nworld * executed / 1e12 / peak, 4),
+            "matrix_time_frac": matrix_time_frac(r["kernels"]),
             "train_gflop_per_image": round(total / 1e9, 2), "final_loss": round(r["final_loss"], 6),
             "sampled_steps": r["sampled_steps"],
         }
@@ -491,6 +552,8 @@ def main():
                 r2 = e.get("roofline") or {}
                 compact.append({"id": e["id"], "img_s": round(e["value"], 1), "ms": e["ms_per_step"], "roofline_frac": r2.get("frac"),
                                 "roofline_family": r2.get("family")})
+        compact[0]["roofline_by_family"] = [f for f in (rf.get("by_family") or []) if "mfma" in (f.get("pipe") or "")]
+        compact[0]["matrix_time_frac"] = rf.get("matrix_time_frac")
         out["config"]["measured"] = "; ".join("%s: %.1f img/s" % (c["id"], c["img_s"]) for c in compact)
         out["configs"] = compact
         out.update(s)
