@@ -178,10 +178,16 @@ __device__ __forceinline__ void cb_compute(f32x16 (&acc)[4][NCO], unsigned a_bas
 // the partial-sum buffer.
 // B16 = 1: the output and the saved activation are known to be bf16 tensors at compile time (the fp32 variants of the loads and
 // stores, and the uniform branches that choose between them per store, drop out).
-template <int NCO, int STATS, int B16 = 0>
+// EDGE = 0: the tile lies inside the image (every BASELINE shape: H % 16 == 0, W % 32 == 0) -- the per-column / per-row selects drop out
+// (they were 588 of the 2550 vector instructions of a 128-channel tile's backward-sums epilogue).
+// The bias is NOT added here: the accumulators start at the bias (cb_init_acc), which takes the place of their zero fill.
+template <int NCO, int STATS, int B16 = 0, int EDGE = 1>
 __device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)[4][NCO], int img, int ty0, int tx0, int co0, int row,
                                             float* red, int tid, int wv, int li, int lh) {
     constexpr int CT = 32 * NCO;
+    // (every per-lane offset below is a function of the lane alone once the edge selects are gone: pinned here, or the compiler hoists ~40
+    // of them out of a persistent caller's tile loop and spills the DMA source pointers of the chunk loop instead)
+    if (!EDGE) asm volatile("" : "+v"(li), "+v"(lh));
     const bool out16 = B16 || p.out16, r16 = B16 || p.r16;
     // epilogue: accumulator register e of (row r, sub-tile c) = pixel (ty0 + 4 wv + r, tx0 + (e&3) + 8 (e>>2) + 4 lh), channel
     // co0 + NCO li + c (see the weight image): one buffer store per pixel and lane.  The 16 per-lane offsets (column, channel
@@ -191,7 +197,8 @@ __device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)
     // in a same-box A/B -- 64 basic blocks instead of one straight store stream -- and was dropped.)
     typedef unsigned ovec_t __attribute__((ext_vector_type(NCO)));
     typedef unsigned hvec_t __attribute__((ext_vector_type(NCO / 2)));
-    float st1[NCO], st2[NCO], bv[NCO];
+    float st1[NCO], st2[NCO];
+    f32x2 st1p[NCO / 2], st2p[NCO / 2];                               // EDGE 0: the same sums, a channel pair per register pair
     const int oes = out16 ? 2 : 4, res = r16 ? 2 : 4;
     const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.N * p.H * p.W * p.ldo * oes), 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(STATS == 2 ? p.bn_r : p.out), 0,
@@ -207,10 +214,10 @@ __device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)
     // inside the image is uniform up to the half-wave (both halves / only lh = 0 / none): a select between three registers
     const int vr = with_r ? (4 * lh * p.bn_ldr + (cl - p.bn_c0)) * res : (int)0x80000000, vr_lo = lh ? (int)0x80000000 : vr;
     const int wrem = p.W - tx0;
-    auto r_voff = [&](int e) { const int c0 = (e & 3) + 8 * (e >> 2); return c0 + 4 < wrem ? vr : (c0 < wrem ? vr_lo : (int)0x80000000); };
-    const float lo = p.relu ? 0.f : -INFINITY;
+    auto r_voff = [&](int e) { const int c0 = (e & 3) + 8 * (e >> 2); return !EDGE || c0 + 4 < wrem ? vr : (c0 < wrem ? vr_lo : (int)0x80000000); };
+    const float lo = p.relu ? 0.f : -INFINITY;                        // (STATS 2 is the data gradient: no bias, no ReLU -- not even the v_max)
 #pragma unroll
-    for (int c = 0; c < NCO; ++c) { bv[c] = p.bias ? p.bias[cl + c] : 0.f; st1[c] = 0.f; st2[c] = 0.f; }
+    for (int c = 0; c < NCO; ++c) { st1[c] = 0.f; st2[c] = 0.f; st1p[c >> 1] = f32x2{0.f, 0.f}; st2p[c >> 1] = f32x2{0.f, 0.f}; }
     // STATS 2 with a bf16 saved activation (the default storage): the 16 loads of a row are issued TWO rows ahead of the row being
     // written (rows 0 and 1 before any arithmetic, row r + 2 before row r is processed), so the memory latency is paid about once
     // per tile instead of eight times -- the per-row half-batches of the fp32 path below cost 0.24 ms of a 0.50 ms launch on
@@ -220,10 +227,10 @@ __device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)
     const bool hoist = STATS == 2 && r16 && !(UNET_CB_ABLATE & 2);
     auto issue_row = [&](int r) {
         const int gy = ty0 + 4 * wv + r;
-        const int sr = ((img * p.H + (gy < p.H ? gy : 0)) * p.W + tx0) * p.bn_ldr * 2;
+        const int sr = ((img * p.H + (!EDGE || gy < p.H ? gy : 0)) * p.W + tx0) * p.bn_ldr * 2;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int vofs = gy < p.H ? r_voff(e) : (int)0x80000000, so_e = sr + ((e & 3) + 8 * (e >> 2)) * p.bn_ldr * 2;
+            const int vofs = !EDGE || gy < p.H ? r_voff(e) : (int)0x80000000, so_e = sr + ((e & 3) + 8 * (e >> 2)) * p.bn_ldr * 2;
             if constexpr (NCO == 4) rvh[r % RING][e] = __builtin_amdgcn_raw_buffer_load_b64(srd_r, vofs, so_e, 0);
             else                    rvh[r % RING][e][0] = __builtin_amdgcn_raw_buffer_load_b32(srd_r, vofs, so_e, 0);
         }
@@ -235,7 +242,7 @@ __device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gy = ty0 + 4 * wv + r;
-        const bool row_ok = gy < p.H;                                                // uniform per wave
+        const bool row_ok = !EDGE || gy < p.H;                                       // uniform per wave
         const int pix0 = (img * p.H + gy) * p.W + tx0;
         const int so = (pix0 * p.ldo + co0) * oes;
         if (hoist && r + RING - 1 < 4) issue_row(r + RING - 1);
@@ -281,14 +288,27 @@ __device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)
 #pragma unroll
             for (int e8 = 0; e8 < 8; ++e8) {
                 const int e = 8 * eh + e8, ce = (e & 3) + 8 * (e >> 2);
-                const bool colok = ce < wlim;
+                const bool colok = !EDGE || ce < wlim;
                 float v[NCO];
 #pragma unroll
                 for (int c = 0; c < NCO; ++c) {
                     asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[r][c][e]));
-                    v[c] = fmaxf(v[c] + bv[c], lo);
-                    if (STATS == 1 && colok) { st1[c] += v[c]; st2[c] += v[c] * v[c]; }
-                    if (STATS == 2 && colok) { st1[c] += v[c]; st2[c] += v[c] * rv[e8][c]; }
+                    // (an asm v_max: fmaxf() on a value the compiler cannot see through is preceded by a canonicalising v_max v, v, v)
+                    if (STATS != 2) asm("v_max_f32 %0, %1, %2" : "=v"(v[c]) : "v"(v[c]), "v"(lo));
+                    if (EDGE && STATS == 1 && colok) { st1[c] += v[c]; st2[c] += v[c] * v[c]; }
+                    if (EDGE && STATS == 2 && colok) { st1[c] += v[c]; st2[c] += v[c] * rv[e8][c]; }
+                }
+                if (!EDGE && STATS != 0) {
+                    // interior tiles: the sums of a channel PAIR as packed fp32 instructions, written out -- left to itself the compiler pairs the
+                    // unconditional updates too, but across pixels, and keeps a row of values alive for it (scratch traffic inside the chunk loop)
+#pragma unroll
+                    for (int c = 0; c < NCO; c += 2) {
+                        f32x2 vv = {v[c], v[c + 1]};
+                        f32x2 ww = vv;
+                        if (STATS == 2) { ww[0] = rv[e8][c]; ww[1] = rv[e8][c + 1]; }
+                        asm("v_pk_add_f32 %0, %0, %1" : "+v"(st1p[c >> 1]) : "v"(vv));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(st2p[c >> 1]) : "v"(vv), "v"(ww));
+                    }
                 }
                 if ((UNET_CB_ABLATE & 1) && v[0] != 1.2345e38f) continue;
                 const int ovoff = colok ? vo + (so + ce * p.ldo * oes) : (int)0x80000000;
@@ -314,6 +334,7 @@ __device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)
         // stat_part[channel / 64][row = pixel tile][channel % 64][2]
 #pragma unroll
         for (int c = 0; c < NCO; ++c) {
+            if (!EDGE) { st1[c] = st1p[c >> 1][c & 1]; st2[c] = st2p[c >> 1][c & 1]; }
             st1[c] += __shfl_xor(st1[c], 32); st2[c] += __shfl_xor(st2[c], 32);
             if (lh == 0) { red[((wv * 32 + li) * NCO + c) * 2] = st1[c]; red[((wv * 32 + li) * NCO + c) * 2 + 1] = st2[c]; }
         }
@@ -327,6 +348,23 @@ __device__ __forceinline__ void cb_epilogue(const ConvBf16Args& p, f32x16 (&acc)
             o[0] = a; o[1] = b;
         }
     }
+}
+
+// Accumulators of a tile start at the bias of their output channel (lane li, sub-tile c: channel co0 + NCO li + c) instead of at zero: the
+// 256 (128) v_accvgpr_write of the fill are there anyway, and the epilogue loses as many v_add.
+template <int NCO>
+__device__ __forceinline__ void cb_init_acc(f32x16 (&acc)[4][NCO], const float (&bv)[NCO]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                // (written as the instruction: a plain `acc = bv` is 256 VGPR copies to the register allocator, which spills them)
+                float t;
+                asm("v_accvgpr_write_b32 %0, %1" : "=a"(t) : "v"(bv[c]));
+                acc[r][c][e] = t;
+            }
 }
 
 // NORM: BatchNorm-apply on load.  The input tensor is the producer layer's conv output r (pre-BatchNorm), and the staging path forms
@@ -454,16 +492,15 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
         for (int j = 0; j < 10; ++j) write_x1(stage, j);
     };
 
-    f32x16 acc[4][NCO];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < NCO; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
-
     // diagnostic builds (scripts/build_variant.sh): bit 0 = no epilogue stores, bit 1 = no saved-activation loads in the STATS 2
     // epilogue, bit 2 = no chunk loop, bit 3 = no prologue loads
+    f32x16 acc[4][NCO];
+    {
+        float bv[NCO];
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) bv[c] = (STATS != 2 && p.bias) ? p.bias[co0 + NCO * li + c] : 0.f;
+        cb_init_acc<NCO>(acc, bv);
+    }
     if (!(UNET_CB_ABLATE & 8)) { issue_x(0); issue_w(0, 0); }
     write_x(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -521,7 +558,8 @@ __device__ __forceinline__ void conv_bf16_body(const ConvBf16Args& p) {
 // 0..4 is worth 1-3 % (kept: see fill), so it is not mainly back-to-back issue either.
 __device__ __attribute__((aligned(256))) uint16_t g_zero_page_b[4096 + 64];       // zero source that out-of-image patch pixels walk over (per channel)
 
-template <int NCO, int STATS>
+// EDGE = 0: H % 16 == 0 and W % 32 == 0 -- no tile crosses the image border, the epilogue's per-column selects are compiled out (cb_epilogue)
+template <int NCO, int STATS, int EDGE = 1>
 __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
     constexpr int CT = 32 * NCO;
     constexpr int WB = 18 * CT * 16;
@@ -617,6 +655,19 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
 
     const int G = (int)gridDim.x;
     Tile cur = tile_at((int)blockIdx.x);
+    // bias of a tile's output channels: loaded one tile ahead by asm statements (a builtin load would be sunk to its use, behind the epilogue)
+    // and complete at the vmcnt(0) that closes the chunk it was issued in
+    float bnx[NCO];
+    auto load_bias = [&](const Tile& c) {
+#pragma unroll
+        for (int k = 0; k < NCO; ++k) bnx[k] = 0.f;
+        if (STATS != 2 && p.bias) {
+            const float* bp = p.bias + c.co0 + NCO * li;
+#pragma unroll
+            for (int k = 0; k < NCO; ++k) asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(bnx[k]) : "v"(bp), "n"(4 * k) : "memory");
+        }
+    };
+    load_bias(cur);
     {
         const Src s0 = sources(cur);
 #pragma unroll
@@ -629,11 +680,8 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
                                                                      // rather than kept in registers across the epilogue
         f32x16 acc[4][NCO];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < NCO; ++c)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+        for (int k = 0; k < NCO; ++k) asm volatile("" : "+v"(bnx[k]));      // (uses stay behind the wait that completed the loads)
+        cb_init_acc<NCO>(acc, bnx);
         for (int c = 0; c < nchunks; c += 2) {                       // Cin % 32 == 0: an even number of chunks, chunk c lives in stage c & 1
             if (UNET_CBS_ABLATE & 2) { for (int g = 0; g < 18; ++g) fill(sf, c + 1, 1, g); }
             else cb_compute<NCO, 0, STAGE, 1>(acc, a_base, b_base, [&](int g) { fill(sf, c + 1, 1, g); }, asel, amask);
@@ -642,13 +690,15 @@ __device__ __forceinline__ void conv_bf16_stream_body(const ConvBf16Args& p) {
             if (cn == nchunks) {                                     // the stream continues with chunk 0 of the workgroup's next tile
                 cn = 0;                                              // (after the last tile: chunk 0 of this one again -- valid memory, never read)
                 if (logical + G < total) { nxt = tile_at(logical + G); sf = sources(nxt); }
+                load_bias(nxt);                                      // lands with this chunk's DMA (vmcnt(0) below)
             }
             if (UNET_CBS_ABLATE & 2) { for (int g = 0; g < 18; ++g) fill(sf, cn, 0, g); }
             else cb_compute<NCO, 1, STAGE, 1>(acc, a_base, b_base, [&](int g) { fill(sf, cn, 0, g); }, asel, amask);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        if (!(UNET_CBS_ABLATE & 4)) cb_epilogue<NCO, STATS, 1>(p, acc, cur.img, cur.ty0, cur.tx0, cur.co0, cur.t % p.n_px, red, tid, wv, li, lh);
+        // (one epilogue per kernel: a uniform branch between an interior and an edge copy made the allocator stage the accumulators through scratch)
+        if (!(UNET_CBS_ABLATE & 4)) cb_epilogue<NCO, STATS, 1, EDGE>(p, acc, cur.img, cur.ty0, cur.tx0, cur.co0, cur.t % p.n_px, red, tid, wv, li, lh);
         cur = nxt;
     }
 }
@@ -669,6 +719,13 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_stream_stats_kernel_128(Conv
 __global__ __launch_bounds__(256, 2) void conv_bf16_stream_stats_kernel_64(ConvBf16Args p) { conv_bf16_stream_body<2, 1>(p); }
 __global__ __launch_bounds__(256, 1) void conv_bf16_stream_bnbwd_kernel_128(ConvBf16Args p) { conv_bf16_stream_body<4, 2>(p); }
 __global__ __launch_bounds__(256, 2) void conv_bf16_stream_bnbwd_kernel_64(ConvBf16Args p) { conv_bf16_stream_body<2, 2>(p); }
+// ... and for images whose tiles all lie inside (every BASELINE shape)
+__global__ __launch_bounds__(256, 1) void conv_bf16_stream_in_kernel_128(ConvBf16Args p) { conv_bf16_stream_body<4, 0, 0>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_stream_in_kernel_64(ConvBf16Args p) { conv_bf16_stream_body<2, 0, 0>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_stream_in_stats_kernel_128(ConvBf16Args p) { conv_bf16_stream_body<4, 1, 0>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_stream_in_stats_kernel_64(ConvBf16Args p) { conv_bf16_stream_body<2, 1, 0>(p); }
+__global__ __launch_bounds__(256, 1) void conv_bf16_stream_in_bnbwd_kernel_128(ConvBf16Args p) { conv_bf16_stream_body<4, 2, 0>(p); }
+__global__ __launch_bounds__(256, 2) void conv_bf16_stream_in_bnbwd_kernel_64(ConvBf16Args p) { conv_bf16_stream_body<2, 2, 0>(p); }
 // forward with BatchNorm-apply on load (NORM)
 __global__ __launch_bounds__(256, 1) void conv_bf16_norm_kernel_128(ConvBf16Args p) { conv_bf16_body<4, 0, 1>(p); }
 __global__ __launch_bounds__(256, 2) void conv_bf16_norm_kernel_64(ConvBf16Args p) { conv_bf16_body<2, 0, 1>(p); }
@@ -734,6 +791,12 @@ int run_conv_bf16(const float* x, int ldx, const void* wp, const float* bias, fl
         // persistent form: one resident wave of workgroups walks the tiles (the grid is the whole tile count when that is smaller)
         const long slots = (long)unet_grid_slots(conv_bf16_cus(), max_workgroups) * (wide ? 1 : 2);
         const dim3 pgrid((unsigned)((long)grid.x < slots ? (long)grid.x : slots));
+        if (H % 16 == 0 && W % 32 == 0) {
+            if (mode == 0) { if (wide) conv_bf16_stream_in_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_in_kernel_64<<<pgrid, 256, 0, st>>>(a); }
+            else if (mode == 1) { if (wide) conv_bf16_stream_in_stats_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_in_stats_kernel_64<<<pgrid, 256, 0, st>>>(a); }
+            else { if (wide) conv_bf16_stream_in_bnbwd_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_in_bnbwd_kernel_64<<<pgrid, 256, 0, st>>>(a); }
+            return UNET_LAUNCH_STATUS();
+        }
         if (mode == 0) { if (wide) conv_bf16_stream_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_kernel_64<<<pgrid, 256, 0, st>>>(a); }
         else if (mode == 1) { if (wide) conv_bf16_stream_stats_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_stats_kernel_64<<<pgrid, 256, 0, st>>>(a); }
         else { if (wide) conv_bf16_stream_bnbwd_kernel_128<<<pgrid, 256, 0, st>>>(a); else conv_bf16_stream_bnbwd_kernel_64<<<pgrid, 256, 0, st>>>(a); }
