@@ -62,8 +62,8 @@ FAMILY = {   # engine profile key -> (kernel description, winograd?, bf16 matrix
     "conv3x3_fwd_winograd_fused": ("wino_fused_stream_stats_kernel (3x3 conv forward + BatchNorm sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "wino_fwd_pmc_traffic.json"),
     "conv3x3_dgrad_winograd_fused": ("wino_fused_stream_kernel / _bnstats (3x3 conv data gradient + producer BatchNorm-backward sums, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)", True, False, "wino_dgrad_pmc_traffic.json"),
     "conv3x3_wgrad_winograd_fused": ("wino_wgrad_fused_kernel (3x3 conv weight gradient, Winograd F(2x2,3x3), reduce over tiles on v_mfma_f32_32x32x2_f32)", True, False, "wino_wgrad_pmc_traffic.json"),
-    "conv3x3_fwd_bf16": ("conv_bf16_stream_stats_kernel_{128,64} (3x3 conv forward + BatchNorm sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "bf16_fwd_pmc_traffic.json"),
-    "conv3x3_dgrad_bf16": ("conv_bf16_stream_bnbwd_kernel_{128,64} (3x3 conv data gradient + producer BatchNorm-backward sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "bf16_dgrad_pmc_traffic.json"),
+    "conv3x3_fwd_bf16": ("conv_bf16_stream[_in]_stats_kernel_{128,64} (3x3 conv forward + BatchNorm sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "bf16_fwd_pmc_traffic.json"),
+    "conv3x3_dgrad_bf16": ("conv_bf16_stream[_in]_bnbwd_kernel_{128,64} (3x3 conv data gradient + producer BatchNorm-backward sums, persistent implicit GEMM on v_mfma_f32_32x32x16_bf16)", False, True, "bf16_dgrad_pmc_traffic.json"),
     "conv3x3_wgrad_bf16": ("wgrad_bf16_dma_kernel (3x3 conv weight gradient, pixel contraction on v_mfma_f32_32x32x16_bf16, LDS-DMA staging)", False, True, "bf16_wgrad_pmc_traffic.json"),
 }
 

@@ -28,10 +28,11 @@ extern "C" {
 #define UNET_ENOSPC (-2)
 
 /* Bumped whenever an exported signature changes; a loader must refuse a library whose unet_hip_abi_version() differs
- * (7: round 5 -- no signature changed, but the operand unet_winograd_weight_transform_x6 / _fold_x6 write is laid out for the round-5 kernel
+ * (8: round 6 -- + unet_bn_finalize_apply_any (statistics finalize merged into the apply launch); the bf16 3x3 kernels start their accumulators at the bias;
+ *  7: round 5 -- no signature changed, but the operand unet_winograd_weight_transform_x6 / _fold_x6 write is laid out for the round-5 kernel
  *  (MFMA A-operand order per 64-channel tile, chunk and point row): an operand and the conv entry point that reads it must come from one library;
  *  6: round 4 -- unet_convT2x2_*_x6; 5: round 4 -- the `_wg` (max_workgroups) entry points of every persistent kernel, unet_standin_collective; 4: round 4 -- the BF16x6 Winograd route: unet_*_x6; 3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
-#define UNET_HIP_ABI_VERSION 7
+#define UNET_HIP_ABI_VERSION 8
 int unet_hip_abi_version(void);
 
 /* ---- Conv2D(3x3, 'same', relu) of UNet._conv_layer, UNet/model.py:28-35 (18 instances, :88-134) ------------------ */
@@ -270,6 +271,17 @@ int unet_bn_bwd_bias(const void* ws, int rows, int C, float* dbias, void* stream
  * (y_bf16: y and pooled) stored as bf16 */
 int unet_bn_apply_any(const void* r, int ldr, int r_bf16, const float* scale, const float* shift, void* y, int ldy, int y_bf16,
                       void* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream);
+/* unet_bn_train_finalize_partials + unet_bn_apply_any in ONE launch (round 6; UNet/model.py:36,47 -- the BatchNormalization of every layer
+ * whose conv left fused partial sums): workgroup b of the apply grid first finalizes channels b, b + grid, ... with the finalize kernel's own
+ * arithmetic (bit-identical mean / invstd / scale / shift / moving statistics), publishes them and every workgroup waits on `counter` until all
+ * C channels are there.  `counter`: one device word owned by this call sequence (zero before the first call); `counter_target` = the value it
+ * must reach = (sum of C over all earlier calls on this counter) + C modulo 2^32 -- the caller keeps the running sum, so the library holds no
+ * state.  scale / shift are written, then read, by this launch. */
+int unet_bn_finalize_apply_any(const float* part, int rows, const float* gamma, const float* beta, float eps, float momentum,
+                               int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd,
+                               uint32_t* counter, uint32_t counter_target,
+                               const void* r, int ldr, int r_bf16, float* scale, float* shift, void* y, int ldy, int y_bf16,
+                               void* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int unet_bn_bwd_from_partials(const float* dy, int lddy, const float* r, int ldr, const float* gamma, const float* mean,
                               const float* invstd, long P, int C, int relu, float* dz, int lddz, float* dgamma, float* dbeta,
                               float* dbias, const float* part_sums, int rows, void* ws, size_t ws_bytes, void* stream);

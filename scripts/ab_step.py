@@ -1,5 +1,6 @@
 """Same-box A/B of the training step between library builds: alternating short `bench.py` runs, one process per run (UNET_HIP_LIB selects the
-build; `-` = the in-tree library).  usage: ab_step.py <bf16|f32> <rounds> name=lib.so [name=lib.so ...] [-- extra bench.py flags]
+build; `-` = the in-tree library; `name=lib.so;VAR=value;...` also sets UNET_* diagnostics variables for that leg, e.g.
+`off=-;UNET_MERGE_BN_FINALIZE=0`).  usage: ab_step.py <bf16|f32> <rounds> name=spec [name=spec ...] [-- extra bench.py flags]
 Prints one line per run and the per-build mean / min / max of ms per step."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +15,9 @@ for r in range(rounds):
     for name, path in builds:
         env = dict(os.environ)
         env.pop("UNET_HIP_LIB", None)
+        path, *sets = path.split(";")
+        for kv in sets:
+            k, v = kv.split("=", 1); env[k] = v
         if path != "-":
             env["UNET_HIP_LIB"] = os.path.join(ROOT, path)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "8", "--no-extra", "--no-cpu-baseline",

@@ -52,8 +52,8 @@ python3 scripts/pmc_traffic.py $ff $fw wino_x6_stream_bnbwd_kernel,wino_x6_strea
 python3 scripts/pmc_traffic.py $nf $nw wino_fused_stream_stats_kernel 17 "512x512x1/2 classes/batch 8/f32 (native fp32 MFMA)" $A32 > $out/${tag}_wino_fwd_pmc_traffic.json
 python3 scripts/pmc_traffic.py $nf $nw wino_fused_stream_bnbwd_kernel,wino_fused_stream_kernel 17 "512x512x1/2 classes/batch 8/f32 (native fp32 MFMA)" $A32 > $out/${tag}_wino_dgrad_pmc_traffic.json
 python3 scripts/pmc_traffic.py $ff $fw wino_wgrad_fused_kernel 17 "512x512x1/2 classes/batch 8/f32" $A32 > $out/${tag}_wino_wgrad_pmc_traffic.json
-python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_stats_kernel,conv_bf16_stats_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 1 > $out/${tag}_bf16_fwd_pmc_traffic.json
-python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_bnbwd_kernel,conv_bf16_bnbwd_kernel,conv_bf16_stream_kernel_,conv_bf16_kernel_ 17 "512x512x3/4 classes/batch 8/bf16" $A16 1 > $out/${tag}_bf16_dgrad_pmc_traffic.json
+python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_stats_kernel,conv_bf16_stream_in_stats_kernel,conv_bf16_stats_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 1 > $out/${tag}_bf16_fwd_pmc_traffic.json
+python3 scripts/pmc_traffic.py $bf $bw conv_bf16_stream_bnbwd_kernel,conv_bf16_stream_in_bnbwd_kernel,conv_bf16_bnbwd_kernel,conv_bf16_stream_kernel_,conv_bf16_stream_in_kernel_,conv_bf16_kernel_ 17 "512x512x3/4 classes/batch 8/bf16" $A16 1 > $out/${tag}_bf16_dgrad_pmc_traffic.json
 python3 scripts/pmc_traffic.py $bf $bw ::wgrad_bf16_dma_kernel,::wgrad_bf16_kernel 17 "512x512x3/4 classes/batch 8/bf16" $A16 > $out/${tag}_bf16_wgrad_pmc_traffic.json
 fi
 if [[ $stages == *3* ]]; then

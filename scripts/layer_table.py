@@ -18,7 +18,8 @@ batch = int(sys.argv[6]) if len(sys.argv) > 6 else 8
 fams = {"f32": {"fwd": ["wino_x6_stream_stats_kernel"], "dgrad": ["wino_x6_stream_bnbwd_kernel", "wino_x6_stream_kernel"], "wgrad": ["wino_wgrad_fused_kernel"]},
         "f32native": {"fwd": ["wino_fused_stream_stats_kernel", "wino_fused_stats_kernel"], "dgrad": ["wino_fused_stream_bnbwd_kernel", "wino_fused_stream_kernel", "wino_fused_bnbwd_kernel", "wino_fused_kernel"],
                 "wgrad": ["wino_wgrad_fused_kernel"]},
-        "bf16": {"fwd": ["conv_bf16_stream_stats_kernel", "conv_bf16_stats_kernel"], "dgrad": ["conv_bf16_stream_bnbwd_kernel", "conv_bf16_stream_kernel_", "conv_bf16_bnbwd_kernel", "conv_bf16_kernel_"],
+        "bf16": {"fwd": ["conv_bf16_stream_stats_kernel", "conv_bf16_stream_in_stats_kernel", "conv_bf16_stats_kernel"],
+                 "dgrad": ["conv_bf16_stream_bnbwd_kernel", "conv_bf16_stream_kernel_", "conv_bf16_stream_in_bnbwd_kernel", "conv_bf16_stream_in_kernel_", "conv_bf16_bnbwd_kernel", "conv_bf16_kernel_"],
                  "wgrad": ["::wgrad_bf16_dma_kernel", "::wgrad_bf16_kernel"]}}[dtype]
 rows = {}
 for r in csv.DictReader(open(path)):

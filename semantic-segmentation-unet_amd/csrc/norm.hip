@@ -234,6 +234,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_partials_kernel(const flo
     }
 }
 
+__global__ void counter_add_kernel(unsigned* counter, unsigned n) { atomicAdd(counter, n); }
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float eps,
                                       int C, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,16 +245,79 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     scale[c] = (float)a; shift[c] = (float)((double)beta[c] - (double)mm[c] * a);
 }
 
+// ---- BatchNorm finalize merged into its consumer's launch (round 6: the small-launch A/B) --------------------------------------------
+// The statistics finalize (rows of partial sums -> mean / invstd / scale / shift / moving statistics) is a <= 7 us kernel between the conv
+// that leaves the partials and the apply pass that needs the coefficients: two launch boundaries on the forward chain per layer.  Merged:
+// workgroup b of the APPLY grid first finalizes channels b, b + grid, ... (the same arithmetic, thread for thread, as
+// bn_train_finalize_partials_kernel -- results are bit-identical), publishes them (release fence + one atomic add on a device counter) and
+// every workgroup waits until the counter shows all C channels before it reads its coefficients.  Finalizing workgroups never wait for a
+// non-finalizing one and have the lowest indices (dispatched first), so the wait cannot deadlock even if the grid is not fully resident.
+// The counter only grows: the host passes the value it must reach (previous target + C), compared modulo 2^32.
+struct BnFin {
+    const float* part; int rows; long P; const float* gamma; const float* beta; float eps, momentum; int unbiased;
+    float* moving_mean; float* moving_var; float* mean; float* invstd; unsigned* counter; unsigned target;
+};
+
+__device__ __forceinline__ void bn_finalize_then_wait(const BnFin& f, int C, float* scale, float* shift) {
+    __shared__ double sh[4][2];
+    int done = 0;
+    for (int c = blockIdx.x; c < C; c += gridDim.x, ++done) {
+        const float* base = f.part + ((size_t)(c >> 6) * f.rows * 64 + (c & 63)) * 2;
+        double s = 0.0, ss = 0.0;
+        for (int k = threadIdx.x; k < f.rows; k += 256) { const float2 v = *reinterpret_cast<const float2*>(base + (size_t)k * 128); s += (double)v.x; ss += (double)v.y; }
+        s = wave_sum(s); ss = wave_sum(ss);
+        __syncthreads();                                   // (sh is reused per channel)
+        if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = s; sh[threadIdx.x >> 6][1] = ss; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s = ((sh[0][0] + sh[1][0]) + sh[2][0]) + sh[3][0]; ss = ((sh[0][1] + sh[1][1]) + sh[2][1]) + sh[3][1];
+            const double m = s / (double)f.P;
+            double var = ss / (double)f.P - m * m;
+            if (var < 0.0) var = 0.0;
+            const double inv = 1.0 / sqrt(var + (double)f.eps);
+            f.mean[c] = (float)m; f.invstd[c] = (float)inv;
+            const double a = (double)f.gamma[c] * inv;
+            // the two values other workgroups of THIS launch read: device-scope stores (written through to where every XCD sees them)
+            __hip_atomic_store(scale + c, (float)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(shift + c, (float)((double)f.beta[c] - m * a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f.moving_mean) {
+                const double uv = (f.unbiased && f.P > 1) ? var * ((double)f.P / (double)(f.P - 1)) : var;
+                f.moving_mean[c] = (float)((double)f.moving_mean[c] * f.momentum + m * (1.0 - (double)f.momentum));
+                f.moving_var[c] = (float)((double)f.moving_var[c] * f.momentum + uv * (1.0 - (double)f.momentum));
+            }
+        }
+    }
+    // No agent-scope fences: a release fence writes back this XCD's whole L2 (the conv output of a moment ago is still dirty in it) and an
+    // acquire in the spin loop invalidates it -- the first cut of this function did both and cost +190 us per launch.  The published values
+    // are device-scope stores, complete (s_waitcnt) before the count moves; readers take them with device-scope loads (bn_coef_load).
+    if (threadIdx.x == 0) {
+        if (done) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_fetch_add(f.counter, (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        while ((int)(__hip_atomic_load(f.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - f.target) < 0) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+}
+
+// coefficients of a lane: plain loads, or -- after a merged finalize in the same launch -- device-scope loads
+template <int VEC> __device__ __forceinline__ void bn_coef_load(float (&v)[VEC], const float* p, bool coherent) {
+    if (!coherent) { vload<VEC>(v, p); return; }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // y = scale * r + shift.  A lane owns one channel group (its scale / shift live in registers) and walks pixels with a grid-wide
 // stride, four pixels per step so that four 16-byte loads are in flight per lane: with one load in flight (the round-1 form, a flat
 // index loop) these passes were latency-bound at ~3.2 TB/s.  flags: bit 0 = y stored as bf16, bit 1 = r stored as bf16.
 template <int VEC>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
-        const float* __restrict__ shift, float* __restrict__ y, int ldy, long P, int C, int tpp, int out16) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ r, int ldr, const float* scale,
+        const float* shift, float* __restrict__ y, int ldy, long P, int C, int tpp, int out16, BnFin fin) {
+    if (fin.part) bn_finalize_then_wait(fin, C, const_cast<float*>(scale), const_cast<float*>(shift));
     const Lay l = make_lay<VEC>(C, tpp);
     if (!l.active) return;
     float a[VEC], b[VEC];
-    vload<VEC>(a, scale + l.c0); vload<VEC>(b, shift + l.c0);
+    bn_coef_load<VEC>(a, scale + l.c0, fin.part != nullptr); bn_coef_load<VEC>(b, shift + l.c0, fin.part != nullptr);
     const long S = (long)gridDim.x * l.npl;
     long pix = (long)blockIdx.x * l.npl + l.pl;
     for (; pix + 3 * S < P; pix += 4 * S) {
@@ -295,15 +360,16 @@ __global__ __launch_bounds__(256) void bn_apply_flat_kernel(const float* __restr
 // one pooled pixel x channel quad: reads the 4 r values, writes the 4 normalised values (the skip tensor) and their first-max
 // (row-major window order, the reference's tie rule) + its index -- the skip tensor is not read back for pooling.
 template <int VEC>
-__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ scale,
-        const float* __restrict__ shift, float* __restrict__ y, int ldy, float* __restrict__ pooled, int ldp, uint8_t* __restrict__ idx,
-        int N, int H, int W, int C, int tpp, int out16) {
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ r, int ldr, const float* scale,
+        const float* shift, float* __restrict__ y, int ldy, float* __restrict__ pooled, int ldp, uint8_t* __restrict__ idx,
+        int N, int H, int W, int C, int tpp, int out16, BnFin fin) {
+    if (fin.part) bn_finalize_then_wait(fin, C, const_cast<float*>(scale), const_cast<float*>(shift));
     const Lay l = make_lay<VEC>(C, tpp);
     if (!l.active) return;
     const int H2 = H / 2, W2 = W / 2;
     const long total = (long)N * H2 * W2, S = (long)gridDim.x * l.npl;
     float a[VEC], b[VEC];
-    vload<VEC>(a, scale + l.c0); vload<VEC>(b, shift + l.c0);
+    bn_coef_load<VEC>(a, scale + l.c0, fin.part != nullptr); bn_coef_load<VEC>(b, shift + l.c0, fin.part != nullptr);
     for (long opix = (long)blockIdx.x * l.npl + l.pl; opix < total; opix += S) {
         long t = opix; const int ox = (int)(t % W2); t /= W2; const int oy = (int)(t % H2); const int n = (int)(t / H2);
         float best[VEC]; uint8_t bi[VEC];
@@ -864,7 +930,8 @@ int apply16_grid(size_t smem) { static int g = 0; if (!g) g = resident_grid(bn_b
 
 // BatchNorm apply (+ 2x2 max pool when pooled != null) for any storage mix; picks the lane layout
 int launch_bn_apply(const float* r, int ldr, int r16, const float* scale, const float* shift, float* y, int ldy, int y16,
-                    float* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, hipStream_t st) {
+                    float* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, hipStream_t st, const BnFin* finp = nullptr) {
+    BnFin fin{}; if (finp) fin = *finp;
     const int flags = (y16 ? 1 : 0) | (r16 ? 2 : 0);
     const long P = (long)N * H * W;
     const bool al = unet_aligned16(r) && unet_aligned16(y) && unet_aligned16(scale) && unet_aligned16(shift) && (!pooled || unet_aligned16(pooled));
@@ -879,17 +946,18 @@ int launch_bn_apply(const float* r, int ldr, int r16, const float* scale, const 
         if (!lanes || vec < 4) return UNET_EINVAL;
         const long total = (long)N * (H / 2) * (W / 2), npl = 256 / tpp;
         long blocks = (total + npl * 2 - 1) / (npl * 2); if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS; if (blocks < 1) blocks = 1;
-        if (vec == 8) bn_apply_pool_kernel<8><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, tpp, flags);
-        else          bn_apply_pool_kernel<4><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, tpp, flags);
+        if (vec == 8) bn_apply_pool_kernel<8><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, tpp, flags, fin);
+        else          bn_apply_pool_kernel<4><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, pooled, ldp, idx, N, H, W, C, tpp, flags, fin);
         return UNET_LAUNCH_STATUS();
     }
     if (lanes) {
         const long npl = 256 / tpp;
         long blocks = (P + npl * 4 - 1) / (npl * 4); if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS; if (blocks < 1) blocks = 1;
-        if (vec == 8)      bn_apply_kernel<8><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, tpp, flags);
-        else if (vec == 4) bn_apply_kernel<4><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, tpp, flags);
-        else               bn_apply_kernel<1><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, tpp, flags);
+        if (vec == 8)      bn_apply_kernel<8><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, tpp, flags, fin);
+        else if (vec == 4) bn_apply_kernel<4><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, tpp, flags, fin);
+        else               bn_apply_kernel<1><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, tpp, flags, fin);
     } else {
+        if (fin.part) return UNET_EINVAL;                                 // (the flat form has no merged finalize: callers check bn_apply_lanes)
         const long total = P * (C / vec);
         long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
         if (vec == 8)      bn_apply_flat_kernel<8><<<(int)blocks, 256, 0, st>>>(r, ldr, scale, shift, y, ldy, P, C, flags);
@@ -1089,6 +1157,36 @@ extern "C" int unet_bn_bwd_bias(const void* ws, int rows, int C, float* dbias, v
 
 // BatchNorm apply (+ optional 2x2 max pool: pooled / idx non-null) with either side stored as bf16: r_bf16 (the conv output it
 // reads), y_bf16 (what it writes, y and pooled alike)
+// unet_bn_train_finalize_partials + unet_bn_apply_any in ONE launch (bn_finalize_then_wait above): same results bit for bit, one launch
+// boundary fewer on the forward chain.  `counter`: a device word that only this call sequence touches, zero at first use; `counter_target` =
+// the value it must reach = (sum of C over every earlier call on this counter) + C, modulo 2^32 (the caller keeps the running sum).
+// Layouts the lane form of the apply kernel does not cover fall back to the two launches (the counter is then advanced by the host's
+// bookkeeping only: the kernel adds C through the finalize kernel's stand-in below, so the running sum stays valid).
+extern "C" int unet_bn_finalize_apply_any(const float* part, int rows, const float* gamma, const float* beta, float eps, float momentum,
+        int unbiased_moving_var, float* moving_mean, float* moving_var, float* mean, float* invstd, uint32_t* counter, uint32_t counter_target,
+        const void* r, int ldr, int r_bf16, float* scale, float* shift, void* y, int ldy, int y_bf16,
+        void* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    UNET_CHECK_ARG(part && rows > 0 && C > 0 && C % 64 == 0 && gamma && beta && mean && invstd && scale && shift && counter);
+    UNET_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
+    UNET_CHECK_ARG(r && y && N > 0 && H > 0 && W > 0 && ldr >= C && ldy >= C && ldr % 4 == 0 && ldy % 4 == 0);
+    UNET_CHECK_ARG(unet_aligned16(r) && unet_aligned16(y) && unet_aligned16(scale) && unet_aligned16(shift) && (pooled == nullptr) == (idx == nullptr));
+    if (pooled) UNET_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && ldp >= C && ldp % 4 == 0 && unet_aligned16(pooled) && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0);
+    const long P = (long)N * H * W;
+    const int vec = (C % 8 == 0 && ldr % 8 == 0 && ldy % 8 == 0 && (!pooled || ldp % 8 == 0) && 256 % (C / 8) == 0) ? 8 : 4;
+    const bool lanes = 256 % (C / vec) == 0;
+    if (!lanes) {        // two launches; the counter still advances by C so that the caller's running sum holds
+        bn_train_finalize_partials_kernel<<<C, 256, 0, (hipStream_t)stream>>>(part, rows, P, C, gamma, beta, eps, momentum,
+            unbiased_moving_var, moving_mean, moving_var, mean, invstd, scale, shift);
+        int rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+        counter_add_kernel<<<1, 1, 0, (hipStream_t)stream>>>(counter, (unsigned)C);
+        rc = UNET_LAUNCH_STATUS(); if (rc) return rc;
+        return launch_bn_apply((const float*)r, ldr, r_bf16 ? 1 : 0, scale, shift, (float*)y, ldy, y_bf16 ? 1 : 0, (float*)pooled, ldp, idx, N, H, W, C, (hipStream_t)stream);
+    }
+    const BnFin fin{part, rows, P, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var, mean, invstd, counter, counter_target};
+    return launch_bn_apply((const float*)r, ldr, r_bf16 ? 1 : 0, scale, shift, (float*)y, ldy, y_bf16 ? 1 : 0, (float*)pooled, ldp, idx,
+                           N, H, W, C, (hipStream_t)stream, &fin);
+}
+
 extern "C" int unet_bn_apply_any(const void* r, int ldr, int r_bf16, const float* scale, const float* shift, void* y, int ldy, int y_bf16,
                                  void* pooled, int ldp, uint8_t* idx, int N, int H, int W, int C, void* stream) {
     UNET_CHECK_ARG(r && scale && shift && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldr >= C && ldy >= C && ldr % 4 == 0 && ldy % 4 == 0);

@@ -303,6 +303,14 @@ class Engine:
             self._ctx6_dirty = False
         return self._ctx6_W[name]
 
+    def _fin_counters(self):
+        """one device word per layer for unet_bn_finalize_apply_any (it only grows; the running targets live here, not in the library)"""
+        if getattr(self, "_fin_cnt", None) is None:
+            self._fin_cnt = torch.zeros(len(self.layers), dtype=torch.int32, device=self.dev)
+            self._fin_index = {n: i for i, (n, _, _, _) in enumerate(self.layers)}
+            self._fin_target = [0] * len(self.layers)
+        return self._fin_cnt
+
     def parameters_changed(self):
         """theta was written from outside (broadcast, checkpoint): every cached transform of the kernels is stale."""
         self._fused_dirty = True
@@ -462,6 +470,23 @@ class Engine:
         sc_out, sh_out = stat_out if stat_out is not None else (s[2], s[3])
         gm, bt = self.p[name + "/gamma"], self.p[name + "/beta"]
         mm, mv = self.moving[name + "/moving_mean"], self.moving[name + "/moving_var"]
+        merged = training and fused_stats is not None and self.opt.merge_bn_finalize and y_out is not None and cout % 64 == 0
+        if merged:
+            # finalize + apply (+ pool) in ONE launch: the apply grid's first workgroups finalize, all wait on the layer's counter word
+            cnt = self._fin_counters()
+            i = self._fin_index[name]
+            self._fin_target[i] = (self._fin_target[i] + cout) & 0xFFFFFFFF
+            self._timed("bn_apply", self._nb(r, y_out, *(pool or ())), L.unet_bn_finalize_apply_any,
+                        _p(fused_stats[0]), fused_stats[1], _p(gm), _p(bt), BN_EPS, BN_MOMENTUM, BN_MOVING_VAR_UNBIASED, _p(mm), _p(mv), _p(s[0]), _p(s[1]),
+                        ctypes.c_void_p(cnt.data_ptr() + 4 * i), self._fin_target[i],
+                        _p(r), _ld(r), int(r.dtype == torch.bfloat16), _p(sc_out), _p(sh_out), _p(y_out), _ld(y_out), int(y_out.dtype == torch.bfloat16),
+                        _p(pool[0]) if pool is not None else None, cout, _p(pool[1]) if pool is not None else None,
+                        r.shape[0], r.shape[1], r.shape[2], cout, st)
+            self._eval_coefs.clear()
+            self.saved[name] = (x, r)
+            self.view[name] = in_view
+            self.coef[name] = (sc_out, sh_out)
+            return y_out
         if training and fused_stats is not None:
             L.unet_bn_train_finalize_partials(_p(fused_stats[0]), fused_stats[1], P, cout, _p(gm), _p(bt), BN_EPS, BN_MOMENTUM,
                                               BN_MOVING_VAR_UNBIASED, _p(mm), _p(mv), _p(s[0]), _p(s[1]), _p(sc_out), _p(sh_out), st)

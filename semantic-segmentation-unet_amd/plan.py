@@ -35,6 +35,8 @@ class EngineOptions:
     bn_on_load: bool = True           # fp32 fused route: BatchNorm-apply folded into the consumer's weights (13 layers)
     fuse_bn_stats: bool = True        # BatchNorm sums from conv / data-gradient epilogues instead of reduction passes
     fuse_pool: bool = True            # BatchNorm apply + max pool in one pass; pool backward inside the BatchNorm backward
+    merge_bn_finalize: bool = False   # statistics finalize inside the BatchNorm-apply launch (unet_bn_finalize_apply_any): one dependent launch fewer per layer.
+    #                                   OFF: measured slower in same-box A/Bs (profiles/r06_small_launch_ab.txt: bf16 +0.5 ms, fp32 +0.2 ms per step)
     bf16_storage: bool = True         # stage 2 (see module docstring)
     bf16_activations: bool = True     # stage 3
     overlap_wgrad: bool = True        # weight gradients on a side stream
@@ -52,7 +54,7 @@ class EngineOptions:
         o.wgrad_route = env.get("UNET_WGRAD_ROUTE", o.wgrad_route)
         o.fp32_matrix = env.get("UNET_FP32_MATRIX", o.fp32_matrix)
         for name, var in (("bn_on_load", "UNET_BN_ON_LOAD"), ("fuse_bn_stats", "UNET_FUSE_BN_STATS"), ("fuse_pool", "UNET_FUSE_POOL"),
-                          ("bf16_storage", "UNET_BF16_STORAGE"), ("bf16_activations", "UNET_BF16_ACTIVATIONS"),
+                          ("merge_bn_finalize", "UNET_MERGE_BN_FINALIZE"), ("bf16_storage", "UNET_BF16_STORAGE"), ("bf16_activations", "UNET_BF16_ACTIVATIONS"),
                           ("overlap_wgrad", "UNET_OVERLAP_WGRAD")):
             if var in env:
                 setattr(o, name, env[var] != "0")

@@ -1367,3 +1367,51 @@ def test_conv3x3_bf16_wgrad_dma_staging_equals_register_staging(hip, shape):
         # full-size layers: against an independent implementation (torch's own weight gradient of the same bf16-valued operands)
         ref = torch.nn.grad.conv2d_weight(x32.permute(0, 3, 1, 2).contiguous(), (co, ci, 3, 3), z32.permute(0, 3, 1, 2).contiguous(), padding=1).permute(2, 3, 1, 0)
         assert (dwa - ref).abs().max().item() < 1e-4 * ref.abs().max().item(), ((dwa - ref).abs().max().item(), ref.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [  # N, H, W, C, rows, r bf16, y bf16, pooled
+    (8, 512, 512, 64, 4096, 1, 1, 0), (8, 512, 512, 64, 4096, 1, 1, 1), (8, 32, 32, 1024, 16, 1, 1, 0), (2, 64, 64, 512, 37, 0, 0, 0),
+    (2, 64, 64, 128, 8, 0, 0, 1), (1, 16, 16, 192, 5, 0, 1, 0), (2, 8, 8, 1024, 3, 1, 0, 0)])
+def test_bn_finalize_merged_into_the_apply_launch_is_bit_identical_to_two_launches(hip, case):
+    # unet_bn_finalize_apply_any (round 6): the statistics finalize runs in the first workgroups of the apply grid, every workgroup waits on a
+    # device counter.  Everything the two-launch form writes must come out bit for bit: mean, invstd, scale, shift, the moving statistics, y,
+    # the pooled tensor and its winners -- on THREE consecutive calls sharing one counter word (the target only grows), with full-resolution row
+    # counts (4096 partial rows), more channels than ... and fewer channels than workgroups, both storages, C = 192 (a layout the lane form of
+    # the apply kernel does not cover: the entry point falls back to two launches and still advances the counter).
+    n, h, w, c, rows, r16, y16, pooled = case
+    g = torch.Generator(device=DEV).manual_seed(c + rows)
+    bf = torch.bfloat16
+    Pn = n * h * w
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    target = 0
+    mm1 = torch.randn(c, device=DEV, generator=g); mv1 = torch.rand(c, device=DEV, generator=g) + 0.5
+    mm2, mv2 = mm1.clone(), mv1.clone()
+    for call in range(3):
+        part = torch.randn((c // 64) * rows * 128, device=DEV, generator=g).abs() * (Pn / rows)
+        part.view(c // 64, rows, 64, 2)[..., 1] += part.view(c // 64, rows, 64, 2)[..., 0] ** 2 / (Pn / rows)      # sum x^2 >= (sum x)^2 / n
+        gm = torch.rand(c, device=DEV, generator=g) + 0.5; bt = torch.randn(c, device=DEV, generator=g)
+        r = torch.randn(n, h, w, c, device=DEV, generator=g)
+        if r16:
+            r = r.to(bf)
+        outs = []
+        for merged in (0, 1):
+            mean, inv, sc, sh = (torch.zeros(c, device=DEV) for _ in range(4))
+            y = torch.zeros(n, h, w, c, device=DEV, dtype=bf if y16 else torch.float32)
+            pl = torch.zeros(n, h // 2, w // 2, c, device=DEV, dtype=y.dtype) if pooled else None
+            ix = torch.zeros(n, h // 2, w // 2, c, device=DEV, dtype=torch.uint8) if pooled else None
+            mm, mv = (mm2, mv2) if merged else (mm1, mv1)
+            if merged:
+                target = (target + c) & 0xFFFFFFFF
+                hip.unet_bn_finalize_apply_any(P(part), rows, P(gm), P(bt), 1e-3, 0.99, 1, P(mm), P(mv), P(mean), P(inv), P(counter), target,
+                                               P(r), c, r16, P(sc), P(sh), P(y), c, y16, P(pl) if pooled else None, c, P(ix) if pooled else None,
+                                               n, h, w, c, ST())
+            else:
+                hip.unet_bn_train_finalize_partials(P(part), rows, Pn, c, P(gm), P(bt), 1e-3, 0.99, 1, P(mm), P(mv), P(mean), P(inv), P(sc), P(sh), ST())
+                hip.unet_bn_apply_any(P(r), c, r16, P(sc), P(sh), P(y), c, y16, P(pl) if pooled else None, c, P(ix) if pooled else None, n, h, w, c, ST())
+            outs.append((mean, inv, sc, sh, mm.clone(), mv.clone(), y, pl, ix))
+        torch.cuda.synchronize()
+        for a, b in zip(*outs):
+            if a is not None:
+                assert torch.equal(a, b), (call, case)
+        assert int(counter.item()) & 0xFFFFFFFF == target
+        assert outs[0][6].float().abs().max().item() > 0.1
