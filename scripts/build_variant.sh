@@ -8,7 +8,8 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 python3 "$root/semantic-segmentation-unet_amd/_build.py" > /dev/null
 cd "$root/semantic-segmentation-unet_amd/csrc"
 name=$1; src=$2; flags=$3
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function $flags -c $src -o /tmp/variant_$name.o
+extra=$(python3 -c "import sys; sys.path.insert(0, '$root/semantic-segmentation-unet_amd'); import _build; print(' '.join(_build.EXTRA_FLAGS.get('$src', [])))")
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function $extra $flags -c $src -o /tmp/variant_$name.o
 objs=""
 for s in $(python3 -c "import sys; sys.path.insert(0, '$root/semantic-segmentation-unet_amd'); import _build; print(' '.join(_build.SOURCES))"); do
     if [ "$s" != "$src" ]; then objs="$objs ${s%.hip}.o"; fi

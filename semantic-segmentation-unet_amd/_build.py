@@ -16,6 +16,10 @@ SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_direct.hip", "winograd.hip"
            "norm.hip", "misc.hip", "crc32c.hip"]
 HEADERS = ["common.h", "wino_epilogue.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-source additions.  winograd_x6.hip: the split steps in the MFMA gaps are scalar fp32 subtractions on purpose -- SLP vectorisation turns the
+# pairs (v0 - lo(h), v1 - hi(h)) of the round-to-nearest split into v_pk_add_f32, which stalls a one-wave-per-SIMD MFMA stream (+17 cycles per gap,
+# profiles/r05_bf16_mfma_gap_costs.txt); the packed column stage of the end-of-tile code is written with vector types and is not affected
+EXTRA_FLAGS = {"winograd_x6.hip": ["-fno-slp-vectorize"]}
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared"]
 
 
@@ -29,7 +33,7 @@ def _sha(*chunks):
 
 def source_stamp(src):
     hdr = [open(os.path.join(CSRC, h), "rb").read() for h in HEADERS]
-    return _sha(" ".join(FLAGS), open(os.path.join(CSRC, src), "rb").read(), *hdr)
+    return _sha(" ".join(FLAGS + EXTRA_FLAGS.get(src, [])), open(os.path.join(CSRC, src), "rb").read(), *hdr)
 
 
 def library_stamp():
@@ -56,7 +60,7 @@ def build_library(force=False, verbose=False):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         stamp = source_stamp(s)
         if force or not os.path.exists(obj) or _read(obj + ".stamp") != stamp:
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

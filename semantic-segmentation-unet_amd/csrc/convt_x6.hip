@@ -33,19 +33,30 @@ struct ConvtX6Args {
     long P;
 };
 
-__device__ __forceinline__ unsigned cx_hi2(float lo, float hi) {       // { bf16 bits of lo (truncated), of hi }, lo in the low half
-    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+// (round 6: pieces by round-to-nearest-even, v_cvt_pk_bf16_f32 -- see winograd_x6.hip: still an exact split, dropped products zero-mean)
+typedef __bf16 cx_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cx_rn2(float lo, float hi) {       // { bf16(lo), bf16(hi) } rounded to nearest even, lo in the low half
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cx_bf16x2));
 }
-__device__ __forceinline__ float cx_trunc(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
+__device__ __forceinline__ float cx_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float cx_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// a value pair -> its three piece pairs (exact: v = h + m + l)
+__device__ __forceinline__ void cx_split2(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cx_rn2(v0, v1);
+    const float a0 = v0 - cx_lo(h), a1 = v1 - cx_hi(h);
+    m = cx_rn2(a0, a1);
+    l = cx_rn2(a0 - cx_lo(m), a1 - cx_hi(m));
+}
 
 // 8 fp32 values -> three 16-byte rows of bf16 pieces (exact: v = h + m + l)
 __device__ __forceinline__ void cx_split8(const f32x4& v0, const f32x4& v1, cx_i32x4& h, cx_i32x4& m, cx_i32x4& l) {
-    float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}, a[8], b[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { a[e] = t[e] - cx_trunc(t[e]); b[e] = a[e] - cx_trunc(a[e]); }
+    const float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        h[e] = (int)cx_hi2(t[2 * e], t[2 * e + 1]); m[e] = (int)cx_hi2(a[2 * e], a[2 * e + 1]); l[e] = (int)cx_hi2(b[2 * e], b[2 * e + 1]);
+        unsigned hp, mp, lp;
+        cx_split2(t[2 * e], t[2 * e + 1], hp, mp, lp);
+        h[e] = (int)hp; m[e] = (int)mp; l[e] = (int)lp;
     }
 }
 
@@ -287,12 +298,9 @@ constexpr int kWgXImg = 16 * kWgXP, kWgZImg = 16 * kWgZP;        // one piece of
 constexpr int kWgStage = 3 * kWgXImg + 12 * kWgZImg;             // 15360 + 36864 = 52224 B
 
 __device__ __forceinline__ void cx_split4(const f32x4& v, cx_u32x2& h, cx_u32x2& m, cx_u32x2& l) {
-    float a[4], b[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { a[e] = v[e] - cx_trunc(v[e]); b[e] = a[e] - cx_trunc(a[e]); }
-    h = cx_u32x2{cx_hi2(v[0], v[1]), cx_hi2(v[2], v[3])};
-    m = cx_u32x2{cx_hi2(a[0], a[1]), cx_hi2(a[2], a[3])};
-    l = cx_u32x2{cx_hi2(b[0], b[1]), cx_hi2(b[2], b[3])};
+    unsigned h0, m0, l0, h1, m1, l1;
+    cx_split2(v[0], v[1], h0, m0, l0); cx_split2(v[2], v[3], h1, m1, l1);
+    h = cx_u32x2{h0, h1}; m = cx_u32x2{m0, m1}; l = cx_u32x2{l0, l1};
 }
 
 __global__ __launch_bounds__(256, 2) void convt_x6_wgrad_kernel(ConvtWgX6Args p) {

@@ -2,12 +2,11 @@
 // Reference layer: UNet._conv_layer, UNet/model.py:28-35 (fp32 in the reference; this is a second ROUTE to the same fp32-grade result,
 // beside the v_mfma_f32_32x32x2_f32 kernels of winograd.hip, which stay selectable).
 //
-// Arithmetic.  An fp32 value is EXACTLY the sum of three bf16 pieces h + m + l (8 + 8 + 8 significant bits, taken by truncation: every
-// piece has the sign of the value and the low piece ends where the fp32 mantissa ends).  With both operands of a product split this way,
+// Arithmetic.  An fp32 value is EXACTLY the sum of three bf16 pieces h + m + l (8 + 8 + 8 significant bits; h = rn(v), m = rn(v - h),
+// l = v - h - m, round-to-nearest-even since round 6 -- rounds 4-5 truncated).  With both operands of a product split this way,
 //     a b  =  ah bh + ah bm + am bh + ah bl + al bh + am bm   +  (am bl + al bm + al bl),
-// the six kept piece products are exact in an fp32 accumulator and the three dropped ones (all of the product's sign: truncation pieces
-// carry their value's sign) sum to at most 2^-21 |a b|, on average 2^-24.5 |a b| -- the size of ONE fp32 multiply's rounding
-// (tests/test_bf16x6_arithmetic.py restates and checks this on the CPU).  Accumulation is fp32 (v_mfma_f32_32x32x16_bf16).  So the result
+// the six kept piece products are exact in an fp32 accumulator and the three dropped ones are zero-mean and sum to at most 2^-23.4 |a b|
+// (rms 2^-26) -- below ONE fp32 multiply's rounding (tests/test_bf16x6_arithmetic.py restates and checks this on the CPU).  Accumulation is fp32 (v_mfma_f32_32x32x16_bf16).  So the result
 // carries the rounding of an fp32 dot product (measured against fp64: tests/test_gpu_fp32_errors.py, tests/test_gpu_x6.py), at 6 x 32
 // matrix-pipe cycles per 32 x 32 x 16 block instead of 8 x 64.  The Winograd transforms themselves (B^T d B on the data, G g G^T on the
 // weights, A^T m A on the result) stay fp32 vector arithmetic.
@@ -81,10 +80,18 @@ __host__ __device__ constexpr int x6_col_of(int pos) { return pos < 9 ? 2 * pos 
 
 struct X6Split { float v[4], a[4], b[4]; unsigned h[2], m[2], l[2]; };
 
-__device__ __forceinline__ unsigned x6_hi2(float lo, float hi) {       // { bf16 bits of lo (truncated) , of hi } packed, lo in the low half
-    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+// Round 6: the pieces are taken by ROUND-TO-NEAREST-EVEN (v_cvt_pk_bf16_f32, two values per instruction) instead of by truncation: h = rn(v),
+// m = rn(v - h), l = v - h - m are still an exact split (|v - h| <= half a bf16 ulp of v and a multiple of v's fp32 ulp: 16 significant bits;
+// the second remainder has at most 8), at the same instruction count (pack 1 + unpack 2 + subtract 2 per value pair and level, where truncation
+// took mask 2 + subtract 2 + pack 1), but the pieces m, l no longer carry the sign of v: the three dropped products am bl + al bm + al bl are
+// zero-mean and bounded by 2^-23.4 |a b| instead of a bias of the product's sign up to 2^-21 (tests/test_bf16x6_arithmetic.py).
+typedef __bf16 x6_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned x6_rn2(float lo, float hi) {       // { bf16(lo), bf16(hi) } rounded to nearest even, lo in the low half
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_bf16x2));
 }
-__device__ __forceinline__ float x6_trunc(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
+__device__ __forceinline__ float x6_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }                 // the two bf16 values of a pair, as fp32
+__device__ __forceinline__ float x6_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
 // Column stage + split of four channels of point J (column J of the wave's row of points) in five steps of 5-6 vector instructions;
 // T[c] = the row-stage result of patch column c.  V[.][0] = t0 - t2, [1] = t1 + t2, [2] = t2 - t1, [3] = t1 - t3.
@@ -104,28 +111,28 @@ template <int K, int J, int G> __device__ __forceinline__ void x6_split_step(X6S
         // (this group's two quads were pinned in the middle of the previous group's last step)
         if constexpr (J == 1) { const f32x4 vv = T[TA][G] + T[TB][G]; s.v[0] = vv[0]; s.v[1] = vv[1]; s.v[2] = vv[2]; s.v[3] = vv[3]; }
         else { const f32x4 vv = T[TA][G] - T[TB][G]; s.v[0] = vv[0]; s.v[1] = vv[1]; s.v[2] = vv[2]; s.v[3] = vv[3]; }
-        s.h[0] = x6_hi2(s.v[0], s.v[1]);
+        s.h[0] = x6_rn2(s.v[0], s.v[1]);
         X6_USE("v"(s.v[0]), "v"(s.v[1]), "v"(s.v[2]), "v"(s.v[3]), "v"(s.h[0]));
     } else if constexpr (K == 1) {
-        s.a[0] = s.v[0] - x6_trunc(s.v[0]); s.a[1] = s.v[1] - x6_trunc(s.v[1]);
-        s.h[1] = x6_hi2(s.v[2], s.v[3]);
+        s.a[0] = s.v[0] - x6_lo(s.h[0]); s.a[1] = s.v[1] - x6_hi(s.h[0]);
+        s.h[1] = x6_rn2(s.v[2], s.v[3]);
         X6_USE("v"(s.a[0]), "v"(s.a[1]), "v"(s.h[1]));
     } else if constexpr (K == 2) {
-        s.a[2] = s.v[2] - x6_trunc(s.v[2]); s.a[3] = s.v[3] - x6_trunc(s.v[3]);
-        s.m[0] = x6_hi2(s.a[0], s.a[1]);
+        s.a[2] = s.v[2] - x6_lo(s.h[1]); s.a[3] = s.v[3] - x6_hi(s.h[1]);
+        s.m[0] = x6_rn2(s.a[0], s.a[1]);
         X6_USE("v"(s.a[2]), "v"(s.a[3]), "v"(s.m[0]));
     } else if constexpr (K == 3) {
-        s.b[0] = s.a[0] - x6_trunc(s.a[0]); s.b[1] = s.a[1] - x6_trunc(s.a[1]);
-        s.m[1] = x6_hi2(s.a[2], s.a[3]);
+        s.b[0] = s.a[0] - x6_lo(s.m[0]); s.b[1] = s.a[1] - x6_hi(s.m[0]);
+        s.m[1] = x6_rn2(s.a[2], s.a[3]);
         X6_USE("v"(s.b[0]), "v"(s.b[1]), "v"(s.m[1]));
     } else {
-        s.b[2] = s.a[2] - x6_trunc(s.a[2]); s.b[3] = s.a[3] - x6_trunc(s.a[3]);
+        s.b[2] = s.a[2] - x6_lo(s.m[1]); s.b[3] = s.a[3] - x6_hi(s.m[1]);
         {                                // the next group's column stage may not start before this point; the two packs below separate the pin from it
             constexpr int JX = G < 3 ? J : ((J + 1) & 3), GX = G < 3 ? G + 1 : 0;      // (behind group 3: group 0 of the next point, built in the next period)
             constexpr int TA = JX == 0 ? 0 : JX == 2 ? 2 : 1, TB = JX == 0 ? 2 : JX == 1 ? 2 : JX == 2 ? 1 : 3;
             X6_PIN("+v"(T[TA][GX]), "+v"(T[TB][GX]), "+v"(s.b[2]), "+v"(s.b[3]));
         }
-        s.l[0] = x6_hi2(s.b[0], s.b[1]); s.l[1] = x6_hi2(s.b[2], s.b[3]);
+        s.l[0] = x6_rn2(s.b[0], s.b[1]); s.l[1] = x6_rn2(s.b[2], s.b[3]);
     }
 }
 // the pieces of channel quad QQ of tile block TB -> the MFMA data operands of buffer vb (dwords 2 QQ, 2 QQ + 1 of pieces h, m, l)
@@ -738,12 +745,13 @@ __global__ __launch_bounds__(256, 1) void wino_x6_stream_bnbwd_kernel(X6Args q, 
 // scale / shift (forward only, nullable): BatchNorm-apply on load -- g is scaled by the PRODUCER's BatchNorm scale per input channel
 // (floored as in winograd.hip's fold).
 __device__ __forceinline__ void x6_pieces8(const float (&t)[8], x6_i32x4& h, x6_i32x4& m, x6_i32x4& l) {
-    float a[8], b[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { a[e] = t[e] - x6_trunc(t[e]); b[e] = a[e] - x6_trunc(a[e]); }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        h[e] = (int)x6_hi2(t[2 * e], t[2 * e + 1]); m[e] = (int)x6_hi2(a[2 * e], a[2 * e + 1]); l[e] = (int)x6_hi2(b[2 * e], b[2 * e + 1]);
+        const unsigned hp = x6_rn2(t[2 * e], t[2 * e + 1]);
+        const float a0 = t[2 * e] - x6_lo(hp), a1 = t[2 * e + 1] - x6_hi(hp);
+        const unsigned mp = x6_rn2(a0, a1);
+        const float b0 = a0 - x6_lo(mp), b1 = a1 - x6_hi(mp);
+        h[e] = (int)hp; m[e] = (int)mp; l[e] = (int)x6_rn2(b0, b1);
     }
 }
 __device__ __forceinline__ void x6_transform_g(const float (&g)[3][3], float (&t)[16]) {

@@ -42,10 +42,14 @@ def test_x6_weight_operand_is_an_exact_split_of_the_fp32_transform(hip, ci, co):
     tot = u6.sum(3)                                                                      # [k/16][r][j][n][16]
     want = Uc.double().reshape(4, 4, ci // 16, 2, co, 8).permute(2, 0, 1, 4, 3, 5).reshape(ci // 16, 4, 4, co, 16)
     assert torch.equal(tot, want)
-    # the pieces are bf16 values of decreasing size with the sign of the whole: |m| < 2^-7 |h|, |l| < 2^-7 |m| (truncation split)
+    # the pieces are bf16 values of decreasing size, each the round-to-nearest-even bf16 of what the larger ones left (round 6; rounds 4-5 truncated):
+    # |m| <= half a bf16 ulp of h = 2^-8 |h|, |l| <= 2^-8 |m| (or 2^-16 |h| where m = 0), and m takes either sign
     h, m, l = u6[:, :, :, 0], u6[:, :, :, 1], u6[:, :, :, 2]
-    assert bool((m.abs() <= h.abs() * 2.0 ** -7).all()) and bool((l.abs() <= m.abs() * 2.0 ** -7 + (m == 0) * h.abs() * 2.0 ** -15).all())
-    assert bool(((h * m) >= 0).all()) and bool(((h * l) >= 0).all())
+    assert bool((m.abs() <= h.abs() * 2.0 ** -8).all()) and bool((l.abs() <= m.abs() * 2.0 ** -8 + (m == 0) * h.abs() * 2.0 ** -16).all())
+    assert 0.3 < ((h * m) < 0).double().mean().item() < 0.7
+    tw = want.float()
+    assert torch.equal(h.float(), tw.to(torch.bfloat16).float())                       # h = rn_bf16(value), torch rounds the same way
+    assert torch.equal(m.float(), (tw - h.float()).to(torch.bfloat16).float())
     # data gradient (k = Cout, n = Cin, rotated filter = the forward transform with points 0 and 3 swapped both ways): against the native
     # batch kernel, which forms it the same way
     uf = torch.empty(16 * ci * co, device=DEV); ud = torch.empty(16 * ci * co, device=DEV)
