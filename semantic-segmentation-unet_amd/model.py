@@ -80,7 +80,15 @@ class _KerasLikeModel:
         """numpy in -> numpy out (the reference's callers run np.squeeze / np.argmax(...).astype on the result,
         UNet/inference.py:105-107,164-166); torch tensor in -> device tensor out (no host copy)."""
         o = self._o
-        xt = torch.as_tensor(np.asarray(x, dtype=np.float32)) if not torch.is_tensor(x) else x.float()
+        if not torch.is_tensor(x):
+            xa = np.asarray(x, dtype=np.float32)
+            # host arrays are checked where they enter: the fp32 route forms fp32 values as three bf16 pieces (csrc/winograd_x6.hip), which turns an
+            # Inf into NaN (Inf - Inf in the split) where TensorFlow's fp32 kernels would carry the Inf -- either way the mask is garbage, so say so
+            if not np.isfinite(xa).all():
+                raise ValueError("input image contains Inf / NaN")
+            xt = torch.as_tensor(xa)
+        else:
+            xt = x.float()
         prob = o.engine.forward(xt, training=bool(training), dropout_masks=dropout_masks)
         if torch.is_tensor(x):
             return prob.clone()      # engine buffers are reused by the next call
