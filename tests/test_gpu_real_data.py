@@ -33,23 +33,27 @@ def test_learns_real_tiles_with_device_augmentation(tmp_path, compute_dtype):
         aug.DeviceAugmenter(rotation_flag=True, reflection_flag=True, jitter_augmentation_severity=0.1, noise_augmentation_severity=0.02,
                             scale_augmentation_severity=0.1, blur_augmentation_max_sigma=2, seed=0, device=dev), 2)
     net = model.UNet(2, 4, 1, learning_rate=1e-3, seed=0, compute_dtype=compute_dtype)
-    losses = []
-    for _ in range(500):           # BN moving statistics (momentum 0.99) need a few hundred steps before eval mode is meaningful
+    # held-out tiles, eval mode (moving statistics), argmax on the device: beat the all-background guess by a wide margin.
+    # Judged on FOUR evaluations (steps 400 .. 700), not one: at lr 1e-3 the eval-mode accuracy of a single step swings between 0.89 and 0.98 on
+    # every route and seed (scripts/real_tiles_spread.py -> profiles/r06_real_tiles_spread.txt: native fp32 reads 0.887 at step 600 of one
+    # seed), so a one-point threshold tests the rounding-level chaos of the trajectory, not the arithmetic -- the round-6 change of the
+    # BF16x6 split moved step 500 of this seed from above to 0.895.  The median of the four is > 0.93 in all twelve measured runs.
+    test_x = torch.as_tensor(np.stack([readers.zscore_normalize(im[None].astype(np.float32)) for im in imgs[12:]]))
+    truth = masks[12:].astype(np.int64)
+    losses, accs, ious = [], [], []
+    for it in range(1, 701):       # BN moving statistics (momentum 0.99) need a few hundred steps before eval mode is meaningful
         x, y = next(pipe)
         losses.append(float(net.train_step((x, y, None, None)).numpy()))
+        if it in (400, 500, 600, 700):
+            pred = net.engine.argmax(net.engine.forward(test_x, training=False)).cpu().numpy()
+            accs.append((pred == truth).mean())
+            inter = ((pred == 1) & (truth == 1)).sum(); union = ((pred == 1) | (truth == 1)).sum()
+            ious.append(inter / max(union, 1))
     pipe.close()
     assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < 0.6 * np.mean(losses[:5])
-
-    # held-out tiles, eval mode (moving statistics), argmax on the device: beat the all-background guess by a wide margin
-    test_x = np.stack([readers.zscore_normalize(im[None].astype(np.float32)) for im in imgs[12:]])
-    prob = net.engine.forward(torch.as_tensor(test_x), training=False)
-    pred = net.engine.argmax(prob).cpu().numpy()
-    truth = masks[12:].astype(np.int64)
-    acc = (pred == truth).mean()
-    inter = ((pred == 1) & (truth == 1)).sum(); union = ((pred == 1) | (truth == 1)).sum()
-    print("%s: held-out pixel accuracy %.4f, IoU %.4f, background fraction %.4f" % (compute_dtype, acc, inter / max(union, 1), (truth == 0).mean()))
-    assert acc > max(0.9, (truth == 0).mean() + 0.05), acc
-    assert inter / max(union, 1) > 0.6, inter / max(union, 1)
+    print("%s: held-out pixel accuracy %s, IoU %s, background fraction %.4f" % (compute_dtype, ["%.4f" % a for a in accs], ["%.4f" % a for a in ious], (truth == 0).mean()))
+    assert np.median(accs) > max(0.92, (truth == 0).mean() + 0.05) and max(accs) > 0.95, accs
+    assert np.median(ious) > 0.6, ious
 
 
 def test_config1_exact_form_bundled_tiles_batch2_through_the_cli(tmp_path):
