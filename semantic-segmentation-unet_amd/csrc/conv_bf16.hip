@@ -855,8 +855,9 @@ struct WgBf16Args {
     int x16, z16;                // xin / dz stored as bf16 (ldx / lddz in elements)
 };
 
-constexpr int kWgXRow = 2 * 36 * 64, kWgDzRow = kWgXRow;            // bytes of one staged row: 2 channel groups x 36 pixels (34 / 32 used) x 64 B
-constexpr int kWgXRing = 6 * kWgXRow;
+#ifndef UNET_WG_DEEP
+#define UNET_WG_DEEP 1          /* DMA form: rows staged three steps ahead (0: two, the round-3 rings) */
+#endif
 
 #define WG_RDTR(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(base), "n"(off))
 #define WG_WAIT_CASE(n) case n: asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); break;
@@ -883,9 +884,18 @@ __device__ __forceinline__ void wg_wait_tied2(int n, bf16x8& a, bf16x8& b0, bf16
 // (ablation of the register path on 512->512 @64^2, ms per launch: MFMA stream 0.096, staging loads 0.022, conversion + LDS writes 0.046
 // -- nine ds_write_b64 per lane and step from ONE wave per SIMD run at a fraction of the LDS store rate -- barrier 0.005, fixed 0.035).
 // The rings grow to 8 input rows / 6 dz rows and the DMA of pass s + 3 is issued at step s: two steps of latency cover instead of one.
+// Round 6: ... and to 10 / 8 rows of 34 pixels (the DMA form needs no padding columns: 18 x 4352 B = 76.5 KB, still two workgroups per CU), the
+// DMA of pass s + 4 issued at step s: THREE steps between a row's issue and its first use.  All channel pairs of a strip run on one XCD at the
+// same time, so every workgroup meets every row's first touch of HBM (2-3 us under load) -- two steps (~2.3 us) did not cover it.
 template <int DMA>
 __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
-    constexpr int XR = DMA ? 8 : 6, ZR = DMA ? 6 : 4;                // ring rows: input / dz
+    constexpr int DEEP = DMA && UNET_WG_DEEP;
+    constexpr int XR = DEEP ? 10 : DMA ? 8 : 6, ZR = DEEP ? 8 : DMA ? 6 : 4;      // ring rows: input / dz
+    constexpr int ZP = ZR / 2;                                       // dz row pairs in the ring
+    constexpr int AHEAD = DEEP ? 4 : 3;                              // step s issues the DMA of pass s + AHEAD
+    constexpr int PIX = DEEP ? 34 : 36;                              // pixel slots of a staged row (34 input / 32 dz columns used)
+    constexpr int kWgGrp = PIX * 64;                                 // one 32-channel group of a row
+    constexpr int kWgXRow = 2 * kWgGrp, kWgDzRow = kWgXRow;          // bytes of one staged row: 2 channel groups x PIX pixels x 64 B
     constexpr int kXRingB = XR * kWgXRow;
     __shared__ __attribute__((aligned(1024))) char smem[(XR + ZR) * kWgXRow];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -909,12 +919,12 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
     const bool is_x = wv < 2;
     const int rho = wv & 1, o = (lane >> 4) & 3, q = lane & 15;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_b*)smem;
-    const unsigned wr_lane = (unsigned)((q >> 3) * (36 * 64) + 9 * o * 64 + (q & 7) * 8);
+    const unsigned wr_lane = (unsigned)((q >> 3) * kWgGrp + 9 * o * 64 + (q & 7) * 8);
     // fragment gathers: 16-lane group g4 = (k half, channel half); lane 4 q4 + pp supplies pixel row q4, channels 4 pp .. 4 pp + 3
     const int g4 = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
     const unsigned frag_lane = (unsigned)((8 * (g4 >> 1) + q4) * 64 + (16 * (g4 & 1) + 4 * pp) * 2);
-    const unsigned a_lane = lds0 + cisub * (36 * 64) + frag_lane;
-    const unsigned b_lane = lds0 + kXRingB + cosub * (36 * 64) + frag_lane;
+    const unsigned a_lane = lds0 + cisub * kWgGrp + frag_lane;
+    const unsigned b_lane = lds0 + kXRingB + cosub * kWgGrp + frag_lane;
 
     const int xes = p.x16 ? 2 : 4, zes = p.z16 ? 2 : 4;
     const char* xb_ptr = reinterpret_cast<const char*>(p.x) + (size_t)ci0 * xes;
@@ -964,16 +974,16 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
             asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wb), "v"(v), "n"(t * 64) : "memory");
         }
     };
-    // DMA form: a row slot (2 groups x 36 pixels x 64 B = 288 16-byte pieces) is filled by five wave-instructions; piece 64 k + lane =
+    // DMA form: a row slot (2 groups x PIX pixels x 64 B = 288 / 272 16-byte pieces) is filled by five wave-instructions; piece 64 k + lane =
     // (group, pixel, 16-byte quarter of the pixel's 32 channels) -- the LDS image is a copy of memory
-    constexpr int NI = 5;
+    constexpr int NI = 5, NPIECE = 2 * PIX * 4;
     unsigned poff[NI]; unsigned pok = 0;                              // per-lane source offset inside the image row 0 / validity bits (per strip)
     int dgrp[NI], dpix[NI], dj[NI];
     if constexpr (DMA) {
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int P = 64 * k + lane;
-            dgrp[k] = P / 144; const int rem = P % 144; dpix[k] = rem >> 2; dj[k] = rem & 3;
+            dgrp[k] = P / (4 * PIX); const int rem = P % (4 * PIX); dpix[k] = rem >> 2; dj[k] = rem & 3;
         }
     }
     // compute step s from LDS: 4 groups (output row yy, k-step ks) x 9 taps; A fragments three ahead, the next group's B at the group start
@@ -981,7 +991,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
         unsigned xb[4], zb[2];
 #pragma unroll
         for (int r = 0; r < 4; ++r) xb[r] = a_lane + (unsigned)(((2 * s + r) % XR) * kWgXRow);
-        zb[0] = b_lane + (unsigned)(((s % (ZR / 2)) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
+        zb[0] = b_lane + (unsigned)(((s % ZP) * 2) * kWgDzRow); zb[1] = zb[0] + kWgDzRow;
         // One asm block per step, generated by scripts/gen_wgrad_bf16_step.py: 56 transposing reads, 36 MFMAs, counted waits (LDS operations
         // retire in order).  Input row r of the step serves tap a = r of output row 0 AND tap a = r - 1 of output row 1, so each of the 24
         // A fragments (4 rows x 3 column shifts x 2 k-steps) is read ONCE and feeds both MFMAs (round 2 read 36: one per MFMA -- 1 KB of
@@ -1122,12 +1132,12 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
     auto dma_issue = [&](int j) {
         const int row = is_x ? y0 - 1 + 2 * j + rho : y0 + 2 * (j - 1) + rho;
         const bool rok = is_x ? (row >= 0 && row < p.H) : (row >= y0 && row < y_end);
-        const int slot = is_x ? (2 * j + rho) % XR : XR + 2 * ((j + 2) % 3) + rho;        // dz rows of step j - 1: slots 2 ((j - 1) % 3), + 1
+        const int slot = is_x ? (2 * j + rho) % XR : XR + 2 * ((j + ZP - 1) % ZP) + rho;  // dz rows of step j - 1: slots 2 ((j - 1) % ZP), + 1
         const char* rb = role_ptr + (size_t)(rok ? row : 0) * role_rowbytes;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const char* src = (rok && ((pok >> k) & 1)) ? rb + poff[k] : reinterpret_cast<const char*>(g_zero_page_b) + dj[k] * 16;
-            if (k < 4 || lane < 32)                                   // pieces 288 .. 319 would land in the next slot
+            if (k < 4 || lane < NPIECE - 256)                         // pieces NPIECE .. 319 would land in the next slot
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void_b*)(smem + slot * kWgXRow + 1024 * k), 16, 0, 0);
         }
     };
@@ -1143,18 +1153,19 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgBf16Args& p) {
 #pragma unroll
             for (int k = 0; k < NI; ++k) {
                 const int gx = is_x ? x0 - 1 + dpix[k] : x0 + dpix[k];
-                const bool ok = 64 * k + lane < 288 && dpix[k] < (is_x ? 34 : 32) && gx >= 0 && gx < p.W;
+                const bool ok = 64 * k + lane < NPIECE && dpix[k] < (is_x ? 34 : 32) && gx >= 0 && gx < p.W;
                 poff[k] = ok ? (unsigned)((((size_t)img * p.H * p.W + gx) * (is_x ? p.ldx : p.lddz)) * 2 + dgrp[k] * 64 + dj[k] * 16) : 0u;
                 pok |= ok ? (1u << k) : 0u;
             }
-            // fill: passes 0, 1 landed, pass 2 in flight.  (The previous strip ended with a barrier and drained its DMAs.)
-            dma_issue(0); dma_issue(1); dma_issue(2);
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NI) : "memory");
+            // fill: passes 0, 1 landed, passes 2 .. AHEAD - 1 in flight.  (The previous strip ended with a barrier and drained its DMAs.)
+#pragma unroll
+            for (int j = 0; j < AHEAD; ++j) dma_issue(j);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((AHEAD - 2) * NI) : "memory");
             for (int s = 0; s < steps; ++s) {
-                if (!(UNET_CB_ABLATE & 2)) dma_issue(s + 3);
+                if (!(UNET_CB_ABLATE & 2)) dma_issue(s + AHEAD);
                 if (!(UNET_CB_ABLATE & 1)) compute(s);
-                // pass s + 2 (issued one step ago) has to be here for step s + 1; pass s + 3 stays in flight
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NI) : "memory");
+                // pass s + 2 has to be here for step s + 1; the passes behind it (one, or two in the deep form) stay in flight
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((AHEAD - 2) * NI) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // DMAs still in flight target slots the next strip fills
             continue;
