@@ -1384,7 +1384,14 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
     int t = blockIdx.x;
     const int total = p.n_px * p.n_co;
     if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
-    const int cot = t / p.n_px; int px = t % p.n_px;
+    // Column tile fastest (round 6; the 3x3 kernels keep it slowest): the 2..16 column tiles of one pixel tile run next to each other on one
+    // XCD, whose L2 then serves the input tile's second .. n-th read -- with the column tile slowest those reads were half a launch apart
+    // (same-box micro-benchmark, four BASELINE shapes: forward + sums 0.383 -> 0.343 ms, data gradient + sums 0.370 -> 0.343 ms).
+#ifndef UNET_CT_COLFAST
+#define UNET_CT_COLFAST 1
+#endif
+    const int cot = UNET_CT_COLFAST ? t % p.n_co : t / p.n_px; int px = UNET_CT_COLFAST ? t / p.n_co : t % p.n_px;
+    const int tpx = px;
     const int bx = px % p.tbx; px /= p.tbx;
     const int by = px % p.tby; const int img = px / p.tby;
     const int n0 = cot * CT, ty0 = 16 * by, tx0 = 32 * bx;
@@ -1615,7 +1622,7 @@ __device__ __forceinline__ void convt_bf16_body(const ConvtBf16Args& p) {
             for (int w4 = 0; w4 < 4; ++w4) { a += red[((w4 * NCO + c) * 32 + l) * 2]; b += red[((w4 * NCO + c) * 32 + l) * 2 + 1]; }
             const int ncol = n0 + tid;
             const int ch = MODE == 1 ? ncol % p.Cout : ncol, tap = MODE == 1 ? ncol / p.Cout : 0;
-            const int rows = MODE == 1 ? 4 * p.n_px : p.n_px, row = MODE == 1 ? 4 * (t % p.n_px) + tap : t % p.n_px;
+            const int rows = MODE == 1 ? 4 * p.n_px : p.n_px, row = MODE == 1 ? 4 * tpx + tap : tpx;
             float* o = p.stat_part + (((size_t)(ch >> 6) * rows + row) * 64 + (ch & 63)) * 2;
             o[0] = a; o[1] = b;
         }
@@ -1636,9 +1643,12 @@ __global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_bnbwd_kernel_128(Conv
 __global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_bnbwd_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 2, 2>(p); }
 // bf16-stored input: LDS-DMA staging
 __global__ __launch_bounds__(256, 1) void convt_bf16_fwd_dma_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 0, 1, 1>(p); }
-__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_dma_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 0, 1, 1>(p); }
+#ifndef UNET_CT_OCC
+#define UNET_CT_OCC 2           /* workgroups per CU of the 64-column forward kernels (bf16-stored input) */
+#endif
+__global__ __launch_bounds__(256, UNET_CT_OCC) void convt_bf16_fwd_dma_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 0, 1, 1>(p); }
 __global__ __launch_bounds__(256, 1) void convt_bf16_fwd_stats_dma_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 1, 1, 1>(p); }
-__global__ __launch_bounds__(256, 1) void convt_bf16_fwd_stats_dma_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 1, 1, 1>(p); }
+__global__ __launch_bounds__(256, UNET_CT_OCC) void convt_bf16_fwd_stats_dma_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 1, 1, 1>(p); }
 __global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_dma_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 0, 2, 1>(p); }
 __global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_dma_kernel_64(ConvtBf16Args p) { convt_bf16_body<2, 0, 2, 1>(p); }
 __global__ __launch_bounds__(256, 1) void convt_bf16_dgrad_bnbwd_dma_kernel_128(ConvtBf16Args p) { convt_bf16_body<4, 2, 2, 1>(p); }
@@ -1672,7 +1682,13 @@ int run_convt_bf16(int mode, const void* x, int ldx, int in16, const void* wp, c
     a.K = mode == 1 ? Cin : 4 * Cout; a.Ncol = mode == 1 ? 4 * Cout : Cin;
     a.tby = (H + 15) / 16; a.tbx = (W + 31) / 32; a.n_px = N * a.tby * a.tbx;
     a.x_bytes = (unsigned)((size_t)N * H * W * (mode == 2 ? 4 : 1) * ldx * (in16 ? 2 : 4));
-    const bool wide = a.Ncol % 128 == 0 && (long)a.n_px * (a.Ncol / 128) >= conv_bf16_cus();
+    // Forward with K <= 256 (up_1, up_2): 4-8 chunks of 32 MFMAs between a prologue whose first loads come from HBM and an epilogue that writes
+    // 128 KB -- one workgroup per CU leaves every one of those latencies exposed.  64-column tiles at TWO workgroups per CU (128 accumulators,
+    // 72 KB of LDS) hide them in each other; the input tile's extra reads come from L2 (column tile fastest).  Same box, forward + sums:
+    // up_1 0.141 -> 0.112 ms, up_2 0.089 -> 0.079; at K >= 512 the wide tile wins (up_3 0.063 either way, up_4 0.050 vs 0.056), and the data
+    // gradient's 64-column kernel with BatchNorm-backward sums does not fit 256 registers (it spills: 0.141 -> 0.161 on up_1).
+    const bool narrow_k = UNET_CT_OCC > 1 && in16 && mode == 1 && a.K <= 256;
+    const bool wide = a.Ncol % 128 == 0 && (long)a.n_px * (a.Ncol / 128) >= conv_bf16_cus() && !narrow_k;
     a.n_co = a.Ncol / (wide ? 128 : 64);
     a.stat_part = stat_part; a.bn_r = r_prev; a.bn_ldr = ldr;
     if (stat_part) {
@@ -1917,12 +1933,19 @@ __device__ __forceinline__ void convt_wgrad_bf16_body(const CtWgBf16Args& p) {
 
 namespace {
 
+#ifndef UNET_CTWG_OCC
+#define UNET_CTWG_OCC 1         /* workgroups per CU of the 64-output-channel weight-gradient kernel (2: and twice the pixel splits) */
+#endif
 __global__ __launch_bounds__(256, 1) void convt_wgrad_bf16_kernel_128(CtWgBf16Args p) { convt_wgrad_bf16_body<2>(p); }
-__global__ __launch_bounds__(256, 1) void convt_wgrad_bf16_kernel_64(CtWgBf16Args p) { convt_wgrad_bf16_body<1>(p); }
+__global__ __launch_bounds__(256, UNET_CTWG_OCC) void convt_wgrad_bf16_kernel_64(CtWgBf16Args p) { convt_wgrad_bf16_body<1>(p); }
 
 void convt_wgrad_bf16_plan(CtWgBf16Args& a, int max_workgroups) {
     // 64-output-channel tiles by default: 128 AGPRs + 103 VGPRs, so the kernel shares a CU with the other stream's kernels (the
     // 128-channel tile takes all 256 AGPRs; alone it is as fast, in the step 0.13 ms slower -- compile with -DUNET_CONVT_WGRAD_WIDE to get it)
+    // Round 6 tried a second workgroup of its OWN per CU (-DUNET_CTWG_OCC=2: launch bounds (256, 2), twice the pixel splits -- a unit is 16
+    // MFMAs per wave between two barriers with register-staged operands): 0.413 -> 0.349 ms over the four BASELINE shapes stand-alone and
+    // -0.13 ms on a single-stream step, but +0.05 ms on the two-stream step the product runs (12.740 -> 12.792 ms, four alternating runs):
+    // the slots it fills are the ones the other stream's kernels were using.  Left at one.
 #ifdef UNET_CONVT_WGRAD_WIDE
     const int cot = a.Cout % 128 == 0 ? 128 : 64;
 #else
@@ -1931,7 +1954,7 @@ void convt_wgrad_bf16_plan(CtWgBf16Args& a, int max_workgroups) {
     a.n_co = a.Cout / cot; a.n_ci = a.Cin / 128;
     a.tbx = (a.W + 31) / 32; a.n_units = a.N * a.H * a.tbx;
     const int npairs = a.n_co * a.n_ci;
-    int splits = unet_grid_slots(conv_bf16_cus(), max_workgroups) / npairs; if (splits < 1) splits = 1; if (splits > a.n_units) splits = a.n_units;
+    int splits = unet_grid_slots(conv_bf16_cus(), max_workgroups) * (cot == 64 ? UNET_CTWG_OCC : 1) / npairs; if (splits < 1) splits = 1; if (splits > a.n_units) splits = a.n_units;
     a.splits = splits;
 }
 
