@@ -32,7 +32,7 @@ extern "C" {
  *  7: round 5 -- no signature changed, but the operand unet_winograd_weight_transform_x6 / _fold_x6 write is laid out for the round-5 kernel
  *  (MFMA A-operand order per 64-channel tile, chunk and point row): an operand and the conv entry point that reads it must come from one library;
  *  6: round 4 -- unet_convT2x2_*_x6; 5: round 4 -- the `_wg` (max_workgroups) entry points of every persistent kernel, unet_standin_collective; 4: round 4 -- the BF16x6 Winograd route: unet_*_x6; 3: + deferred bias gradient of unet_bn_bwd_any; 2: round 3 -- max_workgroups of the fused Winograd weight gradient; 1: rounds 1-2). */
-#define UNET_HIP_ABI_VERSION 8
+#define UNET_HIP_ABI_VERSION 9
 int unet_hip_abi_version(void);
 
 /* ---- Conv2D(3x3, 'same', relu) of UNet._conv_layer, UNet/model.py:28-35 (18 instances, :88-134) ------------------ */
@@ -197,6 +197,14 @@ int unet_convT2x2_fwd_x6(const float* x, int ldx, const void* W6, const float* b
                          int N, int H, int W, int Cin, int Cout, float* stat_part, size_t stat_bytes, void* stream);
 int unet_convT2x2_dgrad_x6(const float* dz, int lddz, const void* W6d, float* dx, int lddx,
                            int N, int H, int W, int Cin, int Cout, void* stream);
+/* ... with the BatchNorm-backward sums of the layer that produced x (UNet/model.py:36 under the tape of :216-219): dx is that layer's dy, r_prev
+ * [N*H*W][ldr] its saved activation; stat_part receives (sum dx, sum dx * r_prev) as (Cin/64) * rows * 128 floats, rows =
+ * unet_convT2x2_x6_bnbwd_rows (one per 128-pixel tile) -- the `sums_part` of unet_bn_bwd_any, which then needs no reduction pass.
+ * r_prev and stat_part both null = unet_convT2x2_dgrad_x6. */
+int unet_convT2x2_x6_bnbwd_rows(int N, int H, int W, int Cin, int Cout);
+int unet_convT2x2_dgrad_x6_sums(const float* dz, int lddz, const void* W6d, float* dx, int lddx,
+                                int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr,
+                                float* stat_part, size_t stat_bytes, void* stream);
 /* weight gradient on the same arithmetic: both operands are activations, split into three bf16 pieces inside the kernel; split-K partials
  * in ws (unet_convT2x2_wgrad_x6_workspace bytes), reduced in split order */
 size_t unet_convT2x2_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout);

@@ -27,7 +27,9 @@ struct ConvtX6Args {
     const uint16_t* b6;      // pre-split weights [K/16][piece 3][Ncols][16 bf16], swizzled
     const float* bias;       // forward (nullable)
     float* out;              // forward: [N][2H][2W][ldo]; gradient: dx [P][ldo]
-    float* stat_part;        // forward, nullable: BatchNorm sums of the output, [Cout/64][rows][64][2], rows = 4 * P / 128
+    float* stat_part;        // forward, nullable: BatchNorm sums of the output, [Cout/64][rows][64][2], rows = 4 * P / 128;
+                             // gradient (the _bnbwd kernels): BatchNorm-BACKWARD sums of the producer layer (sum dx, sum dx * r), [Cin/64][rows][64][2], rows = P / 128
+    const float* bn_r; int bn_ldr;     // gradient + sums: the producer layer's saved activation r [P][bn_ldr] (its dy is dx)
     int lda, ldo, N, H, W, Cin, Cout;
     int K, Ncols, nct;       // reduction length, GEMM columns, column tiles per pixel tile
     long P;
@@ -207,8 +209,19 @@ __device__ __forceinline__ void convt_x6_body(const ConvtX6Args& p) {
                     if constexpr (STATS) { ssum[nb] += y; ssq[nb] = fmaf(y, y, ssq[nb]); }
                 }
             } else {
+                // (+ sums, round 6: dx IS the dy of the layer that produced x, so its BatchNorm-backward sums are taken here from the fp32 accumulators
+                // and that layer's reduction pass -- a read of dy and r -- drops out; the four loads of a pixel are in flight together)
+                float rv[NB];
+                if constexpr (STATS) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) p.out[(long)(base + d) * p.ldo + cho[nb]] = acc[mb][nb][i];
+                    for (int nb = 0; nb < NB; ++nb) rv[nb] = p.bn_r[(long)(base + d) * p.bn_ldr + cho[nb]];
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float v = acc[mb][nb][i];
+                    p.out[(long)(base + d) * p.ldo + cho[nb]] = v;
+                    if constexpr (STATS) { ssum[nb] += v; ssq[nb] = fmaf(v, rv[nb], ssq[nb]); }
+                }
             }
         }
     }
@@ -222,10 +235,10 @@ __device__ __forceinline__ void convt_x6_body(const ConvtX6Args& p) {
         }
         __syncthreads();
         if (tid < NT) {
-            const int n = n0 + tid, t = n / p.Cout, co = n - t * p.Cout;
-            const long rows = 4 * (p.P / 128);
+            const int n = n0 + tid, t = MODE == 0 ? n / p.Cout : 0, co = MODE == 0 ? n - t * p.Cout : n;
+            const long rows = (MODE == 0 ? 4 : 1) * (p.P / 128), row = MODE == 0 ? pt * 4 + t : pt;
             float2 o; o.x = red[tid * 2] + red[(NT + tid) * 2]; o.y = red[tid * 2 + 1] + red[(NT + tid) * 2 + 1];
-            *reinterpret_cast<float2*>(p.stat_part + (((size_t)(co >> 6) * rows + (pt * 4 + t)) * 64 + (co & 63)) * 2) = o;
+            *reinterpret_cast<float2*>(p.stat_part + (((size_t)(co >> 6) * rows + row) * 64 + (co & 63)) * 2) = o;
         }
     }
 }
@@ -234,6 +247,8 @@ __global__ __launch_bounds__(256, 2) void convt_x6_fwd_kernel(ConvtX6Args p) { c
 __global__ __launch_bounds__(256, 2) void convt_x6_fwd_stats_kernel(ConvtX6Args p) { convt_x6_body<0, 4, true>(p); }
 __global__ __launch_bounds__(256, 2) void convt_x6_dgrad_kernel_256(ConvtX6Args p) { convt_x6_body<1, 4, false>(p); }
 __global__ __launch_bounds__(256, 2) void convt_x6_dgrad_kernel_128(ConvtX6Args p) { convt_x6_body<1, 2, false>(p); }
+__global__ __launch_bounds__(256, 2) void convt_x6_dgrad_bnbwd_kernel_256(ConvtX6Args p) { convt_x6_body<1, 4, true>(p); }
+__global__ __launch_bounds__(256, 2) void convt_x6_dgrad_bnbwd_kernel_128(ConvtX6Args p) { convt_x6_body<1, 2, true>(p); }
 
 // Weights W [tap 4][Cout][Cin] (Keras Conv2DTranspose layout, UNet/model.py:41) = Wflat [R = 4 Cout][Cin]  ->  B [K/16][piece 3][Ncols][16 bf16]
 //   mode 0 (forward):       B[k = ci][n = tap * Cout + co] = Wflat[n][k]
@@ -480,22 +495,46 @@ extern "C" int unet_convT2x2_fwd_x6(const float* x, int ldx, const void* W6, con
     return UNET_LAUNCH_STATUS();
 }
 
-// Data gradient: the arguments of unet_convT2x2_dgrad with W6d (mode 1) in place of w
-extern "C" int unet_convT2x2_dgrad_x6(const float* dz, int lddz, const void* W6d, float* dx, int lddx,
-                                      int N, int H, int W, int Cin, int Cout, void* stream) {
+// rows of BatchNorm-backward partials per 64-channel block the data gradient with sums writes: one per 128-pixel tile
+extern "C" int unet_convT2x2_x6_bnbwd_rows(int N, int H, int W, int Cin, int Cout) {
+#ifdef UNET_CTX6_NO_SUMS        /* diagnostic build: the plan then keeps the producer's reduction pass (A/B of the fusion) */
+    return 0;
+#endif
+    return convt_x6_shape_ok(N, H, W, Cin, Cout) ? (int)((long)N * H * W / 128) : 0;
+}
+
+// Data gradient: the arguments of unet_convT2x2_dgrad with W6d (mode 1) in place of w.  r_prev / stat_part (both or neither): dx is the
+// gradient of the BatchNorm output of the layer that produced x, r_prev [N*H*W][ldr] that layer's saved activation -- the kernel also leaves its
+// BatchNorm-backward sums (sum dx, sum dx * r_prev) as (Cin/64) * rows * 128 floats, rows = unet_convT2x2_x6_bnbwd_rows
+// (the form unet_bn_bwd_any takes as `sums_part`)
+extern "C" int unet_convT2x2_dgrad_x6_sums(const float* dz, int lddz, const void* W6d, float* dx, int lddx,
+                                           int N, int H, int W, int Cin, int Cout, const float* r_prev, int ldr,
+                                           float* stat_part, size_t stat_bytes, void* stream) {
     UNET_CHECK_ARG(dz && W6d && dx && convt_x6_shape_ok(N, H, W, Cin, Cout));
     UNET_CHECK_ARG(lddz >= Cout && lddx >= Cin && lddz % 4 == 0 && unet_aligned16(dz) && unet_aligned16(W6d));
+    UNET_CHECK_ARG((r_prev != nullptr) == (stat_part != nullptr) && (!r_prev || (ldr >= Cin && unet_aligned16(stat_part))));
     ConvtX6Args a{};
     a.a = dz; a.b6 = (const uint16_t*)W6d; a.out = dx; a.lda = lddz; a.ldo = lddx;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.P = (long)N * H * W;
     a.K = 4 * Cout; a.Ncols = Cin;
+    a.bn_r = r_prev; a.bn_ldr = ldr; a.stat_part = stat_part;
     const bool wide = Cin % 256 == 0;
     a.nct = Cin / (wide ? 256 : 128);
     const long blocks = (a.P / 128) * a.nct;
     if (blocks <= 0 || blocks > 0x7fffffffL) return UNET_EINVAL;
-    if (wide) convt_x6_dgrad_kernel_256<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
-    else      convt_x6_dgrad_kernel_128<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+    if (stat_part) {
+        if (stat_bytes < (size_t)(Cin / 64) * unet_convT2x2_x6_bnbwd_rows(N, H, W, Cin, Cout) * 128 * sizeof(float)) return UNET_ENOSPC;
+        if (wide) convt_x6_dgrad_bnbwd_kernel_256<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+        else      convt_x6_dgrad_bnbwd_kernel_128<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+    } else {
+        if (wide) convt_x6_dgrad_kernel_256<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+        else      convt_x6_dgrad_kernel_128<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(a);
+    }
     return UNET_LAUNCH_STATUS();
+}
+extern "C" int unet_convT2x2_dgrad_x6(const float* dz, int lddz, const void* W6d, float* dx, int lddx,
+                                      int N, int H, int W, int Cin, int Cout, void* stream) {
+    return unet_convT2x2_dgrad_x6_sums(dz, lddz, W6d, dx, lddx, N, H, W, Cin, Cout, nullptr, 0, nullptr, 0, stream);
 }
 
 // Weight gradient dw [2][2][Cout][Cin] (H, W: INPUT dims); supported as the forward (N*H*W % 128 == 0, Cin % 128 == 0, Cout % 64 == 0).

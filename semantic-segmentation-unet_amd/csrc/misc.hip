@@ -408,7 +408,7 @@ extern "C" int unet_conv3x3_dgrad_direct(const float* dz, int lddz, const float*
     return UNET_LAUNCH_STATUS();
 }
 
-extern "C" int unet_hip_abi_version(void) { return 8; }       // == UNET_HIP_ABI_VERSION of include/unet_hip.h
+extern "C" int unet_hip_abi_version(void) { return 9; }       // == UNET_HIP_ABI_VERSION of include/unet_hip.h
 
 // ---- stand-in for a collective's kernel (measurement aid; include/unet_hip.h) -----------------------------------------------------------
 // RCCL's all-reduce kernels are a few dozen large workgroups that stay resident while the data crosses xGMI.  This one reproduces the

@@ -754,6 +754,7 @@ class Engine:
                 pname, c0, c1 = prod
                 r_prev = self.saved[pname][1]
                 rows = (L.unet_convT2x2_bf16_stats_rows(n, hi, wi, cin, cout, 1) if lp.dgrad == "convt_bf16"
+                        else L.unet_convT2x2_x6_bnbwd_rows(n, hi, wi, cin, cout) if lp.dgrad == "convt_x6"
                         else L.unet_conv3x3_bf16_stats_rows(n, ho, wo, cout, cin) if lp.dgrad == "bf16"
                         else L.unet_conv3x3_fwd_winograd_fused_stats_rows_wg(n, ho, wo, cout, cin, cap))
                 assert rows > 0
@@ -768,8 +769,9 @@ class Engine:
                             _p(dz), cout, z16, _p(self._bf16_kernels(name)[1]), _p(dx), cin, int(dx16), n, hi, wi, cin, cout,
                             _p(r_prev), ldr_prev, r16_prev, _p(part), nbp, st)
             elif lp.dgrad == "convt_x6":
-                self._timed("convt_dgrad_x6", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_dgrad_x6,
-                            _p(dz), cout, _p(self._convt_x6_kernels(name)[1]), _p(dx), cin, n, hi, wi, cin, cout, st)
+                self._timed("convt_dgrad_x6", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_dgrad_x6_sums,
+                            _p(dz), cout, _p(self._convt_x6_kernels(name)[1]), _p(dx), cin, n, hi, wi, cin, cout,
+                            _p(r_prev), ldr_prev, _p(part), nbp, st)
             elif kind == "deconv":
                 self._timed("convt_dgrad", 8.0 * n * hi * wi * cin * cout, L.unet_convT2x2_dgrad, _p(dz), cout, _p(w_), _p(dx), cin, n, hi, wi, cin, cout, st)
             elif kind == "conv1":

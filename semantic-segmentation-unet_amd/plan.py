@@ -319,6 +319,8 @@ def build_plan(opt, number_channels, number_classes, n, h, w, training, want_gra
                 ok = pp.r == F32 and L.unet_conv3x3_fwd_winograd_fused_stats_rows_wg(n, p.ho, p.wo, p.cout, p.cin, opt.cap) > 0
             elif p.dgrad == "convt_bf16":
                 ok = L.unet_convT2x2_bf16_stats_rows(n, p.hi, p.wi, p.cin, p.cout, 1) > 0
+            elif p.dgrad == "convt_x6":
+                ok = pp.r == F32 and L.unet_convT2x2_x6_bnbwd_rows(n, p.hi, p.wi, p.cin, p.cout) > 0
             if ok:
                 c0, c1 = prod[1] * (p.cin // prod[3]), prod[2] * (p.cin // prod[3])
                 p.leaves_sums_for = (prod[0], c0, c1)

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     protos = pkg("_lib").parse_header()
     assert set(protos) == names
     lib_mod = pkg("_lib")
-    assert cdll.unet_hip_abi_version() == lib_mod.header_abi_version() == 8
+    assert cdll.unet_hip_abi_version() == lib_mod.header_abi_version() == 9
     assert cdll.unet_conv3x3_mfma_supported(64, 128) == 1 and cdll.unet_conv3x3_mfma_supported(1, 64) == 0
 
 

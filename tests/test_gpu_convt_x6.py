@@ -107,6 +107,36 @@ def test_forward_and_data_gradient_are_fp32_grade(shape):
     assert L.unet_convT2x2_x6_supported(1, 5, 5, ci, co) == 0 and L.unet_convT2x2_x6_supported(n, h, w, 64, co) == 0
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 128, 64), (1, 16, 16, 256, 128), (1, 12, 32, 384, 64), (8, 64, 64, 512, 256), (8, 256, 256, 128, 64)])
+def test_data_gradient_leaves_the_producers_batchnorm_backward_sums(shape):
+    # unet_convT2x2_dgrad_x6_sums (round 6): dx is the dy of the layer that produced x (dec_Nb -> up_(N-1), UNet/model.py:117-132), so the
+    # kernel's epilogue also leaves that layer's BatchNorm-backward sums (sum dx, sum dx * r) per 128-pixel tile, from its fp32 accumulators:
+    # dx bit-identical to the plain kernel's, sums = those of the stored dx against fp64, a saved activation with a leading dimension > Cin
+    # (the concat buffer), the too-small-buffer and one-null refusals
+    L = pkg("_lib").lib()
+    n, h, w, ci, co = shape
+    x, wT, b, dz = make(shape, 11 + h + ci)
+    _, W6d = operands(L, wT)
+    ldr = ci + 64
+    r = torch.randn(n, h, w, ldr, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3 + ci))
+    rows = L.unet_convT2x2_x6_bnbwd_rows(*shape)
+    assert rows == n * h * w // 128
+    part = torch.full(((ci // 64) * rows * 128,), float("nan"), device=DEV)
+    dx = torch.full((n, h, w, ci), float("nan"), device=DEV); dref = torch.full_like(dx, float("nan"))
+    L.unet_convT2x2_dgrad_x6_sums(P(dz), co, P(W6d), P(dx), ci, n, h, w, ci, co, P(r), ldr, P(part), part.numel() * 4, ST())
+    L.unet_convT2x2_dgrad_x6(P(dz), co, P(W6d), P(dref), ci, n, h, w, ci, co, ST())
+    assert torch.equal(dx, dref)
+    sums = part.view(ci // 64, rows, 64, 2).double().sum(1).reshape(ci, 2)
+    d64, r64 = dx.double().reshape(-1, ci), r[..., :ci].double().reshape(-1, ci)
+    assert torch.allclose(sums[:, 0], d64.sum(0), rtol=0, atol=2e-6 * float(d64.abs().sum(0).max()))
+    assert torch.allclose(sums[:, 1], (d64 * r64).sum(0), rtol=0, atol=2e-6 * float((d64 * r64).abs().sum(0).max()))
+    E = pkg("_lib").UnetHipError
+    with pytest.raises(E, match="workspace too small"):
+        L.unet_convT2x2_dgrad_x6_sums(P(dz), co, P(W6d), P(dx), ci, n, h, w, ci, co, P(r), ldr, P(part), 64, ST())
+    with pytest.raises(E, match="bad argument"):
+        L.unet_convT2x2_dgrad_x6_sums(P(dz), co, P(W6d), P(dx), ci, n, h, w, ci, co, P(r), ldr, None, 0, ST())
+
+
 def test_weight_operands_are_an_exact_three_piece_split():
     L = pkg("_lib").lib()
     ci, co = 128, 64
